@@ -1,0 +1,52 @@
+# Top-level build.  `make all` = everything that can be built on this machine.
+#   hip     mecat_amd/lib/libmecat_hip.so   HIP kernels + C-ABI (gfx950)
+#   host    mecat_amd/bin/mecat2pw          C++ host driver (drop-in CLI) on top of the C-ABI
+#   synth   mecat_amd/lib/libsynth.so + mecat_amd/bin/synth_reads   synthetic read generator
+#   oracle  oracle/liboracle.so             CPU restatement (test infrastructure)
+#   ref     oracle/_ref/*                   unmodified reference (only where /root/reference exists)
+HIPCC ?= /opt/rocm/bin/hipcc
+CC ?= gcc
+CXX ?= g++
+ARCH ?= gfx950
+LIBDIR := mecat_amd/lib
+BINDIR := mecat_amd/bin
+CSRC := mecat_amd/csrc
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I$(CSRC) -Wall -Wno-unused-function
+HIP_SRCS := $(wildcard $(CSRC)/*.hip)
+HIP_HDRS := $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.hpp) include/mecat_hip.h
+HIP_OBJS := $(patsubst $(CSRC)/%.hip,build/%.o,$(HIP_SRCS))
+HOST_SRCS := $(wildcard mecat_amd/host/*.cpp)
+
+.PHONY: all hip host synth oracle ref clean
+all: synth oracle hip host
+	@if [ -d /root/reference/src ]; then $(MAKE) ref; fi
+
+hip: $(LIBDIR)/libmecat_hip.so
+build/%.o: $(CSRC)/%.hip $(HIP_HDRS)
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
+$(LIBDIR)/libmecat_hip.so: $(HIP_OBJS)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(HIP_OBJS) -o $@
+
+host: $(BINDIR)/mecat2pw
+$(BINDIR)/mecat2pw: $(HOST_SRCS) $(wildcard mecat_amd/host/*.h) include/mecat_hip.h $(LIBDIR)/libmecat_hip.so
+	@mkdir -p $(BINDIR)
+	$(CXX) -O2 -std=c++17 -pthread -Wall -Iinclude $(HOST_SRCS) -L$(LIBDIR) -lmecat_hip -Wl,-rpath,'$$ORIGIN/../lib' -o $@
+
+synth: $(LIBDIR)/libsynth.so $(BINDIR)/synth_reads
+$(LIBDIR)/libsynth.so: mecat_amd/tools/synth_reads.c
+	@mkdir -p $(LIBDIR)
+	$(CC) -O2 -fPIC -shared $< -o $@
+$(BINDIR)/synth_reads: mecat_amd/tools/synth_reads.c
+	@mkdir -p $(BINDIR)
+	$(CC) -O2 -DSYNTH_MAIN $< -o $@
+
+oracle:
+	$(MAKE) -C oracle oracle
+ref:
+	$(MAKE) -C oracle ref
+
+clean:
+	rm -rf build $(LIBDIR) $(BINDIR)
+	$(MAKE) -C oracle clean

@@ -1,0 +1,134 @@
+/*
+ * synth_reads — deterministic synthetic long-read generator (test/bench input).
+ *
+ * The reference ships no data; every workload in BASELINE.json is
+ * "synthetic PacBio-/ONT-style reads".  Model:
+ *   genome: uniform random ACGT of length G
+ *   read i: uniform start, template length L (clipped to the genome end), strand by coin flip,
+ *           per template base: delete w.p. pdel, substitute by a uniform base w.p. psub, else copy;
+ *           after each template base insert a uniform base w.p. pins.
+ *   PacBio-style  e: pdel=0.25e psub=0.15e pins=0.60e ; ONT-style e: 0.35e / 0.35e / 0.30e.
+ * RNG: xorshift64*, the genome from stream `seed`, read i from stream splitmix64(seed, i) so reads can be
+ * generated in any order / in parallel with identical output.
+ *
+ * Built both as a CLI (FASTA to stdout/file) and as a tiny shared library used by bench.py and the tests.
+ */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static inline uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+typedef struct { uint64_t s; } rng_t;
+static inline void rng_seed(rng_t* r, uint64_t seed) { r->s = splitmix64(seed); if (!r->s) r->s = 1; }
+static inline uint64_t rng_next(rng_t* r) {
+    uint64_t x = r->s;
+    x ^= x >> 12; x ^= x << 25; x ^= x >> 27;
+    r->s = x;
+    return x * 0x2545F4914F6CDD1Dull;
+}
+static inline double rng_unit(rng_t* r) { return (double)(rng_next(r) >> 11) * (1.0 / 9007199254740992.0); }
+
+/* genome of G codes 0..3 */
+void synth_genome(uint8_t* g, int64_t G, uint64_t seed) {
+    rng_t r; rng_seed(&r, seed ^ 0x47454E4F4D45ull);
+    int64_t i = 0;
+    while (i < G) {
+        uint64_t w = rng_next(&r);
+        for (int k = 0; k < 32 && i < G; ++k, ++i) { g[i] = (uint8_t)(w & 3); w >>= 2; }
+    }
+}
+
+/* one read -> codes 0..3 in out (capacity cap); returns length */
+int synth_one_read(const uint8_t* g, int64_t G, int64_t idx, int L, double pdel, double psub, double pins,
+                   uint64_t seed, uint8_t* out, int cap) {
+    rng_t r; rng_seed(&r, splitmix64(seed) ^ splitmix64((uint64_t)idx * 2 + 1));
+    int64_t tl = L < G ? L : G;
+    int64_t start = (int64_t)(rng_unit(&r) * (double)(G - tl + 1));
+    if (start > G - tl) start = G - tl;
+    int rev = (int)(rng_next(&r) >> 63);
+    int n = 0;
+    for (int64_t t = 0; t < tl && n < cap; ++t) {
+        uint8_t b = rev ? (uint8_t)(3 - g[start + tl - 1 - t]) : g[start + t];
+        double u = rng_unit(&r);
+        if (u < pdel) { /* deleted */ }
+        else if (u < pdel + psub) out[n++] = (uint8_t)(rng_next(&r) >> 62);
+        else out[n++] = b;
+        if (n < cap && rng_unit(&r) < pins) out[n++] = (uint8_t)(rng_next(&r) >> 62);
+    }
+    return n;
+}
+
+void synth_rates(double e, int ont, double* pdel, double* psub, double* pins) {
+    if (ont) { *pdel = 0.35 * e; *psub = 0.35 * e; *pins = 0.30 * e; }
+    else     { *pdel = 0.25 * e; *psub = 0.15 * e; *pins = 0.60 * e; }
+}
+
+/*
+ * Generate `nreads` reads into one contiguous code buffer (0..3), lengths in lens[].
+ * bases must hold nreads * cap bytes where cap = (int)(L*1.25)+64; reads are packed back to back afterwards.
+ * Returns total bases.
+ */
+int64_t synth_reads(int64_t G, int64_t nreads, int L, double e, int ont, uint64_t seed,
+                    uint8_t* bases, int64_t bases_cap, int32_t* lens) {
+    double pdel, psub, pins; synth_rates(e, ont, &pdel, &psub, &pins);
+    uint8_t* g = (uint8_t*)malloc((size_t)G);
+    if (!g) return -1;
+    synth_genome(g, G, seed);
+    int cap = (int)(L * 1.25) + 64;
+    uint8_t* tmp = (uint8_t*)malloc((size_t)cap);
+    int64_t tot = 0;
+    for (int64_t i = 0; i < nreads; ++i) {
+        int n = synth_one_read(g, G, i, L, pdel, psub, pins, seed, tmp, cap);
+        if (tot + n > bases_cap) { free(tmp); free(g); return -2; }
+        memcpy(bases + tot, tmp, (size_t)n);
+        lens[i] = n; tot += n;
+    }
+    free(tmp); free(g);
+    return tot;
+}
+
+int synth_write_fasta(const char* path, const uint8_t* bases, const int32_t* lens, int64_t nreads) {
+    FILE* f = fopen(path, "w");
+    if (!f) return -1;
+    int64_t off = 0;
+    char* line = NULL; int lcap = 0;
+    for (int64_t i = 0; i < nreads; ++i) {
+        int n = lens[i];
+        if (n + 2 > lcap) { lcap = n + 2; line = (char*)realloc(line, (size_t)lcap); }
+        for (int k = 0; k < n; ++k) line[k] = "ACGT"[bases[off + k] & 3];
+        line[n] = '\n';
+        fprintf(f, ">r%lld\n", (long long)i);
+        fwrite(line, 1, (size_t)n + 1, f);
+        off += n;
+    }
+    free(line);
+    return fclose(f);
+}
+
+#ifdef SYNTH_MAIN
+int main(int argc, char** argv) {
+    if (argc < 7) {
+        fprintf(stderr, "usage: %s out.fa nreads L err genome_len seed [ont=0]\n", argv[0]);
+        return 1;
+    }
+    const char* out = argv[1];
+    int64_t n = atoll(argv[2]); int L = atoi(argv[3]); double e = atof(argv[4]);
+    int64_t G = atoll(argv[5]); uint64_t seed = strtoull(argv[6], NULL, 10);
+    int ont = argc > 7 ? atoi(argv[7]) : 0;
+    int64_t cap = n * ((int64_t)(L * 1.25) + 64);
+    uint8_t* bases = (uint8_t*)malloc((size_t)cap);
+    int32_t* lens = (int32_t*)malloc((size_t)n * 4);
+    int64_t tot = synth_reads(G, n, L, e, ont, seed, bases, cap, lens);
+    if (tot < 0) { fprintf(stderr, "synth_reads failed %lld\n", (long long)tot); return 2; }
+    if (synth_write_fasta(out, bases, lens, n)) { perror(out); return 3; }
+    fprintf(stderr, "synth_reads: %lld reads, %lld bases, L=%d e=%.3f G=%lld seed=%llu ont=%d\n",
+            (long long)n, (long long)tot, L, e, (long long)G, (unsigned long long)seed, ont);
+    return 0;
+}
+#endif

@@ -1,0 +1,957 @@
+/*
+ * mecat_oracle.c — plain-C restatement of the reference mecat2pw hot path.  TEST INFRASTRUCTURE ONLY.
+ * See mecat_oracle.h for the rules; every function cites the reference file:line it follows
+ * (paths relative to /root/reference/src/).  Quirks are reproduced literally, not fixed.
+ *
+ * Compile with -ffp-contract=off on x86-64 (SSE2, FLT_EVAL_METHOD 0) so the three floating-point precisions used
+ * by the reference (f32 in find_location, f32 divide + f64 compare in insert_loc, f64 in the neighbour sweeps)
+ * round exactly as g++ -O3 rounds them.
+ */
+#include "mecat_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define MUL_ZV(a) ((a) * ORC_ZV)
+#define DIV_ZV(a) ((a) / ORC_ZV)
+#define MOD_ZV(a) ((a) % ORC_ZV)
+
+static void* xmalloc(size_t n) { void* p = malloc(n ? n : 1); if (!p) { fprintf(stderr, "oracle: malloc fail\n"); abort(); } return p; }
+static void* xcalloc(size_t n) { void* p = calloc(1, n ? n : 1); if (!p) { fprintf(stderr, "oracle: calloc fail\n"); abort(); } return p; }
+
+/* pw_options.cpp:8-13,30-50 and pw_impl.cpp:843-851 */
+void orc_params_default(orc_params* p, int tech)
+{
+    p->maxc = 100;
+    p->tech = tech;
+    p->output_gapped_start_point = 0;
+    p->ddfs_cutoff = 0.25;
+    if (tech == 0) { p->min_align_size = 2000; p->min_kmer_match = 4; p->min_kmer_dist = 1800; }
+    else           { p->min_align_size = 500;  p->min_kmer_match = 2; p->min_kmer_dist = 400; }
+}
+
+/* ------------------------------------------------------------------ A1 / A3: volumes */
+
+/* defs.cpp:3-36 */
+uint8_t orc_encode_base(int c)
+{
+    switch (c) {
+    case '-': return 15;
+    case 'a': case 'A': return 0;  case 'c': case 'C': return 1;  case 'm': case 'M': return 6;
+    case 'g': case 'G': return 2;  case 'r': case 'R': return 4;  case 's': case 'S': return 9;
+    case 'v': case 'V': return 13; case 't': case 'T': return 3;  case 'w': case 'W': return 8;
+    case 'y': case 'Y': return 5;  case 'h': case 'H': return 12; case 'k': case 'K': return 7;
+    case 'd': case 'D': return 11; case 'b': case 'B': return 10; case 'n': case 'N': return 14;
+    }
+    return 16;
+}
+
+/* packed_db.h:98-107 */
+static inline void set_char(uint8_t* p, int64_t idx, uint8_t c) { p[idx >> 2] |= (uint8_t)(c << ((~idx & 3) << 1)); }
+static inline uint8_t get_char(const uint8_t* p, int64_t idx) { return (uint8_t)((p[idx >> 2] >> ((~idx & 3) << 1)) & 3); }
+
+/* add_one_seq (split_database.cpp:103-119) + the `++v->curr` pad of split_raw_dataset (:249-250), for one volume.
+   `codes` are encode-table values (0..15), OR-ed unmasked exactly like the reference. */
+orc_volume* orc_volume_pack(const uint8_t* codes, const int* lens, int nreads, int start_read_id)
+{
+    orc_volume* v = (orc_volume*)xcalloc(sizeof(orc_volume));
+    int64_t tot = 0;
+    for (int i = 0; i < nreads; ++i) tot += lens[i] + 1;
+    if (tot > ORC_MCS) { fprintf(stderr, "oracle: volume too large\n"); abort(); }
+    v->num_reads = nreads;
+    v->start_read_id = start_read_id;
+    v->offs = (orc_offset_t*)xmalloc(sizeof(orc_offset_t) * (size_t)nreads);
+    v->pac = (uint8_t*)xcalloc((size_t)((tot + 3) / 4));
+    int curr = 0;
+    int64_t src = 0;
+    for (int i = 0; i < nreads; ++i) {
+        v->offs[i].offset = curr;
+        v->offs[i].size = lens[i];
+        for (int k = 0; k < lens[i]; ++k) { set_char(v->pac, curr, codes[src + k]); ++curr; }
+        src += lens[i];
+        ++curr; /* pad */
+    }
+    v->num_bases = curr;
+    return v;
+}
+
+/* split_database.cpp:155-181 */
+orc_volume* orc_volume_load(const char* path)
+{
+    FILE* in = fopen(path, "rb");
+    if (!in) return NULL;
+    orc_volume* v = (orc_volume*)xcalloc(sizeof(orc_volume));
+    int ok = fread(&v->num_reads, sizeof(int), 1, in) == 1 && fread(&v->num_bases, sizeof(int), 1, in) == 1 &&
+             fread(&v->start_read_id, sizeof(int), 1, in) == 1;
+    if (!ok) { fclose(in); free(v); return NULL; }
+    v->offs = (orc_offset_t*)xmalloc(sizeof(orc_offset_t) * (size_t)v->num_reads);
+    size_t nb = (size_t)((v->num_bases + 3) / 4);
+    v->pac = (uint8_t*)xmalloc(nb);
+    ok = fread(v->offs, sizeof(orc_offset_t), (size_t)v->num_reads, in) == (size_t)v->num_reads &&
+         fread(v->pac, 1, nb, in) == nb;
+    fclose(in);
+    if (!ok) { orc_volume_free(v); return NULL; }
+    return v;
+}
+
+/* split_database.cpp:135-153 */
+int orc_volume_dump(const orc_volume* v, const char* path)
+{
+    FILE* out = fopen(path, "wb");
+    if (!out) return -1;
+    fwrite(&v->num_reads, sizeof(int), 1, out);
+    fwrite(&v->num_bases, sizeof(int), 1, out);
+    fwrite(&v->start_read_id, sizeof(int), 1, out);
+    fwrite(v->offs, sizeof(orc_offset_t), (size_t)v->num_reads, out);
+    fwrite(v->pac, 1, (size_t)((v->num_bases + 3) / 4), out);
+    return fclose(out);
+}
+
+void orc_volume_free(orc_volume* v)
+{
+    if (!v) return;
+    free(v->offs); free(v->pac); free(v);
+}
+
+/* split_database.cpp:121-133 */
+void orc_extract_one_seq(const orc_volume* v, int id, char* s)
+{
+    int offset = v->offs[id].offset, size = v->offs[id].size;
+    for (int i = 0; i < size; ++i) s[i] = (char)get_char(v->pac, offset + i);
+}
+
+/* pw_impl.cpp:69-81 */
+void orc_reverse_complement(char* dst, const char* src, int size)
+{
+    for (int i = 0; i < size; ++i) dst[size - 1 - i] = (char)(3 - (uint8_t)src[i]);
+}
+
+/* split_database.cpp:15-35 */
+int orc_read_id_from_offset(const orc_volume* v, int offset)
+{
+    int n = v->num_reads;
+    const orc_offset_t* a = v->offs;
+    int left = 0, right = n - 1, mid = (left + right) / 2;
+    if (a[right].offset < offset) return right;
+    while (left <= right) {
+        if (a[mid].offset <= offset && a[mid].offset + a[mid].size > offset) return mid;
+        if (a[mid].offset + a[mid].size <= offset) left = mid + 1;
+        else if (a[mid].offset > offset) right = mid - 1;
+        else { fprintf(stderr, "oracle: offset search error\n"); exit(1); }
+        mid = (left + right) / 2;
+    }
+    return mid;
+}
+
+/* ------------------------------------------------------------------ A2: index (lookup_table.cpp:63-160) */
+
+orc_index* orc_index_build(const orc_volume* v)
+{
+    const int kmer_size = ORC_KMER;
+    const uint32_t index_count = 1u << (kmer_size * 2);
+    const uint32_t leftnum = 34 - 2 * kmer_size;
+    orc_index* index = (orc_index*)xcalloc(sizeof(orc_index));
+    index->counts = (int*)xcalloc(sizeof(int) * (size_t)index_count);
+    /* pass 1, :73-92 */
+    for (int i = 0; i != v->num_reads; ++i) {
+        int read_start = v->offs[i].offset, read_size = v->offs[i].size;
+        uint32_t eit = 0;
+        for (int j = 0; j < read_size; ++j) {
+            uint8_t c = get_char(v->pac, read_start + j);
+            eit = (eit << 2) | c;
+            if (j >= kmer_size - 1) {
+                ++index->counts[eit];
+                eit = eit << leftnum;
+                eit = eit >> leftnum;
+            }
+        }
+    }
+    /* :94-99 */
+    int64_t num_kmers = 0;
+    for (uint32_t i = 0; i != index_count; ++i) {
+        if (index->counts[i] > 128) index->counts[i] = 0;
+        num_kmers += index->counts[i];
+    }
+    index->num_kmers = num_kmers;
+    index->offsets = (int*)xmalloc(sizeof(int) * (size_t)num_kmers);
+    index->starts = (int64_t*)xmalloc(sizeof(int64_t) * (size_t)index_count);
+    /* :111-141 (thread partition by key range does not change bucket order; see fill func :25-61) */
+    num_kmers = 0;
+    for (uint32_t i = 0; i != index_count; ++i) {
+        if (index->counts[i]) { index->starts[i] = num_kmers; num_kmers += index->counts[i]; index->counts[i] = 0; }
+        else index->starts[i] = -1;
+    }
+    /* fill_ref_index_offsets_func :25-61, single key range */
+    for (int i = 0; i < v->num_reads; ++i) {
+        int read_start = v->offs[i].offset, read_size = v->offs[i].size;
+        uint32_t eit = 0;
+        for (int j = 0; j < read_size; ++j) {
+            int k = read_start + j;
+            uint8_t c = get_char(v->pac, k);
+            eit = (eit << 2) | c;
+            if (j >= kmer_size - 1) {
+                if (index->starts[eit] >= 0) {
+                    index->offsets[index->starts[eit] + index->counts[eit]] = k + 1 - kmer_size;
+                    ++index->counts[eit];
+                }
+                eit <<= leftnum;
+                eit >>= leftnum;
+            }
+        }
+    }
+    return index;
+}
+
+void orc_index_free(orc_index* idx)
+{
+    if (!idx) return;
+    free(idx->counts); free(idx->starts); free(idx->offsets); free(idx);
+}
+
+/* ------------------------------------------------------------------ A4-A8: seeding */
+
+struct orc_seeding_bk {             /* pw_impl.h:55-64, pw_impl.cpp:99-119 */
+    int* index_list;
+    int16_t* index_score;
+    orc_back_list* database;
+    int* kmer_ids;
+    int num_segs;
+};
+
+orc_seeding_bk* orc_bk_new(int ref_size)
+{
+    orc_seeding_bk* bk = (orc_seeding_bk*)xcalloc(sizeof(*bk));
+    const int num_segs = ref_size / ORC_ZV + 5;
+    bk->num_segs = num_segs;
+    bk->index_list = (int*)xmalloc(sizeof(int) * (size_t)num_segs);
+    bk->index_score = (int16_t*)xmalloc(sizeof(int16_t) * (size_t)num_segs);
+    bk->database = (orc_back_list*)xmalloc(sizeof(orc_back_list) * (size_t)num_segs);
+    bk->kmer_ids = (int*)xmalloc(sizeof(int) * ORC_MAX_SEQ_SIZE);
+    for (int i = 0; i < num_segs; ++i) {
+        memset(&bk->database[i], 0, sizeof(orc_back_list)); /* the reference leaves the lists uninitialised */
+        bk->database[i].score = 0;
+        bk->database[i].index = -1;
+    }
+    return bk;
+}
+
+void orc_bk_free(orc_seeding_bk* bk)
+{
+    if (!bk) return;
+    free(bk->index_list); free(bk->index_score); free(bk->database); free(bk->kmer_ids); free(bk);
+}
+
+/* pw_impl.cpp:83-97 */
+int orc_extract_kmers(const char* s, int ssize, int* kmer_ids)
+{
+    int num_kmers = (ssize - ORC_KMER) / ORC_BC + 1;
+    for (int i = 0; i < num_kmers; ++i) {
+        int eit = 0, start = i * ORC_BC;
+        for (int j = 0; j < ORC_KMER; ++j) eit = (eit << 2) | s[start + j];
+        kmer_ids[i] = eit;
+    }
+    return num_kmers;
+}
+
+/* pw_impl.cpp:121-159.  FP: int/(int*float) is an f32 divide; "- 1.0" and the compare are f64. */
+void orc_insert_loc(orc_back_list* spr, int loc, int seedn, float len, double cutoff)
+{
+    int list_loc[ORC_SI], list_score[ORC_SI], list_seed[ORC_SI], i, j, minval, mini;
+    for (i = 0; i < ORC_SM; i++) {
+        list_loc[i] = spr->loczhi[i];
+        list_seed[i] = spr->seedno[i];
+        list_score[i] = 0;
+    }
+    list_loc[ORC_SM] = loc;
+    list_seed[ORC_SM] = seedn;
+    list_score[ORC_SM] = 0;
+    mini = -1;
+    minval = 10000;
+    for (i = 0; i < ORC_SM; i++)
+        for (j = i + 1; j < ORC_SI; j++)
+            if (list_seed[j] - list_seed[i] > 0 && list_loc[j] - list_loc[i] > 0 &&
+                fabs((list_loc[j] - list_loc[i]) / ((list_seed[j] - list_seed[i]) * len) - 1.0) < cutoff) {
+                list_score[i]++;
+                list_score[j]++;
+            }
+    for (i = 0; i < ORC_SI; i++)
+        if (minval > list_score[i]) { minval = list_score[i]; mini = i; }
+    if (minval == ORC_SM) {
+        spr->loczhi[ORC_SM - 1] = (int16_t)loc;
+        spr->seedno[ORC_SM - 1] = (int16_t)seedn;
+    } else if (minval < ORC_SM && mini < ORC_SM) {
+        for (i = mini; i < ORC_SM; i++) {
+            spr->loczhi[i] = (int16_t)list_loc[i + 1];
+            spr->seedno[i] = (int16_t)list_seed[i + 1];
+        }
+        spr->score--;
+    }
+}
+
+/* pw_impl.cpp:161-239.  FP: everything before the compare is f32 ("- 1" converts the int). */
+static inline int ddf_f32(int dloc, int dseed, float len, double cutoff)
+{
+    float r = dloc / (dseed * len) - 1;
+    return fabsf(r) < cutoff;
+}
+
+int orc_find_location(int* t_loc, int* t_seedn, int* t_score, int* loc, int k, int* rep_loc,
+                      float len, int read_len1, double cutoff)
+{
+    int i, j, maxval = 0, maxi = 0 /* uninitialised in the reference; only read when maxval >= 5 */, rep = 0, lasti = 0, tempi;
+    for (i = 0; i < k; i++) t_score[i] = 0;
+    for (i = 0; i < k - 1; i++)
+        for (j = i + 1, tempi = t_seedn[i]; j < k; j++)
+            if (tempi != t_seedn[j] && t_seedn[j] - t_seedn[i] > 0 && t_loc[j] - t_loc[i] > 0 &&
+                t_loc[j] - t_loc[i] < read_len1 && ddf_f32(t_loc[j] - t_loc[i], t_seedn[j] - t_seedn[i], len, cutoff)) {
+                t_score[i]++;
+                t_score[j]++;
+                tempi = t_seedn[j];
+            }
+    for (i = 0; i < k; i++) {
+        if (maxval < t_score[i]) { maxval = t_score[i]; maxi = i; rep = 0; }
+        else if (maxval == t_score[i]) { rep++; lasti = i; }
+    }
+    for (i = 0; i < 4; i++) loc[i] = 0;
+    if (maxval >= 5 && rep == maxval) {
+        loc[0] = t_loc[maxi], loc[1] = t_seedn[maxi];
+        *rep_loc = maxi;
+        loc[2] = t_loc[lasti], loc[3] = t_seedn[lasti];
+        return 1;
+    } else if (maxval >= 5 && rep != maxval) {
+        for (j = 0; j < maxi; j++)
+            if (t_seedn[maxi] - t_seedn[j] > 0 && t_loc[maxi] - t_loc[j] > 0 && t_loc[maxi] - t_loc[j] < read_len1 &&
+                ddf_f32(t_loc[maxi] - t_loc[j], t_seedn[maxi] - t_seedn[j], len, cutoff)) {
+                if (loc[0] == 0) { loc[0] = t_loc[j]; loc[1] = t_seedn[j]; *rep_loc = j; }
+                else { loc[2] = t_loc[j]; loc[3] = t_seedn[j]; }
+            }
+        j = maxi;
+        if (loc[0] == 0) { loc[0] = t_loc[j]; loc[1] = t_seedn[j]; *rep_loc = j; }
+        else { loc[2] = t_loc[j]; loc[3] = t_seedn[j]; }
+        for (j = maxi + 1; j < k; j++)
+            if (t_seedn[j] - t_seedn[maxi] > 0 && t_loc[j] - t_loc[maxi] > 0 && t_loc[j] - t_loc[maxi] <= read_len1 &&
+                ddf_f32(t_loc[j] - t_loc[maxi], t_seedn[j] - t_seedn[maxi], len, cutoff)) {
+                if (loc[0] == 0) { loc[0] = t_loc[j]; loc[1] = t_seedn[j]; *rep_loc = j; }
+                else { loc[2] = t_loc[j]; loc[3] = t_seedn[j]; }
+            }
+        return 1;
+    }
+    return 0;
+}
+
+/* pw_impl.cpp:241-286 */
+int orc_seeding(const char* read, int read_size, const orc_index* ridx, orc_seeding_bk* sbk)
+{
+    int* kmer_ids = sbk->kmer_ids;
+    int* index_spr = sbk->index_list;
+    int16_t* index_score = sbk->index_score;
+    int16_t* index_ss = index_score;
+    orc_back_list* database = sbk->database;
+    int num_kmers = orc_extract_kmers(read, read_size, kmer_ids);
+    int used_segs = 0;
+    for (int km = 0; km < num_kmers; ++km) {
+        int num_seeds = ridx->counts[kmer_ids[km]];
+        const int* seed_arr = ridx->starts[kmer_ids[km]] >= 0 ? ridx->offsets + ridx->starts[kmer_ids[km]] : NULL;
+        for (int sid = 0; sid < num_seeds; ++sid) {
+            int seg_id = seed_arr[sid] / ORC_ZV;
+            int seg_off = seed_arr[sid] % ORC_ZV;
+            orc_back_list* spr = database + seg_id;
+            if (spr->score == 0 || spr->seednum < km + 1) {
+                int loc = ++spr->score;
+                if (loc <= ORC_SM) { spr->loczhi[loc - 1] = (int16_t)seg_off; spr->seedno[loc - 1] = (int16_t)(km + 1); }
+                else orc_insert_loc(spr, seg_off, km + 1, ORC_BC, 0.25 /* ddfs_cutoff: 0.25 for both techs, pw_impl.cpp:21-23 */);
+                int s_k;
+                if (seg_id > 0) s_k = spr->score + (spr - 1)->score;
+                else s_k = spr->score;
+                if (spr->index == -1) {
+                    *(index_spr++) = seg_id;
+                    *(index_ss++) = (int16_t)s_k;
+                    spr->index = used_segs++;
+                } else index_score[spr->index] = (int16_t)s_k;
+            }
+            spr->seednum = (int16_t)(km + 1);
+        }
+    }
+    return used_segs;
+}
+
+/* pw_impl.cpp:288-465 */
+int orc_get_candidates(const orc_volume* ref, orc_seeding_bk* sbk, int num_segs, int read_id, int read_size,
+                       char chain, orc_candidate* candidates, int candidatenum, const orc_params* P)
+{
+    const int MAXC = P->maxc, min_kmer_match = P->min_kmer_match, min_kmer_dist = P->min_kmer_dist;
+    const double ddfs_cutoff = P->ddfs_cutoff;
+    int* index_list = sbk->index_list;
+    int* index_spr = index_list;
+    int16_t* index_ss = sbk->index_score;
+    orc_back_list* database = sbk->database;
+    enum { temp_arr_size = 2 * ORC_SM + 10 };
+    int temp_list[temp_arr_size], temp_seedn[temp_arr_size], temp_score[temp_arr_size];
+    orc_candidate *candidate_loc = candidates, candidate_temp;
+    int location_loc[4], repeat_loc = 0;
+    int i, j, k, u_k;
+    memset(&candidate_temp, 0, sizeof(candidate_temp));
+    for (i = 0; i < num_segs; ++i, ++index_spr, ++index_ss)
+        if (*index_ss >= 2 * min_kmer_match) {
+            orc_back_list *spr = database + (*index_spr), *spr1;
+            if (spr->score == 0) continue;
+            int s_k = spr->score;
+            int start_loc = *index_spr;
+            start_loc = MUL_ZV(start_loc);
+            int loc;
+            if ((*index_spr) > 0) {
+                loc = (spr - 1)->score;
+                if (loc > 0) { start_loc = (*index_spr - 1); start_loc = MUL_ZV(start_loc); }
+            } else loc = 0;
+
+            if (!loc)
+                for (j = 0, u_k = 0; j < s_k && j < ORC_SM; ++j) {
+                    temp_list[u_k] = spr->loczhi[j];
+                    temp_seedn[u_k] = spr->seedno[j];
+                    ++u_k;
+                }
+            else {
+                k = loc;
+                u_k = 0;
+                spr1 = spr - 1;
+                for (j = 0; j < k && j < ORC_SM; ++j) {
+                    temp_list[u_k] = spr1->loczhi[j];
+                    temp_seedn[u_k] = spr1->seedno[j];
+                    ++u_k;
+                }
+                for (j = 0; j < s_k && j < ORC_SM; ++j) {
+                    temp_list[u_k] = spr->loczhi[j] + ORC_ZV;
+                    temp_seedn[u_k] = spr->seedno[j];
+                    ++u_k;
+                }
+            }
+            {
+                int f = orc_find_location(temp_list, temp_seedn, temp_score, location_loc, u_k, &repeat_loc, ORC_BC, read_size, ddfs_cutoff);
+                if (!f) continue;
+                if (temp_score[repeat_loc] < 2 * min_kmer_match + 2) continue;
+            }
+            candidate_temp.score = temp_score[repeat_loc];
+            candidate_temp.chain = chain;
+            int loc_seed = temp_seedn[repeat_loc];
+            location_loc[0] = start_loc + location_loc[0];
+            int loc_list = location_loc[0];
+            int sid = orc_read_id_from_offset(ref, location_loc[0]);
+            int sstart = ref->offs[sid].offset;
+            int ssize = ref->offs[sid].size;
+            int send = sstart + ssize + 1;
+            sid += ref->start_read_id;
+            if (sid > read_id) continue;
+            if (sid == read_id) {
+                u_k = DIV_ZV(sstart);
+                spr = database + u_k;
+                s_k = MOD_ZV(sstart);
+                for (j = 0, k = 0; j < spr->score && j < ORC_SM; ++j)
+                    if (spr->loczhi[j] < s_k) { spr->loczhi[k] = spr->loczhi[j]; ++k; }
+                spr->score = (int16_t)k;
+                for (++spr, ++u_k, k = DIV_ZV(send); u_k < k; ++u_k, ++spr) spr->score = 0;
+                for (j = 0, k = 0, s_k = MOD_ZV(send); j < spr->score && j < ORC_SM; ++j)
+                    if (spr->loczhi[j] > s_k) { spr->loczhi[k] = spr->loczhi[j]; ++k; }
+                spr->score = (int16_t)k;
+            } else {
+                candidate_temp.readno = sid;
+                candidate_temp.readstart = sstart;
+                location_loc[1] = (location_loc[1] - 1) * ORC_BC;
+                int left_length1 = location_loc[0] - sstart + ORC_KMER - 1;
+                int right_length1 = send - location_loc[0];
+                int left_length2 = location_loc[1] + ORC_KMER - 1;
+                int right_length2 = read_size - location_loc[1];
+                int num1 = (left_length1 > left_length2) ? left_length2 : left_length1;
+                int num2 = (right_length1 > right_length2) ? right_length2 : right_length1;
+                if (num1 + num2 < min_kmer_dist) continue;
+                candidate_temp.loc1 = location_loc[0] - sstart;
+                candidate_temp.num1 = num1;
+                candidate_temp.loc2 = location_loc[1];
+                candidate_temp.num2 = num2;
+                candidate_temp.left1 = left_length1;
+                candidate_temp.left2 = left_length2;
+                candidate_temp.right1 = right_length1;
+                candidate_temp.right2 = right_length2;
+
+                int seedcount = 0;
+                int nlb = (num1 + ORC_ZV - 1);
+                nlb = DIV_ZV(nlb);
+                for (u_k = *index_spr - 1, spr1 = spr - 1; u_k >= 0 && nlb > 0; spr1--, --nlb, u_k--)
+                    if (spr1->score > 0) {
+                        start_loc = MUL_ZV(u_k);
+                        int scnt = spr1->score < ORC_SM ? spr1->score : ORC_SM;
+                        for (j = 0, s_k = 0; j < scnt; j++)
+                            if (fabs((loc_list - start_loc - spr1->loczhi[j]) / ((loc_seed - spr1->seedno[j]) * ORC_BC * 1.0) - 1.0) < ddfs_cutoff) {
+                                seedcount++;
+                                s_k++;
+                            }
+                        if (s_k * 1.0 / scnt > 0.4) spr1->score = 0;
+                    }
+                int nrb = (num2 + ORC_ZV - 1);
+                nrb = DIV_ZV(nrb);
+                for (u_k = *index_spr + 1, spr1 = spr + 1; nrb; spr1++, --nrb, u_k++)
+                    if (spr1->score > 0) {
+                        start_loc = MUL_ZV(u_k);
+                        int scnt = spr1->score < ORC_SM ? spr1->score : ORC_SM;
+                        for (j = 0, s_k = 0; j < scnt; j++)
+                            if (fabs((start_loc + spr1->loczhi[j] - loc_list) / ((spr1->seedno[j] - loc_seed) * ORC_BC * 1.0) - 1.0) < ddfs_cutoff) {
+                                seedcount++;
+                                s_k++;
+                            }
+                        if (s_k * 1.0 / scnt > 0.4) spr1->score = 0;
+                    }
+
+                candidate_temp.score = candidate_temp.score + seedcount;
+                int low = 0;
+                int high = candidatenum - 1;
+                int mid;
+                while (low <= high) {
+                    mid = (low + high) / 2;
+                    if (mid >= candidatenum || candidate_loc[mid].score < candidate_temp.score) high = mid - 1;
+                    else low = mid + 1;
+                }
+                if (candidatenum < MAXC) for (u_k = candidatenum - 1; u_k > high; u_k--) candidate_loc[u_k + 1] = candidate_loc[u_k];
+                else for (u_k = candidatenum - 2; u_k > high; u_k--) candidate_loc[u_k + 1] = candidate_loc[u_k];
+                if (high + 1 < MAXC) candidate_loc[high + 1] = candidate_temp;
+                if (candidatenum < MAXC) candidatenum++;
+                else candidatenum = MAXC;
+            }
+        }
+    for (i = 0, index_spr = index_list; i < num_segs; i++, index_spr++) {
+        database[*index_spr].score = 0;
+        database[*index_spr].index = -1;
+    }
+    return candidatenum;
+}
+
+/* candidate_detect pw_impl.cpp:742-765 / pairwise_mapping :653-672 */
+int orc_seed_read(const orc_volume* ref, const orc_volume* reads, const orc_index* ridx, orc_seeding_bk* bk,
+                  int rid, int chain_as_char, const orc_params* p, orc_candidate* out)
+{
+    int rsize = reads->offs[rid].size;
+    char* read1 = (char*)xmalloc((size_t)rsize + 1);
+    char* read2 = (char*)xmalloc((size_t)rsize + 1);
+    orc_extract_one_seq(reads, rid, read1);
+    orc_reverse_complement(read2, read1, rsize);
+    int n = 0;
+    for (int s = 0; s < 2; ++s) {
+        const char* read = s ? read2 : read1;
+        char chain = chain_as_char ? (s ? 'R' : 'F') : (char)(s ? 1 : 0);
+        int num_segs = orc_seeding(read, rsize, ridx, bk);
+        n = orc_get_candidates(ref, bk, num_segs, rid + reads->start_read_id, rsize, chain, out, n, p);
+    }
+    free(read1); free(read2);
+    return n;
+}
+
+/* ------------------------------------------------------------------ A9: .can */
+
+/* candidate_detect pw_impl.cpp:767-792 */
+void orc_can_record(const orc_candidate* c, int qid, int qsize, int ssize, orc_ext_candidate* ec)
+{
+    int qstart = c->loc2, sstart = c->loc1;
+    if (qstart && sstart) { qstart += ORC_KMER / 2; sstart += ORC_KMER / 2; }
+    memset(ec, 0, sizeof(*ec));
+    ec->qid = qid; ec->qdir = c->chain; ec->qext = qstart;
+    ec->sid = c->readno; ec->sdir = 0; ec->sext = sstart;
+    ec->score = c->score; ec->qsize = qsize; ec->ssize = ssize;
+    if (ec->qdir == 1) ec->qext = ec->qsize - 1 - ec->qext;
+    if (ec->sdir == 1) ec->sext = ec->ssize - 1 - ec->sext;
+}
+
+/* alignment.cpp:18-32 */
+int orc_can_line(const orc_ext_candidate* ec, char* buf)
+{
+    return sprintf(buf, "%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\n", ec->qid, ec->sid, ec->qdir, ec->sdir,
+                   ec->qext, ec->sext, ec->score, ec->qsize, ec->ssize);
+}
+
+/* ------------------------------------------------------------------ A10-A12: dw */
+
+typedef struct { int d, k, pre_k, x1, y1, x2, y2; } dpath2;      /* DPathData2, diff_gapalign.h:126-129 */
+typedef struct { int x, y; } path_point;                        /* diff_gapalign.h:131-134 */
+typedef struct { int aln_str_size, dist, aln_q_s, aln_q_e, aln_t_s, aln_t_e; char *q_aln_str, *t_aln_str; } alignment_t;
+
+struct orc_aligner {                                            /* DiffAligner + OutputStore, diff_gapalign.h:76-199 */
+    int segment_size, row_size, column_size;
+    int *dynq, *dynt;
+    alignment_t align;
+    dpath2* d_path;
+    path_point* aln_path;
+    char *left1, *left2, *right1, *right2;
+    int left_size, right_size;
+    int64_t n_blocks, n_cells, n_snake;
+};
+
+orc_aligner* orc_aligner_new(void)
+{
+    orc_aligner* a = (orc_aligner*)xcalloc(sizeof(*a));
+    a->segment_size = 500; a->row_size = 4096; a->column_size = 4096;           /* DiffAlignParameters::init(0) */
+    a->dynq = (int*)xmalloc(sizeof(int) * 4096);
+    a->dynt = (int*)xmalloc(sizeof(int) * 4096);
+    a->align.q_aln_str = (char*)xmalloc(4096);
+    a->align.t_aln_str = (char*)xmalloc(4096);
+    a->d_path = (dpath2*)xmalloc(sizeof(dpath2) * 5000000);
+    a->aln_path = (path_point*)xmalloc(sizeof(path_point) * 5000000);
+    a->left1 = (char*)xmalloc(ORC_MAX_SEQ_SIZE); a->left2 = (char*)xmalloc(ORC_MAX_SEQ_SIZE);
+    a->right1 = (char*)xmalloc(ORC_MAX_SEQ_SIZE); a->right2 = (char*)xmalloc(ORC_MAX_SEQ_SIZE);
+    return a;
+}
+
+void orc_aligner_free(orc_aligner* a)
+{
+    if (!a) return;
+    free(a->dynq); free(a->dynt); free(a->align.q_aln_str); free(a->align.t_aln_str); free(a->d_path);
+    free(a->aln_path); free(a->left1); free(a->left2); free(a->right1); free(a->right2); free(a);
+}
+
+void orc_dw_counters(const orc_aligner* a, int64_t* blocks, int64_t* cells, int64_t* snake)
+{
+    *blocks = a->n_blocks; *cells = a->n_cells; *snake = a->n_snake;
+}
+
+static inline char extract_char(const char* A, int i, int forward) { return forward ? A[i] : A[-i]; } /* gapalign.h:27-35 */
+
+/* std::lower_bound over (d,k) — DPathDataExtractor, diff_gapalign.cpp:12-37 */
+static const dpath2* dpath_lower_bound(const dpath2* list, int n, int d, int k)
+{
+    int lo = 0, cnt = n;
+    while (cnt > 0) {
+        int step = cnt / 2, mid = lo + step;
+        int less = (list[mid].d == d) ? (list[mid].k < k) : (list[mid].d < d);
+        if (less) { lo = mid + 1; cnt -= step + 1; } else cnt = step;
+    }
+    return list + lo;
+}
+
+/* diff_gapalign.cpp:39-104 */
+static void get_align_string(const char* query, int q_len, const char* target, int t_len, const dpath2* d_path,
+                             int d_path_size, path_point* aln_path, alignment_t* align, int d, int k, int right_extend)
+{
+    int cd = d, ck = k, aln_path_idx = 0, i;
+    while (cd >= 0 && aln_path_idx < q_len + t_len + 1) {
+        const dpath2* aux = dpath_lower_bound(d_path, d_path_size, cd, ck);
+        aln_path[aln_path_idx].x = aux->x2; aln_path[aln_path_idx].y = aux->y2; ++aln_path_idx;
+        aln_path[aln_path_idx].x = aux->x1; aln_path[aln_path_idx].y = aux->y1; ++aln_path_idx;
+        ck = aux->pre_k;
+        cd -= 1;
+    }
+    --aln_path_idx;
+    int cx = aln_path[aln_path_idx].x, cy = aln_path[aln_path_idx].y;
+    align->aln_q_s = cx;
+    align->aln_t_s = cy;
+    int aln_pos = 0;
+    while (aln_path_idx > 0) {
+        --aln_path_idx;
+        int nx = aln_path[aln_path_idx].x, ny = aln_path[aln_path_idx].y;
+        if (cx == nx && cy == ny) continue;
+        if (cx == nx && cy != ny) {
+            for (i = 0; i < ny - cy; ++i) {
+                align->q_aln_str[aln_pos + i] = ORC_GAP_CODE;
+                align->t_aln_str[aln_pos + i] = extract_char(target, cy + i, right_extend);
+            }
+            aln_pos += ny - cy;
+        } else if (cx != nx && cy == ny) {
+            for (i = 0; i < nx - cx; ++i) {
+                align->q_aln_str[aln_pos + i] = extract_char(query, cx + i, right_extend);
+                align->t_aln_str[aln_pos + i] = ORC_GAP_CODE;
+            }
+            aln_pos += nx - cx;
+        } else {
+            for (i = 0; i < nx - cx; ++i) align->q_aln_str[aln_pos + i] = extract_char(query, cx + i, right_extend);
+            for (i = 0; i < ny - cy; ++i) align->t_aln_str[aln_pos + i] = extract_char(target, cy + i, right_extend);
+            aln_pos += ny - cy;
+        }
+        cx = nx; cy = ny;
+    }
+    align->aln_str_size = aln_pos;
+}
+
+/* diff_gapalign.cpp:107-219 */
+static int align_core(orc_aligner* A, const char* query, int q_len, const char* target, int t_len, int band_tolerance,
+                      int get_aln_str, alignment_t* align, int* V, int* U, dpath2* d_path, path_point* aln_path, int right_extend)
+{
+    int k_offset, d, k, k2, best_m, min_k, new_min_k, max_k, new_max_k, pre_k;
+    int x = -1, y = -1, max_d, band_size;
+    unsigned long d_path_idx = 0, max_idx = 0;
+    int aligned = 0;
+    int best_x = -1, best_y = -1, best_d = q_len + t_len + 100, best_k = 0, best_d_path_idx = -1;
+
+    max_d = (int)(.3 * (q_len + t_len));
+    k_offset = max_d;
+    band_size = band_tolerance * 2;
+    align->aln_str_size = 0; align->aln_q_s = align->aln_q_e = 0; align->aln_t_s = align->aln_t_e = 0; /* Alignment::init */
+    best_m = -1;
+    min_k = 0;
+    max_k = 0;
+    for (d = 0; d < max_d; ++d) {
+        if (max_k - min_k > band_size) break;
+        for (k = min_k; k <= max_k; k += 2) {
+            if (k == min_k || (k != max_k && V[k - 1 + k_offset] < V[k + 1 + k_offset])) { pre_k = k + 1; x = V[k + 1 + k_offset]; }
+            else { pre_k = k - 1; x = V[k - 1 + k_offset] + 1; }
+            y = x - k;
+            d_path[d_path_idx].d = d; d_path[d_path_idx].k = k; d_path[d_path_idx].x1 = x; d_path[d_path_idx].y1 = y;
+            int x0 = x;
+            if (right_extend) while (x < q_len && y < t_len && query[x] == target[y]) { ++x; ++y; }
+            else while (x < q_len && y < t_len && query[-x] == target[-y]) { ++x; ++y; }
+            A->n_snake += x - x0; A->n_cells += 1;
+            d_path[d_path_idx].x2 = x; d_path[d_path_idx].y2 = y; d_path[d_path_idx].pre_k = pre_k;
+            ++d_path_idx;
+            V[k + k_offset] = x;
+            U[k + k_offset] = x + y;
+            if (x + y > best_m) { best_m = x + y; best_x = x; best_y = y; best_d = d; best_k = k; best_d_path_idx = (int)d_path_idx; }
+            if (x >= q_len || y >= t_len) { aligned = 1; max_idx = d_path_idx; break; }
+        }
+        new_min_k = max_k;
+        new_max_k = min_k;
+        for (k2 = min_k; k2 <= max_k; k2 += 2)
+            if (U[k2 + k_offset] >= best_m - band_tolerance) {
+                if (k2 < new_min_k) new_min_k = k2;
+                if (k2 > new_max_k) new_max_k = k2;
+            }
+        max_k = new_max_k + 1;
+        min_k = new_min_k - 1;
+        if (aligned) {
+            align->aln_q_e = x; align->aln_t_e = y; align->dist = d;
+            align->aln_str_size = (x + y + d) / 2;
+            align->aln_q_s = 0; align->aln_t_s = 0;
+            if (get_aln_str) get_align_string(query, q_len, target, t_len, d_path, (int)max_idx, aln_path, align, d, k, right_extend);
+            break;
+        }
+    }
+    if (!aligned) {
+        if (best_x > 0) {
+            align->aln_q_e = best_x; align->aln_t_e = best_y; align->dist = best_d;
+            align->aln_str_size = (best_x + best_y + best_d) / 2;
+            align->aln_q_s = 0; align->aln_t_s = 0;
+            if (get_aln_str) get_align_string(query, q_len, target, t_len, d_path, best_d_path_idx, aln_path, align, best_d, best_k, right_extend);
+        } else {
+            align->aln_q_e = 0; align->aln_t_e = 0; align->dist = 0; align->aln_str_size = 0;
+            align->aln_q_s = 0; align->aln_t_s = 0;
+        }
+    }
+    return (align->aln_q_e == q_len || align->aln_t_e == t_len);
+}
+
+int orc_align(orc_aligner* a, const char* q, int qlen, const char* t, int tlen, int band_tol, int get_aln,
+              int right_extend, int* res, char* q_aln, char* t_aln)
+{
+    memset(a->dynq, 0, sizeof(int) * 4096);
+    memset(a->dynt, 0, sizeof(int) * 4096);
+    const char* qq = right_extend ? q : q + qlen - 1;
+    const char* tt = right_extend ? t : t + tlen - 1;
+    int r = align_core(a, qq, qlen, tt, tlen, band_tol, get_aln, &a->align, a->dynq, a->dynt, a->d_path, a->aln_path, right_extend);
+    res[0] = a->align.aln_str_size; res[1] = a->align.dist; res[2] = a->align.aln_q_s; res[3] = a->align.aln_q_e;
+    res[4] = a->align.aln_t_s; res[5] = a->align.aln_t_e;
+    if (get_aln && q_aln) { memcpy(q_aln, a->align.q_aln_str, (size_t)a->align.aln_str_size); memcpy(t_aln, a->align.t_aln_str, (size_t)a->align.aln_str_size); }
+    return r;
+}
+
+/* gapalign.cpp:9-45 */
+static int retrieve_next_aln_block(const char* query, int qidx, int qsize, const char* target, int tidx, int tsize,
+                                   int desired_block_size, int forward, const char** Q, const char** T, int* qblk, int* tblk)
+{
+    int last_block;
+    int qleft = qsize - qidx, tleft = tsize - tidx;
+    if (qleft < desired_block_size + 100 || tleft < desired_block_size + 100) {
+        int a = (int)(tleft + tleft * 0.2), b = (int)(qleft + qleft * 0.2);
+        *qblk = qleft < a ? qleft : a;
+        *tblk = tleft < b ? tleft : b;
+        last_block = 1;
+    } else { *qblk = desired_block_size; *tblk = desired_block_size; last_block = 0; }
+    if (forward) { *Q = query + qidx; *T = target + tidx; }
+    else { *Q = query - qidx; *T = target - tidx; }
+    return last_block;
+}
+
+/* gapalign.cpp:47-68 */
+static int trim_mismatch_end(const char* qaln, const char* taln, int aln_size, int mat_cnt, int* qcnt, int* tcnt, int* aln_cnt)
+{
+    int m = 0, k;
+    for (k = aln_size - 1, *qcnt = 0, *tcnt = 0, *aln_cnt = 0; k >= 0 && m < mat_cnt; --k) {
+        ++*aln_cnt;
+        if (qaln[k] != ORC_GAP_CODE) ++*qcnt;
+        if (taln[k] != ORC_GAP_CODE) ++*tcnt;
+        if (qaln[k] == taln[k]) ++m; else m = 0;
+    }
+    return m == mat_cnt && k > 0;
+}
+
+/* diff_gapalign.cpp:221-292 */
+static void dw_in_one_direction(orc_aligner* A, const char* query, int query_size, const char* target, int target_size, int right_extend)
+{
+    const int kTailMatchBP = 4;
+    const int kBlkSize = A->segment_size;
+    int qidx = 0, tidx = 0, qblk, tblk;
+    const char *seq1, *seq2;
+    alignment_t* align = &A->align;
+    while (1) {
+        memset(A->dynq, 0, sizeof(int) * (size_t)A->row_size);
+        memset(A->dynt, 0, sizeof(int) * (size_t)A->column_size);
+        int last_block = retrieve_next_aln_block(query, qidx, query_size, target, tidx, target_size, kBlkSize, right_extend, &seq1, &seq2, &qblk, &tblk);
+        int mx = qblk > tblk ? qblk : tblk;
+        A->n_blocks += 1;
+        align_core(A, seq1, qblk, seq2, tblk, (int)(0.3 * mx), 400, align, A->dynq, A->dynt, A->d_path, A->aln_path, right_extend);
+        int qcnt = 0, tcnt = 0, acnt = 0;
+        int trim = trim_mismatch_end(align->q_aln_str, align->t_aln_str, align->aln_str_size, kTailMatchBP, &qcnt, &tcnt, &acnt);
+        if (!trim) break;
+        int full_map = 0;
+        if (qblk - align->aln_q_e <= 20 || tblk - align->aln_t_e <= 20) full_map = 1;
+        if (last_block || (!full_map)) { qcnt -= kTailMatchBP; tcnt -= kTailMatchBP; acnt -= kTailMatchBP; }
+        align->aln_str_size -= acnt;
+        if (right_extend) {
+            memcpy(A->right1 + A->right_size, align->q_aln_str, (size_t)align->aln_str_size);
+            memcpy(A->right2 + A->right_size, align->t_aln_str, (size_t)align->aln_str_size);
+            A->right_size += align->aln_str_size;
+        } else {
+            memcpy(A->left1 + A->left_size, align->q_aln_str, (size_t)align->aln_str_size);
+            memcpy(A->left2 + A->left_size, align->t_aln_str, (size_t)align->aln_str_size);
+            A->left_size += align->aln_str_size;
+        }
+        if (last_block || (!full_map)) break;
+        qidx += (align->aln_q_e - qcnt);
+        tidx += (align->aln_t_e - tcnt);
+    }
+}
+
+/* diff_gapalign.cpp:294-349 ; identity counting = OutputStore::calc_ident diff_gapalign.h:90-97 */
+int orc_dw_go(orc_aligner* A, const char* query, int qstart, int qsize, const char* target, int tstart, int tsize,
+              int min_aln_size, orc_aln_result* out)
+{
+    A->left_size = A->right_size = 0;
+    A->n_blocks = A->n_cells = A->n_snake = 0;
+    A->align.aln_str_size = 0; A->align.aln_q_s = A->align.aln_q_e = 0; A->align.aln_t_s = A->align.aln_t_e = 0;
+    dw_in_one_direction(A, query + qstart - 1, qstart, target + tstart - 1, tstart, 0);
+    dw_in_one_direction(A, query + qstart, qsize - qstart, target + tstart, tsize - tstart, 1);
+    int i = 0, j = 0, k, n = 0, idx = 0;
+    for (k = A->left_size - 1; k >= 0; --k, ++idx) {
+        if (A->left1[k] != ORC_GAP_CODE) ++i;
+        if (A->left2[k] != ORC_GAP_CODE) ++j;
+        if (A->left1[k] == A->left2[k]) ++n;
+    }
+    out->query_start = qstart - i;
+    out->target_start = tstart - j;
+    for (k = 0, i = 0, j = 0; k < A->right_size; ++k, ++idx) {
+        if (A->right1[k] != ORC_GAP_CODE) ++i;
+        if (A->right2[k] != ORC_GAP_CODE) ++j;
+        if (A->right1[k] == A->right2[k]) ++n;
+    }
+    out->query_end = qstart + i;
+    out->target_end = tstart + j;
+    out->matches = n;
+    out->columns = idx;
+    out->ok = idx >= min_aln_size;
+    return out->ok;
+}
+
+/* ------------------------------------------------------------------ A14: m4 */
+
+/* pw_impl.cpp:467-506 ; ident = 100.0 * n / out_store_size, 0.0 when empty (diff_gapalign.h:90-97) */
+void orc_m4_fill(const orc_aln_result* r, int qid, int sid, char qchain, int qsize, int ssize,
+                 int qstart, int sstart, int vscore, orc_m4* m)
+{
+    m->qid = sid;
+    m->sid = qid;
+    m->ident = r->columns == 0 ? 0.0 : 100.0 * r->matches / r->columns;
+    m->vscore = vscore;
+    m->qdir = 0;
+    m->qoff = r->target_start;
+    m->qend = r->target_end;
+    m->qsize = ssize;
+    m->ssize = qsize;
+    m->qext = sstart;
+    if (qchain == 'F') {
+        m->sdir = 0;
+        m->soff = r->query_start;
+        m->send = r->query_end;
+        m->sext = qstart;
+    } else {
+        m->sdir = 1;
+        m->soff = qsize - r->query_end;
+        m->send = qsize - r->query_start;
+        m->sext = qsize - 1 - qstart;
+    }
+}
+
+void orc_m4_std_sort(orc_m4* list, int n);  /* m4sort.cpp: std::sort with CmpM4RecordByQidAndOvlpSize (pw_impl.cpp:539-548, 581) */
+
+/* check_records_containment pw_impl.cpp:550-574 */
+static void check_records_containment(const orc_m4* m4v, int s, int e, int* valid)
+{
+    const int soft = 100;
+    for (int i = s; i < e; ++i) {
+        if (!valid[i]) continue;
+        int qb1 = (int)m4v[i].qoff, qe1 = (int)m4v[i].qend, sb1 = (int)m4v[i].soff, se1 = (int)m4v[i].send;
+        for (int j = i + 1; j < e; ++j) {
+            if (!valid[j]) continue;
+            if (m4v[i].sdir != m4v[j].sdir) continue;
+            int qb2 = (int)m4v[j].qoff, qe2 = (int)m4v[j].qend, sb2 = (int)m4v[j].soff, se2 = (int)m4v[j].send;
+            if (qb2 + soft >= qb1 && qe2 - soft <= qe1 && sb2 + soft >= sb1 && se2 - soft <= se1) valid[j] = 0;
+        }
+    }
+}
+
+/* append_m4v pw_impl.cpp:576-610 (without the buffered print) */
+int orc_m4_postfilter(orc_m4* llist, int n, orc_m4* out)
+{
+    orc_m4_std_sort(llist, n);
+    int* valid = (int*)xmalloc(sizeof(int) * (size_t)(n + 1));
+    for (int i = 0; i < n; ++i) valid[i] = 1;
+    int i = 0, j;
+    while (i < n) {
+        int64_t qid = llist[i].qid;
+        j = i + 1;
+        while (j < n && llist[j].qid == qid) ++j;
+        if (j - i > 1) check_records_containment(llist, i, j, valid);
+        i = j;
+    }
+    int m = 0;
+    for (i = 0; i < n; ++i) if (valid[i]) out[m++] = llist[i];
+    free(valid);
+    return m;
+}
+
+/* output_m4record pw_impl.cpp:509-531 ; ostream<<double default == "%g" with precision 6 */
+int orc_m4_line(const orc_m4* m, int gapped, char* buf)
+{
+    int n = sprintf(buf, "%lld\t%lld\t%g\t%d\t%d\t%lld\t%lld\t%lld\t%d\t%lld\t%lld\t%lld", (long long)m->qid, (long long)m->sid,
+                    m->ident, m->vscore, m->qdir, (long long)m->qoff, (long long)m->qend, (long long)m->qsize, m->sdir,
+                    (long long)m->soff, (long long)m->send, (long long)m->ssize);
+    if (gapped) n += sprintf(buf + n, "\t%lld\t%lld", (long long)m->qext, (long long)m->sext);
+    buf[n++] = '\n'; buf[n] = 0;
+    return n;
+}
+
+/* pairwise_mapping pw_impl.cpp:651-700 for one read (PacBio / DiffAligner only; XdropAligner is SURVEY row A13, next) */
+int orc_map_read(const orc_volume* ref, const orc_volume* reads, const orc_index* ridx, orc_seeding_bk* bk,
+                 orc_aligner* al, int rid, const orc_params* p, orc_m4* out)
+{
+    orc_candidate* cands = (orc_candidate*)xmalloc(sizeof(orc_candidate) * (size_t)p->maxc);
+    orc_m4* m4v = (orc_m4*)xmalloc(sizeof(orc_m4) * (size_t)p->maxc);
+    int rsize = reads->offs[rid].size;
+    char* read1 = (char*)xmalloc((size_t)rsize + 1);
+    char* read2 = (char*)xmalloc((size_t)rsize + 1);
+    char* subject = (char*)xmalloc(ORC_MAX_SEQ_SIZE);
+    orc_extract_one_seq(reads, rid, read1);
+    orc_reverse_complement(read2, read1, rsize);
+    int nc = orc_seed_read(ref, reads, ridx, bk, rid, 1, p, cands);
+    int num_m4 = 0;
+    for (int s = 0; s < nc; ++s) {
+        const char* read = cands[s].chain == 'F' ? read1 : read2;
+        int lid = cands[s].readno - ref->start_read_id;
+        orc_extract_one_seq(ref, lid, subject);
+        int sstart = cands[s].loc1, qstart = cands[s].loc2;
+        if (qstart && sstart) { qstart += ORC_KMER / 2; sstart += ORC_KMER / 2; }
+        int ssize = ref->offs[lid].size;
+        orc_aln_result r;
+        if (orc_dw_go(al, read, qstart, rsize, subject, sstart, ssize, p->min_align_size, &r)) {
+            orc_m4_fill(&r, rid + reads->start_read_id, cands[s].readno, cands[s].chain, rsize, ssize, qstart, sstart,
+                        cands[s].score, m4v + num_m4);
+            ++num_m4;
+        }
+    }
+    int kept = orc_m4_postfilter(m4v, num_m4, out);
+    free(cands); free(m4v); free(read1); free(read2); free(subject);
+    return kept;
+}

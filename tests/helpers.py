@@ -1,0 +1,258 @@
+"""ctypes bindings used by the tests only: the synthetic read generator, the CPU oracle (oracle/liboracle.so) and,
+when it was built in this container, the harness around the unmodified reference (oracle/_ref/libref_harness.so).
+
+Nothing here is imported by the product package (mecat_amd/).
+"""
+import ctypes as C
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+NK = 1 << 26
+
+
+def _build(target):
+    subprocess.run(["make", "-s", target], cwd=ROOT, check=True, stdout=subprocess.DEVNULL)
+
+
+# ----------------------------------------------------------------------------- synthetic reads
+_synth = None
+
+
+def synth_lib():
+    global _synth
+    if _synth is None:
+        p = os.path.join(ROOT, "mecat_amd", "lib", "libsynth.so")
+        if not os.path.exists(p):
+            _build("synth")
+        L = C.CDLL(p)
+        L.synth_reads.restype = C.c_int64
+        L.synth_reads.argtypes = [C.c_int64, C.c_int64, C.c_int, C.c_double, C.c_int, C.c_uint64,
+                                  C.c_void_p, C.c_int64, C.c_void_p]
+        L.synth_write_fasta.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int64]
+        _synth = L
+    return _synth
+
+
+def synth_reads(nreads, L, err, genome, seed, ont=0):
+    """-> (codes uint8[total] in 0..3, lens int32[nreads])"""
+    lib = synth_lib()
+    cap = nreads * (int(L * 1.25) + 64)
+    bases = np.empty(cap, dtype=np.uint8)
+    lens = np.empty(nreads, dtype=np.int32)
+    tot = lib.synth_reads(genome, nreads, L, err, ont, seed, bases.ctypes.data, cap, lens.ctypes.data)
+    assert tot >= 0, tot
+    return bases[:tot].copy(), lens
+
+
+def write_fasta(path, codes, lens):
+    assert synth_lib().synth_write_fasta(path.encode(), codes.ctypes.data, lens.ctypes.data, len(lens)) == 0
+
+
+# ----------------------------------------------------------------------------- oracle
+class OffsetT(C.Structure):
+    _fields_ = [("offset", C.c_int), ("size", C.c_int)]
+
+
+class OrcVolume(C.Structure):
+    _fields_ = [("num_reads", C.c_int), ("num_bases", C.c_int), ("start_read_id", C.c_int),
+                ("offs", C.POINTER(OffsetT)), ("pac", C.POINTER(C.c_uint8))]
+
+
+class OrcIndex(C.Structure):
+    _fields_ = [("counts", C.POINTER(C.c_int)), ("starts", C.POINTER(C.c_int64)), ("offsets", C.POINTER(C.c_int)),
+                ("num_kmers", C.c_int64)]
+
+
+class OrcCandidate(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("loc1", "loc2", "left1", "left2", "right1", "right2", "score", "num1", "num2",
+                                       "readno", "readstart")] + [("chain", C.c_char)]
+
+
+class OrcParams(C.Structure):
+    _fields_ = [("maxc", C.c_int), ("min_align_size", C.c_int), ("min_kmer_match", C.c_int), ("min_kmer_dist", C.c_int),
+                ("ddfs_cutoff", C.c_double), ("tech", C.c_int), ("output_gapped_start_point", C.c_int)]
+
+
+class OrcBackList(C.Structure):
+    _fields_ = [("score", C.c_int16), ("loczhi", C.c_int16 * 40), ("seedno", C.c_int16 * 40), ("seednum", C.c_int16),
+                ("index", C.c_int)]
+
+
+class OrcExtCandidate(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("qdir", "qid", "qext", "qsize", "qoff", "qend", "sdir", "sid", "sext", "ssize",
+                                       "soff", "send", "score")]
+
+
+class OrcM4(C.Structure):
+    _fields_ = [("qid", C.c_int64), ("sid", C.c_int64), ("ident", C.c_double), ("vscore", C.c_int), ("qdir", C.c_int),
+                ("qoff", C.c_int64), ("qend", C.c_int64), ("qsize", C.c_int64), ("sdir", C.c_int),
+                ("soff", C.c_int64), ("send", C.c_int64), ("ssize", C.c_int64), ("qext", C.c_int64), ("sext", C.c_int64)]
+
+
+class OrcAlnResult(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("ok", "query_start", "query_end", "target_start", "target_end", "matches", "columns")]
+
+
+assert C.sizeof(OrcCandidate) == 48 and C.sizeof(OrcBackList) == 168 and C.sizeof(OrcM4) == 104 and C.sizeof(OrcExtCandidate) == 52
+
+_orc = None
+
+
+def orc():
+    global _orc
+    if _orc is None:
+        p = os.path.join(ROOT, "oracle", "liboracle.so")
+        _build("oracle")
+        L = C.CDLL(p)
+        vp = C.c_void_p
+        L.orc_params_default.argtypes = [C.POINTER(OrcParams), C.c_int]
+        L.orc_volume_pack.restype = C.POINTER(OrcVolume)
+        L.orc_volume_pack.argtypes = [vp, vp, C.c_int, C.c_int]
+        L.orc_volume_load.restype = C.POINTER(OrcVolume)
+        L.orc_volume_load.argtypes = [C.c_char_p]
+        L.orc_volume_dump.argtypes = [C.POINTER(OrcVolume), C.c_char_p]
+        L.orc_volume_free.argtypes = [C.POINTER(OrcVolume)]
+        L.orc_extract_one_seq.argtypes = [C.POINTER(OrcVolume), C.c_int, vp]
+        L.orc_read_id_from_offset.argtypes = [C.POINTER(OrcVolume), C.c_int]
+        L.orc_index_build.restype = C.POINTER(OrcIndex)
+        L.orc_index_build.argtypes = [C.POINTER(OrcVolume)]
+        L.orc_index_free.argtypes = [C.POINTER(OrcIndex)]
+        L.orc_bk_new.restype = vp
+        L.orc_bk_new.argtypes = [C.c_int]
+        L.orc_bk_free.argtypes = [vp]
+        L.orc_insert_loc.argtypes = [C.POINTER(OrcBackList), C.c_int, C.c_int, C.c_float, C.c_double]
+        L.orc_find_location.argtypes = [vp, vp, vp, vp, C.c_int, C.POINTER(C.c_int), C.c_float, C.c_int, C.c_double]
+        L.orc_seed_read.argtypes = [C.POINTER(OrcVolume), C.POINTER(OrcVolume), C.POINTER(OrcIndex), vp, C.c_int, C.c_int,
+                                    C.POINTER(OrcParams), vp]
+        L.orc_can_record.argtypes = [C.POINTER(OrcCandidate), C.c_int, C.c_int, C.c_int, C.POINTER(OrcExtCandidate)]
+        L.orc_can_line.argtypes = [C.POINTER(OrcExtCandidate), C.c_char_p]
+        L.orc_aligner_new.restype = vp
+        L.orc_aligner_free.argtypes = [vp]
+        L.orc_align.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]
+        L.orc_dw_go.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.POINTER(OrcAlnResult)]
+        L.orc_dw_counters.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.orc_m4_fill.argtypes = [C.POINTER(OrcAlnResult), C.c_int, C.c_int, C.c_char, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_int, C.POINTER(OrcM4)]
+        L.orc_m4_postfilter.argtypes = [vp, C.c_int, vp]
+        L.orc_m4_line.argtypes = [C.POINTER(OrcM4), C.c_int, C.c_char_p]
+        L.orc_map_read.argtypes = [C.POINTER(OrcVolume), C.POINTER(OrcVolume), C.POINTER(OrcIndex), vp, vp, C.c_int,
+                                   C.POINTER(OrcParams), vp]
+        _orc = L
+    return _orc
+
+
+def orc_params(tech=0, maxc=100, **kw):
+    p = OrcParams()
+    orc().orc_params_default(C.byref(p), tech)
+    p.maxc = maxc
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+CAND_DTYPE = np.dtype([(n, np.int32) for n in ("loc1", "loc2", "left1", "left2", "right1", "right2", "score", "num1",
+                                               "num2", "readno", "readstart", "chain")])
+
+
+def orc_pack(codes, lens, start_read_id=0):
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    lens = np.ascontiguousarray(lens, dtype=np.int32)
+    return orc().orc_volume_pack(codes.ctypes.data, lens.ctypes.data, len(lens), start_read_id)
+
+
+def vol_arrays(v):
+    """-> (offs int32[n,2], pac uint8[(num_bases+3)//4]) copies"""
+    vv = v.contents
+    offs = np.ctypeslib.as_array(C.cast(vv.offs, C.POINTER(C.c_int)), shape=(vv.num_reads, 2)).copy()
+    pac = np.ctypeslib.as_array(vv.pac, shape=((vv.num_bases + 3) // 4,)).copy()
+    return offs, pac
+
+
+def orc_seed_all(ref, reads, idx, params, chain_as_char=0, rids=None):
+    """candidates of every read (both strands) -> list of structured arrays (chain widened to int32)"""
+    L = orc()
+    bk = L.orc_bk_new(ref.contents.num_bases)
+    out = (OrcCandidate * params.maxc)()
+    res = []
+    n = reads.contents.num_reads
+    for rid in (range(n) if rids is None else rids):
+        k = L.orc_seed_read(ref, reads, idx, bk, rid, chain_as_char, C.byref(params), out)
+        a = np.zeros(k, dtype=CAND_DTYPE)
+        for i in range(k):
+            c = out[i]
+            a[i] = (c.loc1, c.loc2, c.left1, c.left2, c.right1, c.right2, c.score, c.num1, c.num2, c.readno, c.readstart,
+                    ord(c.chain))
+        res.append(a)
+    L.orc_bk_free(bk)
+    return res
+
+
+def can_lines_from_cands(cands_per_read, reads_offs, ref_offs, reads_start_id=0, ref_start_id=0):
+    """A9 formatting of candidate arrays (host logic restated in numpy for tests): list of text lines"""
+    lines = []
+    for rid, a in enumerate(cands_per_read):
+        qsize = int(reads_offs[rid, 1])
+        for c in a:
+            qext, sext = int(c["loc2"]), int(c["loc1"])
+            if qext and sext:
+                qext += 6
+                sext += 6
+            qdir = int(c["chain"])
+            if qdir == 1:
+                qext = qsize - 1 - qext
+            ssize = int(ref_offs[int(c["readno"]) - ref_start_id, 1])
+            lines.append("%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d" % (rid + reads_start_id, int(c["readno"]), qdir, 0, qext, sext,
+                                                               int(c["score"]), qsize, ssize))
+    return lines
+
+
+def sha256_lines(lines):
+    h = hashlib.sha256()
+    for ln in sorted(lines):
+        h.update(ln.encode() + b"\n")
+    return h.hexdigest()
+
+
+# ----------------------------------------------------------------------------- reference harness (this container only)
+_ref = None
+
+
+def ref_available():
+    return os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libref_harness.so"))
+
+
+def ref_bin():
+    p = os.path.join(ROOT, "oracle", "_ref", "mecat2pw")
+    return p if os.path.exists(p) else None
+
+
+def ref():
+    global _ref
+    if _ref is None:
+        L = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_harness.so"))
+        vp = C.c_void_p
+        L.refh_load_volume.restype = vp
+        L.refh_load_volume.argtypes = [C.c_char_p]
+        L.refh_free_volume.argtypes = [vp]
+        for f in ("refh_vol_num_reads", "refh_vol_num_bases", "refh_vol_start_id"):
+            getattr(L, f).argtypes = [vp]
+        L.refh_vol_offsets.argtypes = [vp, vp]
+        L.refh_vol_pac.argtypes = [vp, vp]
+        L.refh_split.argtypes = [C.c_char_p, C.c_char_p]
+        L.refh_build_index.restype = vp
+        L.refh_build_index.argtypes = [vp, C.c_int]
+        L.refh_free_index.argtypes = [vp]
+        L.refh_index_dump.restype = C.c_long
+        L.refh_index_dump.argtypes = [vp, vp, vp]
+        L.refh_seed_read.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp]
+        L.refh_insert_loc.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_float]
+        L.refh_find_location.argtypes = [vp, vp, vp, vp, C.c_int, C.POINTER(C.c_int), C.c_float, C.c_int]
+        L.refh_align.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]
+        L.refh_dw_go.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, C.POINTER(C.c_double)]
+        _ref = L
+    return _ref

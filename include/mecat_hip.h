@@ -1,0 +1,127 @@
+/*
+ * mecat_hip.h — C ABI of libmecat_hip.so: the MI355X (gfx950) implementation of mecat2pw's hot path.
+ *
+ * This is the drop-in boundary.  MECAT has no plugin/FFI layer; the hot path sits behind three
+ * function seams inside the mecat2pw binary, and each entry point below replaces one of them (reference file:line,
+ * relative to /root/reference/src/):
+ *
+ *   mhip_index_build      <- create_ref_index / destroy_ref_index      common/lookup_table.h:13-17, lookup_table.cpp:63
+ *   mhip_seed_reads       <- seeding + get_candidates, both strands     mecat2pw/pw_impl.cpp:241, :288, loop at :752-765
+ *   mhip_align_candidates <- GapAligner::go + accessors (DiffAligner)   common/gapalign.h:4-25, diff_gapalign.cpp:294,
+ *                                                                       called at mecat2pw/pw_impl.cpp:688-697
+ *   mhip_volume_upload    <- load_volume's in-memory volume_t           common/split_database.h:18-24, split_database.cpp:155
+ *   mhip_params           <- the file-static tuning values              mecat2pw/pw_impl.cpp:18-26, set at :838-851
+ *
+ * Conventions (mirroring the reference where it has any): plain C types only; opaque handles with explicit *_free;
+ * every call returns 0 on success and non-zero on failure with the message in mhip_last_error() (the reference
+ * abort()s instead — the host driver maps non-zero to abort-with-message).  Handles are immutable after creation and
+ * may be shared by host threads; a context (one HIP stream + scratch) must not be used by two threads at once.
+ * There is NO CPU fallback: every entry point fails if no gfx950 device is usable.
+ *
+ * INTEGRATION.md shows the binding a MECAT maintainer would add to call these from pw_impl.cpp.
+ */
+#ifndef MECAT_HIP_H
+#define MECAT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MHIP_ABI_VERSION 1
+#define MHIP_KMER_SIZE 13          /* pw_impl.cpp:20 */
+#define MHIP_MAX_SEQ_SIZE 500000   /* common/defs.h:202 */
+
+typedef struct mhip_ctx mhip_ctx;        /* device + stream + scratch arena */
+typedef struct mhip_volume mhip_volume;  /* device-resident 2-bit volume (volume_t) */
+typedef struct mhip_index mhip_index;    /* device-resident k-mer index (ref_index) */
+
+typedef struct { int32_t offset, size; } mhip_offset_t;      /* offset_t, split_database.h:9-11 */
+
+/* candidate_save, mecat2pw/pw_impl.h:21-25 — same field order, 48 bytes; `chain` is 0/1 (FWD/REV, common/defs.h:196-197),
+   the 'F'/'R' spelling of pairwise_mapping is derived by the caller */
+typedef struct {
+    int32_t loc1, loc2, left1, left2, right1, right2, score, num1, num2, readno, readstart;
+    int32_t chain;
+} mhip_candidate;
+
+typedef struct {
+    int32_t maxc;            /* -n  MAXC, default 100 (pw_options.cpp:9) */
+    int32_t min_align_size;  /* -a  2000 pacbio / 500 nanopore */
+    int32_t min_kmer_match;  /* -k  4 / 2 */
+    int32_t min_kmer_dist;   /* 1800 / 400 (pw_impl.cpp:845,848) */
+    int32_t tech;            /* 0 pacbio (DiffAligner), 1 nanopore */
+    double  ddfs_cutoff;     /* 0.25 (pw_impl.cpp:21-23) */
+} mhip_params;
+
+/* what mecat2pw consumes of an alignment: go()'s return value, the four coordinates and the identity counts
+   (ident = 100.0 * matches / columns is formed by the caller in double, diff_gapalign.h:90-97) */
+typedef struct {
+    int32_t ok, query_start, query_end, target_start, target_end, matches, columns;
+    int32_t blocks;          /* number of 500-bp blocks aligned (work counter) */
+} mhip_aln_result;
+
+/* one alignment job: candidate `cand` of query read `qid_local` (index inside the query volume) */
+typedef struct {
+    int32_t qid_local;       /* read index in the query volume */
+    int32_t sid_local;       /* read index in the reference volume (candidate.readno - ref.start_read_id) */
+    int32_t chain;           /* 0 forward query, 1 reverse-complemented query */
+    int32_t qstart, sstart;  /* extension start points AFTER the +kmer_size/2 adjustment of pw_impl.cpp:681-685 */
+} mhip_aln_job;
+
+int  mhip_abi_version(void);
+const char* mhip_last_error(void);
+int  mhip_device_count(void);
+
+/* `stream` may be NULL (the context creates its own) or a hipStream_t the caller owns (e.g. torch's current stream). */
+int  mhip_ctx_create(int device, void* stream, mhip_ctx** out);
+void mhip_ctx_destroy(mhip_ctx* ctx);
+int  mhip_ctx_sync(mhip_ctx* ctx);
+void mhip_params_default(mhip_params* p, int tech);           /* pw_options.cpp:30-50 + pw_impl.cpp:843-851 */
+
+/* per-kernel timing with HIP events on the context's stream (for bench.py's roofline block).
+   set_profiling(1) makes every launch record start/stop events; kernel_stats returns, for the kernel whose name
+   matches `name`, the number of launches and the summed duration in ms since the last reset. */
+int  mhip_ctx_set_profiling(mhip_ctx* ctx, int on);
+int  mhip_ctx_kernel_stats(mhip_ctx* ctx, const char* name, int64_t* launches, double* total_ms);
+int  mhip_ctx_kernel_names(mhip_ctx* ctx, char* buf, int buflen);   /* '\n'-separated */
+int  mhip_ctx_reset_stats(mhip_ctx* ctx);
+/* device work counters accumulated by seed/align calls since the last reset:
+   [0] query k-mer lookups  [1] bucket hits H  [2] candidates emitted  [3] dw blocks  [4] d-path cells  [5] snake bases
+   [6] aligned query bases  [7] alignments ok */
+int  mhip_ctx_counters(mhip_ctx* ctx, int64_t out[8]);
+
+/* volume: host arrays exactly as load_volume() leaves them (pac = (num_bases+3)/4 bytes) */
+int  mhip_volume_upload(mhip_ctx* ctx, const uint8_t* pac, const mhip_offset_t* offs, int num_reads, int num_bases,
+                        int start_read_id, mhip_volume** out);
+void mhip_volume_free(mhip_volume* v);
+int  mhip_volume_num_reads(const mhip_volume* v);
+int  mhip_volume_num_bases(const mhip_volume* v);
+
+/* index of one volume (k = 13).  Buckets with more than 128 occurrences are empty; bucket contents ascend. */
+int  mhip_index_build(mhip_ctx* ctx, const mhip_volume* v, mhip_index** out);
+void mhip_index_free(mhip_index* idx);
+int64_t mhip_index_num_kmers(const mhip_index* idx);
+/* parity/debug: counts[4^13] (kept occurrences) and/or offsets[num_kmers]; either may be NULL */
+int  mhip_index_download(mhip_ctx* ctx, const mhip_index* idx, int32_t* counts, int32_t* offsets);
+
+/* candidates of reads [rid_begin, rid_end) of `reads` against (`ref`, `idx`): for read r the list is written to
+   out[(r - rid_begin) * maxc ...] in the reference's list order (score descending, stable), out_counts[r - rid_begin]
+   entries.  `out`/`out_counts` are HOST pointers here and DEVICE pointers in the _dev variant (results stay in HBM,
+   e.g. for the multi-GPU all-gather). */
+int  mhip_seed_reads(mhip_ctx* ctx, const mhip_index* idx, const mhip_volume* ref, const mhip_volume* reads,
+                     int rid_begin, int rid_end, const mhip_params* p, mhip_candidate* out, int32_t* out_counts);
+int  mhip_seed_reads_dev(mhip_ctx* ctx, const mhip_index* idx, const mhip_volume* ref, const mhip_volume* reads,
+                         int rid_begin, int rid_end, const mhip_params* p, void* d_out, void* d_out_counts);
+
+/* dw extension of n jobs (PacBio / DiffAligner semantics); jobs/out are HOST pointers (_dev: DEVICE pointers) */
+int  mhip_align_candidates(mhip_ctx* ctx, const mhip_volume* ref, const mhip_volume* reads, const mhip_aln_job* jobs,
+                           int n, int min_align_size, mhip_aln_result* out);
+int  mhip_align_candidates_dev(mhip_ctx* ctx, const mhip_volume* ref, const mhip_volume* reads, const void* d_jobs,
+                               int n, int min_align_size, void* d_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

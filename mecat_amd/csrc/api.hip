@@ -1,0 +1,221 @@
+// api.hip — context, volume and bookkeeping entry points of the C ABI (include/mecat_hip.h).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "common.h"
+
+static thread_local char g_err[1024] = "";
+
+void mhip_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" {
+
+int mhip_abi_version(void) { return MHIP_ABI_VERSION; }
+const char* mhip_last_error(void) { return g_err; }
+
+int mhip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void mhip_params_default(mhip_params* p, int tech) {
+    // pw_options.cpp:8-13,30-50 ; pw_impl.cpp:843-851
+    p->maxc = 100;
+    p->tech = tech;
+    p->ddfs_cutoff = 0.25;
+    if (tech == 0) { p->min_align_size = 2000; p->min_kmer_match = 4; p->min_kmer_dist = 1800; }
+    else           { p->min_align_size = 500;  p->min_kmer_match = 2; p->min_kmer_dist = 400; }
+}
+
+int mhip_ctx_create(int device, void* stream, mhip_ctx** out) {
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        mhip_set_error("no HIP device available (%s); libmecat_hip has no CPU fallback", hipGetErrorString(e));
+        return -1;
+    }
+    if (device < 0 || device >= n) { mhip_set_error("device %d out of range (have %d)", device, n); return -1; }
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        mhip_set_error("device %d is %s; libmecat_hip is built for gfx950 only", device, prop.gcnArchName);
+        return -1;
+    }
+    mhip_ctx* c = new mhip_ctx();
+    c->device = device;
+    c->num_cus = prop.multiProcessorCount;
+    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+    else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; mhip_set_error("hipStreamCreate failed"); return -1; }
+        c->own_stream = true;
+    }
+    // 8 public counters (mecat_hip.h) + 8 debug slots
+    if (hipMalloc((void**)&c->d_counters, 16 * sizeof(int64_t)) != hipSuccess) { delete c; mhip_set_error("hipMalloc counters failed"); return -1; }
+    (void)hipMemsetAsync(c->d_counters, 0, 16 * sizeof(int64_t), c->stream);
+    *out = c;
+    return 0;
+}
+
+void mhip_ctx_destroy(mhip_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    for (auto& kv : c->bufs) if (kv.second.p) (void)hipFree(kv.second.p);
+    if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int mhip_ctx_sync(mhip_ctx* c) {
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int mhip_ctx_set_profiling(mhip_ctx* c, int on) {
+    if (c->drain_events()) return -1;
+    c->profiling = on != 0;
+    return 0;
+}
+
+int mhip_ctx_reset_stats(mhip_ctx* c) {
+    if (c->drain_events()) return -1;
+    c->stats.clear();
+    HIPCHK(hipMemsetAsync(c->d_counters, 0, 16 * sizeof(int64_t), c->stream));
+    return 0;
+}
+
+// debug slots 8..15 (8: dw blocks re-run with spilled rows)
+int mhip_debug_counter(mhip_ctx* c, int slot, int64_t* out) {
+    if (slot < 0 || slot >= 16) return -1;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(out, c->d_counters + slot, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int mhip_ctx_kernel_stats(mhip_ctx* c, const char* name, int64_t* launches, double* total_ms) {
+    if (c->drain_events()) return -1;
+    auto it = c->stats.find(name);
+    if (it == c->stats.end()) { *launches = 0; *total_ms = 0.0; return 0; }
+    *launches = it->second.launches;
+    *total_ms = it->second.ms;
+    return 0;
+}
+
+int mhip_ctx_kernel_names(mhip_ctx* c, char* buf, int buflen) {
+    if (c->drain_events()) return -1;
+    std::string s;
+    for (auto& kv : c->stats) { s += kv.first; s += "\n"; }
+    snprintf(buf, (size_t)buflen, "%s", s.c_str());
+    return 0;
+}
+
+int mhip_ctx_counters(mhip_ctx* c, int64_t out[8]) {
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(out, c->d_counters, 8 * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int mhip_volume_upload(mhip_ctx* c, const uint8_t* pac, const mhip_offset_t* offs, int num_reads, int num_bases,
+                       int start_read_id, mhip_volume** out) {
+    *out = nullptr;
+    if (num_reads < 0 || num_bases < 0) { mhip_set_error("bad volume sizes"); return -1; }
+    HIPCHK(hipSetDevice(c->device));
+    mhip_volume* v = new mhip_volume();
+    v->device = c->device;
+    v->num_reads = num_reads;
+    v->num_bases = num_bases;
+    v->start_read_id = start_read_id;
+    size_t nb = ((size_t)num_bases + 3) / 4;
+    v->pac_bytes = ((nb + 63) / 64) * 64 + 128;     // zero padding so whole-word window loads never leave the buffer
+    if (hipMalloc((void**)&v->d_pac, v->pac_bytes) != hipSuccess ||
+        hipMalloc((void**)&v->d_offs, sizeof(mhip_offset_t) * (size_t)(num_reads + 1)) != hipSuccess) {
+        mhip_set_error("hipMalloc failed for a %zu-byte volume", v->pac_bytes);
+        mhip_volume_free(v);
+        return -1;
+    }
+    HIPCHK(hipMemsetAsync(v->d_pac, 0, v->pac_bytes, c->stream));
+    if (nb) HIPCHK(hipMemcpyAsync(v->d_pac, pac, nb, hipMemcpyHostToDevice, c->stream));
+    v->h_offs.assign(offs, offs + num_reads);
+    if (num_reads) HIPCHK(hipMemcpyAsync(v->d_offs, offs, sizeof(mhip_offset_t) * (size_t)num_reads, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *out = v;
+    return 0;
+}
+
+void mhip_volume_free(mhip_volume* v) {
+    if (!v) return;
+    (void)hipSetDevice(v->device);
+    if (v->d_pac) (void)hipFree(v->d_pac);
+    if (v->d_offs) (void)hipFree(v->d_offs);
+    delete v;
+}
+
+int mhip_volume_num_reads(const mhip_volume* v) { return v->num_reads; }
+int mhip_volume_num_bases(const mhip_volume* v) { return v->num_bases; }
+
+}  // extern "C"
+
+int mhip_ctx::scratch(const char* name, size_t bytes, void** out) {
+    DevBuf& b = bufs[name];
+    if (b.cap < bytes) {
+        if (b.p) {
+            HIPCHK(hipStreamSynchronize(stream));
+            HIPCHK(hipFree(b.p));
+            b.p = nullptr;
+            b.cap = 0;
+        }
+        size_t want = bytes + bytes / 8 + 4096;
+        hipError_t e = hipMalloc(&b.p, want);
+        if (e != hipSuccess) {
+            b.p = nullptr;
+            mhip_set_error("hipMalloc of %zu bytes for scratch '%s' failed: %s", want, name, hipGetErrorString(e));
+            return -1;
+        }
+        b.cap = want;
+    }
+    *out = b.p;
+    return 0;
+}
+
+hipEvent_t mhip_ctx::get_event() {
+    if (!ev_pool.empty()) {
+        hipEvent_t e = ev_pool.back();
+        ev_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+int mhip_ctx::drain_events() {
+    if (pending.empty()) return 0;
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamSynchronize(stream));
+    for (auto& p : pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            KStat& s = stats[p.name];
+            s.launches += 1;
+            s.ms += ms;
+        }
+        ev_pool.push_back(p.a);
+        ev_pool.push_back(p.b);
+    }
+    pending.clear();
+    return 0;
+}

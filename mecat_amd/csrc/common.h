@@ -1,0 +1,141 @@
+// common.h — shared host/device declarations of libmecat_hip (gfx950 only; wave = 64 lanes).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "mecat_hip.h"
+
+#define WAVE 64
+#define NKMER (1u << 26)          // 4^13 direct-address buckets
+#define KMER_MASK 0x3FFFFFFu
+#define ZV 2000                   // reference segment length, mecat2pw/pw_impl.h:16
+#define BC 10                     // query k-mer stride, pw_impl.h:12
+#define SM 40                     // seeds kept per segment, pw_impl.h:13
+#define MAX_BUCKET 128            // lookup_table.cpp:97
+
+void mhip_set_error(const char* fmt, ...);
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) {                                                                        \
+            mhip_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e));       \
+            return -1;                                                                                 \
+        }                                                                                              \
+    } while (0)
+
+struct KStat {
+    int64_t launches = 0;
+    double ms = 0.0;
+};
+
+struct PendingEv {
+    std::string name;
+    hipEvent_t a, b;
+};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct mhip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool profiling = false;
+    std::map<std::string, KStat> stats;
+    std::vector<PendingEv> pending;
+    std::vector<hipEvent_t> ev_pool;
+    std::map<std::string, DevBuf> bufs;   // named scratch buffers, grown on demand, freed with the context
+    int64_t* d_counters = nullptr;        // 8 work counters (see mecat_hip.h)
+    int num_cus = 256;
+    int dbg_flags = 0;                    // bit 0: mhip_seed_reads stops after seed_build (tests/debug only)
+    std::vector<char> dbg_blob;           // SeedArrays of the last seed batch
+    int dbg_ns = 0;
+
+    // returns a device buffer of at least `bytes` (contents undefined)
+    int scratch(const char* name, size_t bytes, void** out);
+    int drain_events();
+    hipEvent_t get_event();
+};
+
+struct mhip_volume {
+    int device = 0;
+    int num_reads = 0;
+    int num_bases = 0;          // incl. one pad base per read
+    int start_read_id = 0;
+    uint32_t* d_pac = nullptr;  // 2-bit store as big-endian-in-byte bytes, padded with >= 64 zero bytes
+    mhip_offset_t* d_offs = nullptr;
+    std::vector<mhip_offset_t> h_offs;
+    size_t pac_bytes = 0;
+};
+
+struct mhip_index {
+    int device = 0;
+    uint32_t* d_starts = nullptr;   // [NKMER + 1] bucket boundaries into d_offsets (dropped buckets are empty)
+    int32_t* d_offsets = nullptr;   // [num_kmers] k-mer start positions, ascending inside a bucket
+    int64_t num_kmers = 0;
+    int num_bases = 0;
+};
+
+// launch helper: optional HIP-event timing per kernel name on the context's stream
+struct LaunchTimer {
+    mhip_ctx* ctx;
+    hipEvent_t a = nullptr, b = nullptr;
+    const char* name;
+    LaunchTimer(mhip_ctx* c, const char* n) : ctx(c), name(n) {
+        if (ctx->profiling) {
+            a = ctx->get_event();
+            b = ctx->get_event();
+            (void)hipEventRecord(a, ctx->stream);
+        }
+    }
+    ~LaunchTimer() {
+        if (ctx->profiling) {
+            (void)hipEventRecord(b, ctx->stream);
+            ctx->pending.push_back({name, a, b});
+        }
+    }
+};
+
+#define LAUNCH(ctx, name, kernel, grid, block, shmem, ...)                                   \
+    do {                                                                                     \
+        LaunchTimer _lt((ctx), (name));                                                      \
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (shmem), (ctx)->stream, __VA_ARGS__); \
+    } while (0)
+
+#ifdef __HIPCC__
+// ---------------------------------------------------------------- device helpers
+
+// 16 bases per 32-bit word, first base in the most significant bits (packed_db.h:98-107 read as big-endian words)
+__device__ __forceinline__ uint32_t pac_word(const uint32_t* __restrict__ pac, int64_t w) {
+    return __builtin_bswap32(pac[w]);
+}
+// code (0..3) of volume base `idx`
+__device__ __forceinline__ uint32_t pac_base(const uint32_t* __restrict__ pac, int64_t idx) {
+    uint32_t w = pac_word(pac, idx >> 4);
+    return (w >> ((~(uint32_t)idx & 15u) << 1)) & 3u;
+}
+// the 13-mer starting at volume base `idx` (MSB-first id, lookup_table.cpp:77-90 / pw_impl.cpp:83-97)
+__device__ __forceinline__ uint32_t pac_kmer(const uint32_t* __restrict__ pac, int64_t idx) {
+    int64_t w = idx >> 4;
+    uint64_t W = ((uint64_t)pac_word(pac, w) << 32) | pac_word(pac, w + 1);
+    int sh = 64 - 26 - (int)((idx & 15) << 1);
+    return (uint32_t)(W >> sh) & KMER_MASK;
+}
+// reverse complement of a 13-mer id
+__device__ __forceinline__ uint32_t kmer_revcomp(uint32_t k) {
+    uint32_t x = ~k;                                        // complement every 2-bit code (3 - c)
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+    x = __builtin_bswap32(x);                               // now the 16 2-bit groups are reversed
+    return (x >> 6) & KMER_MASK;                            // the 13 wanted groups were the low 26 bits -> top 26 bits
+}
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+#endif

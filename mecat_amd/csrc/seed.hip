@@ -1,0 +1,853 @@
+// seed.hip — k-mer probe, DDF block-scoring seed filter and candidate selection.
+//
+// Replaces, for a batch of query reads and both strands of each:
+//   extract_kmers      mecat2pw/pw_impl.cpp:83-97      query k-mers at stride 10
+//   seeding            mecat2pw/pw_impl.cpp:241-286    bucket walk, per-2kb-segment seed lists (Back_List), index_score
+//   insert_loc         mecat2pw/pw_impl.cpp:121-159    >40-seeds-per-segment overflow policy
+//   find_location      mecat2pw/pw_impl.cpp:161-239    DDF vote inside a segment pair
+//   get_candidates     mecat2pw/pw_impl.cpp:288-465    gate, subject lookup, self-hit scrub, neighbour sweeps, top-MAXC
+//
+// The reference keeps a 168-byte Back_List per 2 kb of reference per thread (126 MB at 1.5 Gbase) and updates it in
+// hit order.  That state is order dependent (SURVEY.md §7 "hard parts" 1-3), so the GPU formulation is a replay:
+//
+//   seed_probe  (block / strand)  2-bit read -> 13-mers (reverse strand by index arithmetic) -> bucket (start, count)
+//                                 from the starts[] table, exclusive scan -> per-k-mer hit offsets, hits per strand
+//   seed_scan   (one block)       exclusive scan of hits per strand -> region of every strand in the batch arrays
+//   seed_emit   (block / strand)  expand buckets: key = seg:21 | km:16 | off:11 written in (km, position) order,
+//                                 i.e. in the order the reference visits the hits; coalesced by an LDS prefix search
+//   seed_sort   (block / strand)  stable LSD radix sort on the seg bits only (7-8 bits per pass): ranking by
+//                                 wave64 ballot multi-split, per-wave cursors in LDS, no atomics in the scatter loop.
+//                                 Stability keeps (km, position) order inside a segment == the reference's visit order.
+//   seed_build  (block / strand)  "recorded" events = first hit of each (segment, km) (pw_impl.cpp:265,282);
+//                                 ballot/prefix compaction into per-segment seed lists; segments with > 40 recorded
+//                                 events replay insert_loc one wave per segment (exact-diagonal fast path for the
+//                                 read hitting itself); index_score incl. the left neighbour's score at the time of
+//                                 the segment's last event; gated segments ordered by first-touch time
+//   seed_cand   (wave / read)     sequential replay of get_candidates over the gated segments of F then R strand:
+//                                 lanes evaluate the O(n^2) DDF votes, the sweeps and the list shifts in parallel
+//
+// FP: find_location is all f32, insert_loc divides in f32 and compares in f64, the sweeps are f64;
+// built with -ffp-contract=off and hipcc's default correctly-rounded f32 division.
+//
+// Known divergence: reads longer than 327 670 bases (seed numbers overflow the reference's `short`).
+#include <string.h>
+
+#include <algorithm>
+
+#include "common.h"
+
+#define SEED_BLOCK 256
+#define SEED_WAVES (SEED_BLOCK / WAVE)
+#define KEY_OFF_BITS 11
+#define KEY_KM_BITS 16
+#define KEY_SEG_SHIFT (KEY_OFF_BITS + KEY_KM_BITS)   // 27
+#define MAXC_LIMIT 1024
+
+struct SeedArrays {
+    // per batch
+    const uint32_t* km_base;     // [ns]   first k-mer slot of the strand
+    uint32_t* km_bstart;         // [sumK] bucket start in index offsets[]
+    uint32_t* km_hpre;           // [sumK] exclusive prefix of bucket sizes inside the strand
+    uint32_t* strand_hits;       // [ns]
+    uint64_t* hit_base;          // [ns + 1]
+    uint64_t* keysA;             // [Htot]
+    uint64_t* keysB;             // [Htot]
+    uint32_t* ent;               // [Htot] recorded events: off << 16 | (uint16)(km + 1)
+    uint32_t* ent_fin;           // [Htot] final 40-entry lists of overflowed segments (same indexing as ent)
+    uint16_t* escore;            // [Htot] score after each recorded event (overflowed segments only)
+    uint32_t* seg_id;            // [Htot] segment table, ascending seg id
+    uint32_t* seg_start;         // [Htot] first recorded event of the segment in ent[]
+    int32_t* seg_score;          // [Htot] live Back_List.score (bit 30 set: lists live in ent_fin)
+    uint32_t* seg_kmlast;        // [Htot] km of the segment's last recorded event
+    uint64_t* seg_tfirst;        // [Htot] first-touch time (km << 32 | position)
+    uint32_t* gated;             // [Htot] segment-table indices passing the index_score gate, in first-touch order
+    uint32_t* nseg;              // [ns]
+    uint32_t* nrec;              // [ns]
+    uint32_t* ngated;            // [ns]
+};
+
+#define OVF_FLAG 0x40000000
+
+__device__ __forceinline__ int kmers_of(int L) { return L < MHIP_KMER_SIZE ? 0 : (L - MHIP_KMER_SIZE) / BC + 1; }
+
+// block-wide exclusive scan of one value per thread (SEED_BLOCK threads); returns the exclusive prefix, total in *total
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wtot /*[SEED_WAVES]*/, uint32_t* total) {
+    uint32_t incl = v;
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t n = __shfl_up(incl, o);
+        if (lane_id() >= o) incl += n;
+    }
+    __syncthreads();   // protect wtot from the previous use
+    if (lane_id() == 63) wtot[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < SEED_WAVES; ++w) {
+        if (w < (int)(threadIdx.x >> 6)) base += wtot[w];
+        tot += wtot[w];
+    }
+    *total = tot;
+    return base + incl - v;
+}
+
+// ------------------------------------------------------------------------------------------------ probe
+__global__ __launch_bounds__(SEED_BLOCK) void seed_probe(const uint32_t* __restrict__ pac, const mhip_offset_t* __restrict__ roffs,
+                                                         int rid_begin, const uint32_t* __restrict__ starts, SeedArrays A,
+                                                         unsigned long long* __restrict__ counters) {
+    __shared__ uint32_t wtot[SEED_WAVES];
+    const int s = blockIdx.x;
+    const int rid = rid_begin + (s >> 1);
+    const bool rev = s & 1;
+    const int off = roffs[rid].offset, L = roffs[rid].size;
+    const int K = kmers_of(L);
+    const uint32_t kb = A.km_base[s];
+    uint32_t run = 0;
+    for (int t0 = 0; t0 < K; t0 += SEED_BLOCK) {
+        int km = t0 + threadIdx.x;
+        uint32_t cnt = 0, bs = 0;
+        if (km < K) {
+            uint32_t id;
+            if (!rev) id = pac_kmer(pac, (int64_t)off + (int64_t)km * BC);
+            else id = kmer_revcomp(pac_kmer(pac, (int64_t)off + L - MHIP_KMER_SIZE - (int64_t)km * BC));
+            bs = starts[id];
+            cnt = starts[id + 1] - bs;
+        }
+        uint32_t tot;
+        uint32_t ex = block_excl_scan(cnt, wtot, &tot);
+        if (km < K) {
+            A.km_bstart[kb + km] = bs;
+            A.km_hpre[kb + km] = run + ex;
+        }
+        run += tot;
+    }
+    if (threadIdx.x == 0) {
+        A.strand_hits[s] = run;
+        atomicAdd(&counters[0], (unsigned long long)K);
+        atomicAdd(&counters[1], (unsigned long long)run);
+    }
+}
+
+// exclusive scan of strand_hits[ns] -> hit_base[ns + 1] (single block, sequential over tiles)
+__global__ __launch_bounds__(1024) void seed_scan(const uint32_t* __restrict__ hits, int ns, uint64_t* __restrict__ base) {
+    __shared__ uint64_t wtot[16];
+    __shared__ uint64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int t0 = 0; t0 < ns; t0 += 1024) {
+        int i = t0 + threadIdx.x;
+        uint64_t v = i < ns ? hits[i] : 0;
+        uint64_t incl = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            uint64_t n = __shfl_up(incl, o);
+            if (lane_id() >= o) incl += n;
+        }
+        if (lane_id() == 63) wtot[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        uint64_t b = carry;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) b += wtot[w];
+        if (i < ns) base[i] = b + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = b + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) base[ns] = carry;
+}
+
+// ------------------------------------------------------------------------------------------------ emit
+__global__ __launch_bounds__(SEED_BLOCK) void seed_emit(const mhip_offset_t* __restrict__ roffs, int rid_begin,
+                                                        const int32_t* __restrict__ offsets, SeedArrays A) {
+    __shared__ uint32_t pre[SEED_BLOCK + 1];
+    __shared__ uint32_t bst[SEED_BLOCK];
+    const int s = blockIdx.x;
+    const int rid = rid_begin + (s >> 1);
+    const int K = kmers_of(roffs[rid].size);
+    const uint32_t kb = A.km_base[s];
+    const uint32_t H = A.strand_hits[s];
+    uint64_t* __restrict__ out = A.keysA + A.hit_base[s];
+    for (int t0 = 0; t0 < K; t0 += SEED_BLOCK) {
+        int km = t0 + threadIdx.x;
+        __syncthreads();
+        if (km < K) { pre[threadIdx.x] = A.km_hpre[kb + km]; bst[threadIdx.x] = A.km_bstart[kb + km]; }
+        int nk = min(SEED_BLOCK, K - t0);
+        if ((int)threadIdx.x == nk - 1) pre[nk] = (t0 + nk < K) ? A.km_hpre[kb + t0 + nk] : H;
+        __syncthreads();
+        const uint32_t h0 = pre[0], h1 = pre[nk];
+        for (uint32_t h = h0 + threadIdx.x; h < h1; h += SEED_BLOCK) {
+            // last k with pre[k] <= h
+            int lo = 0, hi = nk;   // invariant pre[lo] <= h < pre[hi]
+            while (hi - lo > 1) {
+                int mid = (lo + hi) >> 1;
+                if (pre[mid] <= h) lo = mid; else hi = mid;
+            }
+            uint32_t r = h - pre[lo];
+            uint32_t pos = (uint32_t)offsets[bst[lo] + r];
+            uint32_t seg = pos / ZV, so = pos - seg * ZV;
+            out[h] = ((uint64_t)seg << KEY_SEG_SHIFT) | ((uint64_t)(t0 + lo) << KEY_OFF_BITS) | so;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ sort (one LSD pass)
+// digit = (key >> shift) & (2^bits - 1), bits <= 8.  Wave w of the block owns the w-th quarter of the strand's keys.
+__global__ __launch_bounds__(SEED_BLOCK) void seed_sort_pass(SeedArrays A, int from_b, int shift, int bits) {
+    __shared__ uint32_t hist[SEED_WAVES][256];
+    __shared__ uint32_t wtot[SEED_WAVES];
+    const int s = blockIdx.x;
+    const uint32_t H = A.strand_hits[s];
+    if (H == 0) return;
+    const uint64_t hb = A.hit_base[s];
+    const uint64_t* __restrict__ src = (from_b ? A.keysB : A.keysA) + hb;
+    uint64_t* __restrict__ dst = (from_b ? A.keysA : A.keysB) + hb;
+    const int w = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t mask = (1u << bits) - 1u;
+    const uint32_t chunk = (((H + SEED_WAVES - 1) / SEED_WAVES) + 63u) & ~63u;
+    const uint32_t lo = min(H, w * chunk), hi = min(H, lo + chunk);
+    for (int i = threadIdx.x; i < SEED_WAVES * 256; i += SEED_BLOCK) (&hist[0][0])[i] = 0;
+    __syncthreads();
+    for (uint32_t i = lo + lane; i < hi; i += 64) atomicAdd(&hist[w][(uint32_t)(src[i] >> shift) & mask], 1u);
+    __syncthreads();
+    {
+        // thread t = bin t: bases in (bin major, wave minor) order
+        uint32_t c[SEED_WAVES], tot = 0;
+#pragma unroll
+        for (int q = 0; q < SEED_WAVES; ++q) { c[q] = hist[q][threadIdx.x]; tot += c[q]; }
+        uint32_t all;
+        uint32_t ex = block_excl_scan(tot, wtot, &all);
+#pragma unroll
+        for (int q = 0; q < SEED_WAVES; ++q) { hist[q][threadIdx.x] = ex; ex += c[q]; }
+    }
+    __syncthreads();
+    volatile uint32_t* cur = hist[w];
+    const uint64_t lt = (1ull << lane) - 1ull;
+    for (uint32_t i0 = lo; i0 < hi; i0 += 64) {
+        uint32_t i = i0 + lane;
+        bool valid = i < hi;
+        uint64_t key = valid ? src[i] : 0;
+        uint32_t d = (uint32_t)(key >> shift) & mask;
+        uint64_t peers = __ballot(valid);
+        for (int b = 0; b < bits; ++b) {
+            uint64_t m = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? m : ~m;
+        }
+        uint32_t rank = __popcll(peers & lt);
+        uint32_t base = valid ? cur[d] : 0;
+        if (valid) dst[base + rank] = key;
+        if (valid && rank == 0) cur[d] = base + (uint32_t)__popcll(peers);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ build
+__device__ __forceinline__ uint32_t key_seg(uint64_t k) { return (uint32_t)(k >> KEY_SEG_SHIFT); }
+__device__ __forceinline__ uint32_t key_km(uint64_t k) { return (uint32_t)(k >> KEY_OFF_BITS) & 0xFFFFu; }
+__device__ __forceinline__ uint32_t key_off(uint64_t k) { return (uint32_t)k & 0x7FFu; }
+__device__ __forceinline__ int ent_loc(uint32_t e) { return (int)(e >> 16); }
+__device__ __forceinline__ int ent_seed(uint32_t e) { return (int)(int16_t)(e & 0xFFFFu); }
+
+// f32 divide, f64 compare: the DDF test of insert_loc (pw_impl.cpp:135)
+__device__ __forceinline__ bool ddf_insert(int dloc, int dseed, double cutoff) {
+    float r = (float)dloc / ((float)dseed * 10.0f);
+    return fabs((double)r - 1.0) < cutoff;
+}
+// all-f32 DDF test of find_location (pw_impl.cpp:165,196,222)
+__device__ __forceinline__ bool ddf_find(int dloc, int dseed, double cutoff) {
+    float r = (float)dloc / ((float)dseed * 10.0f) - 1.0f;
+    return (double)fabsf(r) < cutoff;
+}
+
+// insert_loc replay for one overflowed segment by one wave.  Events e = 40.. c-1 (0-based) arrive one by one.
+// lane i (< 40) holds list entry i.  Writes the final 40 entries to fin[] and the score after each event to esc[].
+__device__ void replay_overflow(const uint32_t* __restrict__ ev, int c, uint32_t* __restrict__ fin, uint16_t* __restrict__ esc,
+                                double cutoff, int* score_out) {
+    const int lane = lane_id();
+    int loc = 0, seed = 0;
+    if (lane < SM) { uint32_t e = ev[lane]; loc = ent_loc(e); seed = ent_seed(e); }
+    for (int e = lane; e < SM; e += 64) esc[e] = (uint16_t)(e + 1);
+    int score = SM;
+    for (int e = SM; e < c; ++e) {
+        uint32_t ne = ev[e];
+        const int nloc = ent_loc(ne), nseed = ent_seed(ne);
+        ++score;   // loc = ++spr->score (pw_impl.cpp:267)
+        // element 40 of the 41-entry working list is the new seed
+        int myloc = lane < SM ? loc : nloc, myseed = lane < SM ? seed : nseed;
+        // fast path: all 41 entries on one exact diagonal with strictly increasing seed numbers -> every pair passes
+        int nxloc = __shfl_down(myloc, 1), nxseed = __shfl_down(myseed, 1);
+        bool chain_ok = lane >= SM || (nxseed - myseed > 0 && nxloc - myloc == (nxseed - myseed) * BC);
+        int minval, mini;
+        if (__all(chain_ok)) {
+            minval = SM; mini = 0;
+        } else {
+            int sc = 0;
+            for (int i = 0; i < SM; ++i) {
+                int li = __shfl(myloc, i), si = __shfl(myseed, i);
+                bool pass = lane > i && lane <= SM && myseed - si > 0 && myloc - li > 0 && ddf_insert(myloc - li, myseed - si, cutoff);
+                uint64_t b = __ballot(pass);
+                sc += pass ? 1 : 0;
+                if (lane == i) sc += __popcll(b);
+            }
+            int v = lane <= SM ? sc : 0x7fffffff;
+            int m = v;
+            for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o));
+            minval = m;
+            mini = __ffsll((unsigned long long)__ballot(v == m)) - 1;   // first index holding the minimum
+        }
+        if (minval == SM) {
+            if (lane == SM - 1) { loc = nloc; seed = nseed; }
+        } else if (minval < SM && mini < SM) {
+            // delete entry mini, shift left, append the new one
+            int sl = __shfl_down(myloc, 1), ss = __shfl_down(myseed, 1);
+            if (lane >= mini && lane < SM) { loc = sl; seed = ss; }
+            --score;
+        }
+        if (lane == 0) esc[e] = (uint16_t)score;
+    }
+    if (lane < SM) fin[lane] = ((uint32_t)loc << 16) | ((uint32_t)seed & 0xFFFFu);
+    *score_out = score;
+}
+
+__global__ __launch_bounds__(SEED_BLOCK) void seed_build(SeedArrays A, int sorted_in_b, int min_kmer_match, double cutoff) {
+    __shared__ uint32_t wtot[SEED_WAVES];
+    __shared__ uint32_t s_cnt[4];          // 0: overflow count, 1: gated count
+    const int s = blockIdx.x;
+    const uint32_t H = A.strand_hits[s];
+    const uint64_t hb = A.hit_base[s];
+    if (H == 0) {
+        if (threadIdx.x == 0) { A.nseg[s] = 0; A.nrec[s] = 0; A.ngated[s] = 0; }
+        return;
+    }
+    const uint64_t* __restrict__ S = (sorted_in_b ? A.keysB : A.keysA) + hb;
+    uint32_t* ovf_list = (uint32_t*)((sorted_in_b ? A.keysA : A.keysB) + hb);   // free sort buffer: overflow work list
+    uint64_t* gate_tmp = (sorted_in_b ? A.keysA : A.keysB) + hb;                // later: unsorted gated keys
+    uint32_t* ent = A.ent + hb;
+    uint32_t* fin = A.ent_fin + hb;
+    uint16_t* esc = A.escore + hb;
+    uint32_t* seg_id = A.seg_id + hb;
+    uint32_t* seg_start = A.seg_start + hb;
+    int32_t* seg_score = A.seg_score + hb;
+    uint32_t* seg_kmlast = A.seg_kmlast + hb;
+    uint64_t* seg_tfirst = A.seg_tfirst + hb;
+    uint32_t* gated = A.gated + hb;
+
+    // ---- phase A: recorded events and segment heads
+    uint32_t rec_run = 0, seg_run = 0;
+    for (uint32_t t0 = 0; t0 < H; t0 += SEED_BLOCK) {
+        uint32_t i = t0 + threadIdx.x;
+        bool in = i < H;
+        uint64_t key = in ? S[i] : 0, prev = (in && i > 0) ? S[i - 1] : 0;
+        bool head = in && (i == 0 || key_seg(key) != key_seg(prev));
+        bool rec = in && (head || key_km(key) != key_km(prev));
+        uint32_t rtot, stot;
+        uint32_t rpos = rec_run + block_excl_scan(rec ? 1u : 0u, wtot, &rtot);
+        uint32_t spos = seg_run + block_excl_scan(head ? 1u : 0u, wtot, &stot);
+        if (rec) ent[rpos] = (key_off(key) << 16) | ((key_km(key) + 1u) & 0xFFFFu);
+        if (head) {
+            seg_id[spos] = key_seg(key);
+            seg_start[spos] = rpos;
+            seg_tfirst[spos] = ((uint64_t)key_km(key) << 32) | (uint64_t)(key_seg(key) * (uint32_t)ZV + key_off(key));
+            if (spos > 0) seg_kmlast[spos - 1] = key_km(prev);
+        }
+        rec_run += rtot;
+        seg_run += stot;
+    }
+    const uint32_t nrec = rec_run, nseg = seg_run;
+    if (threadIdx.x == 0) {
+        seg_kmlast[nseg - 1] = key_km(S[H - 1]);
+        A.nseg[s] = nseg;
+        A.nrec[s] = nrec;
+        s_cnt[0] = 0;
+        s_cnt[1] = 0;
+    }
+    __syncthreads();
+
+    // ---- phase B: scores; collect overflowed segments
+    for (uint32_t g = threadIdx.x; g < nseg; g += SEED_BLOCK) {
+        uint32_t st = seg_start[g], en = (g + 1 < nseg) ? seg_start[g + 1] : nrec;
+        uint32_t c = en - st;
+        if (c > SM) { uint32_t k = atomicAdd(&s_cnt[0], 1u); ovf_list[k] = g; seg_score[g] = OVF_FLAG; }
+        else seg_score[g] = (int32_t)c;
+    }
+    __syncthreads();
+
+    // ---- phase C: replay insert_loc, one wave per overflowed segment
+    {
+        const uint32_t novf = s_cnt[0];
+        for (uint32_t k = threadIdx.x >> 6; k < novf; k += SEED_WAVES) {
+            uint32_t g = ovf_list[k];
+            uint32_t st = seg_start[g], en = (g + 1 < nseg) ? seg_start[g + 1] : nrec;
+            int sc;
+            replay_overflow(ent + st, (int)(en - st), fin + st, esc + st, cutoff, &sc);
+            if (lane_id() == 0) seg_score[g] = sc | OVF_FLAG;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase D: index_score = own score + left neighbour's score at the time of the last event (pw_impl.cpp:270-280)
+    for (uint32_t g = threadIdx.x; g < nseg; g += SEED_BLOCK) {
+        int own = seg_score[g] & ~OVF_FLAG;
+        int s_k = own;
+        uint32_t sid = seg_id[g];
+        if (g > 0 && sid > 0 && seg_id[g - 1] == sid - 1) {
+            // events of the left neighbour with km <= km_last happened before this segment's last event
+            uint32_t st = seg_start[g - 1], en = seg_start[g];
+            uint32_t t = seg_kmlast[g] + 1u;     // compare on km + 1 as stored
+            uint32_t lo = st, hi = en;           // first event with (km + 1) > t
+            while (lo < hi) {
+                uint32_t mid = (lo + hi) >> 1;
+                if ((ent[mid] & 0xFFFFu) <= t) lo = mid + 1; else hi = mid;
+            }
+            int left = 0;
+            if (lo > st) left = (seg_score[g - 1] & OVF_FLAG) ? (int)esc[lo - 1] : (int)(lo - st);
+            s_k += left;
+        }
+        if ((int)(int16_t)s_k >= 2 * min_kmer_match) {
+            uint32_t k = atomicAdd(&s_cnt[1], 1u);
+            gate_tmp[k] = (uint64_t)g;   // index only; ordered below by seg_tfirst
+        }
+    }
+    __syncthreads();
+
+    // ---- phase E: order gated segments by first-touch time (rank sort; first-touch times are unique)
+    {
+        const uint32_t ng = s_cnt[1];
+        for (uint32_t a = threadIdx.x; a < ng; a += SEED_BLOCK) {
+            uint32_t ga = (uint32_t)gate_tmp[a];
+            uint64_t ta = seg_tfirst[ga];
+            uint32_t rank = 0;
+            for (uint32_t b = 0; b < ng; ++b) rank += seg_tfirst[(uint32_t)gate_tmp[b]] < ta ? 1u : 0u;
+            gated[rank] = ga;
+        }
+        if (threadIdx.x == 0) A.ngated[s] = ng;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ candidates
+struct CandLds {
+    int t_loc[2 * SM + 10];
+    int t_seed[2 * SM + 10];
+};
+
+// index of segment `seg` in the strand's segment table, or -1
+__device__ __forceinline__ int seg_find(const uint32_t* __restrict__ seg_id, int nseg, uint32_t seg) {
+    int lo = 0, hi = nseg;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (seg_id[mid] < seg) lo = mid + 1; else hi = mid;
+    }
+    return (lo < nseg && seg_id[lo] == seg) ? lo : -1;
+}
+
+// get_read_id_from_offset_list (common/split_database.cpp:15-35), literally
+__device__ __forceinline__ int read_id_from_offset(const mhip_offset_t* __restrict__ a, int n, int offset) {
+    int left = 0, right = n - 1, mid = (left + right) / 2;
+    if (a[right].offset < offset) return right;
+    while (left <= right) {
+        int o = a[mid].offset, z = a[mid].size;
+        if (o <= offset && o + z > offset) return mid;
+        if (o + z <= offset) left = mid + 1;
+        else right = mid - 1;
+        mid = (left + right) / 2;
+    }
+    return mid;
+}
+
+// one wave per read: F strand then R strand into one top-MAXC list kept in LDS (12 ints per entry)
+__global__ __launch_bounds__(WAVE) void seed_cand(SeedArrays A, const mhip_offset_t* __restrict__ ref_offs, int ref_nreads,
+                                                  int ref_start_id, const mhip_offset_t* __restrict__ roffs, int rid_begin,
+                                                  int reads_start_id, mhip_params P, mhip_candidate* __restrict__ out,
+                                                  int32_t* __restrict__ out_counts, unsigned long long* __restrict__ counters) {
+    extern __shared__ __attribute__((aligned(16))) int smem[];
+    int* clist = smem;                                  // [maxc][12]
+    CandLds* T = (CandLds*)(smem + P.maxc * 12);
+    const int lane = lane_id();
+    const int r = blockIdx.x;
+    const int rid = rid_begin + r;
+    const int read_id = rid + reads_start_id;
+    const int read_size = roffs[rid].size;
+    const int MAXC = P.maxc;
+    const double cutoff = P.ddfs_cutoff;
+    int ncand = 0;
+
+    for (int strand = 0; strand < 2; ++strand) {
+        const int s = 2 * r + strand;
+        const uint64_t hb = A.hit_base[s];
+        const int nseg = (int)A.nseg[s];
+        const int ng = (int)A.ngated[s];
+        if (A.strand_hits[s] == 0) continue;
+        uint32_t* ent = A.ent + hb;
+        uint32_t* fin = A.ent_fin + hb;
+        const uint32_t* seg_id = A.seg_id + hb;
+        const uint32_t* seg_start = A.seg_start + hb;
+        int32_t* seg_score = A.seg_score + hb;
+        const uint32_t* gated = A.gated + hb;
+#define SEG_LIST(g) (((seg_score[g] & OVF_FLAG) ? fin : ent) + seg_start[g])
+#define SEG_SCORE(g) (seg_score[g] & ~OVF_FLAG)
+#define SET_SCORE(g, v) seg_score[g] = (seg_score[g] & OVF_FLAG) | (v)
+
+        for (int gi = 0; gi < ng; ++gi) {
+            const int g = (int)gated[gi];
+            const int seg = (int)seg_id[g];
+            int s_k = SEG_SCORE(g);
+            if (s_k == 0) continue;
+            int start_loc = seg * ZV;
+            int loc = 0;
+            const bool has_left = seg > 0 && g > 0 && seg_id[g - 1] == (uint32_t)(seg - 1);
+            if (has_left) loc = SEG_SCORE(g - 1);
+            if (loc > 0) start_loc = (seg - 1) * ZV;
+            const int n1 = loc > 0 ? min(loc, SM) : 0, n2 = min(s_k, SM);
+            const int k = n1 + n2;
+            __syncthreads();
+            for (int i = lane; i < k; i += 64) {
+                uint32_t e = i < n1 ? SEG_LIST(g - 1)[i] : SEG_LIST(g)[i - n1];
+                T->t_loc[i] = ent_loc(e) + ((i >= n1 && loc > 0) ? ZV : 0);
+                T->t_seed[i] = ent_seed(e);
+            }
+            __syncthreads();
+            // ---- find_location (pw_impl.cpp:161-239): lane owns entries i0 = lane and i1 = lane + 64
+            const int i0 = lane, i1 = lane + 64;
+            const int l0 = i0 < k ? T->t_loc[i0] : 0, d0 = i0 < k ? T->t_seed[i0] : 0;
+            const int l1 = i1 < k ? T->t_loc[i1] : 0, d1 = i1 < k ? T->t_seed[i1] : 0;
+            int temp0 = d0, temp1 = d1, sc0 = 0, sc1 = 0;
+            for (int j = 1; j < k; ++j) {
+                const int lj = T->t_loc[j], dj = T->t_seed[j];
+                bool v0 = i0 < j && temp0 != dj && dj - d0 > 0 && lj - l0 > 0 && lj - l0 < read_size && ddf_find(lj - l0, dj - d0, cutoff);
+                bool v1 = i1 < j && i1 < k && temp1 != dj && dj - d1 > 0 && lj - l1 > 0 && lj - l1 < read_size && ddf_find(lj - l1, dj - d1, cutoff);
+                if (v0) { ++sc0; temp0 = dj; }
+                if (v1) { ++sc1; temp1 = dj; }
+                int votes = __popcll(__ballot(v0)) + __popcll(__ballot(v1));
+                if (j < 64) { if (lane == j) sc0 += votes; }
+                else if (lane == j - 64) sc1 += votes;
+            }
+            int mv = max(i0 < k ? sc0 : -1, i1 < k ? sc1 : -1);
+            for (int o = 32; o > 0; o >>= 1) mv = max(mv, __shfl_xor(mv, o));
+            const int maxval = mv;
+            if (maxval < 5) continue;
+            const uint64_t eq0 = __ballot(i0 < k && sc0 == maxval), eq1 = __ballot(i1 < k && sc1 == maxval);
+            const int maxi = eq0 ? __ffsll((unsigned long long)eq0) - 1 : 64 + __ffsll((unsigned long long)eq1) - 1;
+            const int rep = __popcll(eq0) + __popcll(eq1) - 1;
+            int rep_loc;
+            if (rep == maxval) {
+                rep_loc = maxi;
+            } else {
+                const int lm = T->t_loc[maxi], dm = T->t_seed[maxi];
+                // selected = DDF-consistent with maxi (before: "< read_len", after: "<= read_len"), plus maxi itself
+                bool q0 = false, q1 = false;
+                if (i0 < k) {
+                    if (i0 < maxi) q0 = dm - d0 > 0 && lm - l0 > 0 && lm - l0 < read_size && ddf_find(lm - l0, dm - d0, cutoff);
+                    else if (i0 == maxi) q0 = true;
+                    else q0 = d0 - dm > 0 && l0 - lm > 0 && l0 - lm <= read_size && ddf_find(l0 - lm, d0 - dm, cutoff);
+                }
+                if (i1 < k) {
+                    if (i1 < maxi) q1 = dm - d1 > 0 && lm - l1 > 0 && lm - l1 < read_size && ddf_find(lm - l1, dm - d1, cutoff);
+                    else if (i1 == maxi) q1 = true;
+                    else q1 = d1 - dm > 0 && l1 - lm > 0 && l1 - lm <= read_size && ddf_find(l1 - lm, d1 - dm, cutoff);
+                }
+                const uint64_t s0m = __ballot(q0), s1m = __ballot(q1);
+                const uint64_t z0 = __ballot(q0 && l0 != 0), z1 = __ballot(q1 && l1 != 0);
+                // loc[0] == 0 doubles as "unset" (pw_impl.cpp:198,211,224): first selected entry with a non-zero
+                // location wins; if every selected location is 0 the last selected entry wins
+                if (z0) rep_loc = __ffsll((unsigned long long)z0) - 1;
+                else if (z1) rep_loc = 64 + __ffsll((unsigned long long)z1) - 1;
+                else if (s1m) rep_loc = 64 + (63 - __clzll((unsigned long long)s1m));
+                else rep_loc = 63 - __clzll((unsigned long long)s0m);
+            }
+            const int vote = rep_loc < 64 ? __shfl(sc0, rep_loc) : __shfl(sc1, rep_loc - 64);
+            if (vote < 2 * P.min_kmer_match + 2) continue;
+            const int loc_seed = T->t_seed[rep_loc];
+            const int loc_list = start_loc + T->t_loc[rep_loc];
+            int sid = read_id_from_offset(ref_offs, ref_nreads, loc_list);
+            const int sstart = ref_offs[sid].offset, ssize = ref_offs[sid].size;
+            const int send = sstart + ssize + 1;
+            sid += ref_start_id;
+            if (sid > read_id) continue;
+            if (sid == read_id) {
+                // scrub the read's own region (pw_impl.cpp:371-383); only loczhi is compacted, seedno is not
+                int u_k = sstart / ZV;
+                int gg = seg_find(seg_id, nseg, (uint32_t)u_k);
+                if (gg >= 0) {
+                    const int lim = sstart % ZV, cnt = min(SEG_SCORE(gg), SM);
+                    uint32_t* L = SEG_LIST(gg);
+                    uint32_t e = lane < cnt ? L[lane] : 0;
+                    bool keep = lane < cnt && ent_loc(e) < lim;
+                    uint64_t km = __ballot(keep);
+                    int dstp = __popcll(km & ((1ull << lane) - 1ull));
+                    __syncthreads();
+                    if (keep) L[dstp] = (L[dstp] & 0xFFFFu) | (e & 0xFFFF0000u);
+                    __syncthreads();
+                    if (lane == 0) SET_SCORE(gg, __popcll(km));
+                }
+                ++u_k;
+                const int kend = send / ZV;
+                {
+                    // segments strictly between: score = 0
+                    int lo = 0, hi = nseg;
+                    while (lo < hi) { int mid = (lo + hi) >> 1; if ((int)seg_id[mid] < u_k) lo = mid + 1; else hi = mid; }
+                    for (int x = lo + lane; x < nseg && (int)seg_id[x] < kend; x += 64) SET_SCORE(x, 0);
+                }
+                const int tail_seg = max(u_k, kend);
+                gg = seg_find(seg_id, nseg, (uint32_t)tail_seg);
+                __syncthreads();
+                if (gg >= 0) {
+                    const int lim = send % ZV, cnt = min(SEG_SCORE(gg), SM);
+                    uint32_t* L = SEG_LIST(gg);
+                    uint32_t e = lane < cnt ? L[lane] : 0;
+                    bool keep = lane < cnt && ent_loc(e) > lim;
+                    uint64_t km = __ballot(keep);
+                    int dstp = __popcll(km & ((1ull << lane) - 1ull));
+                    __syncthreads();
+                    if (keep) L[dstp] = (L[dstp] & 0xFFFFu) | (e & 0xFFFF0000u);
+                    __syncthreads();
+                    if (lane == 0) SET_SCORE(gg, __popcll(km));
+                }
+                __syncthreads();
+                continue;
+            }
+            // ---- geometry (pw_impl.cpp:386-403)
+            const int loc2 = (loc_seed - 1) * BC;
+            const int left1 = loc_list - sstart + MHIP_KMER_SIZE - 1, right1 = send - loc_list;
+            const int left2 = loc2 + MHIP_KMER_SIZE - 1, right2 = read_size - loc2;
+            const int num1 = left1 > left2 ? left2 : left1, num2 = right1 > right2 ? right2 : right1;
+            if (num1 + num2 < P.min_kmer_dist) continue;
+            // ---- neighbour sweeps (pw_impl.cpp:405-438), f64
+            int seedcount = 0;
+            {
+                int nlb = (num1 + ZV - 1) / ZV;
+                const int lowest = max(0, seg - nlb);          // segments seg-1 .. lowest
+                for (int x = g - 1; x >= 0 && (int)seg_id[x] >= lowest; --x) {
+                    const int sc = SEG_SCORE(x);
+                    if (sc <= 0) continue;
+                    const int sl = (int)seg_id[x] * ZV, scnt = min(sc, SM);
+                    bool ok = false;
+                    if (lane < scnt) {
+                        uint32_t e = SEG_LIST(x)[lane];
+                        ok = fabs((double)(loc_list - sl - ent_loc(e)) / ((double)((loc_seed - ent_seed(e)) * BC) * 1.0) - 1.0) < cutoff;
+                    }
+                    const int agree = __popcll(__ballot(ok));
+                    seedcount += agree;
+                    if (agree * 1.0 / scnt > 0.4) { if (lane == 0) SET_SCORE(x, 0); }
+                    __syncthreads();
+                }
+                int nrb = (num2 + ZV - 1) / ZV;
+                const int highest = seg + nrb;                  // segments seg+1 .. highest
+                for (int x = g + 1; x < nseg && (int)seg_id[x] <= highest; ++x) {
+                    const int sc = SEG_SCORE(x);
+                    if (sc <= 0) continue;
+                    const int sl = (int)seg_id[x] * ZV, scnt = min(sc, SM);
+                    bool ok = false;
+                    if (lane < scnt) {
+                        uint32_t e = SEG_LIST(x)[lane];
+                        ok = fabs((double)(sl + ent_loc(e) - loc_list) / ((double)((ent_seed(e) - loc_seed) * BC) * 1.0) - 1.0) < cutoff;
+                    }
+                    const int agree = __popcll(__ballot(ok));
+                    seedcount += agree;
+                    if (agree * 1.0 / scnt > 0.4) { if (lane == 0) SET_SCORE(x, 0); }
+                    __syncthreads();
+                }
+            }
+            const int cscore = vote + seedcount;
+            // ---- stable insertion into the descending top-MAXC list (pw_impl.cpp:442-455)
+            int ge = 0;
+            for (int i = lane; i < ncand; i += 64) ge += clist[i * 12 + 6] >= cscore ? 1 : 0;
+            for (int o = 32; o > 0; o >>= 1) ge += __shfl_xor(ge, o);
+            const int pos = ge;                                  // == high + 1
+            const int last_src = (ncand < MAXC) ? ncand - 1 : ncand - 2;
+            __syncthreads();
+            for (int top = last_src; top >= pos; top -= 64) {
+                const int i = top - lane;
+                int v[12];
+                if (i >= pos) {
+#pragma unroll
+                    for (int q = 0; q < 12; ++q) v[q] = clist[i * 12 + q];
+                }
+                __syncthreads();
+                if (i >= pos) {
+#pragma unroll
+                    for (int q = 0; q < 12; ++q) clist[(i + 1) * 12 + q] = v[q];
+                }
+                __syncthreads();
+            }
+            if (pos < MAXC && lane == 0) {
+                int* c = clist + pos * 12;
+                c[0] = loc_list - sstart; c[1] = loc2; c[2] = left1; c[3] = left2; c[4] = right1; c[5] = right2;
+                c[6] = cscore; c[7] = num1; c[8] = num2; c[9] = sid; c[10] = sstart; c[11] = strand;
+            }
+            if (ncand < MAXC) ++ncand;
+            __syncthreads();
+        }
+#undef SEG_LIST
+#undef SEG_SCORE
+#undef SET_SCORE
+    }
+    __syncthreads();
+    int* o = (int*)(out + (size_t)r * MAXC);
+    for (int i = lane; i < ncand * 12; i += 64) o[i] = clist[i];
+    if (lane == 0) {
+        out_counts[r] = ncand;
+        atomicAdd(&counters[2], (unsigned long long)ncand);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static int bits_for(uint32_t maxv) {
+    int b = 0;
+    while ((1ull << b) <= maxv) ++b;
+    return b < 1 ? 1 : b;
+}
+
+static int seed_batch(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref, const mhip_volume* reads, int rb, int re,
+                      const mhip_params* P, mhip_candidate* d_out, int32_t* d_counts) {
+    const int nr = re - rb, ns = 2 * nr;
+    std::vector<uint32_t> kmb((size_t)ns);
+    uint64_t sumK = 0;
+    for (int r = 0; r < nr; ++r) {
+        int L = reads->h_offs[(size_t)(rb + r)].size;
+        int K = L < MHIP_KMER_SIZE ? 0 : (L - MHIP_KMER_SIZE) / BC + 1;
+        kmb[(size_t)2 * r] = (uint32_t)sumK; sumK += (uint64_t)K;
+        kmb[(size_t)2 * r + 1] = (uint32_t)sumK; sumK += (uint64_t)K;
+    }
+    if (sumK >= 0xFFFFFFFFull) { mhip_set_error("seed batch too large"); return -1; }
+    SeedArrays A;
+    memset(&A, 0, sizeof(A));
+    uint32_t* d_kmb;
+    if (c->scratch("sd_kmbase", sizeof(uint32_t) * (size_t)ns, (void**)&d_kmb)) return -1;
+    if (c->scratch("sd_kmbstart", sizeof(uint32_t) * (size_t)(sumK + 1), (void**)&A.km_bstart)) return -1;
+    if (c->scratch("sd_kmhpre", sizeof(uint32_t) * (size_t)(sumK + 1), (void**)&A.km_hpre)) return -1;
+    if (c->scratch("sd_hits", sizeof(uint32_t) * (size_t)ns, (void**)&A.strand_hits)) return -1;
+    if (c->scratch("sd_hbase", sizeof(uint64_t) * (size_t)(ns + 1), (void**)&A.hit_base)) return -1;
+    if (c->scratch("sd_nseg", sizeof(uint32_t) * (size_t)ns, (void**)&A.nseg)) return -1;
+    if (c->scratch("sd_nrec", sizeof(uint32_t) * (size_t)ns, (void**)&A.nrec)) return -1;
+    if (c->scratch("sd_ngated", sizeof(uint32_t) * (size_t)ns, (void**)&A.ngated)) return -1;
+    A.km_base = d_kmb;
+    HIPCHK(hipMemcpyAsync(d_kmb, kmb.data(), sizeof(uint32_t) * (size_t)ns, hipMemcpyHostToDevice, c->stream));
+    LAUNCH(c, "seed_probe", seed_probe, ns, SEED_BLOCK, 0, (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs, rb,
+           (const uint32_t*)idx->d_starts, A, (unsigned long long*)c->d_counters);
+    LAUNCH(c, "seed_scan", seed_scan, 1, 1024, 0, (const uint32_t*)A.strand_hits, ns, A.hit_base);
+    uint64_t Htot = 0;
+    HIPCHK(hipMemcpyAsync(&Htot, A.hit_base + ns, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));   // also orders the kmb host buffer
+    const size_t Hc = (size_t)Htot + 64;
+    if (c->scratch("sd_keysA", sizeof(uint64_t) * Hc, (void**)&A.keysA)) return -1;
+    if (c->scratch("sd_keysB", sizeof(uint64_t) * Hc, (void**)&A.keysB)) return -1;
+    if (c->scratch("sd_ent", sizeof(uint32_t) * Hc, (void**)&A.ent)) return -1;
+    if (c->scratch("sd_entfin", sizeof(uint32_t) * Hc, (void**)&A.ent_fin)) return -1;
+    if (c->scratch("sd_escore", sizeof(uint16_t) * Hc, (void**)&A.escore)) return -1;
+    if (c->scratch("sd_segid", sizeof(uint32_t) * Hc, (void**)&A.seg_id)) return -1;
+    if (c->scratch("sd_segstart", sizeof(uint32_t) * Hc, (void**)&A.seg_start)) return -1;
+    if (c->scratch("sd_segscore", sizeof(int32_t) * Hc, (void**)&A.seg_score)) return -1;
+    if (c->scratch("sd_segkmlast", sizeof(uint32_t) * Hc, (void**)&A.seg_kmlast)) return -1;
+    if (c->scratch("sd_segtfirst", sizeof(uint64_t) * Hc, (void**)&A.seg_tfirst)) return -1;
+    if (c->scratch("sd_gated", sizeof(uint32_t) * Hc, (void**)&A.gated)) return -1;
+    int in_b = 0;
+    if (Htot > 0) {
+        LAUNCH(c, "seed_emit", seed_emit, ns, SEED_BLOCK, 0, (const mhip_offset_t*)reads->d_offs, rb, (const int32_t*)idx->d_offsets, A);
+        const int nbits = bits_for((uint32_t)(ref->num_bases / ZV));
+        const int npass = (nbits + 7) / 8;
+        const int per = (nbits + npass - 1) / npass;
+        int done = 0;
+        for (int p = 0; p < npass; ++p) {
+            int b = std::min(per, nbits - done);
+            LAUNCH(c, "seed_sort_pass", seed_sort_pass, ns, SEED_BLOCK, 0, A, in_b, KEY_SEG_SHIFT + done, b);
+            done += b;
+            in_b ^= 1;
+        }
+    }
+    LAUNCH(c, "seed_build", seed_build, ns, SEED_BLOCK, 0, A, in_b, (int)P->min_kmer_match, P->ddfs_cutoff);
+    c->dbg_blob.assign((const char*)&A, (const char*)&A + sizeof(A));
+    c->dbg_ns = ns;
+    if (c->dbg_flags & 1) {
+        HIPCHK(hipMemsetAsync(d_counts, 0, sizeof(int32_t) * (size_t)nr, c->stream));
+        return 0;
+    }
+    const size_t lds = sizeof(int) * 12 * (size_t)P->maxc + sizeof(CandLds);
+    LAUNCH(c, "seed_cand", seed_cand, nr, WAVE, lds, A, (const mhip_offset_t*)ref->d_offs, ref->num_reads, ref->start_read_id,
+           (const mhip_offset_t*)reads->d_offs, rb, reads->start_read_id, *P, d_out, d_counts, (unsigned long long*)c->d_counters);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// reads per launch: bounded by an estimate of the hits they produce (batch arrays cost ~ 60 bytes per hit)
+static int next_batch_end(const mhip_index* idx, const mhip_volume* reads, int rb, int re) {
+    const double hits_per_lookup = (double)idx->num_kmers / (double)NKMER + 2.0;
+    const double budget = 160e6;   // hits per launch (~10 GB of batch arrays)
+    double acc = 0;
+    int r = rb;
+    while (r < re) {
+        int L = reads->h_offs[(size_t)r].size;
+        double k = L < MHIP_KMER_SIZE ? 0 : (double)((L - MHIP_KMER_SIZE) / BC + 1);
+        acc += 2.0 * k * hits_per_lookup;
+        ++r;
+        if (acc > budget || r - rb >= (1 << 20)) break;
+    }
+    return r;
+}
+
+extern "C" {
+
+int mhip_seed_reads_dev(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref, const mhip_volume* reads, int rid_begin,
+                        int rid_end, const mhip_params* P, void* d_out, void* d_out_counts) {
+    HIPCHK(hipSetDevice(c->device));
+    if (rid_begin < 0 || rid_end > reads->num_reads || rid_begin > rid_end) { mhip_set_error("bad read range [%d,%d)", rid_begin, rid_end); return -1; }
+    if (P->maxc < 1 || P->maxc > MAXC_LIMIT) { mhip_set_error("maxc %d outside 1..%d", P->maxc, MAXC_LIMIT); return -1; }
+    if (ref->num_reads == 0) { mhip_set_error("empty reference volume"); return -1; }
+    int rb = rid_begin;
+    while (rb < rid_end) {
+        int re = next_batch_end(idx, reads, rb, rid_end);
+        if (seed_batch(c, idx, ref, reads, rb, re, P, (mhip_candidate*)d_out + (size_t)(rb - rid_begin) * P->maxc,
+                       (int32_t*)d_out_counts + (rb - rid_begin)))
+            return -1;
+        rb = re;
+    }
+    return 0;
+}
+
+int mhip_seed_reads(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref, const mhip_volume* reads, int rid_begin,
+                    int rid_end, const mhip_params* P, mhip_candidate* out, int32_t* out_counts) {
+    HIPCHK(hipSetDevice(c->device));
+    const size_t n = (size_t)std::max(0, rid_end - rid_begin);
+    if (n == 0) return 0;
+    mhip_candidate* d_out;
+    int32_t* d_cnt;
+    if (c->scratch("sd_out", sizeof(mhip_candidate) * n * (size_t)P->maxc, (void**)&d_out)) return -1;
+    if (c->scratch("sd_outcnt", sizeof(int32_t) * n, (void**)&d_cnt)) return -1;
+    if (mhip_seed_reads_dev(c, idx, ref, reads, rid_begin, rid_end, P, d_out, d_cnt)) return -1;
+    HIPCHK(hipMemcpyAsync(out_counts, d_cnt, sizeof(int32_t) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(out, d_out, sizeof(mhip_candidate) * n * (size_t)P->maxc, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ---- debug / test access to the per-strand state of the last seed batch (not part of the product ABI) ----
+int mhip_debug_set_flags(mhip_ctx* c, int flags) { c->dbg_flags = flags; return 0; }
+
+// what: 0 header {H, nseg, nrec, ngated}, 1 seg_id, 2 seg_score, 3 seg_start, 4 ent, 5 ent_fin, 6 gated, 7 sorted keys (u64)
+int mhip_debug_strand(mhip_ctx* c, int strand, int what, void* out, int64_t cap_bytes, int sorted_in_b) {
+    HIPCHK(hipSetDevice(c->device));
+    if (c->dbg_blob.size() != sizeof(SeedArrays) || strand < 0 || strand >= c->dbg_ns) { mhip_set_error("no debug state"); return -1; }
+    SeedArrays A;
+    memcpy(&A, c->dbg_blob.data(), sizeof(A));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    uint32_t H, nseg, nrec, ng;
+    uint64_t hb;
+    HIPCHK(hipMemcpy(&H, A.strand_hits + strand, 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&nseg, A.nseg + strand, 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&nrec, A.nrec + strand, 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&ng, A.ngated + strand, 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&hb, A.hit_base + strand, 8, hipMemcpyDeviceToHost));
+    const void* src = nullptr;
+    size_t bytes = 0;
+    uint32_t hdr[4] = {H, nseg, nrec, ng};
+    switch (what) {
+    case 0: if (cap_bytes < 16) return -1; memcpy(out, hdr, 16); return 0;
+    case 1: src = A.seg_id + hb; bytes = 4ull * nseg; break;
+    case 2: src = A.seg_score + hb; bytes = 4ull * nseg; break;
+    case 3: src = A.seg_start + hb; bytes = 4ull * nseg; break;
+    case 4: src = A.ent + hb; bytes = 4ull * nrec; break;
+    case 5: src = A.ent_fin + hb; bytes = 4ull * nrec; break;
+    case 6: src = A.gated + hb; bytes = 4ull * ng; break;
+    case 7: src = (sorted_in_b ? A.keysB : A.keysA) + hb; bytes = 8ull * H; break;
+    default: mhip_set_error("bad what"); return -1;
+    }
+    if ((int64_t)bytes > cap_bytes) { mhip_set_error("debug buffer too small"); return -1; }
+    if (bytes) HIPCHK(hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,217 @@
+"""ctypes mirror of include/mecat_hip.h (see that header for the reference functions each call replaces)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libmecat_hip.so")
+
+
+class MhipError(RuntimeError):
+    pass
+
+
+class Offset(C.Structure):
+    _fields_ = [("offset", C.c_int32), ("size", C.c_int32)]
+
+
+class Candidate(C.Structure):
+    """candidate_save (mecat2pw/pw_impl.h:21-25)"""
+    _fields_ = [(n, C.c_int32) for n in ("loc1", "loc2", "left1", "left2", "right1", "right2", "score", "num1", "num2",
+                                         "readno", "readstart", "chain")]
+
+
+class Params(C.Structure):
+    _fields_ = [("maxc", C.c_int32), ("min_align_size", C.c_int32), ("min_kmer_match", C.c_int32),
+                ("min_kmer_dist", C.c_int32), ("tech", C.c_int32), ("ddfs_cutoff", C.c_double)]
+
+
+class AlnResult(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("ok", "query_start", "query_end", "target_start", "target_end", "matches",
+                                         "columns", "blocks")]
+
+
+class AlnJob(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("qid_local", "sid_local", "chain", "qstart", "sstart")]
+
+
+CAND_DTYPE = np.dtype([(n, np.int32) for n, _ in Candidate._fields_])
+ALN_DTYPE = np.dtype([(n, np.int32) for n, _ in AlnResult._fields_])
+JOB_DTYPE = np.dtype([(n, np.int32) for n, _ in AlnJob._fields_])
+assert CAND_DTYPE.itemsize == C.sizeof(Candidate) == 48
+
+_lib = None
+
+
+def lib():
+    """Loads libmecat_hip.so; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not os.path.exists(p):
+        raise MhipError("%s is missing: run `make hip` (python -c 'import __graft_entry__ as g; g.build()'). "
+                        "There is no CPU fallback." % p)
+    L = C.CDLL(p)
+    vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
+    L.mhip_last_error.restype = C.c_char_p
+    L.mhip_ctx_create.argtypes = [i32, vp, C.POINTER(vp)]
+    L.mhip_ctx_destroy.argtypes = [vp]
+    L.mhip_ctx_sync.argtypes = [vp]
+    L.mhip_params_default.argtypes = [C.POINTER(Params), i32]
+    L.mhip_ctx_set_profiling.argtypes = [vp, i32]
+    L.mhip_ctx_kernel_stats.argtypes = [vp, C.c_char_p, C.POINTER(i64), C.POINTER(C.c_double)]
+    L.mhip_ctx_kernel_names.argtypes = [vp, C.c_char_p, i32]
+    L.mhip_ctx_reset_stats.argtypes = [vp]
+    L.mhip_ctx_counters.argtypes = [vp, C.POINTER(i64)]
+    L.mhip_volume_upload.argtypes = [vp, vp, vp, i32, i32, i32, C.POINTER(vp)]
+    L.mhip_volume_free.argtypes = [vp]
+    L.mhip_volume_num_reads.argtypes = [vp]
+    L.mhip_volume_num_bases.argtypes = [vp]
+    L.mhip_index_build.argtypes = [vp, vp, C.POINTER(vp)]
+    L.mhip_index_free.argtypes = [vp]
+    L.mhip_index_num_kmers.restype = i64
+    L.mhip_index_num_kmers.argtypes = [vp]
+    L.mhip_index_download.argtypes = [vp, vp, vp, vp]
+    L.mhip_seed_reads.argtypes = [vp, vp, vp, vp, i32, i32, C.POINTER(Params), vp, vp]
+    L.mhip_seed_reads_dev.argtypes = [vp, vp, vp, vp, i32, i32, C.POINTER(Params), vp, vp]
+    L.mhip_align_candidates.argtypes = [vp, vp, vp, vp, i32, i32, vp]
+    L.mhip_align_candidates_dev.argtypes = [vp, vp, vp, vp, i32, i32, vp]
+    assert L.mhip_abi_version() == 1
+    _lib = L
+    return L
+
+
+def _chk(rc):
+    if rc != 0:
+        raise MhipError(lib().mhip_last_error().decode())
+
+
+def default_params(tech=0, **kw):
+    p = Params()
+    lib().mhip_params_default(C.byref(p), tech)
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+class Context:
+    def __init__(self, device=0, stream=None):
+        self.h = C.c_void_p()
+        _chk(lib().mhip_ctx_create(device, stream, C.byref(self.h)))
+        self.device = device
+
+    def close(self):
+        if self.h:
+            lib().mhip_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def sync(self):
+        _chk(lib().mhip_ctx_sync(self.h))
+
+    def set_profiling(self, on=True):
+        _chk(lib().mhip_ctx_set_profiling(self.h, int(on)))
+
+    def reset_stats(self):
+        _chk(lib().mhip_ctx_reset_stats(self.h))
+
+    def kernel_stats(self):
+        buf = C.create_string_buffer(8192)
+        _chk(lib().mhip_ctx_kernel_names(self.h, buf, len(buf)))
+        out = {}
+        for name in buf.value.decode().split("\n"):
+            if not name:
+                continue
+            n, ms = C.c_int64(), C.c_double()
+            _chk(lib().mhip_ctx_kernel_stats(self.h, name.encode(), C.byref(n), C.byref(ms)))
+            out[name] = (n.value, ms.value)
+        return out
+
+    def counters(self):
+        a = (C.c_int64 * 8)()
+        _chk(lib().mhip_ctx_counters(self.h, a))
+        names = ("lookups", "hits", "candidates", "dw_blocks", "dw_cells", "snake_bases", "aligned_bases", "aln_ok")
+        return dict(zip(names, [int(x) for x in a]))
+
+
+class Volume:
+    """device-resident volume_t; `pac`, `offs` as load_volume() leaves them (uint8[(num_bases+3)//4], int32[n,2])"""
+
+    def __init__(self, ctx, pac, offs, num_bases, start_read_id=0):
+        pac = np.ascontiguousarray(pac, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.int32).reshape(-1, 2)
+        assert len(pac) >= (num_bases + 3) // 4
+        self.h = C.c_void_p()
+        self.offs = offs
+        self.num_reads = len(offs)
+        self.num_bases = int(num_bases)
+        self.start_read_id = start_read_id
+        _chk(lib().mhip_volume_upload(ctx.h, pac.ctypes.data, offs.ctypes.data, len(offs), num_bases, start_read_id,
+                                      C.byref(self.h)))
+
+    @classmethod
+    def from_file(cls, ctx, path):
+        """reads a wrk/vol<k> file (layout of dump_volume, common/split_database.cpp:135-153)"""
+        with open(path, "rb") as f:
+            hdr = np.fromfile(f, dtype=np.int32, count=3)
+            offs = np.fromfile(f, dtype=np.int32, count=2 * int(hdr[0])).reshape(-1, 2)
+            pac = np.fromfile(f, dtype=np.uint8, count=(int(hdr[1]) + 3) // 4)
+        return cls(ctx, pac, offs, int(hdr[1]), int(hdr[2]))
+
+    def free(self):
+        if self.h:
+            lib().mhip_volume_free(self.h)
+            self.h = C.c_void_p()
+
+
+class Index:
+    def __init__(self, ctx, vol):
+        self.h = C.c_void_p()
+        self.ctx = ctx
+        _chk(lib().mhip_index_build(ctx.h, vol.h, C.byref(self.h)))
+
+    @property
+    def num_kmers(self):
+        return lib().mhip_index_num_kmers(self.h)
+
+    def download(self, want_counts=True, want_offsets=True):
+        counts = np.empty(1 << 26, dtype=np.int32) if want_counts else None
+        offs = np.empty(self.num_kmers, dtype=np.int32) if want_offsets else None
+        _chk(lib().mhip_index_download(self.ctx.h, self.h, counts.ctypes.data if want_counts else None,
+                                       offs.ctypes.data if want_offsets else None))
+        return counts, offs
+
+    def free(self):
+        if self.h:
+            lib().mhip_index_free(self.h)
+            self.h = C.c_void_p()
+
+
+def seed_reads(ctx, idx, ref, reads, rid_begin, rid_end, params):
+    """-> (cands structured array [n, maxc], counts int32[n]) on the host"""
+    n = rid_end - rid_begin
+    out = np.zeros((n, params.maxc), dtype=CAND_DTYPE)
+    cnt = np.zeros(n, dtype=np.int32)
+    _chk(lib().mhip_seed_reads(ctx.h, idx.h, ref.h, reads.h, rid_begin, rid_end, C.byref(params), out.ctypes.data,
+                               cnt.ctypes.data))
+    return out, cnt
+
+
+def seed_reads_dev(ctx, idx, ref, reads, rid_begin, rid_end, params, d_out, d_counts):
+    _chk(lib().mhip_seed_reads_dev(ctx.h, idx.h, ref.h, reads.h, rid_begin, rid_end, C.byref(params), d_out, d_counts))
+
+
+def align_candidates(ctx, ref, reads, jobs, min_align_size):
+    jobs = np.ascontiguousarray(jobs, dtype=JOB_DTYPE)
+    out = np.zeros(len(jobs), dtype=ALN_DTYPE)
+    if len(jobs):
+        _chk(lib().mhip_align_candidates(ctx.h, ref.h, reads.h, jobs.ctypes.data, len(jobs), min_align_size, out.ctypes.data))
+    return out
+
+
+def align_candidates_dev(ctx, ref, reads, d_jobs, n, min_align_size, d_out):
+    _chk(lib().mhip_align_candidates_dev(ctx.h, ref.h, reads.h, d_jobs, n, min_align_size, d_out))

@@ -545,6 +545,25 @@ int orc_seed_read(const orc_volume* ref, const orc_volume* reads, const orc_inde
     return n;
 }
 
+int orc_seeding_state(const char* read, int read_size, const orc_index* ridx, orc_seeding_bk* bk, int cap,
+                      int* seg_ids, int16_t* idx_score, int16_t* scores, int16_t* loczhi, int16_t* seedno)
+{
+    int n = orc_seeding(read, read_size, ridx, bk);
+    for (int i = 0; i < n; ++i) {
+        int sgi = bk->index_list[i];
+        if (i < cap) {
+            seg_ids[i] = sgi;
+            idx_score[i] = bk->index_score[i];
+            scores[i] = bk->database[sgi].score;
+            memcpy(loczhi + (size_t)i * ORC_SM, bk->database[sgi].loczhi, sizeof(int16_t) * ORC_SM);
+            memcpy(seedno + (size_t)i * ORC_SM, bk->database[sgi].seedno, sizeof(int16_t) * ORC_SM);
+        }
+        bk->database[sgi].score = 0;
+        bk->database[sgi].index = -1;
+    }
+    return n;
+}
+
 /* ------------------------------------------------------------------ A9: .can */
 
 /* candidate_detect pw_impl.cpp:767-792 */

@@ -119,6 +119,11 @@ int orc_get_candidates(const orc_volume* ref, orc_seeding_bk* bk, int num_segs, 
 int orc_seed_read(const orc_volume* ref, const orc_volume* reads, const orc_index* ridx, orc_seeding_bk* bk,
                   int rid, int chain_as_char, const orc_params* p, orc_candidate* out);
 
+/* test/debug: run orc_seeding for one strand, copy the state get_candidates would see, then reset the touched segments.
+   seg_ids/idx_score in index_list (first-touch) order; scores[i], loczhi[i*40..], seedno[i*40..] for segment seg_ids[i]. */
+int orc_seeding_state(const char* read, int read_size, const orc_index* ridx, orc_seeding_bk* bk, int cap,
+                      int* seg_ids, int16_t* idx_score, int16_t* scores, int16_t* loczhi, int16_t* seedno);
+
 /* ---- A9: .can records ---- */
 void orc_can_record(const orc_candidate* c, int qid, int qsize, int ssize, orc_ext_candidate* ec); /* :767-792 */
 int orc_can_line(const orc_ext_candidate* ec, char* buf);    /* alignment.cpp:18-32 ; returns length */

@@ -1,0 +1,194 @@
+"""GPU parity tests: the HIP path (through the C ABI of include/mecat_hip.h) against the CPU oracle on the same seeded
+inputs, and against the committed golden vectors generated from the unmodified reference.  Bit-exact bar: every index
+entry, candidate field and overlap coordinate is integer work."""
+import ctypes as C
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+G = json.load(open(os.path.join(H.GOLDEN, "golden.json")))
+
+
+def sha(b):
+    return hashlib.sha256(b).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import mecat_amd.hip as M
+    return M
+
+
+@pytest.fixture(scope="module")
+def ctx(hip):
+    c = hip.Context(0)
+    yield c
+    c.close()
+
+
+_cache = {}
+
+
+def dataset(name, hip, ctx):
+    """-> dict(codes, lens, ov (oracle volume), oidx (oracle index), offs, pac, gv (gpu volume), gidx (gpu index))"""
+    if name in _cache:
+        return _cache[name]
+    if name in G["sets"]:
+        g = G["sets"][name]["gen"]
+    else:
+        g = dict(nreads=int(name.split("_")[1]), L=int(name.split("_")[2]), err=0.15, genome=int(name.split("_")[3]),
+                 seed=int(name.split("_")[4]), ont=0)
+    codes, lens = H.synth_reads(g["nreads"], g["L"], g["err"], g["genome"], g["seed"], g["ont"])
+    ov = H.orc_pack(codes, lens)
+    oidx = H.orc().orc_index_build(ov)
+    offs, pac = H.vol_arrays(ov)
+    gv = hip.Volume(ctx, pac, offs, ov.contents.num_bases, 0)
+    gidx = hip.Index(ctx, gv)
+    d = dict(codes=codes, lens=lens, ov=ov, oidx=oidx, offs=offs, pac=pac, gv=gv, gidx=gidx, tech=g["ont"])
+    _cache[name] = d
+    return d
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_ont", "config1"])
+def test_index_matches_oracle_and_golden(name, hip, ctx):
+    d = dataset(name, hip, ctx)
+    counts, offsets = d["gidx"].download()
+    oi = d["oidx"].contents
+    assert d["gidx"].num_kmers == oi.num_kmers
+    ocounts = np.ctypeslib.as_array(oi.counts, shape=(H.NK,))
+    assert np.array_equal(counts, ocounts)
+    assert np.array_equal(offsets, np.ctypeslib.as_array(oi.offsets, shape=(oi.num_kmers,)))
+    gi = G["sets"][name]["index"]
+    assert sha(counts.tobytes()) == gi["counts_sha256"] and sha(offsets.tobytes()) == gi["offsets_sha256"]
+
+
+def test_index_ragged_edge_cases(hip, ctx):
+    """reads shorter than k, length exactly k, a 1-base read, > 128 copies of one k-mer (bucket dropped)"""
+    rng = np.random.default_rng(3)
+    rep = rng.integers(0, 4, size=13).astype(np.uint8)
+    reads = [rng.integers(0, 4, size=n).astype(np.uint8) for n in (1, 5, 12, 13, 14, 40, 300, 16, 17, 31, 32, 33)]
+    reads += [np.concatenate([rep, rng.integers(0, 4, size=7).astype(np.uint8)]) for _ in range(140)]
+    reads += [rng.integers(0, 4, size=int(n)).astype(np.uint8) for n in rng.integers(1, 200, size=50)]
+    lens = np.array([len(r) for r in reads], dtype=np.int32)
+    codes = np.concatenate(reads)
+    ov = H.orc_pack(codes, lens)
+    oidx = H.orc().orc_index_build(ov)
+    offs, pac = H.vol_arrays(ov)
+    gv = hip.Volume(ctx, pac, offs, ov.contents.num_bases, 0)
+    gi = hip.Index(ctx, gv)
+    counts, offsets = gi.download()
+    oi = oidx.contents
+    assert gi.num_kmers == oi.num_kmers
+    assert np.array_equal(counts, np.ctypeslib.as_array(oi.counts, shape=(H.NK,)))
+    assert np.array_equal(offsets, np.ctypeslib.as_array(oi.offsets, shape=(oi.num_kmers,)))
+    k = int("".join(str(int(x)) for x in rep), 4)
+    assert counts[k] == 0      # 140 > 128 occurrences: dropped
+    gi.free()
+    gv.free()
+
+
+def _gpu_cands(hip, ctx, d, params, rids=None):
+    n = len(d["lens"])
+    out, cnt = hip.seed_reads(ctx, d["gidx"], d["gv"], d["gv"], 0, n, params)
+    return out, cnt
+
+
+def _cmp_cands(got, cnt, want_list):
+    bad = []
+    for rid, w in enumerate(want_list):
+        g = got[rid][: cnt[rid]]
+        ok = cnt[rid] == len(w) and all(np.array_equal(g[f], w[f]) for f in H.CAND_DTYPE.names)
+        if not ok:
+            bad.append(rid)
+    return bad
+
+
+@pytest.mark.parametrize("name,maxc", [("tiny", 100), ("tiny", 5), ("tiny_ont", 100), ("tiny_ont", 5), ("config1", 100)])
+def test_candidates_match_oracle(name, maxc, hip, ctx):
+    d = dataset(name, hip, ctx)
+    p = hip.default_params(d["tech"], maxc=maxc)
+    got, cnt = _gpu_cands(hip, ctx, d, p)
+    want = H.orc_seed_all(d["ov"], d["ov"], d["oidx"], H.orc_params(tech=d["tech"], maxc=maxc))
+    bad = _cmp_cands(got, cnt, want)
+    if bad:
+        rid = bad[0]
+        msg = "%d/%d reads differ; first rid %d\nGPU: %s\nORC: %s" % (len(bad), len(want), rid, got[rid][: cnt[rid]], want[rid])
+        pytest.fail(msg)
+    assert int(cnt.sum()) > 0
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_ont", "config1"])
+def test_can_lines_match_golden(name, hip, ctx):
+    d = dataset(name, hip, ctx)
+    p = hip.default_params(d["tech"])
+    got, cnt = _gpu_cands(hip, ctx, d, p)
+    cands = [got[r][: cnt[r]] for r in range(len(cnt))]
+    lines = sorted(H.can_lines_from_cands(cands, d["offs"], d["offs"]))
+    assert len(lines) == G["sets"][name]["can_lines"]
+    assert sha(("\n".join(lines) + "\n").encode()) == G["sets"][name]["can_sorted_sha256"]
+
+
+def test_candidates_small_batches_equal_one_batch(hip, ctx):
+    """the read range may be cut anywhere: per-read results do not depend on the batch"""
+    d = dataset("tiny", hip, ctx)
+    p = hip.default_params(0)
+    full, cnt = _gpu_cands(hip, ctx, d, p)
+    for (a, b) in [(0, 1), (1, 7), (7, 130), (130, 200)]:
+        out, c = hip.seed_reads(ctx, d["gidx"], d["gv"], d["gv"], a, b, p)
+        assert np.array_equal(c, cnt[a:b])
+        for r in range(a, b):
+            assert np.array_equal(out[r - a][: c[r - a]], full[r][: cnt[r]])
+
+
+def test_two_volume_grid_cell(hip, ctx):
+    """query volume != reference volume (start_read_id > 0): off-diagonal grid cell (i, j > i)"""
+    codes, lens = H.synth_reads(300, 3000, 0.15, 40000, 21)
+    cut = 170
+    nb = int(lens[:cut].sum())
+    v0 = H.orc_pack(codes[:nb], lens[:cut], 0)
+    v1 = H.orc_pack(codes[nb:], lens[cut:], cut)
+    oidx = H.orc().orc_index_build(v0)
+    o0, p0 = H.vol_arrays(v0)
+    o1, p1 = H.vol_arrays(v1)
+    g0 = hip.Volume(ctx, p0, o0, v0.contents.num_bases, 0)
+    g1 = hip.Volume(ctx, p1, o1, v1.contents.num_bases, cut)
+    gi = hip.Index(ctx, g0)
+    p = hip.default_params(0)
+    got, cnt = hip.seed_reads(ctx, gi, g0, g1, 0, len(lens) - cut, p)
+    want = H.orc_seed_all(v0, v1, oidx, H.orc_params(tech=0))
+    assert not _cmp_cands(got, cnt, want)
+    assert int(cnt.sum()) > 50
+    for x in (gi, g0, g1):
+        x.free()
+
+
+def test_empty_and_short_reads(hip, ctx):
+    """reads shorter than one k-mer produce no lookups; a volume of only such reads yields no candidates"""
+    rng = np.random.default_rng(4)
+    lens = np.array([3, 12, 13, 25, 1, 2000, 2000], dtype=np.int32)
+    base = rng.integers(0, 4, size=2000).astype(np.uint8)
+    reads = [rng.integers(0, 4, size=n).astype(np.uint8) for n in lens[:5]] + [base, base.copy()]
+    codes = np.concatenate(reads)
+    ov = H.orc_pack(codes, lens)
+    oidx = H.orc().orc_index_build(ov)
+    offs, pac = H.vol_arrays(ov)
+    gv = hip.Volume(ctx, pac, offs, ov.contents.num_bases, 0)
+    gi = hip.Index(ctx, gv)
+    p = hip.default_params(0, min_kmer_dist=100)
+    got, cnt = hip.seed_reads(ctx, gi, gv, gv, 0, len(lens), p)
+    keep = [0, 2, 3, 4, 5, 6]
+    want = H.orc_seed_all(ov, ov, oidx, H.orc_params(tech=0, min_kmer_dist=100), rids=keep)
+    # rid 1 (12 bases): the reference computes (12-13)/10+1 = 1 k-mer and reads past the read (undefined);
+    # we define: a read shorter than k has no k-mers
+    assert cnt[1] == 0 and cnt[0] == 0
+    assert not _cmp_cands(got[keep], cnt[keep], want)
+    assert cnt[6] >= 1     # the duplicate read finds its twin
+    gi.free()
+    gv.free()

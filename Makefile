@@ -37,10 +37,10 @@ $(BINDIR)/mecat2pw: $(HOST_SRCS) $(wildcard mecat_amd/host/*.h) include/mecat_hi
 synth: $(LIBDIR)/libsynth.so $(BINDIR)/synth_reads
 $(LIBDIR)/libsynth.so: mecat_amd/tools/synth_reads.c
 	@mkdir -p $(LIBDIR)
-	$(CC) -O2 -fPIC -shared $< -o $@
+	$(CC) -O2 -fopenmp -fPIC -shared $< -o $@
 $(BINDIR)/synth_reads: mecat_amd/tools/synth_reads.c
 	@mkdir -p $(BINDIR)
-	$(CC) -O2 -DSYNTH_MAIN $< -o $@
+	$(CC) -O2 -fopenmp -DSYNTH_MAIN $< -o $@
 
 oracle:
 	$(MAKE) -C oracle oracle

@@ -1,0 +1,271 @@
+#!/usr/bin/env python3
+"""bench.py — the mecat2pw hot path on MI355X: index build -> seed/DDF filter -> dw extension.
+
+One "step" = one full pass of the hot path over the workload, inputs (the 2-bit volume) already resident in HBM:
+    index build of the volume  ->  candidates of every read (both strands)  ->  dw extension of every candidate
+Workload (BASELINE.json configs[1]): 100 000 synthetic PacBio-style reads x 15 kb @ 15 % error, 30x of a
+50 Mb random genome, seed 2, k = 13, all-vs-all (one volume, one grid cell).  `--workload config1` = 1 000 x 10 kb.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...      (one rank per GPU, RCCL)
+
+N > 1 (strong scaling, total work fixed): every rank rebuilds the index itself (recompute beats moving up to 6 GB of
+positions over a 153 GB/s xGMI link), seeds reads r, r+N, r+2N, ... and the per-read candidate lists are exchanged with
+one RCCL all-gather of padded slabs; the extension stage takes every N-th candidate and its results are all-gathered so
+rank 0 holds the complete overlap set.
+
+Prints ONE JSON line on rank 0 (see the task contract): value = candidate overlaps/sec of the whole job, plus
+aligned Gbase/sec, a `roofline` block for the dominant kernel and a `cpu_baseline` block (the unmodified reference
+mecat2pw from oracle/_ref, or the oracle port, timed on this host on a bounded sample).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(workload, nthreads):
+    """reference mecat2pw (kind "reference") on a bounded sample with the same read length / error / coverage"""
+    from mecat_amd import workload as W
+    n, L, err, G, seed, ont = W.CONFIGS[workload]
+    sn = min(n, 3000)
+    sG = max(int(G * sn / n), 2 * L)
+    codes, lens = W.synth_reads(sn, L, err, sG, seed, ont)
+    d = tempfile.mkdtemp(prefix="mecat_cpu_")
+    fa = os.path.join(d, "s.fa")
+    W.write_fasta(fa, codes, lens)
+    ref = os.path.join(ROOT, "oracle", "_ref", "mecat2pw")
+    sample = "%d reads x %d bp @ %.0f%% error, genome %d (same coverage), seed %d" % (sn, L, err * 100, sG, seed)
+    if os.path.exists(ref):
+        res = {}
+        for task, name in ((0, "can"), (1, "m4")):
+            out = os.path.join(d, "o." + name)
+            t0 = time.time()
+            p = subprocess.run([ref, "-j", str(task), "-d", fa, "-o", out, "-w", os.path.join(d, "w" + name), "-t", str(nthreads),
+                                "-g", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            wall = time.time() - t0
+            if p.returncode != 0:
+                return {"value": None, "unit": "candidates/s", "cores": nthreads, "kind": "reference", "sample": sample,
+                        "error": p.stderr[-300:]}
+            tm = dict(re.findall(r"\[([a-z_ 0-9]+)\] takes ([0-9.]+) secs", p.stderr))
+            hot = float(tm.get("create_ref_index", 0)) + float(tm.get("process volume 0", 0))
+            lines = open(out).read().splitlines()
+            res[name] = (len(lines), hot, wall, lines)
+        ncan, hot0, wall0, _ = res["can"]
+        nm4, hot1, wall1, m4 = res["m4"]
+        abases = sum(int(x.split("\t")[6]) - int(x.split("\t")[5]) for x in m4)
+        return {"value": ncan / hot0, "unit": "candidates/s", "cores": nthreads, "kind": "reference", "sample": sample,
+                "candidates": ncan, "hot_path_s": hot0, "wall_s": wall0,
+                "j1_overlaps_per_s": nm4 / hot1, "j1_aligned_gbase_per_s": abases / 1e9 / hot1, "j1_hot_path_s": hot1}
+    # fall back to the oracle port (single thread)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers as H
+    ov = H.orc_pack(codes, lens)
+    t0 = time.time()
+    oidx = H.orc().orc_index_build(ov)
+    cands = H.orc_seed_all(ov, ov, oidx, H.orc_params(tech=ont))
+    dt = time.time() - t0
+    ncan = sum(len(a) for a in cands)
+    return {"value": ncan / dt, "unit": "candidates/s", "cores": 1, "kind": "port", "sample": sample, "candidates": ncan,
+            "hot_path_s": dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="config2")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-align", action="store_true", help="-j 0 only (index + candidates)")
+    ap.add_argument("--stats", default="", help="write per-kernel stats JSON here (rank 0)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from mecat_amd import hip as M
+    from mecat_amd import workload as W
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    n, L, err, G, seed, ont = W.CONFIGS[args.workload]
+    t0 = time.time()
+    codes, lens = W.synth_reads(n, L, err, G, seed, ont)
+    pac, offs, num_bases = W.pack_volume(codes, lens)
+    del codes
+    if rank == 0:
+        log("[bench] %s: %d reads, %d bases incl. pads, generated+packed in %.1fs" % (args.workload, n, num_bases, time.time() - t0))
+
+    stream = torch.cuda.current_stream(dev)
+    ctx = M.Context(local_rank, stream.cuda_stream)
+    vol = M.Volume(ctx, pac, offs, num_bases, 0)
+    del pac
+    params = M.default_params(ont)
+    maxc = params.maxc
+
+    # static shard of the (only) grid cell: read r -> rank r % world
+    n_local = (n - rank + world - 1) // world
+    n_pad = (n + world - 1) // world
+    d_cands = torch.zeros((n_pad, maxc, 12), dtype=torch.int32, device=dev)
+    d_counts = torch.zeros((n_pad,), dtype=torch.int32, device=dev)
+    if world > 1:
+        g_cands = torch.empty((world, n_pad, maxc, 12), dtype=torch.int32, device=dev)
+        g_counts = torch.empty((world, n_pad), dtype=torch.int32, device=dev)
+    d_jobs = torch.empty((n_pad * world * maxc // world + maxc, 5), dtype=torch.int32, device=dev)
+    d_res = torch.empty((d_jobs.shape[0], 8), dtype=torch.int32, device=dev)
+
+    def one_step(collect=False):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev[0].record(stream)
+        idx = M.Index(ctx, vol)
+        ev[1].record(stream)
+        M.seed_reads_strided_dev(ctx, idx, vol, vol, rank, world, n_local, params, d_cands.data_ptr(), d_counts.data_ptr())
+        if world > 1:
+            # exchange step: RCCL all-gather of the per-read candidate slabs (48-byte candidate_save records)
+            dist.all_gather_into_tensor(g_counts, d_counts)
+            dist.all_gather_into_tensor(g_cands, d_cands)
+            # table row i of rank r is read r + i * world  ->  read-major order
+            full_counts = g_counts.transpose(0, 1).reshape(-1)[:n].contiguous()
+            full_cands = g_cands.transpose(0, 1).reshape(n_pad * world, maxc, 12)[:n].contiguous()
+        else:
+            full_counts, full_cands = d_counts, d_cands
+        ev[2].record(stream)
+        njobs = 0
+        if not args.no_align:
+            njobs = M.jobs_from_candidates_dev(ctx, full_cands.data_ptr(), full_counts.data_ptr(), n, maxc, 0, 1, 0, rank, world,
+                                               d_jobs.data_ptr())
+            M.align_candidates_dev(ctx, vol, vol, d_jobs.data_ptr(), njobs, params.min_align_size, d_res.data_ptr())
+            if world > 1:
+                cap = torch.tensor([njobs], dtype=torch.int64, device=dev)
+                dist.all_reduce(cap, op=dist.ReduceOp.MAX)
+                m = int(cap.item())
+                g_res = torch.empty((world, m, 8), dtype=torch.int32, device=dev)
+                dist.all_gather_into_tensor(g_res, d_res[:m].contiguous())
+        ev[3].record(stream)
+        idx_handle = idx
+        stream.synchronize()
+        out = {"ncand": int(full_counts.sum().item()), "njobs": njobs,
+               "ms": [ev[i].elapsed_time(ev[i + 1]) for i in range(3)]}
+        if collect and not args.no_align:
+            r = d_res[:njobs]
+            ok = r[:, 0] != 0
+            out["aln_ok"] = int(ok.sum().item())
+            out["aligned_bases"] = int((r[:, 2] - r[:, 1])[ok].sum().item())
+        idx_handle.free()
+        return out
+
+    for _ in range(args.warmup):
+        one_step()
+    ctx.set_profiling(True)
+    ctx.reset_stats()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    outs = [one_step(collect=True) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    kstats = ctx.kernel_stats()
+    counters = ctx.counters()
+    ctx.set_profiling(False)
+
+    last = outs[-1]
+    ncand = last["ncand"]
+    aln = torch.tensor([last.get("aln_ok", 0), last.get("aligned_bases", 0)], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(aln, op=dist.ReduceOp.SUM)
+    aln_ok, aligned_bases = int(aln[0].item()), int(aln[1].item())
+
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        phase = np.mean([o["ms"] for o in outs], axis=0)
+        # dominant kernel by summed HIP-event time on the launch stream
+        dom = max(kstats.items(), key=lambda kv: kv[1][1]) if kstats else ("none", (1, 0.0))
+        dname, (dl, dms) = dom
+        per_step = lambda k: counters[k] / args.steps          # noqa: E731
+        lookups, hits, cands_c = per_step("lookups"), per_step("hits"), per_step("candidates")
+        strands = 2 * n_local
+        # algorithmic bytes per step, this rank's share
+        N = num_bases
+        idx_obj_kmers = None
+        b_idx = 2 * (N / 4) + 3 * 4 * (1 << 26)
+        b_seed = (lens.astype(np.int64)[rank::world].sum() * 2) / 4 + 8 * lookups + 4 * hits + 48 * cands_c
+        b_aln = per_step("aligned_bases") * 2 / 4 + 32 * last["njobs"]
+        phase_of = {"idx": b_idx, "seed": b_seed, "dw": b_aln}
+        pk = "idx" if dname.startswith("idx") else ("dw" if dname.startswith("dw") else "seed")
+        launches_per_step = max(1, dl // args.steps)
+        alg_per_launch = phase_of[pk] / launches_per_step
+        avg_ms = dms / max(1, dl)
+        achieved = alg_per_launch / 1e9 / (avg_ms / 1e3) if avg_ms > 0 else 0.0
+        roof = {"bound": "hbm", "kernel": dname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": alg_per_launch, "avg_launch_ms": avg_ms, "launches": dl,
+                "phase_bytes_per_step": {k: float(v) for k, v in phase_of.items()},
+                "note": "algorithmic bytes of the kernel's phase (SURVEY.md §8d) / launches; scratch/sort traffic not counted"}
+        if pk == "dw":
+            roof["dw_cells_per_s"] = per_step("dw_cells") / (phase[2] / 1e3) if phase[2] > 0 else None
+            roof["dw_snake_bases_per_s"] = per_step("snake_bases") / (phase[2] / 1e3) if phase[2] > 0 else None
+        line = {
+            "metric": "candidate overlaps/sec", "value": ncand / (ms_step / 1e3), "unit": "candidates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "%s: %d reads x %d bp @ %.0f%% error, genome %d, seed %d, k=13, all-vs-all, -j 1 (index+seed+dw)"
+                                   % (args.workload, n, L, err * 100, G, seed), "reads": n, "bases": int(num_bases),
+                       "parallelism": "reads%%%d" % world},
+            "candidates": ncand, "overlaps_ok": aln_ok, "aligned_gbase_per_s": aligned_bases / 1e9 / (ms_step / 1e3),
+            "overlaps_per_s": aln_ok / (ms_step / 1e3),
+            "phase_ms": {"index": float(phase[0]), "seed": float(phase[1]), "align": float(phase[2])},
+            "candidates_per_s_index_seed_phases": ncand / ((phase[0] + phase[1]) / 1e3),
+            "aligned_gbase_per_s_align_phase": (aligned_bases / 1e9 / (phase[2] / 1e3)) if phase[2] > 0 else None,
+            "counters_per_step": {k: v / args.steps for k, v in counters.items()},
+            "roofline": roof,
+        }
+        if args.stats:
+            json.dump({"kernels": {k: {"launches": v[0], "total_ms": v[1]} for k, v in kstats.items()}, "line": line},
+                      open(args.stats, "w"), indent=1)
+        log("[bench] kernel ms/step: " + ", ".join("%s=%.2f" % (k, v[1] / args.steps) for k, v in sorted(kstats.items(), key=lambda kv: -kv[1][1])))
+        if world == 1 and not args.no_cpu:
+            try:
+                line["cpu_baseline"] = cpu_baseline(args.workload, os.cpu_count() or 1)
+            except Exception as e:  # the GPU number must survive a CPU-leg problem
+                line["cpu_baseline"] = {"value": None, "unit": "candidates/s", "cores": os.cpu_count(), "kind": "reference",
+                                        "sample": "failed: %r" % (e,)}
+        print(json.dumps(line), flush=True)
+    vol.free()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -115,6 +115,21 @@ int  mhip_seed_reads(mhip_ctx* ctx, const mhip_index* idx, const mhip_volume* re
 int  mhip_seed_reads_dev(mhip_ctx* ctx, const mhip_index* idx, const mhip_volume* ref, const mhip_volume* reads,
                          int rid_begin, int rid_end, const mhip_params* p, void* d_out, void* d_out_counts);
 
+/* same for the reads rid_begin + i * rid_stride, i in [0, n): the static multi-GPU shard of a (ref volume, query volume)
+   grid cell — rank r of P seeds reads r, r + P, r + 2P, ... (work per read grows with the read id inside a diagonal cell
+   because candidates with sid > qid are dropped, pw_impl.cpp:370, so the shard is cyclic, not contiguous) */
+int  mhip_seed_reads_strided_dev(mhip_ctx* ctx, const mhip_index* idx, const mhip_volume* ref, const mhip_volume* reads,
+                                 int rid_begin, int rid_stride, int n, const mhip_params* p, void* d_out, void* d_out_counts);
+
+/* candidate lists -> alignment jobs, on the device (the loop head of pairwise_mapping, pw_impl.cpp:674-686: the
+   +kmer_size/2 shift of both start points only when both are non-zero).  d_cands[n_reads][maxc], d_counts[n_reads];
+   read i of the table is query read rid_begin + i * rid_stride.  Only jobs with (job index % part_count) == part_index
+   are emitted (multi-GPU split of the extension stage; 0/1 = all).  d_jobs must hold n_reads * maxc entries;
+   *num_jobs receives the number written. */
+int  mhip_jobs_from_candidates_dev(mhip_ctx* ctx, const void* d_cands, const void* d_counts, int n_reads, int maxc,
+                                   int rid_begin, int rid_stride, int ref_start_read_id, int part_index, int part_count,
+                                   void* d_jobs, int* num_jobs);
+
 /* dw extension of n jobs (PacBio / DiffAligner semantics); jobs/out are HOST pointers (_dev: DEVICE pointers) */
 int  mhip_align_candidates(mhip_ctx* ctx, const mhip_volume* ref, const mhip_volume* reads, const mhip_aln_job* jobs,
                            int n, int min_align_size, mhip_aln_result* out);

@@ -294,7 +294,72 @@ __global__ void dw_stitch(const mhip_aln_job* __restrict__ jobs, const DirResult
     }
 }
 
+// candidate table -> job list (pw_impl.cpp:674-686).  Single block: running exclusive scan of the counts over tiles.
+__global__ __launch_bounds__(1024) void dw_make_jobs(const mhip_candidate* __restrict__ cands, const int32_t* __restrict__ counts,
+                                                     int n_reads, int maxc, int rid_begin, int rid_stride, int ref_start_id,
+                                                     int part_index, int part_count, mhip_aln_job* __restrict__ jobs,
+                                                     int* __restrict__ num_jobs) {
+    __shared__ unsigned int wtot[16];
+    __shared__ unsigned int carry_all, carry_mine;
+    if (threadIdx.x == 0) { carry_all = 0; carry_mine = 0; }
+    __syncthreads();
+    for (int t0 = 0; t0 < n_reads; t0 += 1024) {
+        const int i = t0 + threadIdx.x;
+        const unsigned int c = i < n_reads ? (unsigned int)counts[i] : 0u;
+        unsigned int incl = c;
+        for (int o = 1; o < 64; o <<= 1) {
+            unsigned int v = __shfl_up(incl, o);
+            if (lane_id() >= o) incl += v;
+        }
+        if (lane_id() == 63) wtot[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        unsigned int base = carry_all;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += wtot[w];
+        const unsigned int first = base + incl - c;          // global index of this read's first candidate
+        for (unsigned int j = 0; j < c; ++j) {
+            const unsigned int g = first + j;
+            if (part_count > 1 && (int)(g % (unsigned)part_count) != part_index) continue;
+            const unsigned int slot = part_count > 1 ? g / (unsigned)part_count : g;
+            const mhip_candidate cd = cands[(size_t)i * maxc + j];
+            mhip_aln_job jb;
+            jb.qid_local = rid_begin + i * rid_stride;
+            jb.sid_local = cd.readno - ref_start_id;
+            jb.chain = cd.chain;
+            int qstart = cd.loc2, sstart = cd.loc1;
+            if (qstart && sstart) { qstart += MHIP_KMER_SIZE / 2; sstart += MHIP_KMER_SIZE / 2; }
+            jb.qstart = qstart;
+            jb.sstart = sstart;
+            jobs[slot] = jb;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_all = base + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const unsigned int tot = carry_all;
+        unsigned int mine = tot;
+        if (part_count > 1) mine = tot / (unsigned)part_count + ((unsigned)part_index < tot % (unsigned)part_count ? 1u : 0u);
+        *num_jobs = (int)mine;
+        (void)carry_mine;
+    }
+}
+
 extern "C" {
+
+int mhip_jobs_from_candidates_dev(mhip_ctx* c, const void* d_cands, const void* d_counts, int n_reads, int maxc, int rid_begin,
+                                  int rid_stride, int ref_start_read_id, int part_index, int part_count, void* d_jobs, int* num_jobs) {
+    HIPCHK(hipSetDevice(c->device));
+    *num_jobs = 0;
+    if (n_reads <= 0) return 0;
+    if (part_count < 1) part_count = 1;
+    int* d_n;
+    if (c->scratch("al_njobs", 64, (void**)&d_n)) return -1;
+    LAUNCH(c, "dw_make_jobs", dw_make_jobs, 1, 1024, 0, (const mhip_candidate*)d_cands, (const int32_t*)d_counts, n_reads, maxc,
+           rid_begin, rid_stride, ref_start_read_id, part_index, part_count, (mhip_aln_job*)d_jobs, d_n);
+    HIPCHK(hipMemcpyAsync(num_jobs, d_n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
 
 int mhip_align_candidates_dev(mhip_ctx* c, const mhip_volume* ref, const mhip_volume* reads, const void* d_jobs, int n,
                               int min_align_size, void* d_out) {

@@ -92,11 +92,11 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wtot /
 
 // ------------------------------------------------------------------------------------------------ probe
 __global__ __launch_bounds__(SEED_BLOCK) void seed_probe(const uint32_t* __restrict__ pac, const mhip_offset_t* __restrict__ roffs,
-                                                         int rid_begin, const uint32_t* __restrict__ starts, SeedArrays A,
+                                                         int rid_begin, int rid_stride, const uint32_t* __restrict__ starts, SeedArrays A,
                                                          unsigned long long* __restrict__ counters) {
     __shared__ uint32_t wtot[SEED_WAVES];
     const int s = blockIdx.x;
-    const int rid = rid_begin + (s >> 1);
+    const int rid = rid_begin + (s >> 1) * rid_stride;
     const bool rev = s & 1;
     const int off = roffs[rid].offset, L = roffs[rid].size;
     const int K = kmers_of(L);
@@ -154,12 +154,12 @@ __global__ __launch_bounds__(1024) void seed_scan(const uint32_t* __restrict__ h
 }
 
 // ------------------------------------------------------------------------------------------------ emit
-__global__ __launch_bounds__(SEED_BLOCK) void seed_emit(const mhip_offset_t* __restrict__ roffs, int rid_begin,
+__global__ __launch_bounds__(SEED_BLOCK) void seed_emit(const mhip_offset_t* __restrict__ roffs, int rid_begin, int rid_stride,
                                                         const int32_t* __restrict__ offsets, SeedArrays A) {
     __shared__ uint32_t pre[SEED_BLOCK + 1];
     __shared__ uint32_t bst[SEED_BLOCK];
     const int s = blockIdx.x;
-    const int rid = rid_begin + (s >> 1);
+    const int rid = rid_begin + (s >> 1) * rid_stride;
     const int K = kmers_of(roffs[rid].size);
     const uint32_t kb = A.km_base[s];
     const uint32_t H = A.strand_hits[s];
@@ -451,7 +451,7 @@ __device__ __forceinline__ int read_id_from_offset(const mhip_offset_t* __restri
 
 // one wave per read: F strand then R strand into one top-MAXC list kept in LDS (12 ints per entry)
 __global__ __launch_bounds__(WAVE) void seed_cand(SeedArrays A, const mhip_offset_t* __restrict__ ref_offs, int ref_nreads,
-                                                  int ref_start_id, const mhip_offset_t* __restrict__ roffs, int rid_begin,
+                                                  int ref_start_id, const mhip_offset_t* __restrict__ roffs, int rid_begin, int rid_stride,
                                                   int reads_start_id, mhip_params P, mhip_candidate* __restrict__ out,
                                                   int32_t* __restrict__ out_counts, unsigned long long* __restrict__ counters) {
     extern __shared__ __attribute__((aligned(16))) int smem[];
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(WAVE) void seed_cand(SeedArrays A, const mhip_offse
     CandLds* T = (CandLds*)(smem + P.maxc * 12);
     const int lane = lane_id();
     const int r = blockIdx.x;
-    const int rid = rid_begin + r;
+    const int rid = rid_begin + r * rid_stride;
     const int read_id = rid + reads_start_id;
     const int read_size = roffs[rid].size;
     const int MAXC = P.maxc;
@@ -692,13 +692,15 @@ static int bits_for(uint32_t maxv) {
     return b < 1 ? 1 : b;
 }
 
-static int seed_batch(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref, const mhip_volume* reads, int rb, int re,
-                      const mhip_params* P, mhip_candidate* d_out, int32_t* d_counts) {
-    const int nr = re - rb, ns = 2 * nr;
+// reads rid0 + i * stride for i in [ib, ie)
+static int seed_batch(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref, const mhip_volume* reads, int rid0, int stride,
+                      int ib, int ie, const mhip_params* P, mhip_candidate* d_out, int32_t* d_counts) {
+    const int nr = ie - ib, ns = 2 * nr;
+    const int rb = rid0 + ib * stride;
     std::vector<uint32_t> kmb((size_t)ns);
     uint64_t sumK = 0;
     for (int r = 0; r < nr; ++r) {
-        int L = reads->h_offs[(size_t)(rb + r)].size;
+        int L = reads->h_offs[(size_t)(rb + r * stride)].size;
         int K = L < MHIP_KMER_SIZE ? 0 : (L - MHIP_KMER_SIZE) / BC + 1;
         kmb[(size_t)2 * r] = (uint32_t)sumK; sumK += (uint64_t)K;
         kmb[(size_t)2 * r + 1] = (uint32_t)sumK; sumK += (uint64_t)K;
@@ -717,7 +719,7 @@ static int seed_batch(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref
     if (c->scratch("sd_ngated", sizeof(uint32_t) * (size_t)ns, (void**)&A.ngated)) return -1;
     A.km_base = d_kmb;
     HIPCHK(hipMemcpyAsync(d_kmb, kmb.data(), sizeof(uint32_t) * (size_t)ns, hipMemcpyHostToDevice, c->stream));
-    LAUNCH(c, "seed_probe", seed_probe, ns, SEED_BLOCK, 0, (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs, rb,
+    LAUNCH(c, "seed_probe", seed_probe, ns, SEED_BLOCK, 0, (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs, rb, stride,
            (const uint32_t*)idx->d_starts, A, (unsigned long long*)c->d_counters);
     LAUNCH(c, "seed_scan", seed_scan, 1, 1024, 0, (const uint32_t*)A.strand_hits, ns, A.hit_base);
     uint64_t Htot = 0;
@@ -737,7 +739,7 @@ static int seed_batch(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref
     if (c->scratch("sd_gated", sizeof(uint32_t) * Hc, (void**)&A.gated)) return -1;
     int in_b = 0;
     if (Htot > 0) {
-        LAUNCH(c, "seed_emit", seed_emit, ns, SEED_BLOCK, 0, (const mhip_offset_t*)reads->d_offs, rb, (const int32_t*)idx->d_offsets, A);
+        LAUNCH(c, "seed_emit", seed_emit, ns, SEED_BLOCK, 0, (const mhip_offset_t*)reads->d_offs, rb, stride, (const int32_t*)idx->d_offsets, A);
         const int nbits = bits_for((uint32_t)(ref->num_bases / ZV));
         const int npass = (nbits + 7) / 8;
         const int per = (nbits + npass - 1) / npass;
@@ -758,19 +760,19 @@ static int seed_batch(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref
     }
     const size_t lds = sizeof(int) * 12 * (size_t)P->maxc + sizeof(CandLds);
     LAUNCH(c, "seed_cand", seed_cand, nr, WAVE, lds, A, (const mhip_offset_t*)ref->d_offs, ref->num_reads, ref->start_read_id,
-           (const mhip_offset_t*)reads->d_offs, rb, reads->start_read_id, *P, d_out, d_counts, (unsigned long long*)c->d_counters);
+           (const mhip_offset_t*)reads->d_offs, rb, stride, reads->start_read_id, *P, d_out, d_counts, (unsigned long long*)c->d_counters);
     HIPCHK(hipGetLastError());
     return 0;
 }
 
 // reads per launch: bounded by an estimate of the hits they produce (batch arrays cost ~ 60 bytes per hit)
-static int next_batch_end(const mhip_index* idx, const mhip_volume* reads, int rb, int re) {
+static int next_batch_end(const mhip_index* idx, const mhip_volume* reads, int rid0, int stride, int rb, int re) {
     const double hits_per_lookup = (double)idx->num_kmers / (double)NKMER + 2.0;
     const double budget = 160e6;   // hits per launch (~10 GB of batch arrays)
     double acc = 0;
     int r = rb;
     while (r < re) {
-        int L = reads->h_offs[(size_t)r].size;
+        int L = reads->h_offs[(size_t)(rid0 + r * stride)].size;
         double k = L < MHIP_KMER_SIZE ? 0 : (double)((L - MHIP_KMER_SIZE) / BC + 1);
         acc += 2.0 * k * hits_per_lookup;
         ++r;
@@ -781,21 +783,30 @@ static int next_batch_end(const mhip_index* idx, const mhip_volume* reads, int r
 
 extern "C" {
 
-int mhip_seed_reads_dev(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref, const mhip_volume* reads, int rid_begin,
-                        int rid_end, const mhip_params* P, void* d_out, void* d_out_counts) {
+int mhip_seed_reads_strided_dev(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref, const mhip_volume* reads, int rid_begin,
+                                int rid_stride, int n, const mhip_params* P, void* d_out, void* d_out_counts) {
     HIPCHK(hipSetDevice(c->device));
-    if (rid_begin < 0 || rid_end > reads->num_reads || rid_begin > rid_end) { mhip_set_error("bad read range [%d,%d)", rid_begin, rid_end); return -1; }
+    if (n < 0 || rid_stride < 1 || rid_begin < 0 || (n > 0 && (int64_t)rid_begin + (int64_t)(n - 1) * rid_stride >= reads->num_reads)) {
+        mhip_set_error("bad read selection begin %d stride %d n %d", rid_begin, rid_stride, n);
+        return -1;
+    }
     if (P->maxc < 1 || P->maxc > MAXC_LIMIT) { mhip_set_error("maxc %d outside 1..%d", P->maxc, MAXC_LIMIT); return -1; }
     if (ref->num_reads == 0) { mhip_set_error("empty reference volume"); return -1; }
-    int rb = rid_begin;
-    while (rb < rid_end) {
-        int re = next_batch_end(idx, reads, rb, rid_end);
-        if (seed_batch(c, idx, ref, reads, rb, re, P, (mhip_candidate*)d_out + (size_t)(rb - rid_begin) * P->maxc,
-                       (int32_t*)d_out_counts + (rb - rid_begin)))
+    int ib = 0;
+    while (ib < n) {
+        int ie = next_batch_end(idx, reads, rid_begin, rid_stride, ib, n);
+        if (seed_batch(c, idx, ref, reads, rid_begin, rid_stride, ib, ie, P, (mhip_candidate*)d_out + (size_t)ib * P->maxc,
+                       (int32_t*)d_out_counts + ib))
             return -1;
-        rb = re;
+        ib = ie;
     }
     return 0;
+}
+
+int mhip_seed_reads_dev(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref, const mhip_volume* reads, int rid_begin,
+                        int rid_end, const mhip_params* P, void* d_out, void* d_out_counts) {
+    if (rid_begin < 0 || rid_end > reads->num_reads || rid_begin > rid_end) { mhip_set_error("bad read range [%d,%d)", rid_begin, rid_end); return -1; }
+    return mhip_seed_reads_strided_dev(c, idx, ref, reads, rid_begin, 1, rid_end - rid_begin, P, d_out, d_out_counts);
 }
 
 int mhip_seed_reads(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref, const mhip_volume* reads, int rid_begin,

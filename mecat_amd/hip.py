@@ -79,6 +79,8 @@ def lib():
     L.mhip_index_download.argtypes = [vp, vp, vp, vp]
     L.mhip_seed_reads.argtypes = [vp, vp, vp, vp, i32, i32, C.POINTER(Params), vp, vp]
     L.mhip_seed_reads_dev.argtypes = [vp, vp, vp, vp, i32, i32, C.POINTER(Params), vp, vp]
+    L.mhip_seed_reads_strided_dev.argtypes = [vp, vp, vp, vp, i32, i32, i32, C.POINTER(Params), vp, vp]
+    L.mhip_jobs_from_candidates_dev.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, C.POINTER(i32)]
     L.mhip_align_candidates.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     L.mhip_align_candidates_dev.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     assert L.mhip_abi_version() == 1
@@ -203,6 +205,18 @@ def seed_reads(ctx, idx, ref, reads, rid_begin, rid_end, params):
 
 def seed_reads_dev(ctx, idx, ref, reads, rid_begin, rid_end, params, d_out, d_counts):
     _chk(lib().mhip_seed_reads_dev(ctx.h, idx.h, ref.h, reads.h, rid_begin, rid_end, C.byref(params), d_out, d_counts))
+
+
+def seed_reads_strided_dev(ctx, idx, ref, reads, rid_begin, rid_stride, n, params, d_out, d_counts):
+    _chk(lib().mhip_seed_reads_strided_dev(ctx.h, idx.h, ref.h, reads.h, rid_begin, rid_stride, n, C.byref(params), d_out, d_counts))
+
+
+def jobs_from_candidates_dev(ctx, d_cands, d_counts, n_reads, maxc, rid_begin, rid_stride, ref_start_id, part_index, part_count,
+                             d_jobs):
+    n = C.c_int32(0)
+    _chk(lib().mhip_jobs_from_candidates_dev(ctx.h, d_cands, d_counts, n_reads, maxc, rid_begin, rid_stride, ref_start_id,
+                                             part_index, part_count, d_jobs, C.byref(n)))
+    return n.value
 
 
 def align_candidates(ctx, ref, reads, jobs, min_align_size):

@@ -1,0 +1,274 @@
+// main.cpp — mecat2pw: all-vs-all long-read overlapper, MI355X host driver (drop-in for the reference binary).
+//
+// Same process boundary as the reference: command line (options.cpp), wrk/vol<k> + wrk/fileindex.txt
+// (volume.cpp), per-reference-volume result files wrk/r_<i>.working -> wrk/r_<i> with skip-if-finished resume, final
+// `cat` in volume order (reference: mecat2pw/pw.cpp:14-85), `.can` lines (common/alignment.cpp:18-32) and `.m4` lines
+// (mecat2pw/pw_impl.cpp:509-531).  What the reference does in its pthread workers (pw_impl.cpp:623-818) is done by three
+// calls into libmecat_hip.so per (reference volume, query volume) grid cell: index build, seed_reads, align_candidates.
+// Record assembly, the per-read m4 post-filter (std::sort + containment, pw_impl.cpp:539-610) and text output stay on
+// the host.  There is no CPU fallback for the kernels: any failure aborts with the library's message.
+//
+// Additive, environment-only knobs:  MECAT_HIP_DEVICE=<n> (default 0),  MECAT_HIP_SLAB=<reads per seed call>.
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/time.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "mecat_hip.h"
+#include "options.h"
+#include "volume.h"
+
+#define DIE(...)                                                  \
+    do {                                                          \
+        fprintf(stderr, "[%s, %u] ", __func__, __LINE__);         \
+        fprintf(stderr, __VA_ARGS__);                             \
+        fprintf(stderr, "\n");                                    \
+        abort();                                                  \
+    } while (0)
+#define MCHK(call)                                                 \
+    do {                                                           \
+        if ((call) != 0) DIE("%s failed: %s", #call, mhip_last_error()); \
+    } while (0)
+
+struct ScopedTimer {   // DynamicTimer, common/defs.h:175-191
+    std::string name;
+    struct timeval t0;
+    explicit ScopedTimer(const std::string& n) : name(n) { fprintf(stderr, "[%s] begins.\n", name.c_str()); gettimeofday(&t0, NULL); }
+    ~ScopedTimer() {
+        struct timeval t1;
+        gettimeofday(&t1, NULL);
+        fprintf(stderr, "[%s] takes %.2f secs.\n", name.c_str(), t1.tv_sec - t0.tv_sec + 1e-6 * (t1.tv_usec - t0.tv_usec));
+    }
+};
+
+struct M4Record {      // common/alignment.h:21-37
+    int64_t qid, sid;
+    double ident;
+    int vscore, qdir;
+    int64_t qoff, qend, qsize;
+    int sdir;
+    int64_t soff, send, ssize, qext, sext;
+};
+
+struct CmpM4ByQidAndOvlpSize {   // pw_impl.cpp:539-548 ; std::sort keeps libstdc++'s tie order like the reference
+    bool operator()(const M4Record& a, const M4Record& b) const {
+        if (a.qid != b.qid) return a.qid < b.qid;
+        const int64_t qa = a.qend - a.qoff, sa = a.send - a.soff, qb = b.qend - b.qoff, sb = b.send - b.soff;
+        const int o1 = (int)std::min(qa, sa), o2 = (int)std::min(qb, sb);
+        return o1 > o2;
+    }
+};
+
+// pw_impl.cpp:550-574
+static void check_records_containment(const M4Record* v, int s, int e, std::vector<int>& valid) {
+    const int soft = 100;
+    for (int i = s; i < e; ++i) {
+        if (!valid[i]) continue;
+        const int qb1 = (int)v[i].qoff, qe1 = (int)v[i].qend, sb1 = (int)v[i].soff, se1 = (int)v[i].send;
+        for (int j = i + 1; j < e; ++j) {
+            if (!valid[j]) continue;
+            if (v[i].sdir != v[j].sdir) continue;
+            const int qb2 = (int)v[j].qoff, qe2 = (int)v[j].qend, sb2 = (int)v[j].soff, se2 = (int)v[j].send;
+            if (qb2 + soft >= qb1 && qe2 - soft <= qe1 && sb2 + soft >= sb1 && se2 - soft <= se1) valid[j] = 0;
+        }
+    }
+}
+
+struct OutBuf {
+    FILE* f;
+    std::vector<char> buf;
+    size_t n = 0;
+    explicit OutBuf(FILE* file) : f(file), buf(8u << 20) {}
+    void room(size_t need) { if (n + need > buf.size()) flush(); }
+    void flush() { if (n && fwrite(buf.data(), 1, n, f) != n) DIE("write error!"); n = 0; }
+};
+
+static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, const std::vector<std::string>& vn, FILE* out) {
+    mhip_params P;
+    mhip_params_default(&P, opt.tech);
+    P.maxc = opt.num_candidates;
+    P.min_align_size = opt.min_align_size;
+    P.min_kmer_match = opt.min_kmer_match;
+    if (opt.task == TASK_ALN && opt.tech == TECH_NANOPORE)
+        DIE("-x 1 -j 1 needs the X-drop aligner (SURVEY.md row A13), which is not available in this build; use -j 0 or -x 0");
+
+    HostVolume ref;
+    load_volume(vn[svid], &ref);
+    mhip_volume* dref = NULL;
+    MCHK(mhip_volume_upload(ctx, ref.pac.data(), ref.offs.data(), ref.num_reads, ref.num_bases, ref.start_read_id, &dref));
+    mhip_index* idx = NULL;
+    {
+        ScopedTimer t("create_ref_index");
+        MCHK(mhip_index_build(ctx, dref, &idx));
+    }
+    printf("number of kmers: %lld\n", (long long)mhip_index_num_kmers(idx));
+
+    const char* slab_env = getenv("MECAT_HIP_SLAB");
+    const int slab = slab_env ? std::max(1, atoi(slab_env)) : 20000;
+    OutBuf ob(out);
+    std::vector<mhip_candidate> cands;
+    std::vector<int32_t> counts;
+    std::vector<mhip_aln_job> jobs;
+    std::vector<mhip_aln_result> res;
+    std::vector<M4Record> m4v;
+    std::vector<int> valid;
+
+    for (int vid = svid; vid < (int)vn.size(); ++vid) {
+        char info[64];
+        snprintf(info, sizeof(info), "process volume %d", vid);
+        ScopedTimer t(info);
+        fprintf(stderr, "[%s, %u] processing %s\n\n", __func__, __LINE__, vn[vid].c_str());
+        HostVolume rd_store;
+        const HostVolume* rd = &ref;
+        mhip_volume* dreads = dref;
+        if (vid != svid) {
+            load_volume(vn[vid], &rd_store);
+            rd = &rd_store;
+            MCHK(mhip_volume_upload(ctx, rd->pac.data(), rd->offs.data(), rd->num_reads, rd->num_bases, rd->start_read_id, &dreads));
+        }
+        for (int rb = 0; rb < rd->num_reads; rb += slab) {
+            const int re = std::min(rd->num_reads, rb + slab), nr = re - rb;
+            cands.resize((size_t)nr * P.maxc);
+            counts.resize((size_t)nr);
+            MCHK(mhip_seed_reads(ctx, idx, dref, dreads, rb, re, &P, cands.data(), counts.data()));
+            if (opt.task == TASK_SEED) {
+                // candidate_detect, pw_impl.cpp:767-801 ; line format alignment.cpp:18-32
+                for (int r = 0; r < nr; ++r) {
+                    const int qsize = rd->offs[(size_t)(rb + r)].size, qid = rb + r + rd->start_read_id;
+                    for (int k = 0; k < counts[(size_t)r]; ++k) {
+                        const mhip_candidate& c = cands[(size_t)r * P.maxc + k];
+                        int qext = c.loc2, sext = c.loc1;
+                        if (qext && sext) { qext += MHIP_KMER_SIZE / 2; sext += MHIP_KMER_SIZE / 2; }
+                        const int ssize = ref.offs[(size_t)(c.readno - ref.start_read_id)].size;
+                        if (c.chain == 1) qext = qsize - 1 - qext;
+                        ob.room(160);
+                        ob.n += (size_t)snprintf(&ob.buf[ob.n], 160, "%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\n", qid, c.readno, c.chain, 0,
+                                                 qext, sext, c.score, qsize, ssize);
+                    }
+                }
+                continue;
+            }
+            // pairwise_mapping, pw_impl.cpp:674-700
+            jobs.clear();
+            for (int r = 0; r < nr; ++r)
+                for (int k = 0; k < counts[(size_t)r]; ++k) {
+                    const mhip_candidate& c = cands[(size_t)r * P.maxc + k];
+                    mhip_aln_job j;
+                    j.qid_local = rb + r;
+                    j.sid_local = c.readno - ref.start_read_id;
+                    j.chain = c.chain;
+                    j.qstart = c.loc2;
+                    j.sstart = c.loc1;
+                    if (j.qstart && j.sstart) { j.qstart += MHIP_KMER_SIZE / 2; j.sstart += MHIP_KMER_SIZE / 2; }
+                    jobs.push_back(j);
+                }
+            res.resize(jobs.size());
+            MCHK(mhip_align_candidates(ctx, dref, dreads, jobs.data(), (int)jobs.size(), P.min_align_size, res.data()));
+            size_t ji = 0;
+            for (int r = 0; r < nr; ++r) {
+                const int qsize = rd->offs[(size_t)(rb + r)].size, qid = rb + r + rd->start_read_id;
+                m4v.clear();
+                for (int k = 0; k < counts[(size_t)r]; ++k, ++ji) {
+                    const mhip_aln_result& a = res[ji];
+                    if (!a.ok) continue;
+                    const mhip_candidate& c = cands[(size_t)r * P.maxc + k];
+                    const mhip_aln_job& j = jobs[ji];
+                    const int ssize = ref.offs[(size_t)j.sid_local].size;
+                    M4Record m;     // fill_m4record, pw_impl.cpp:467-506
+                    m.qid = c.readno;
+                    m.sid = qid;
+                    m.ident = a.columns == 0 ? 0.0 : 100.0 * a.matches / a.columns;   // OutputStore::calc_ident
+                    m.vscore = c.score;
+                    m.qdir = 0;
+                    m.qoff = a.target_start;
+                    m.qend = a.target_end;
+                    m.qsize = ssize;
+                    m.ssize = qsize;
+                    m.qext = j.sstart;
+                    if (c.chain == 0) { m.sdir = 0; m.soff = a.query_start; m.send = a.query_end; m.sext = j.qstart; }
+                    else { m.sdir = 1; m.soff = qsize - a.query_end; m.send = qsize - a.query_start; m.sext = qsize - 1 - j.qstart; }
+                    m4v.push_back(m);
+                }
+                // append_m4v, pw_impl.cpp:576-610
+                std::sort(m4v.begin(), m4v.end(), CmpM4ByQidAndOvlpSize());
+                const int n = (int)m4v.size();
+                valid.assign((size_t)n, 1);
+                for (int i = 0; i < n;) {
+                    int e = i + 1;
+                    while (e < n && m4v[(size_t)e].qid == m4v[(size_t)i].qid) ++e;
+                    if (e - i > 1) check_records_containment(m4v.data(), i, e, valid);
+                    i = e;
+                }
+                for (int i = 0; i < n; ++i) {
+                    if (!valid[(size_t)i]) continue;
+                    const M4Record& m = m4v[(size_t)i];
+                    ob.room(320);
+                    char* p = &ob.buf[ob.n];
+                    int w = snprintf(p, 256, "%lld\t%lld\t%g\t%d\t%d\t%lld\t%lld\t%lld\t%d\t%lld\t%lld\t%lld", (long long)m.qid,
+                                     (long long)m.sid, m.ident, m.vscore, m.qdir, (long long)m.qoff, (long long)m.qend,
+                                     (long long)m.qsize, m.sdir, (long long)m.soff, (long long)m.send, (long long)m.ssize);
+                    if (opt.output_gapped_start_point) w += snprintf(p + w, 64, "\t%lld\t%lld", (long long)m.qext, (long long)m.sext);
+                    p[w++] = '\n';
+                    ob.n += (size_t)w;
+                }
+            }
+        }
+        ob.flush();
+        if (dreads != dref) mhip_volume_free(dreads);
+    }
+    mhip_index_free(idx);
+    mhip_volume_free(dref);
+}
+
+static std::string results_name(const char* wrk_dir, int vid, bool working) {
+    std::string s(wrk_dir);
+    if (s.empty() || s[s.size() - 1] != '/') s += '/';
+    s += "r_" + std::to_string(vid);
+    if (working) s += ".working";
+    return s;
+}
+
+int main(int argc, char* argv[]) {
+    Options opt;
+    if (parse_arguments(argc, argv, &opt)) {
+        print_usage(argv[0]);
+        return 1;
+    }
+    const int num_vols = split_raw_dataset(opt.reads, opt.wrk_dir);
+    const std::string idx_name = index_file_name(opt.wrk_dir);
+    printf("%s\n", idx_name.c_str());
+    const std::vector<std::string> vn = load_volume_names(idx_name);
+    if ((int)vn.size() != num_vols) DIE("assertion 'num_vols == vn->num_vols' failed");
+
+    mhip_ctx* ctx = NULL;
+    const char* dev_env = getenv("MECAT_HIP_DEVICE");
+    if (mhip_ctx_create(dev_env ? atoi(dev_env) : 0, NULL, &ctx) != 0) DIE("cannot use the GPU: %s", mhip_last_error());
+
+    for (int i = 0; i < num_vols; ++i) {
+        const std::string fin = results_name(opt.wrk_dir, i, false);
+        if (access(fin.c_str(), F_OK) == 0) {
+            fprintf(stderr, "[%s, %u] volume %d has been finished\n\n", __func__, __LINE__, i);
+            continue;
+        }
+        const std::string wrk = results_name(opt.wrk_dir, i, true);
+        FILE* out = fopen(wrk.c_str(), "w");
+        if (!out) DIE("failed to open file '%s' with mode 'ios::out'", wrk.c_str());
+        process_one_volume(opt, ctx, i, vn, out);
+        if (fclose(out) != 0) DIE("write error!");
+        if (rename(wrk.c_str(), fin.c_str()) != 0) DIE("cannot rename %s", wrk.c_str());
+    }
+    mhip_ctx_destroy(ctx);
+
+    // merge_results, pw.cpp:34-46
+    for (int i = 0; i < num_vols; ++i) {
+        const std::string cmd = std::string("cat ") + results_name(opt.wrk_dir, i, false) + (i == 0 ? " >" : " >> ") + opt.output;
+        if (system(cmd.c_str()) != 0) DIE("'%s' failed", cmd.c_str());
+    }
+    return 0;
+}

@@ -1,0 +1,30 @@
+// volume.h — host side of the working-directory file protocol: FASTA/FASTQ -> 2-bit volumes
+// (wrk/vol<k>, wrk/fileindex.txt) byte-identical to the reference's split_raw_dataset
+// (common/split_database.cpp:221-266), and the loader for those files (:155-181).
+#pragma once
+
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "mecat_hip.h"
+
+static const long kMaxVolumeBases = 2140000000L;   // MCS, common/split_database.h:6
+
+struct HostVolume {
+    int num_reads = 0;
+    int num_bases = 0;         // incl. one pad base per read
+    int start_read_id = 0;
+    std::vector<mhip_offset_t> offs;
+    std::vector<uint8_t> pac;  // (num_bases + 3) / 4 bytes
+};
+
+// Splits `reads` into volumes inside `wrk_dir`; returns the number of volumes.  Aborts with the reference's messages on
+// malformed input (FastaReader, common/fasta_reader.cpp:6-130).
+int split_raw_dataset(const char* reads, const char* wrk_dir);
+
+std::string volume_file_name(const char* wrk_dir, int vol);      // generate_vol_file_name, split_database.cpp:183-192
+std::string index_file_name(const char* wrk_dir);                // generate_idx_file_name, split_database.cpp:194-200
+std::vector<std::string> load_volume_names(const std::string& idx_file);   // split_database.cpp:373-392
+void load_volume(const std::string& path, HostVolume* v);        // split_database.cpp:155-181 (exit(1) if missing)

@@ -81,16 +81,33 @@ int64_t synth_reads(int64_t G, int64_t nreads, int L, double e, int ont, uint64_
     if (!g) return -1;
     synth_genome(g, G, seed);
     int cap = (int)(L * 1.25) + 64;
-    uint8_t* tmp = (uint8_t*)malloc((size_t)cap);
+    if (bases_cap < nreads * (int64_t)cap) { free(g); return -2; }
+    /* every read has its own RNG stream: generate in place at slot i * cap in parallel, then compact in order */
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t i = 0; i < nreads; ++i)
+        lens[i] = synth_one_read(g, G, i, L, pdel, psub, pins, seed, bases + i * cap, cap);
     int64_t tot = 0;
     for (int64_t i = 0; i < nreads; ++i) {
-        int n = synth_one_read(g, G, i, L, pdel, psub, pins, seed, tmp, cap);
-        if (tot + n > bases_cap) { free(tmp); free(g); return -2; }
-        memcpy(bases + tot, tmp, (size_t)n);
-        lens[i] = n; tot += n;
+        if (tot != i * cap) memmove(bases + tot, bases + i * cap, (size_t)lens[i]);
+        tot += lens[i];
     }
-    free(tmp); free(g);
+    free(g);
     return tot;
+}
+
+/* 2-bit volume image of reads given as codes 0..3 (layout of common/split_database.cpp:103-119,249-250 in the reference:
+   first base in the two MSBs of a byte, one zero pad base after every read).  pac must hold (total + nreads + 3) / 4
+   zeroed bytes, offs 2 * nreads ints (offset, size).  Returns num_bases (incl. pads). */
+int64_t synth_pack_volume(const uint8_t* codes, const int32_t* lens, int64_t nreads, uint8_t* pac, int32_t* offs) {
+    int64_t curr = 0, src = 0;
+    for (int64_t i = 0; i < nreads; ++i) {
+        offs[2 * i] = (int32_t)curr; offs[2 * i + 1] = lens[i];
+        for (int k = 0; k < lens[i]; ++k, ++curr)
+            pac[curr >> 2] |= (uint8_t)((codes[src + k] & 3) << ((~curr & 3) << 1));
+        src += lens[i];
+        ++curr;
+    }
+    return curr;
 }
 
 int synth_write_fasta(const char* path, const uint8_t* bases, const int32_t* lens, int64_t nreads) {

@@ -1,0 +1,69 @@
+"""End-to-end drop-in test on the GPU box: the mecat2pw driver binary produces the same multiset of .can / .m4 lines as
+the unmodified reference (golden files generated in the build container), keeps the wrk/ resume protocol."""
+import json
+import os
+import subprocess
+
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+G = json.load(open(os.path.join(H.GOLDEN, "golden.json")))
+BIN = os.path.join(H.ROOT, "mecat_amd", "bin", "mecat2pw")
+
+
+def _fasta(tmp_path, name):
+    g = G["sets"][name]["gen"]
+    codes, lens = H.synth_reads(g["nreads"], g["L"], g["err"], g["genome"], g["seed"], g["ont"])
+    fa = str(tmp_path / (name + ".fa"))
+    H.write_fasta(fa, codes, lens)
+    return fa
+
+
+def _run(tmp_path, fa, args, name):
+    out = str(tmp_path / name)
+    r = subprocess.run([BIN, "-d", fa, "-o", out, "-w", str(tmp_path / ("w_" + name)), "-t", "4"] + args, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return sorted(open(out).read().splitlines()), r
+
+
+def test_cli_can_tiny(tmp_path):
+    fa = _fasta(tmp_path, "tiny")
+    lines, r = _run(tmp_path, fa, ["-j", "0"], "t.can")
+    assert lines == open(os.path.join(H.GOLDEN, "tiny.can.sorted")).read().splitlines()
+    assert "number of kmers: %d" % G["sets"]["tiny"]["index"]["num_kmers"] in r.stdout
+
+
+def test_cli_can_nanopore_mode(tmp_path):
+    fa = _fasta(tmp_path, "tiny_ont")
+    lines, _ = _run(tmp_path, fa, ["-j", "0", "-x", "1"], "o.can")
+    assert lines == open(os.path.join(H.GOLDEN, "tiny_ont.can.sorted")).read().splitlines()
+
+
+@pytest.mark.parametrize("g", [0, 1])
+def test_cli_m4_tiny(tmp_path, g):
+    fa = _fasta(tmp_path, "tiny")
+    lines, _ = _run(tmp_path, fa, ["-j", "1", "-g", str(g)], "t%d.m4" % g)
+    assert lines == open(os.path.join(H.GOLDEN, "tiny.g%d.m4.sorted" % g)).read().splitlines()
+
+
+def test_cli_default_task_is_align_and_small_slabs(tmp_path):
+    """-j defaults to 1 (pw_options.cpp:33); result independent of the host slab size"""
+    fa = _fasta(tmp_path, "tiny")
+    env = dict(os.environ, MECAT_HIP_SLAB="37")
+    out = str(tmp_path / "d.m4")
+    r = subprocess.run([BIN, "-d", fa, "-o", out, "-w", str(tmp_path / "wd")], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert sorted(open(out).read().splitlines()) == open(os.path.join(H.GOLDEN, "tiny.g0.m4.sorted")).read().splitlines()
+
+
+def test_cli_resume_skips_finished_volume(tmp_path):
+    fa = _fasta(tmp_path, "tiny")
+    wrk = tmp_path / "w_resume"
+    wrk.mkdir()
+    (wrk / "r_0").write_text("sentinel\n")
+    out = str(tmp_path / "r.can")
+    r = subprocess.run([BIN, "-j", "0", "-d", fa, "-o", out, "-w", str(wrk)], capture_output=True, text=True)
+    assert r.returncode == 0 and "volume 0 has been finished" in r.stderr
+    assert open(out).read() == "sentinel\n"

@@ -1,0 +1,116 @@
+"""CPU-side checks of the product's host logic (no GPU): the C ABI library loads and exports every symbol declared in
+include/mecat_hip.h, fails loudly without a device, and the mecat2pw driver keeps the reference's CLI/file protocol."""
+import ctypes as C
+import hashlib
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+G = json.load(open(os.path.join(H.GOLDEN, "golden.json")))
+BIN = os.path.join(H.ROOT, "mecat_amd", "bin", "mecat2pw")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    subprocess.run(["make", "-s", "hip", "host", "synth"], cwd=H.ROOT, check=True, stdout=subprocess.DEVNULL)
+
+
+def test_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(H.ROOT, "include", "mecat_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(mhip_[a-z_0-9]+)\s*\(", hdr))
+    assert len(names) >= 20
+    lib = C.CDLL(os.path.join(H.ROOT, "mecat_amd", "lib", "libmecat_hip.so"))
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, missing
+    assert lib.mhip_abi_version() == 1
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import mecat_amd.hip as M
+    with pytest.raises(M.MhipError) as e:
+        M.Context(0)
+    assert "no CPU fallback" in str(e.value)
+
+
+def test_product_does_not_reference_oracle():
+    """rule: nothing under mecat_amd/ or include/ may import, link or call oracle/"""
+    bad = []
+    for base in ("mecat_amd", "include"):
+        for dp, _, fs in os.walk(os.path.join(H.ROOT, base)):
+            for f in fs:
+                if f.endswith((".py", ".h", ".hip", ".cpp", ".c", ".hpp")):
+                    txt = open(os.path.join(dp, f), errors="ignore").read()
+                    if re.search(r"oracle/|liboracle|orc_[a-z]+\(|import helpers", txt):
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad
+
+
+def test_cli_usage_and_validation(tmp_path):
+    r = subprocess.run([BIN], capture_output=True, text=True)
+    assert r.returncode == 1 and "usage:" in r.stderr and "dataset must be specified." in r.stderr
+    r = subprocess.run([BIN, "-d", "x.fa", "-o", "o", "-w", str(tmp_path / "w"), "-j", "3"], capture_output=True, text=True)
+    assert r.returncode == 1 and "task (-j) must be 0 or 1, not 3." in r.stderr
+    r = subprocess.run([BIN, "-d", "x.fa", "-o", "o", "-w", str(tmp_path / "w"), "-g", "2"], capture_output=True, text=True)
+    assert r.returncode == 1 and "must be either '0' or '1'" in r.stderr
+    r = subprocess.run([BIN, "-d", "x.fa", "-o", "o", "-w", str(tmp_path / "w"), "-q"], capture_output=True, text=True)
+    assert r.returncode == 1 and "unrecognised option" in r.stderr
+
+
+def _run_split(tmp_path, text, name="in.fa"):
+    fa = tmp_path / name
+    fa.write_bytes(text)
+    wrk = tmp_path / ("w_" + name)
+    r = subprocess.run([BIN, "-j", "0", "-d", str(fa), "-o", str(tmp_path / "o"), "-w", str(wrk)], capture_output=True, text=True)
+    return r, wrk
+
+
+def test_cli_volume_bytes_match_reference_golden(tmp_path):
+    """FASTA -> wrk/vol0 + fileindex.txt byte-identical to the reference (the split runs before any GPU call)"""
+    g = G["sets"]["tiny"]["gen"]
+    codes, lens = H.synth_reads(g["nreads"], g["L"], g["err"], g["genome"], g["seed"], g["ont"])
+    fa = str(tmp_path / "tiny.fa")
+    H.write_fasta(fa, codes, lens)
+    wrk = str(tmp_path / "wrk")
+    subprocess.run([BIN, "-j", "0", "-d", fa, "-o", str(tmp_path / "o"), "-w", wrk], capture_output=True)
+    assert hashlib.sha256(open(os.path.join(wrk, "vol0"), "rb").read()).hexdigest() == G["sets"]["tiny"]["vol0_sha256"]
+    assert open(os.path.join(wrk, "fileindex.txt")).read() == wrk + "/vol0\n"
+
+
+def test_cli_fasta_fastq_quirks(tmp_path):
+    """record grammar of the reference reader: FASTQ, CR/LF flavours, comments, ';' tails, lower case, multi-line"""
+    O = H.orc()
+    reads = ["ACGTACGTTTGACCA", "ggcattacgatcagg", "TTTTACGTACGGGTA"]
+    variants = {
+        "plain.fa": b">a\nACGTACGTTTGACCA\n>b\nggcattacgatcagg\n>c\nTTTTACGTACGGGTA\n",
+        "crlf.fa": b">a\r\nACGTACGTTTGACCA\r\n>b\r\nggcattacgatcagg\r\n>c\r\nTTTTACGTACGGGTA",
+        "cr.fa": b">a\rACGTACGTTTGACCA\r>b\rggcattacgatcagg\r>c\rTTTTACGTACGGGTA\r",
+        "multi.fa": b"#comment\n>a\nACGTACG\nTTTGACCA\n\n>b\nggcattac;ignored\ngatcagg\n!x\n>c\nTTTTACGTACGGGTA\n",
+        "fq.fq": b"@a\nACGTACGTTTGACCA\n+\n@@@@IIIIIIIIIII\n@b\nggcattacgatcagg\n+b\n>>>>IIIIIIIIIII\n@c\nTTTTACGTACGGGTA\n+\nIIIIIIIIIIIIIII\n",
+    }
+    codes = np.array([O.orc_encode_base(ord(ch)) for r in reads for ch in r], dtype=np.uint8)
+    lens = np.array([len(r) for r in reads], dtype=np.int32)
+    ov = H.orc_pack(codes, lens)
+    want = str(tmp_path / "want_vol0")
+    O.orc_volume_dump(ov, want.encode())
+    for name, text in variants.items():
+        r, wrk = _run_split(tmp_path, text, name)
+        assert open(os.path.join(wrk, "vol0"), "rb").read() == open(want, "rb").read(), name
+
+
+def test_cli_rejects_malformed_input(tmp_path):
+    r, _ = _run_split(tmp_path, b"ACGT\n>a\nACGT\n", "nodef.fa")
+    assert r.returncode != 0 and "doesn't start with a defline" in r.stderr
+    r, _ = _run_split(tmp_path, b">a\n>b\nACGT\n", "noseq.fa")
+    assert r.returncode != 0 and "sequence data is missing" in r.stderr
+    r, _ = _run_split(tmp_path, b">a\nACGT@ACGT\n", "bad.fa")
+    assert r.returncode != 0 and "invalid residue" in r.stderr

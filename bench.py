@@ -44,7 +44,9 @@ def cpu_baseline(workload, nthreads):
     """reference mecat2pw (kind "reference") on a bounded sample with the same read length / error / coverage"""
     from mecat_amd import workload as W
     n, L, err, G, seed, ont = W.CONFIGS[workload]
-    sn = min(n, 3000)
+    # the reference hands out reads in chunks of 500 (CHUNK_SIZE, mecat2pw/pw_impl.h:15): at most sn/500 threads are busy
+    sn = min(n, 16000)
+    nthreads = max(1, min(nthreads, (sn + 499) // 500))
     sG = max(int(G * sn / n), 2 * L)
     codes, lens = W.synth_reads(sn, L, err, sG, seed, ont)
     d = tempfile.mkdtemp(prefix="mecat_cpu_")
@@ -120,8 +122,11 @@ def main():
     if rank == 0:
         log("[bench] %s: %d reads, %d bases incl. pads, generated+packed in %.1fs" % (args.workload, n, num_bases, time.time() - t0))
 
-    stream = torch.cuda.current_stream(dev)
+    # a dedicated (non-null) stream shared by torch (events, RCCL) and the library's launches
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
     ctx = M.Context(local_rank, stream.cuda_stream)
+    assert stream.cuda_stream != 0
     vol = M.Volume(ctx, pac, offs, num_bases, 0)
     del pac
     params = M.default_params(ont)
@@ -253,6 +258,16 @@ def main():
         if args.stats:
             json.dump({"kernels": {k: {"launches": v[0], "total_ms": v[1]} for k, v in kstats.items()}, "line": line},
                       open(args.stats, "w"), indent=1)
+        try:
+            dbg = []
+            M.lib().mhip_debug_counter.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
+            for slot in range(8, 13):
+                v = C.c_int64()
+                M.lib().mhip_debug_counter(ctx.h, slot, C.byref(v))
+                dbg.append(v.value // args.steps)
+            log("[bench] dw debug/step: spills=%d rows=%d fast_rows=%d wide_rows=%d unaligned_blocks=%d" % tuple(dbg))
+        except Exception as e:
+            log("[bench] no debug counters: %r" % (e,))
         log("[bench] kernel ms/step: " + ", ".join("%s=%.2f" % (k, v[1] / args.steps) for k, v in sorted(kstats.items(), key=lambda kv: -kv[1][1])))
         if world == 1 and not args.no_cpu:
             try:

@@ -16,10 +16,13 @@
 // length >= 4".  Only that tail of the path is traced.
 //
 // Mapping: one wave per (candidate, direction); a direction is a sequential chain of blocks; inside a block the
-// d-loop is sequential and the <= 217 diagonals of the band are the lanes (up to 4 per lane).  Everything hot lives
-// in LDS: V/U wavefront arrays (diagonal -> furthest x, x + y), the two 2-bit->byte block sequences, and a 16-row ring
-// of the most recent d-rows (u16 x per diagonal) for the tail traceback.  A path whose last >= 4 snake is more than
-// 16 rows back (p ~ 3e-5 at 15 % error) re-runs the block with the rows spilled to a per-wave global scratch.
+// d-loop is sequential and the <= 217 diagonals of the band are the lanes (up to 4 per lane).  Per-wave LDS (9.2 KB):
+//   V[]      furthest x per diagonal (int16; x + y is recomputed as 2x - k, no U array)
+//   Qp/Tp    the two block sequences, 2 bits per base MSB-first, staged straight from the packed volume with two
+//            word loads per lane (reverse / reverse-complement views by a 2-bit-group reversal and a bit complement)
+//   ring     the most recent 16 d-rows (u16 x per diagonal) + their band limits, for the tail traceback
+// Snakes compare 16 bases per step: XOR of two unaligned 32-bit windows + count-leading-zeros.  A path whose last
+// >= 4 snake is more than 16 rows back re-runs the block with all rows spilled to a per-wave global scratch.
 // Waves are persistent and pull (candidate, direction) units from an atomic cursor; a second tiny kernel stitches the
 // two directions (query_start = qstart - left bases, ...).
 //
@@ -32,12 +35,13 @@
 #define AL_BLOCK 256
 #define AL_WAVES (AL_BLOCK / WAVE)
 #define SEG_BLK 500            // DiffAlignParameters::segment_size, diff_gapalign.h:35
-#define MAX_QB 736             // last block (gapalign.cpp:24-30): one side < 600, the other <= int(599 * 1.2) = 718
-#define MAX_TB 736
+#define MAX_BLK 736            // last block (gapalign.cpp:24-30): one side < 600, the other <= int(599 * 1.2) = 718
+#define SEQ_WORDS 52           // 736 / 16 = 46 words + window slack
 #define MAX_D 400              // int(0.3 * (599 + 718)) = 395
 #define VU_LEN (2 * MAX_D + 8)
 #define ROW_W 224              // diagonals per d-row: (2 * int(0.3 * 718)) / 2 + 1 = 216
 #define RING 16
+#define GROW_STRIDE ((size_t)MAX_D * ROW_W + 2 * (MAX_D + 8))   // u16 per wave: rows + rmin + rmax
 
 struct DirResult {
     int32_t qbases, tbases, matches, columns, blocks, pad;
@@ -45,124 +49,274 @@ struct DirResult {
 
 struct AlnWaveLds {
     int16_t V[VU_LEN];
-    int16_t U[VU_LEN];
-    int16_t rmin[MAX_D + 8];
-    int16_t rmax[MAX_D + 8];
+    uint32_t Qp[SEQ_WORDS];
+    uint32_t Tp[SEQ_WORDS];
     uint16_t ring[RING * ROW_W];
-    uint8_t Q[MAX_QB];
-    uint8_t T[MAX_TB];
+    int16_t rmin[RING];
+    int16_t rmax[RING];
 };
 
 struct SeqView {
     const uint32_t* pac;
-    int off;        // volume offset of the read
-    int len;        // read length
-    int rc;         // 1: reverse-complemented view
-    int start;      // first logical position of the extension (qstart or qstart - 1)
-    int step;       // +1 right extension, -1 left extension
+    int64_t off;    // volume offset of the read
+    int A, B;       // original index of logical extension position i is A + B * i  (B = +1 / -1)
+    int comp;       // 1: complement (reverse-complemented query)
 };
 
-// code of logical extension position i (0-based from the seed point)
-__device__ __forceinline__ uint32_t seq_at(const SeqView& s, int i) {
-    int p = s.start + s.step * i;                       // position in the strand's coordinate
-    if (s.rc) return 3u - pac_base(s.pac, (int64_t)s.off + (s.len - 1 - p));
-    return pac_base(s.pac, (int64_t)s.off + p);
+__device__ __forceinline__ uint32_t rev_groups(uint32_t x) {     // reverse the 16 2-bit groups of a word
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+    return __builtin_bswap32(x);
+}
+// 16 volume bases starting at idx >= 0, first base in the top 2 bits
+__device__ __forceinline__ uint32_t pac_win16(const uint32_t* __restrict__ pac, int64_t idx) {
+    const int64_t w = idx >> 4;
+    const uint64_t W = ((uint64_t)pac_word(pac, w) << 32) | pac_word(pac, w + 1);
+    return (uint32_t)((W << ((idx & 15) << 1)) >> 32);
+}
+// logical bases i0 .. i0+15 of a view, first in the top 2 bits (bases past the block are don't-care)
+__device__ __forceinline__ uint32_t view_word(const SeqView& s, int i0) {
+    const int64_t o0 = s.off + s.A + (int64_t)s.B * i0;
+    uint32_t w;
+    if (s.B > 0) w = pac_win16(s.pac, o0);
+    else {
+        const int64_t lo = o0 - 15;                     // volume bases lo .. o0, to be reversed
+        w = lo >= 0 ? pac_win16(s.pac, lo) : (pac_win16(s.pac, 0) >> ((-lo) << 1));
+        w = rev_groups(w);
+    }
+    return s.comp ? ~w : w;
+}
+// ({hi, lo} << s) >> 32 for s in 0..30, branch-free (HIP's __funnelshift_l lowers to a divergent branch on s == 0)
+__device__ __forceinline__ uint32_t funnel_l(uint32_t lo, uint32_t hi, int s) {
+    const uint32_t r = __builtin_amdgcn_alignbit(hi, lo, (32 - s) & 31);
+    return s ? r : hi;
+}
+// 16 bases of a staged block starting at base x
+__device__ __forceinline__ uint32_t lds_win16(const uint32_t* P, int x) {
+    const int w = x >> 4;
+    return funnel_l(P[w + 1], P[w], (x & 15) << 1);      // ({P[w], P[w+1]} << s) >> 32
 }
 
+// number of leading equal bases (0..32) of the 32-base windows at Q[x..] and T[y..]
+__device__ __forceinline__ int match32(const uint32_t* Q, int x, const uint32_t* T, int y) {
+    const int wq = x >> 4, sq = (x & 15) << 1, wt = y >> 4, st = (y & 15) << 1;
+    const uint32_t q0 = Q[wq], q1 = Q[wq + 1], q2 = Q[wq + 2], t0 = T[wt], t1 = T[wt + 1], t2 = T[wt + 2];
+    const uint32_t dh = funnel_l(q1, q0, sq) ^ funnel_l(t1, t0, st);
+    const uint32_t dl = funnel_l(q2, q1, sq) ^ funnel_l(t2, t1, st);
+    const int nh = __clz(dh) >> 1, nl = 16 + (__clz(dl) >> 1);      // __clz(0) == 32
+    return dh ? nh : nl;
+}
+
+// ---- wave64 reductions on the DPP network (no LDS traffic): quad swaps, half-row / row mirrors, row broadcasts.
+// Fused v_<op>_dpp steps in inline asm (hipcc emits mov + nop + mov_dpp + op per step); a DPP source written by the
+// previous VALU instruction needs two wait states, hence the s_nop 1 between steps (cdna_hip_programming.md §5.7).
+#define DPP_REDUCE_ASM(OPC)                                                                           \
+    asm volatile("s_nop 1\n\t" OPC " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"   \
+                 "s_nop 1\n\t" OPC " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"   \
+                 "s_nop 1\n\t" OPC " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"        \
+                 "s_nop 1\n\t" OPC " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"             \
+                 "s_nop 1\n\t" OPC " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"           \
+                 "s_nop 1\n\t" OPC " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"           \
+                 "s_nop 1"                                                                             \
+                 : "+v"(v));                                                                           \
+    return __builtin_amdgcn_readlane(v, 63);
+__device__ __forceinline__ int wave_max(int v) { DPP_REDUCE_ASM("v_max_i32_dpp") }
+__device__ __forceinline__ int wave_min(int v) { DPP_REDUCE_ASM("v_min_i32_dpp") }
+
+// One d-row for NJ diagonals per lane (straight-line: lanes past the last diagonal recompute the last one -- same
+// addresses, same values -- so nothing is predicated per lane).  Returns the wave-reduced keys
+//   bkey = (x+y) << 10 | (1023 - (k + k_offset))   max  -> first maximum of x + y in k order (diff_gapalign.cpp:160-167)
+//   hkey = (k + k_offset) << 10 | x                min  -> lowest diagonal that reached an end (:168-169), or INT_MAX
+// and leaves x + y of the lane's diagonals in S-independent registers via xy[] for the band update.
+template <int NJ, bool SPILL>
+__device__ __forceinline__ void row_body(AlnWaveLds& S, uint16_t* __restrict__ grow, const int lane, const int d, const int nslot,
+                                         const int min_k, const int max_k, const int k_offset, const int q_len, const int t_len,
+                                         const int best_m, const int band_tol, unsigned int& snake, int& bkey_out, int& hkey_out,
+                                         int& x0_out) {
+    int xs[NJ], ys[NJ], kks[NJ];
+    // start points (:138-142)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int t = min(lane + 64 * j, nslot - 1);
+        const int k = min_k + 2 * t;
+        kks[j] = k + k_offset;
+        const int vl = S.V[k - 1 + k_offset], vr = S.V[k + 1 + k_offset];
+        const int x = (k == min_k || (k != max_k && vl < vr)) ? vr : vl + 1;
+        xs[j] = x; ys[j] = x - k;
+    }
+    // snakes, 32 bases per round; a round is idempotent for a diagonal that already stopped
+    bool more;
+    do {
+        more = false;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int x = xs[j], y = ys[j];
+            const int lim = min(q_len - x, t_len - y);
+            const int n0 = match32(S.Qp, x, S.Tp, min(y, MAX_BLK));
+            const int n = max(0, min(n0, lim));
+            xs[j] = x + n; ys[j] = y + n;
+            snake += (unsigned int)n;
+            more |= (n == 32) & (lim > 32);
+        }
+    } while (__ballot(more));
+    __builtin_amdgcn_wave_barrier();
+    int bkey = -1, hkey = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int t = min(lane + 64 * j, nslot - 1);
+        S.V[kks[j]] = (int16_t)xs[j];
+        if (SPILL) grow[(size_t)d * ROW_W + t] = (uint16_t)xs[j];
+        else S.ring[(d % RING) * ROW_W + t] = (uint16_t)xs[j];
+        bkey = max(bkey, ((xs[j] + ys[j]) << 10) | (1023 - kks[j]));
+        hkey = min(hkey, (xs[j] >= q_len || ys[j] >= t_len) ? ((kks[j] << 10) | xs[j]) : 0x7fffffff);
+    }
+    bkey_out = wave_max(bkey);
+    hkey_out = wave_min(hkey);
+    x0_out = xs[0];
+}
+
+// Fast d-row: at most 64 diagonals and the band moved left by exactly one diagonal (no pruning on the left), so
+// diagonal k of this row sits in the lane that held k+1 in the previous row and k-1 is one lane to the left: the two
+// start candidates come from a register and one wave_shr:1 DPP move instead of LDS.  The lowest end-reaching diagonal
+// and the first maximum are found with ballots (lane order == diagonal order) instead of key reductions.
+template <bool SPILL>
+__device__ __forceinline__ void row_fast(AlnWaveLds& S, uint16_t* __restrict__ grow, const int lane, const int d, const int nslot,
+                                         const int min_k, const int max_k, const int k_offset, const int q_len, const int t_len,
+                                         unsigned int& snake, int& xreg, int& m_out, int& bkey_out, int& hkey_out) {
+    const bool act = lane < nslot;
+    const int k = min_k + 2 * lane;
+    const int vr = xreg;
+    const int vl = __builtin_amdgcn_update_dpp(0, xreg, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+    int x = (lane == 0 || (k != max_k && vl < vr)) ? vr : vl + 1;       // :138-142
+    if (!act) x = 0;
+    int y = act ? x - k : 0;
+    bool more;
+    do {
+        const int lim = min(q_len - x, t_len - y);
+        const int n0 = match32(S.Qp, x, S.Tp, min(y, MAX_BLK));
+        const int n = max(0, min(n0, lim));
+        x += n; y += n;
+        snake += act ? (unsigned int)n : 0u;
+        more = act & (n == 32) & (lim > 32);
+    } while (__ballot(more));
+    __builtin_amdgcn_wave_barrier();
+    if (act) {
+        S.V[k + k_offset] = (int16_t)x;
+        if (SPILL) grow[(size_t)d * ROW_W + lane] = (uint16_t)x;
+        else S.ring[(d % RING) * ROW_W + lane] = (uint16_t)x;
+    }
+    const int m = act ? x + y : -1;
+    const int rm = wave_max(m);
+    const int lb = __ffsll((unsigned long long)__ballot(m == rm)) - 1;          // first maximum in k order
+    bkey_out = (rm << 10) | (1023 - (min_k + 2 * lb + k_offset));
+    const unsigned long long hb = __ballot(act && (x >= q_len || y >= t_len));   // lowest diagonal that reached an end
+    if (hb) {
+        const int lh = __ffsll(hb) - 1;
+        hkey_out = ((min_k + 2 * lh + k_offset) << 10) | __builtin_amdgcn_readlane(x, lh);
+    } else hkey_out = 0x7fffffff;
+    xreg = x;
+    m_out = m;
+}
+
+// band update (:172-179) on U[k] = x + y = 2 V[k] - k of the row just written.  Neutral elements are the reference's
+// initial values (new_min_k = max_k, new_max_k = min_k).
+template <bool SPILL>
+__device__ __forceinline__ void band_keys(AlnWaveLds& S, const int lane, const int nj, const int nslot, const int min_k, const int max_k,
+                                          const int k_offset, const int best_m, const int band_tol, int& nmin, int& nmax) {
+    int lo = max_k, hi = min_k;
+    for (int j = 0; j < nj; ++j) {
+        const int t = min(lane + 64 * j, nslot - 1);
+        const int k = min_k + 2 * t;
+        const bool q = 2 * (int)S.V[k + k_offset] - k >= best_m - band_tol;
+        lo = min(lo, q ? k : max_k);
+        hi = max(hi, q ? k : min_k);
+    }
+    nmin = wave_min(lo);
+    nmax = wave_max(hi);
+}
+
+struct DwStats { unsigned int rows, fast_rows, wide_rows, unaligned, spills; };
+
 struct BlockOut {
-    int aligned_or_best;   // 1 when an alignment string exists (aln_str_size > 0 possible)
+    int aligned_or_best;   // 1 when an alignment exists (aln_str_size > 0 possible)
     int qe, te, dist;      // aln_q_e, aln_t_e, dist
     int qcnt, tcnt, acnt;  // trim_mismatch_end outputs
     int trim_ok;
     int fallback;          // ring too short for the tail traceback
 };
 
-// One block: Align + tail traceback + trim_mismatch_end.  `grow` == nullptr -> rows in the LDS ring, else global rows.
-__device__ void align_block(AlnWaveLds& S, int q_len, int t_len, uint16_t* __restrict__ grow, BlockOut& o,
-                            unsigned long long& cells, unsigned long long& snake) {
+// One block: Align + tail traceback + trim_mismatch_end.  SPILL = false: d-rows in the LDS ring; true: in global rows.
+template <bool SPILL>
+__device__ void align_block(AlnWaveLds& S, const int q_len, const int t_len, uint16_t* __restrict__ grow, BlockOut& o,
+                            unsigned int& cells, unsigned int& snake, DwStats& st) {
     const int lane = lane_id();
     const int band_tol = (int)(0.3 * (q_len > t_len ? q_len : t_len));      // dw_in_one_direction passes 0.3 * max(qblk, tblk)
     const int max_d = (int)(.3 * (q_len + t_len));
     const int k_offset = max_d;
     const int band_size = band_tol * 2;
-    for (int i = lane; i < 2 * max_d + 4 && i < VU_LEN; i += 64) { S.V[i] = 0; S.U[i] = 0; }
+    int16_t* g_rmin = (int16_t*)(grow + (size_t)MAX_D * ROW_W);
+    int16_t* g_rmax = g_rmin + (MAX_D + 8);
+    for (int i = lane; i < 2 * max_d + 4 && i < VU_LEN; i += 64) S.V[i] = 0;     // V is zero-filled per block (:232-233)
     __builtin_amdgcn_wave_barrier();
     int best_m = -1, best_x = -1, best_y = -1, best_d = 0, best_k = 0;
     int min_k = 0, max_k = 0;
     int aligned = 0, end_x = 0, end_y = 0, end_d = 0, end_k = 0;
     o.fallback = 0;
     int d, last_row = -1;
+    int xreg = 0, reg_min_k = 0;      // previous row's x per lane (valid when that row had <= 64 diagonals)
+    bool reg_ok = false;
     for (d = 0; d < max_d; ++d) {
         if (max_k - min_k > band_size) break;
         last_row = d;
         const int nslot = (max_k - min_k) / 2 + 1;
-        if (lane == 0) { S.rmin[d] = (int16_t)min_k; S.rmax[d] = (int16_t)max_k; }
-        uint16_t* row = grow ? grow + (size_t)d * ROW_W : S.ring + (d % RING) * ROW_W;
-        int my_m = -1, my_x = 0, my_k = 0;          // best (first max) among this lane's diagonals
-        int hit_k = 0x7fffffff, hit_x = 0;          // lowest diagonal of this lane that reached an end
-        int xs[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int t = lane + 64 * j;
-            xs[j] = -1;
-            if (t < nslot) {
-                const int k = min_k + 2 * t;
-                int x;
-                const int vl = S.V[k - 1 + k_offset], vr = S.V[k + 1 + k_offset];
-                if (k == min_k || (k != max_k && vl < vr)) x = vr; else x = vl + 1;
-                int y = x - k;
-                const int x0 = x;
-                while (x < q_len && y < t_len && S.Q[x] == S.T[y]) { ++x; ++y; }
-                snake += (unsigned long long)(x - x0);
-                xs[j] = x;
-                if (x + y > my_m) { my_m = x + y; my_x = x; my_k = k; }
-                if ((x >= q_len || y >= t_len) && k < hit_k) { hit_k = k; hit_x = x; }
-            }
+        const int nj = (nslot + 63) >> 6;            // diagonals per lane this row (uniform)
+        if (lane == 0) {
+            if (SPILL) { g_rmin[d] = (int16_t)min_k; g_rmax[d] = (int16_t)max_k; }
+            else { S.rmin[d % RING] = (int16_t)min_k; S.rmax[d % RING] = (int16_t)max_k; }
         }
-        cells += (unsigned long long)__popcll(__ballot(xs[0] >= 0)) + __popcll(__ballot(xs[1] >= 0)) +
-                 __popcll(__ballot(xs[2] >= 0)) + __popcll(__ballot(xs[3] >= 0));
+        int bkey, hkey, x0 = 0, mreg = 0;
+        const bool fast = nj == 1 && reg_ok && min_k == reg_min_k - 1;
+        if (fast) {
+            row_fast<SPILL>(S, grow, lane, d, nslot, min_k, max_k, k_offset, q_len, t_len, snake, xreg, mreg, bkey, hkey);
+        } else {
+            switch (nj) {
+            case 1: row_body<1, SPILL>(S, grow, lane, d, nslot, min_k, max_k, k_offset, q_len, t_len, best_m, band_tol, snake, bkey, hkey, x0); break;
+            case 2: row_body<2, SPILL>(S, grow, lane, d, nslot, min_k, max_k, k_offset, q_len, t_len, best_m, band_tol, snake, bkey, hkey, x0); break;
+            case 3: row_body<3, SPILL>(S, grow, lane, d, nslot, min_k, max_k, k_offset, q_len, t_len, best_m, band_tol, snake, bkey, hkey, x0); break;
+            default: row_body<4, SPILL>(S, grow, lane, d, nslot, min_k, max_k, k_offset, q_len, t_len, best_m, band_tol, snake, bkey, hkey, x0); break;
+            }
+            xreg = x0;
+        }
+        bkey = __builtin_amdgcn_readfirstlane(bkey);      // wave-uniform: keep the bookkeeping on the scalar unit
+        hkey = __builtin_amdgcn_readfirstlane(hkey);
+        reg_ok = nj == 1;
+        reg_min_k = min_k;
+        st.rows += 1; st.fast_rows += fast ? 1u : 0u; st.wide_rows += nj > 1 ? 1u : 0u;
+        cells += (unsigned int)nslot;
+        {
+            const int rm = bkey >> 10, rk = 1023 - (bkey & 1023) - k_offset;
+            if (rm > best_m) { best_m = rm; best_x = (rm + rk) / 2; best_y = best_x - rk; best_d = d; best_k = rk; }
+        }
+        // band update (:172-179): needs the new best_m.  When both outermost diagonals qualify, so does the whole range.
+        int nmin, nmax;
+        bool whole = false;
+        if (fast) {
+            const int m0 = __builtin_amdgcn_readlane(mreg, 0), ml = __builtin_amdgcn_readlane(mreg, nslot - 1);
+            whole = m0 >= best_m - band_tol && ml >= best_m - band_tol;
+        }
+        if (whole) { nmin = min_k; nmax = max_k; }
+        else band_keys<SPILL>(S, lane, nj, nslot, min_k, max_k, k_offset, best_m, band_tol, nmin, nmax);
+        max_k = __builtin_amdgcn_readfirstlane(nmax) + 1;
+        min_k = __builtin_amdgcn_readfirstlane(nmin) - 1;
         __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int t = lane + 64 * j;
-            if (t < nslot) {
-                const int k = min_k + 2 * t;
-                S.V[k + k_offset] = (int16_t)xs[j];
-                S.U[k + k_offset] = (int16_t)(2 * xs[j] - k);
-                row[t] = (uint16_t)xs[j];
-            }
+        if (hkey != 0x7fffffff) {
+            aligned = 1; end_k = (hkey >> 10) - k_offset; end_x = hkey & 1023; end_y = end_x - end_k; end_d = d;
+            break;
         }
-        // first maximum of x + y in (d, k) order (diff_gapalign.cpp:160-167)
-        int rm = my_m, rk = my_k, rx = my_x;
-        for (int off = 32; off > 0; off >>= 1) {
-            int om = __shfl_xor(rm, off), ok = __shfl_xor(rk, off), ox = __shfl_xor(rx, off);
-            if (om > rm || (om == rm && ok < rk)) { rm = om; rk = ok; rx = ox; }
-        }
-        if (rm > best_m) { best_m = rm; best_x = rx; best_y = rx - rk; best_d = d; best_k = rk; }
-        // lowest diagonal that reached an end (the sequential k loop breaks there, :168-169)
-        int hk = hit_k, hx = hit_x;
-        for (int off = 32; off > 0; off >>= 1) {
-            int ok = __shfl_xor(hk, off), ox = __shfl_xor(hx, off);
-            if (ok < hk) { hk = ok; hx = ox; }
-        }
-        __builtin_amdgcn_wave_barrier();
-        // band update (:172-179)
-        int nmin = max_k, nmax = min_k;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int t = lane + 64 * j;
-            if (t < nslot) {
-                const int k2 = min_k + 2 * t;
-                if (S.U[k2 + k_offset] >= best_m - band_tol) { nmin = min(nmin, k2); nmax = max(nmax, k2); }
-            }
-        }
-        for (int off = 32; off > 0; off >>= 1) { nmin = min(nmin, __shfl_xor(nmin, off)); nmax = max(nmax, __shfl_xor(nmax, off)); }
-        max_k = nmax + 1;
-        min_k = nmin - 1;
-        if (hk != 0x7fffffff) { aligned = 1; end_x = hx; end_y = hx - hk; end_d = d; end_k = hk; break; }
     }
     o.trim_ok = 0; o.qcnt = o.tcnt = o.acnt = 0;
     if (!aligned) {
+        st.unaligned += 1;
         if (best_x > 0) { end_x = best_x; end_y = best_y; end_d = best_d; end_k = best_k; }
         else { o.aligned_or_best = 0; o.qe = o.te = o.dist = 0; return; }
     }
@@ -175,14 +329,21 @@ __device__ void align_block(AlnWaveLds& S, int q_len, int t_len, uint16_t* __res
         int x1, pre_k = 0, takes_q = 0;
         if (cd == 0) x1 = 0;   // V is zero-filled: the d = 0 point starts at (0, 0)
         else {
-            if (!grow && last_row - (cd - 1) >= RING) { o.fallback = 1; return; }
-            const uint16_t* prow = grow ? grow + (size_t)(cd - 1) * ROW_W : S.ring + ((cd - 1) % RING) * ROW_W;
-            const int pmin = S.rmin[cd - 1], pmax = S.rmax[cd - 1];
-            const int cmin = S.rmin[cd], cmax = S.rmax[cd];
-            // values the forward pass read: row d-1 inside its band, the zero fill outside (never hit in practice)
+            if (!SPILL && last_row - (cd - 1) >= RING) { o.fallback = 1; return; }
+            int pmin, pmax, cmin, cmax, vl = 0, vr = 0;
             const int kl = ck - 1, kr = ck + 1;
-            const int vl = (kl >= pmin && kl <= pmax) ? (int)prow[(kl - pmin) >> 1] : 0;
-            const int vr = (kr >= pmin && kr <= pmax) ? (int)prow[(kr - pmin) >> 1] : 0;
+            // values the forward pass read: row d-1 inside its band (always the case), else the zero fill
+            if (SPILL) {
+                pmin = g_rmin[cd - 1]; pmax = g_rmax[cd - 1]; cmin = g_rmin[cd]; cmax = g_rmax[cd];
+                const uint16_t* prow = grow + (size_t)(cd - 1) * ROW_W;
+                if (kl >= pmin && kl <= pmax) vl = prow[(kl - pmin) >> 1];
+                if (kr >= pmin && kr <= pmax) vr = prow[(kr - pmin) >> 1];
+            } else {
+                pmin = S.rmin[(cd - 1) % RING]; pmax = S.rmax[(cd - 1) % RING]; cmin = S.rmin[cd % RING]; cmax = S.rmax[cd % RING];
+                const uint16_t* prow = S.ring + ((cd - 1) % RING) * ROW_W;
+                if (kl >= pmin && kl <= pmax) vl = prow[(kl - pmin) >> 1];
+                if (kr >= pmin && kr <= pmax) vr = prow[(kr - pmin) >> 1];
+            }
             if (ck == cmin || (ck != cmax && vl < vr)) { x1 = vr; pre_k = kr; takes_q = 0; }
             else { x1 = vl + 1; pre_k = kl; takes_q = 1; }
         }
@@ -204,12 +365,14 @@ __global__ __launch_bounds__(AL_BLOCK) void dw_extend(const uint32_t* __restrict
                                                       const mhip_aln_job* __restrict__ jobs, int n, DirResult* __restrict__ dres,
                                                       uint16_t* __restrict__ gscratch, unsigned int* __restrict__ cursor,
                                                       unsigned long long* __restrict__ counters) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    AlnWaveLds& S = ((AlnWaveLds*)smem_raw)[threadIdx.x >> 6];
+    __shared__ AlnWaveLds lds[AL_WAVES];
+    AlnWaveLds& S = lds[threadIdx.x >> 6];
     const int lane = lane_id();
     const int gw = blockIdx.x * AL_WAVES + (threadIdx.x >> 6);
-    uint16_t* grow = gscratch + (size_t)gw * ((size_t)MAX_D * ROW_W);
+    uint16_t* grow = gscratch + (size_t)gw * GROW_STRIDE;
     unsigned long long cells = 0, snake = 0, nblocks = 0, nfallback = 0;
+    unsigned int ucells = 0, usnake = 0;
+    DwStats st = {0, 0, 0, 0, 0};
     while (true) {
         unsigned int unit = 0;
         if (lane == 0) unit = atomicAdd(cursor, 1u);
@@ -218,12 +381,17 @@ __global__ __launch_bounds__(AL_BLOCK) void dw_extend(const uint32_t* __restrict
         const mhip_aln_job jb = jobs[unit >> 1];
         const int right = unit & 1;
         const int qsize = qoffs[jb.qid_local].size, tsize = roffs[jb.sid_local].size;
+        // extension views: logical position i of the query is strand position qstart + i (right) or qstart - 1 - i (left);
+        // strand position p of a reverse-complemented query is original index qsize - 1 - p, complemented
         SeqView q, t;
-        q.pac = qpac; q.off = qoffs[jb.qid_local].offset; q.len = qsize; q.rc = jb.chain;
-        t.pac = rpac; t.off = roffs[jb.sid_local].offset; t.len = tsize; t.rc = 0;
+        q.pac = qpac; q.off = qoffs[jb.qid_local].offset; q.comp = jb.chain;
+        t.pac = rpac; t.off = roffs[jb.sid_local].offset; t.comp = 0;
         int query_size, target_size;
-        if (right) { q.start = jb.qstart; q.step = 1; t.start = jb.sstart; t.step = 1; query_size = qsize - jb.qstart; target_size = tsize - jb.sstart; }
-        else { q.start = jb.qstart - 1; q.step = -1; t.start = jb.sstart - 1; t.step = -1; query_size = jb.qstart; target_size = jb.sstart; }
+        const int qs0 = right ? jb.qstart : jb.qstart - 1, step = right ? 1 : -1;
+        if (jb.chain) { q.A = qsize - 1 - qs0; q.B = -step; } else { q.A = qs0; q.B = step; }
+        t.A = right ? jb.sstart : jb.sstart - 1; t.B = step;
+        if (right) { query_size = qsize - jb.qstart; target_size = tsize - jb.sstart; }
+        else { query_size = jb.qstart; target_size = jb.sstart; }
         int qidx = 0, tidx = 0;
         DirResult R = {0, 0, 0, 0, 0, 0};
         while (true) {
@@ -238,12 +406,14 @@ __global__ __launch_bounds__(AL_BLOCK) void dw_extend(const uint32_t* __restrict
             if (qblk < 0) qblk = 0;
             if (tblk < 0) tblk = 0;
             __builtin_amdgcn_wave_barrier();
-            for (int i = lane; i < qblk; i += 64) S.Q[i] = (uint8_t)seq_at(q, qidx + i);
-            for (int i = lane; i < tblk; i += 64) S.T[i] = (uint8_t)seq_at(t, tidx + i);
+            if (lane < SEQ_WORDS) {
+                S.Qp[lane] = (lane * 16 < qblk + 16) ? view_word(q, qidx + lane * 16) : 0u;
+                S.Tp[lane] = (lane * 16 < tblk + 16) ? view_word(t, tidx + lane * 16) : 0u;
+            }
             __builtin_amdgcn_wave_barrier();
             BlockOut o;
-            align_block(S, qblk, tblk, nullptr, o, cells, snake);
-            if (o.fallback) { ++nfallback; align_block(S, qblk, tblk, grow, o, cells, snake); }
+            align_block<false>(S, qblk, tblk, grow, o, ucells, usnake, st);
+            if (o.fallback) { ++nfallback; align_block<true>(S, qblk, tblk, grow, o, ucells, usnake, st); }
             ++nblocks;
             R.blocks += 1;
             if (!o.aligned_or_best || !o.trim_ok) break;
@@ -261,15 +431,21 @@ __global__ __launch_bounds__(AL_BLOCK) void dw_extend(const uint32_t* __restrict
             tidx += o.te - tcnt;
         }
         if (lane == 0) dres[unit] = R;
+        cells += ucells; snake += usnake;
+        ucells = 0; usnake = 0;
     }
+    // snake bases are counted per lane
+    for (int off = 32; off > 0; off >>= 1) snake += __shfl_xor(snake, off);
     if (lane == 0) {
         atomicAdd(&counters[3], nblocks);
         atomicAdd(&counters[4], cells);
-        atomicAdd(&counters[8], nfallback);       // debug slot: blocks re-run with global rows
+        atomicAdd(&counters[5], snake);
+        atomicAdd(&counters[8], nfallback);       // debug slots: blocks re-run with spilled rows, rows, fast rows, wide rows, unaligned blocks
+        atomicAdd(&counters[9], (unsigned long long)st.rows);
+        atomicAdd(&counters[10], (unsigned long long)st.fast_rows);
+        atomicAdd(&counters[11], (unsigned long long)st.wide_rows);
+        atomicAdd(&counters[12], (unsigned long long)st.unaligned);
     }
-    // snake bases are per lane
-    for (int off = 32; off > 0; off >>= 1) snake += __shfl_xor(snake, off);
-    if (lane == 0) atomicAdd(&counters[5], snake);
 }
 
 // stitch the two directions (diff_gapalign.cpp:309-348)
@@ -300,8 +476,8 @@ __global__ __launch_bounds__(1024) void dw_make_jobs(const mhip_candidate* __res
                                                      int part_index, int part_count, mhip_aln_job* __restrict__ jobs,
                                                      int* __restrict__ num_jobs) {
     __shared__ unsigned int wtot[16];
-    __shared__ unsigned int carry_all, carry_mine;
-    if (threadIdx.x == 0) { carry_all = 0; carry_mine = 0; }
+    __shared__ unsigned int carry_all;
+    if (threadIdx.x == 0) carry_all = 0;
     __syncthreads();
     for (int t0 = 0; t0 < n_reads; t0 += 1024) {
         const int i = t0 + threadIdx.x;
@@ -340,7 +516,6 @@ __global__ __launch_bounds__(1024) void dw_make_jobs(const mhip_candidate* __res
         unsigned int mine = tot;
         if (part_count > 1) mine = tot / (unsigned)part_count + ((unsigned)part_index < tot % (unsigned)part_count ? 1u : 0u);
         *num_jobs = (int)mine;
-        (void)carry_mine;
     }
 }
 
@@ -365,18 +540,18 @@ int mhip_align_candidates_dev(mhip_ctx* c, const mhip_volume* ref, const mhip_vo
                               int min_align_size, void* d_out) {
     HIPCHK(hipSetDevice(c->device));
     if (n <= 0) return 0;
-    const int waves_per_cu = 12;                        // LDS: 3 blocks x 4 waves x 13.4 KB per CU
-    int grid = c->num_cus * waves_per_cu / AL_WAVES;
+    const int waves_per_cu = 16;                        // 4 waves per SIMD (VGPR budget); LDS 5.7 KB per wave
+    const int max_waves = c->num_cus * waves_per_cu;
+    int grid = max_waves / AL_WAVES;
     grid = std::min(grid, (2 * n + AL_WAVES - 1) / AL_WAVES);
     DirResult* d_dres;
     uint16_t* d_g;
     unsigned int* d_cur;
     if (c->scratch("al_dres", sizeof(DirResult) * 2 * (size_t)n, (void**)&d_dres)) return -1;
-    if (c->scratch("al_rows", sizeof(uint16_t) * (size_t)MAX_D * ROW_W * (size_t)(c->num_cus * waves_per_cu), (void**)&d_g)) return -1;
+    if (c->scratch("al_rows", sizeof(uint16_t) * GROW_STRIDE * (size_t)max_waves, (void**)&d_g)) return -1;
     if (c->scratch("al_cursor", 64, (void**)&d_cur)) return -1;
     HIPCHK(hipMemsetAsync(d_cur, 0, 4, c->stream));
-    const size_t lds = sizeof(AlnWaveLds) * AL_WAVES;
-    LAUNCH(c, "dw_extend", dw_extend, grid, AL_BLOCK, lds, (const uint32_t*)ref->d_pac, (const mhip_offset_t*)ref->d_offs,
+    LAUNCH(c, "dw_extend", dw_extend, grid, AL_BLOCK, 0, (const uint32_t*)ref->d_pac, (const mhip_offset_t*)ref->d_offs,
            (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs, (const mhip_aln_job*)d_jobs, n, d_dres, d_g, d_cur,
            (unsigned long long*)c->d_counters);
     LAUNCH(c, "dw_stitch", dw_stitch, (n + 255) / 256, 256, 0, (const mhip_aln_job*)d_jobs, (const DirResult*)d_dres, n,

@@ -133,13 +133,11 @@ def main():
     maxc = params.maxc
 
     # static shard of the (only) grid cell: read r -> rank r % world
-    n_local = (n - rank + world - 1) // world
-    n_pad = (n + world - 1) // world
+    from mecat_amd import shard as S
+    n_local = S.local_count(n, rank, world)
+    n_pad = S.padded_count(n, world)
     d_cands = torch.zeros((n_pad, maxc, 12), dtype=torch.int32, device=dev)
     d_counts = torch.zeros((n_pad,), dtype=torch.int32, device=dev)
-    if world > 1:
-        g_cands = torch.empty((world, n_pad, maxc, 12), dtype=torch.int32, device=dev)
-        g_counts = torch.empty((world, n_pad), dtype=torch.int32, device=dev)
     d_jobs = torch.empty((n_pad * world * maxc // world + maxc, 5), dtype=torch.int32, device=dev)
     d_res = torch.empty((d_jobs.shape[0], 8), dtype=torch.int32, device=dev)
 
@@ -149,15 +147,8 @@ def main():
         idx = M.Index(ctx, vol)
         ev[1].record(stream)
         M.seed_reads_strided_dev(ctx, idx, vol, vol, rank, world, n_local, params, d_cands.data_ptr(), d_counts.data_ptr())
-        if world > 1:
-            # exchange step: RCCL all-gather of the per-read candidate slabs (48-byte candidate_save records)
-            dist.all_gather_into_tensor(g_counts, d_counts)
-            dist.all_gather_into_tensor(g_cands, d_cands)
-            # table row i of rank r is read r + i * world  ->  read-major order
-            full_counts = g_counts.transpose(0, 1).reshape(-1)[:n].contiguous()
-            full_cands = g_cands.transpose(0, 1).reshape(n_pad * world, maxc, 12)[:n].contiguous()
-        else:
-            full_counts, full_cands = d_counts, d_cands
+        # exchange step: RCCL all-gather of the per-read candidate slabs (48-byte candidate_save records)
+        full_cands, full_counts = S.all_gather_candidates(d_cands, d_counts, n, world)
         ev[2].record(stream)
         njobs = 0
         if not args.no_align:
@@ -165,11 +156,9 @@ def main():
                                                d_jobs.data_ptr())
             M.align_candidates_dev(ctx, vol, vol, d_jobs.data_ptr(), njobs, params.min_align_size, d_res.data_ptr())
             if world > 1:
-                cap = torch.tensor([njobs], dtype=torch.int64, device=dev)
-                dist.all_reduce(cap, op=dist.ReduceOp.MAX)
-                m = int(cap.item())
-                g_res = torch.empty((world, m, 8), dtype=torch.int32, device=dev)
-                dist.all_gather_into_tensor(g_res, d_res[:m].contiguous())
+                total_jobs = int(full_counts.sum().item())
+                all_res = S.all_gather_results(d_res, njobs, total_jobs, world)   # rank 0 holds the complete overlap set
+                assert all_res.shape[0] == total_jobs
         ev[3].record(stream)
         idx_handle = idx
         stream.synchronize()

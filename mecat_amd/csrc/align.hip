@@ -28,6 +28,8 @@
 //
 // Roofline: integer compare + LDS; HBM traffic is the two block sequences (2 bits per base) and a 32-byte result, so the
 // HBM fraction is small by construction; cells and snake bases are counted for the VALU/LDS view.
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "common.h"
@@ -97,12 +99,16 @@ __device__ __forceinline__ uint32_t lds_win16(const uint32_t* P, int x) {
     return funnel_l(P[w + 1], P[w], (x & 15) << 1);      // ({P[w], P[w+1]} << s) >> 32
 }
 
-// number of leading equal bases (0..32) of the 32-base windows at Q[x..] and T[y..]
+// number of leading equal bases (0..32) of the 32-base windows at Q[x..] and T[y..].  Qp/Tp carry one leading pad
+// word (base i lives in word (i >> 4) + 1), so the window is ({P[w], P[w+1], P[w+2]} << s) with s in 2..32 and the
+// v_alignbit shift 32 - s in 0..30: no special case for a word-aligned start.
 __device__ __forceinline__ int match32(const uint32_t* Q, int x, const uint32_t* T, int y) {
-    const int wq = x >> 4, sq = (x & 15) << 1, wt = y >> 4, st = (y & 15) << 1;
+    const int xx = x + 15, yy = y + 15;
+    const int wq = xx >> 4, wt = yy >> 4;
+    const int hq = 30 - ((xx & 15) << 1), ht = 30 - ((yy & 15) << 1);
     const uint32_t q0 = Q[wq], q1 = Q[wq + 1], q2 = Q[wq + 2], t0 = T[wt], t1 = T[wt + 1], t2 = T[wt + 2];
-    const uint32_t dh = funnel_l(q1, q0, sq) ^ funnel_l(t1, t0, st);
-    const uint32_t dl = funnel_l(q2, q1, sq) ^ funnel_l(t2, t1, st);
+    const uint32_t dh = __builtin_amdgcn_alignbit(q0, q1, hq) ^ __builtin_amdgcn_alignbit(t0, t1, ht);
+    const uint32_t dl = __builtin_amdgcn_alignbit(q1, q2, hq) ^ __builtin_amdgcn_alignbit(t1, t2, ht);
     const int nh = __clz(dh) >> 1, nl = 16 + (__clz(dl) >> 1);      // __clz(0) == 32
     return dh ? nh : nl;
 }
@@ -175,20 +181,22 @@ __device__ __forceinline__ void row_body(AlnWaveLds& S, uint16_t* __restrict__ g
     x0_out = xs[0];
 }
 
-// Fast d-row: at most 64 diagonals and the band moved left by exactly one diagonal (no pruning on the left), so
-// diagonal k of this row sits in the lane that held k+1 in the previous row and k-1 is one lane to the left: the two
-// start candidates come from a register and one wave_shr:1 DPP move instead of LDS.  The lowest end-reaching diagonal
+// Fast d-row: at most 64 diagonals and the band's left edge moved by -1 (no pruning on the left, SHL = false) or by +1
+// (one diagonal pruned on the left, SHL = true).  The previous row is still in a register: diagonal k of this row sits
+// in the lane that held k+1 (SHL = false) resp. k-1 (SHL = true) in the previous row, and the other neighbour is one
+// lane away: one wave_shr:1 / wave_shl:1 DPP move replaces the two LDS reads of V.  The lowest end-reaching diagonal
 // and the first maximum are found with ballots (lane order == diagonal order) instead of key reductions.
-template <bool SPILL>
+template <bool SPILL, bool SHL>
 __device__ __forceinline__ void row_fast(AlnWaveLds& S, uint16_t* __restrict__ grow, const int lane, const int d, const int nslot,
                                          const int min_k, const int max_k, const int k_offset, const int q_len, const int t_len,
                                          unsigned int& snake, int& xreg, int& m_out, int& bkey_out, int& hkey_out) {
     const bool act = lane < nslot;
     const int k = min_k + 2 * lane;
-    const int vr = xreg;
-    const int vl = __builtin_amdgcn_update_dpp(0, xreg, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+    int vl, vr;
+    if (SHL) { vl = xreg; vr = __builtin_amdgcn_update_dpp(0, xreg, 0x130 /* wave_shl:1 */, 0xF, 0xF, false); }
+    else { vr = xreg; vl = __builtin_amdgcn_update_dpp(0, xreg, 0x138 /* wave_shr:1 */, 0xF, 0xF, false); }
     int x = (lane == 0 || (k != max_k && vl < vr)) ? vr : vl + 1;       // :138-142
-    if (!act) x = 0;
+    x = act ? x : 0;
     int y = act ? x - k : 0;
     bool more;
     do {
@@ -196,20 +204,21 @@ __device__ __forceinline__ void row_fast(AlnWaveLds& S, uint16_t* __restrict__ g
         const int n0 = match32(S.Qp, x, S.Tp, min(y, MAX_BLK));
         const int n = max(0, min(n0, lim));
         x += n; y += n;
-        snake += act ? (unsigned int)n : 0u;
-        more = act & (n == 32) & (lim > 32);
-    } while (__ballot(more));
+        snake += (unsigned int)n;           // inactive lanes sit at (0, 0) of both sequences; corrected below
+        more = (n == 32) & (lim > 32);
+    } while (__ballot(more) & (nslot >= 64 ? ~0ull : ((1ull << nslot) - 1ull)));
     __builtin_amdgcn_wave_barrier();
     if (act) {
         S.V[k + k_offset] = (int16_t)x;
         if (SPILL) grow[(size_t)d * ROW_W + lane] = (uint16_t)x;
         else S.ring[(d % RING) * ROW_W + lane] = (uint16_t)x;
-    }
+    } else snake -= (unsigned int)x;        // what the idle lane "matched" from (0, 0)
+    const unsigned long long amask = nslot >= 64 ? ~0ull : ((1ull << nslot) - 1ull);
     const int m = act ? x + y : -1;
     const int rm = wave_max(m);
-    const int lb = __ffsll((unsigned long long)__ballot(m == rm)) - 1;          // first maximum in k order
+    const int lb = __ffsll((unsigned long long)(__ballot(m == rm) & amask)) - 1;          // first maximum in k order
     bkey_out = (rm << 10) | (1023 - (min_k + 2 * lb + k_offset));
-    const unsigned long long hb = __ballot(act && (x >= q_len || y >= t_len));   // lowest diagonal that reached an end
+    const unsigned long long hb = __ballot(x >= q_len || y >= t_len) & amask;              // lowest diagonal that reached an end
     if (hb) {
         const int lh = __ffsll(hb) - 1;
         hkey_out = ((min_k + 2 * lh + k_offset) << 10) | __builtin_amdgcn_readlane(x, lh);
@@ -275,9 +284,13 @@ __device__ void align_block(AlnWaveLds& S, const int q_len, const int t_len, uin
             else { S.rmin[d % RING] = (int16_t)min_k; S.rmax[d % RING] = (int16_t)max_k; }
         }
         int bkey, hkey, x0 = 0, mreg = 0;
-        const bool fast = nj == 1 && reg_ok && min_k == reg_min_k - 1;
-        if (fast) {
-            row_fast<SPILL>(S, grow, lane, d, nslot, min_k, max_k, k_offset, q_len, t_len, snake, xreg, mreg, bkey, hkey);
+        const bool fast_r = nj == 1 && reg_ok && min_k == reg_min_k - 1;
+        const bool fast_l = nj == 1 && reg_ok && min_k == reg_min_k + 1 && nslot <= 63;
+        const bool fast = fast_r || fast_l;
+        if (fast_r) {
+            row_fast<SPILL, false>(S, grow, lane, d, nslot, min_k, max_k, k_offset, q_len, t_len, snake, xreg, mreg, bkey, hkey);
+        } else if (fast_l) {
+            row_fast<SPILL, true>(S, grow, lane, d, nslot, min_k, max_k, k_offset, q_len, t_len, snake, xreg, mreg, bkey, hkey);
         } else {
             switch (nj) {
             case 1: row_body<1, SPILL>(S, grow, lane, d, nslot, min_k, max_k, k_offset, q_len, t_len, best_m, band_tol, snake, bkey, hkey, x0); break;
@@ -406,9 +419,9 @@ __global__ __launch_bounds__(AL_BLOCK) void dw_extend(const uint32_t* __restrict
             if (qblk < 0) qblk = 0;
             if (tblk < 0) tblk = 0;
             __builtin_amdgcn_wave_barrier();
-            if (lane < SEQ_WORDS) {
-                S.Qp[lane] = (lane * 16 < qblk + 16) ? view_word(q, qidx + lane * 16) : 0u;
-                S.Tp[lane] = (lane * 16 < tblk + 16) ? view_word(t, tidx + lane * 16) : 0u;
+            if (lane < SEQ_WORDS) {     // word 0 is the pad word, word 1 + j holds logical bases 16j .. 16j+15
+                S.Qp[lane] = (lane > 0 && (lane - 1) * 16 < qblk + 32) ? view_word(q, qidx + (lane - 1) * 16) : 0u;
+                S.Tp[lane] = (lane > 0 && (lane - 1) * 16 < tblk + 32) ? view_word(t, tidx + (lane - 1) * 16) : 0u;
             }
             __builtin_amdgcn_wave_barrier();
             BlockOut o;
@@ -540,7 +553,8 @@ int mhip_align_candidates_dev(mhip_ctx* c, const mhip_volume* ref, const mhip_vo
                               int min_align_size, void* d_out) {
     HIPCHK(hipSetDevice(c->device));
     if (n <= 0) return 0;
-    const int waves_per_cu = 16;                        // 4 waves per SIMD (VGPR budget); LDS 5.7 KB per wave
+    int waves_per_cu = 16;                              // 4 waves per SIMD (VGPR budget); LDS 9.2 KB per wave
+    if (const char* e = getenv("MECAT_DW_WAVES")) waves_per_cu = std::max(4, std::min(16, atoi(e)));   // tuning/debug knob
     const int max_waves = c->num_cus * waves_per_cu;
     int grid = max_waves / AL_WAVES;
     grid = std::min(grid, (2 * n + AL_WAVES - 1) / AL_WAVES);

@@ -28,6 +28,7 @@
 //
 // Roofline: integer compare + LDS; HBM traffic is the two block sequences (2 bits per base) and a 32-byte result, so the
 // HBM fraction is small by construction; cells and snake bases are counted for the VALU/LDS view.
+#include <stddef.h>
 #include <stdlib.h>
 
 #include <algorithm>
@@ -461,6 +462,304 @@ __global__ __launch_bounds__(AL_BLOCK) void dw_extend(const uint32_t* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// dw_extend2 — two (candidate, direction) units per wave, one per 32-lane half.
+//
+// The adaptive band keeps ~25 diagonals alive on average (config 2: 6.0e9 rows, 1.5e11 cells), so a whole wave per
+// unit leaves 60 % of the lanes idle and the kernel is VALU-issue bound.  Here each half-wave runs its own unit; the
+// two halves advance in lock step only inside a block (row d of both blocks is one pass over the code, a finished half
+// idles until the other block ends) and fetch new units independently at block boundaries.  Everything that is a
+// scalar in the one-unit kernel (band limits, best point, block sizes ...) is a per-half-uniform VGPR value here;
+// per-half row maxima use a 5-step DPP chain (quad swaps, half/row mirrors, row_bcast:15) + two readlanes, first-index
+// decisions use the two 32-bit halves of a ballot.  d-rows live in a 1024-entry circular buffer per half (rows are
+// packed back to back: the average row is 25 entries, so ~40 rows stay traceable); the rare block whose tail
+// traceback needs an overwritten row is re-run by the one-unit code path with rows spilled to global scratch.
+#define RCAP 1024
+#define RROWS 64
+struct HalfLds {
+    int16_t V[VU_LEN];
+    uint32_t Qp[SEQ_WORDS];
+    uint32_t Tp[SEQ_WORDS];
+    uint16_t ring[RCAP];
+    uint32_t rlin[RROWS];
+    int16_t rmin[RROWS];
+    int16_t rmax[RROWS];
+};
+static_assert(offsetof(HalfLds, Qp) == offsetof(AlnWaveLds, Qp) && offsetof(HalfLds, Tp) == offsetof(AlnWaveLds, Tp),
+              "the spill fallback reuses V/Qp/Tp in place");
+
+// max over each 32-lane half, returned in every lane of the half
+__device__ __forceinline__ int half_max(int v) {
+    asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "+v"(v));
+    const int a = __builtin_amdgcn_readlane(v, 31), b = __builtin_amdgcn_readlane(v, 63);
+    return (lane_id() & 32) ? b : a;
+}
+__device__ __forceinline__ int half_min(int v) { return -half_max(-v); }
+
+__global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __restrict__ rpac, const mhip_offset_t* __restrict__ roffs,
+                                                       const uint32_t* __restrict__ qpac, const mhip_offset_t* __restrict__ qoffs,
+                                                       const mhip_aln_job* __restrict__ jobs, int n, DirResult* __restrict__ dres,
+                                                       uint16_t* __restrict__ gscratch, unsigned int* __restrict__ cursor,
+                                                       unsigned long long* __restrict__ counters) {
+    __shared__ HalfLds lds[AL_WAVES][2];
+    const int lane = lane_id(), hh = lane >> 5, sl = lane & 31;
+    HalfLds& S = lds[threadIdx.x >> 6][hh];
+    const int gw = blockIdx.x * AL_WAVES + (threadIdx.x >> 6);
+    uint16_t* grow = gscratch + (size_t)gw * GROW_STRIDE;
+    unsigned long long cells = 0, snake = 0, nblocks = 0, nfallback = 0, nrows = 0, nidle = 0;
+    unsigned int usnake = 0;
+
+    // per-half unit state (uniform inside a half)
+    bool need_unit = true, exhausted = false;
+    unsigned int unit = 0;
+    SeqView q, t;
+    q.pac = qpac; t.pac = rpac; q.off = 0; t.off = 0; q.A = q.B = t.A = t.B = 0; q.comp = t.comp = 0;
+    int query_size = 0, target_size = 0, qidx = 0, tidx = 0;
+    int Rq = 0, Rt = 0, Rm = 0, Rc = 0, Rb = 0;
+
+    while (true) {
+        // ---- 1. a half without a unit pulls the next one
+        if (need_unit && !exhausted) {
+            unsigned int u = 0;
+            if (sl == 0) u = atomicAdd(cursor, 1u);
+            u = __shfl(u, hh << 5);
+            if (u >= 2u * (unsigned)n) exhausted = true;
+            else {
+                unit = u;
+                const mhip_aln_job jb = jobs[u >> 1];
+                const int right = u & 1;
+                const int qsize = qoffs[jb.qid_local].size, tsize = roffs[jb.sid_local].size;
+                q.off = qoffs[jb.qid_local].offset; q.comp = jb.chain;
+                t.off = roffs[jb.sid_local].offset; t.comp = 0;
+                const int qs0 = right ? jb.qstart : jb.qstart - 1, step = right ? 1 : -1;
+                if (jb.chain) { q.A = qsize - 1 - qs0; q.B = -step; } else { q.A = qs0; q.B = step; }
+                t.A = right ? jb.sstart : jb.sstart - 1; t.B = step;
+                if (right) { query_size = qsize - jb.qstart; target_size = tsize - jb.sstart; }
+                else { query_size = jb.qstart; target_size = jb.sstart; }
+                qidx = tidx = 0;
+                Rq = Rt = Rm = Rc = Rb = 0;
+                need_unit = false;
+            }
+        }
+        if (!__ballot(!exhausted)) break;
+        const bool live = !exhausted;
+
+        // ---- 2. block setup: retrieve_next_aln_block (gapalign.cpp:9-45) + staging
+        const int qleft = query_size - qidx, tleft = target_size - tidx;
+        int qblk, tblk, last_block;
+        if (qleft < SEG_BLK + 100 || tleft < SEG_BLK + 100) {
+            qblk = min(qleft, (int)(tleft + tleft * 0.2));
+            tblk = min(tleft, (int)(qleft + qleft * 0.2));
+            last_block = 1;
+        } else { qblk = SEG_BLK; tblk = SEG_BLK; last_block = 0; }
+        qblk = live ? max(qblk, 0) : 0;
+        tblk = live ? max(tblk, 0) : 0;
+        const int q_len = qblk, t_len = tblk;
+        const int band_tol = (int)(0.3 * (q_len > t_len ? q_len : t_len));
+        const int max_d = (int)(.3 * (q_len + t_len));
+        const int k_offset = max_d;
+        const int band_size = band_tol * 2;
+        __builtin_amdgcn_wave_barrier();
+        for (int w = sl; w < SEQ_WORDS; w += 32) {
+            S.Qp[w] = (live && w > 0 && (w - 1) * 16 < qblk + 32) ? view_word(q, qidx + (w - 1) * 16) : 0u;
+            S.Tp[w] = (live && w > 0 && (w - 1) * 16 < tblk + 32) ? view_word(t, tidx + (w - 1) * 16) : 0u;
+        }
+        for (int i = sl; i < 2 * max_d + 4 && i < VU_LEN; i += 32) S.V[i] = 0;
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- 3. rows (Align, diff_gapalign.cpp:107-219)
+        int best_m = -1, best_x = -1, best_d = 0, best_k = 0;
+        int min_k = 0, max_k = 0;
+        int aligned = 0, end_x = 0, end_k = 0, end_d = 0, last_row = -1;
+        unsigned int lin = 0;
+        bool rowing = live;
+        for (int d = 0;; ++d) {
+            rowing = rowing && d < max_d && (max_k - min_k <= band_size);
+            const unsigned long long rmask = __ballot(rowing);
+            if (!rmask) break;
+            nrows += 1;
+            nidle += (rmask == ~0ull) ? 0u : 1u;
+            const int nslot = rowing ? (max_k - min_k) / 2 + 1 : 0;
+            unsigned int pos0 = lin & (RCAP - 1);
+            if (pos0 + (unsigned)nslot > RCAP) { lin += RCAP - pos0; pos0 = 0; }
+            if (rowing && sl == 0) { S.rmin[d & (RROWS - 1)] = (int16_t)min_k; S.rmax[d & (RROWS - 1)] = (int16_t)max_k; S.rlin[d & (RROWS - 1)] = lin; }
+            if (rowing) last_row = d;
+            const int ns_a = __builtin_amdgcn_readlane(nslot, 0), ns_b = __builtin_amdgcn_readlane(nslot, 32);
+            const int NJ = (max(ns_a, ns_b) + 31) >> 5;
+            int bm = -1, hk = 0x7fffffff, m0 = -1;
+            for (int j = 0; j < NJ; ++j) {
+                const int tt = sl + 32 * j;
+                const bool act = rowing && tt < nslot;
+                const int k = min_k + 2 * tt, kk = k + k_offset;
+                const int ix = act ? kk : 1;
+                const int vl = S.V[ix - 1], vr = S.V[ix + 1];
+                int x = (k == min_k || (k != max_k && vl < vr)) ? vr : vl + 1;       // :138-142
+                x = act ? x : 0;
+                int y = act ? x - k : 0;
+                bool more;
+                do {
+                    const int lim = min(q_len - x, t_len - y);
+                    const int n0 = match32(S.Qp, x, S.Tp, min(max(y, 0), MAX_BLK));
+                    const int nn = act ? max(0, min(n0, lim)) : 0;
+                    x += nn; y += nn;
+                    usnake += (unsigned int)nn;
+                    more = act & (nn == 32) & (lim > 32);
+                } while (__ballot(more));
+                if (act) {
+                    S.V[kk] = (int16_t)x;
+                    S.ring[pos0 + tt] = (uint16_t)x;
+                    bm = max(bm, ((x + y) << 10) | (1023 - kk));
+                    if (x >= q_len || y >= t_len) hk = min(hk, (kk << 10) | x);
+                }
+                if (j == 0) m0 = act ? x + y : -1;
+            }
+            lin += (unsigned)nslot;
+            cells += (unsigned long long)(ns_a + ns_b);
+            __builtin_amdgcn_wave_barrier();
+            // first maximum of x + y in k order (:160-167); lowest diagonal that reached an end (:168-169)
+            const int bkey = half_max(bm);
+            int hkey = 0x7fffffff;
+            if (__ballot(hk != 0x7fffffff)) hkey = half_min(hk);
+            if (rowing) {
+                const int rm = bkey >> 10, rk = 1023 - (bkey & 1023) - k_offset;
+                if (rm > best_m) { best_m = rm; best_x = (rm + rk) / 2; best_d = d; best_k = rk; }
+            }
+            // band update (:172-179)
+            int nmin = max_k, nmax = min_k;
+            if (NJ == 1) {
+                const unsigned long long qb = __ballot(rowing && sl < nslot && m0 >= best_m - band_tol);
+                const unsigned int qa = (unsigned int)qb, qbh = (unsigned int)(qb >> 32);
+                const unsigned int mine = hh ? qbh : qa;
+                if (mine) { nmin = min_k + 2 * (__ffs((int)mine) - 1); nmax = min_k + 2 * (31 - __clz((int)mine)); }
+            } else {
+                int lo = 0x7fffffff, hi = -0x7fffffff;
+                for (int j = 0; j < NJ; ++j) {
+                    const int tt = sl + 32 * j;
+                    const bool act = rowing && tt < nslot;
+                    const int k = min_k + 2 * tt;
+                    const int u = act ? 2 * (int)S.V[k + k_offset] - k : -0x40000000;
+                    if (act && u >= best_m - band_tol) { lo = min(lo, k); hi = max(hi, k); }
+                }
+                lo = half_min(lo); hi = half_max(hi);
+                if (lo != 0x7fffffff) { nmin = lo; nmax = hi; }
+            }
+            if (rowing) {
+                max_k = nmax + 1;
+                min_k = nmin - 1;
+                if (hkey != 0x7fffffff) {
+                    aligned = 1; end_k = (hkey >> 10) - k_offset; end_x = hkey & 1023; end_d = d;
+                    rowing = false;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+
+        // ---- 4. tail traceback == trim_mismatch_end(.., 4, ..) (gapalign.cpp:47-68)
+        bool has_aln = live && (aligned || best_x > 0);
+        if (!aligned) { end_x = best_x; end_k = best_k; end_d = best_d; }
+        const int end_y = end_x - end_k;
+        const int aln_size = (end_x + end_y + end_d) / 2;
+        int cd = end_d, ck = end_k, cx2 = end_x;
+        int qcnt = 0, tcnt = 0, acnt = 0, found = 0;
+        bool fallback = false;
+        bool tracing = has_aln;
+        while (__ballot(tracing)) {
+            if (tracing) {
+                int x1 = 0, pre_k = 0, takes_q = 0;
+                if (cd > 0) {
+                    const int r = cd - 1;
+                    const unsigned int rl = S.rlin[r & (RROWS - 1)];
+                    if (last_row - r >= RROWS || lin - rl > RCAP) { fallback = true; tracing = false; }
+                    else {
+                        const int pmin = S.rmin[r & (RROWS - 1)], pmax = S.rmax[r & (RROWS - 1)];
+                        const int cmin = S.rmin[cd & (RROWS - 1)], cmax = S.rmax[cd & (RROWS - 1)];
+                        const unsigned int pb = rl & (RCAP - 1);
+                        const int kl = ck - 1, kr = ck + 1;
+                        int vl = 0, vr = 0;
+                        if (kl >= pmin && kl <= pmax) vl = S.ring[pb + ((kl - pmin) >> 1)];
+                        if (kr >= pmin && kr <= pmax) vr = S.ring[pb + ((kr - pmin) >> 1)];
+                        if (ck == cmin || (ck != cmax && vl < vr)) { x1 = vr; pre_k = kr; takes_q = 0; }
+                        else { x1 = vl + 1; pre_k = kl; takes_q = 1; }
+                    }
+                }
+                if (tracing) {
+                    const int sn = cx2 - x1;
+                    if (sn >= 4) { acnt += 4; qcnt += 4; tcnt += 4; found = 1; tracing = false; }
+                    else {
+                        acnt += sn; qcnt += sn; tcnt += sn;
+                        if (cd == 0) tracing = false;
+                        else {
+                            acnt += 1;
+                            if (takes_q) { qcnt += 1; cx2 = x1 - 1; } else { tcnt += 1; cx2 = x1; }
+                            ck = pre_k;
+                            --cd;
+                        }
+                    }
+                }
+            }
+        }
+        int o_qe = end_x, o_te = end_y, o_dist = end_d;
+        int trim_ok = has_aln && found && (aln_size - acnt >= 2);
+
+        // ---- 5. rare: the tail needs a row that left the ring -> re-run that half's block with spilled rows
+        const unsigned long long fb = __ballot(fallback);
+        if (fb) {
+            for (int hx = 0; hx < 2; ++hx) {
+                if (!((fb >> (hx * 32)) & 1ull)) continue;
+                const int ql = __builtin_amdgcn_readlane(q_len, hx * 32), tl = __builtin_amdgcn_readlane(t_len, hx * 32);
+                BlockOut o;
+                unsigned int c2 = 0, s2 = 0;
+                DwStats st2 = {0, 0, 0, 0, 0};
+                align_block<true>(*(AlnWaveLds*)&lds[threadIdx.x >> 6][hx], ql, tl, grow, o, c2, s2, st2);
+                ++nfallback;
+                if (hh == hx) {
+                    has_aln = o.aligned_or_best; o_qe = o.qe; o_te = o.te; o_dist = o.dist;
+                    qcnt = o.qcnt; tcnt = o.tcnt; acnt = o.acnt; trim_ok = o.aligned_or_best && o.trim_ok;
+                }
+            }
+        }
+
+        // ---- 6. block accounting (dw_in_one_direction, diff_gapalign.cpp:259-290)
+        if (live) {
+            nblocks += (sl == 0) ? 1u : 0u;
+            Rb += 1;
+            bool stop = !has_aln || !trim_ok;
+            if (!stop) {
+                const int full_map = (qblk - o_qe <= 20 || tblk - o_te <= 20);
+                const bool fin = last_block || !full_map;
+                if (fin) { qcnt -= 4; tcnt -= 4; acnt -= 4; }
+                Rc += (o_qe + o_te + o_dist) / 2 - acnt;
+                Rm += (o_qe + o_te - o_dist) / 2 - (qcnt + tcnt - acnt);
+                Rq += o_qe - qcnt;
+                Rt += o_te - tcnt;
+                if (fin) stop = true;
+                else { qidx += o_qe - qcnt; tidx += o_te - tcnt; }
+            }
+            if (stop) {
+                if (sl == 0) { DirResult R = {Rq, Rt, Rm, Rc, Rb, 0}; dres[unit] = R; }
+                need_unit = true;
+            }
+        }
+        snake += usnake;
+        usnake = 0;
+    }
+    for (int off = 32; off > 0; off >>= 1) { snake += __shfl_xor(snake, off); nblocks += __shfl_xor(nblocks, off); }
+    if (lane == 0) {
+        atomicAdd(&counters[3], nblocks);
+        atomicAdd(&counters[4], cells);
+        atomicAdd(&counters[5], snake);
+        atomicAdd(&counters[8], nfallback);
+        atomicAdd(&counters[9], nrows);          // dual rows
+        atomicAdd(&counters[10], nidle);         // dual rows with one idle half
+    }
+}
+
 // stitch the two directions (diff_gapalign.cpp:309-348)
 __global__ void dw_stitch(const mhip_aln_job* __restrict__ jobs, const DirResult* __restrict__ dres, int n, int min_aln,
                           mhip_aln_result* __restrict__ out, unsigned long long* __restrict__ counters) {
@@ -565,9 +864,17 @@ int mhip_align_candidates_dev(mhip_ctx* c, const mhip_volume* ref, const mhip_vo
     if (c->scratch("al_rows", sizeof(uint16_t) * GROW_STRIDE * (size_t)max_waves, (void**)&d_g)) return -1;
     if (c->scratch("al_cursor", 64, (void**)&d_cur)) return -1;
     HIPCHK(hipMemsetAsync(d_cur, 0, 4, c->stream));
-    LAUNCH(c, "dw_extend", dw_extend, grid, AL_BLOCK, 0, (const uint32_t*)ref->d_pac, (const mhip_offset_t*)ref->d_offs,
-           (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs, (const mhip_aln_job*)d_jobs, n, d_dres, d_g, d_cur,
-           (unsigned long long*)c->d_counters);
+    const char* kv = getenv("MECAT_DW_KERNEL");      // debug knob: 1 = one unit per wave, default 2 = one unit per half-wave
+    if (kv && atoi(kv) == 1) {
+        LAUNCH(c, "dw_extend", dw_extend, grid, AL_BLOCK, 0, (const uint32_t*)ref->d_pac, (const mhip_offset_t*)ref->d_offs,
+               (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs, (const mhip_aln_job*)d_jobs, n, d_dres, d_g, d_cur,
+               (unsigned long long*)c->d_counters);
+    } else {
+        grid = std::min(max_waves / AL_WAVES, (n + AL_WAVES - 1) / AL_WAVES);
+        LAUNCH(c, "dw_extend2", dw_extend2, grid, AL_BLOCK, 0, (const uint32_t*)ref->d_pac, (const mhip_offset_t*)ref->d_offs,
+               (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs, (const mhip_aln_job*)d_jobs, n, d_dres, d_g, d_cur,
+               (unsigned long long*)c->d_counters);
+    }
     LAUNCH(c, "dw_stitch", dw_stitch, (n + 255) / 256, 256, 0, (const mhip_aln_job*)d_jobs, (const DirResult*)d_dres, n,
            min_align_size, (mhip_aln_result*)d_out, (unsigned long long*)c->d_counters);
     HIPCHK(hipGetLastError());

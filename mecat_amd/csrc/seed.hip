@@ -30,6 +30,7 @@
 // built with -ffp-contract=off and hipcc's default correctly-rounded f32 division.
 //
 // Known divergence: reads longer than 327 670 bases (seed numbers overflow the reference's `short`).
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -42,13 +43,21 @@
 #define KEY_KM_BITS 16
 #define KEY_SEG_SHIFT (KEY_OFF_BITS + KEY_KM_BITS)   // 27
 #define MAXC_LIMIT 1024
+#define FLT_BITS 15                 // relevance filter: 2^15 4-bit hit counters per strand
+#define FLT_M (1 << FLT_BITS)
+#define HOT_TAB 2048                // hash set of hot segments
+#define HOT_CAP 1536                // more distinct hot segments than this -> the strand is not filtered
 
 struct SeedArrays {
     // per batch
     const uint32_t* km_base;     // [ns]   first k-mer slot of the strand
     uint32_t* km_bstart;         // [sumK] bucket start in index offsets[]
-    uint32_t* km_hpre;           // [sumK] exclusive prefix of bucket sizes inside the strand
-    uint32_t* strand_hits;       // [ns]
+    uint32_t* km_cnt;            // [sumK] bucket size
+    uint32_t* km_rpre;           // [sumK] exclusive prefix (inside the strand) of the hits kept per k-mer
+    uint32_t* strand_hits_all;   // [ns]   bucket hits of the strand (before the relevance filter)
+    uint32_t* strand_hits;       // [ns]   hits kept (emitted, sorted, built)
+    uint32_t* hot_list;          // [ns * HOT_CAP] sorted hot segments of the strand
+    int32_t* hot_count;          // [ns]   number of hot segments, -1 = strand not filtered
     uint64_t* hit_base;          // [ns + 1]
     uint64_t* keysA;             // [Htot]
     uint64_t* keysB;             // [Htot]
@@ -113,15 +122,15 @@ __global__ __launch_bounds__(SEED_BLOCK) void seed_probe(const uint32_t* __restr
             cnt = starts[id + 1] - bs;
         }
         uint32_t tot;
-        uint32_t ex = block_excl_scan(cnt, wtot, &tot);
+        (void)block_excl_scan(cnt, wtot, &tot);
         if (km < K) {
             A.km_bstart[kb + km] = bs;
-            A.km_hpre[kb + km] = run + ex;
+            A.km_cnt[kb + km] = cnt;
         }
         run += tot;
     }
     if (threadIdx.x == 0) {
-        A.strand_hits[s] = run;
+        A.strand_hits_all[s] = run;
         atomicAdd(&counters[0], (unsigned long long)K);
         atomicAdd(&counters[1], (unsigned long long)run);
     }
@@ -153,36 +162,188 @@ __global__ __launch_bounds__(1024) void seed_scan(const uint32_t* __restrict__ h
     if (threadIdx.x == 0) base[ns] = carry;
 }
 
-// ------------------------------------------------------------------------------------------------ emit
-__global__ __launch_bounds__(SEED_BLOCK) void seed_emit(const mhip_offset_t* __restrict__ roffs, int rid_begin, int rid_stride,
-                                                        const int32_t* __restrict__ offsets, SeedArrays A) {
-    __shared__ uint32_t pre[SEED_BLOCK + 1];
-    __shared__ uint32_t bst[SEED_BLOCK];
+// ------------------------------------------------------------------------------------------------ hit iteration
+// 16 lanes per query k-mer: a bucket (<= 128 ascending positions, ~22 on average) is read in 64-byte pieces, lane `sub`
+// takes entries sub, sub + 16, ...  `f(km, r, pos, valid)` is called by all 16 lanes of the group together (group-uniform
+// control flow), so it may use the group's 16 bits of a wave ballot.
+template <typename F>
+__device__ __forceinline__ void for_each_hit16(const SeedArrays& A, const int32_t* __restrict__ offsets, const uint32_t kb, const int K, F f) {
+    const int g = threadIdx.x >> 4, sub = threadIdx.x & 15;
+    for (int km = g; km < K; km += SEED_BLOCK / 16) {
+        const uint32_t bs = A.km_bstart[kb + km], cnt = A.km_cnt[kb + km];
+        for (uint32_t r0 = 0; r0 < cnt; r0 += 16) {
+            const uint32_t r = r0 + sub;
+            const bool valid = r < cnt;
+            f(km, r, valid ? (uint32_t)offsets[bs + r] : 0u, valid);
+        }
+    }
+}
+__device__ __forceinline__ uint32_t group_bits(unsigned long long ballot) { return (uint32_t)(ballot >> (threadIdx.x & 48)) & 0xFFFFu; }
+
+// sweeps of get_candidates reach ceil(num / ZV) segments, num <= read length + 12 (pw_impl.cpp:388-425); +1 for seg - 1
+__device__ __forceinline__ int sweep_reach(int L) { return (L + MHIP_KMER_SIZE - 1 + ZV - 1) / ZV + 1; }
+
+// relevance bitmap over hashed segment ids: bit (seg mod 2^16) is set for every segment within `reach` of a hot segment.
+// A hash collision can only keep an irrelevant hit (5 % at config 2), never drop a relevant one.
+#define REL_BITS 16
+#define REL_WORDS ((1 << REL_BITS) / 32)
+__device__ __forceinline__ void rel_build(uint32_t* rel, const uint32_t* hot, int nh, int reach) {
+    for (int i = threadIdx.x; i < REL_WORDS; i += SEED_BLOCK) rel[i] = 0;
+    __syncthreads();
+    const int span = 2 * reach + 1;
+    for (int i = threadIdx.x; i < nh * span; i += SEED_BLOCK) {
+        const int seg = (int)hot[i / span] - reach + (i % span);
+        if (seg >= 0) {
+            const uint32_t e = (uint32_t)seg & ((1u << REL_BITS) - 1u);
+            atomicOr(&rel[e >> 5], 1u << (e & 31u));
+        }
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ bool rel_test(const uint32_t* rel, uint32_t seg) {
+    const uint32_t e = seg & ((1u << REL_BITS) - 1u);
+    return (rel[e >> 5] >> (e & 31u)) & 1u;
+}
+
+// ------------------------------------------------------------------------------------------------ relevance filter
+// Most bucket hits are random 13-mer matches that land alone in their 2 kb segment and can never matter:
+// get_candidates only looks at segments whose index_score (own + left neighbour's seed count) reaches 2 * min_kmer_match
+// (pw_impl.cpp:309) and, from those, at most ceil((L + 12) / 2000) segments to either side (:405-438).  With h(seg) = bucket
+// hits in a segment (an upper bound of its seed count), a segment is HOT when h(seg-1) + h(seg) or h(seg) + h(seg+1) reaches
+// the gate; only hits within `sweep_reach` segments of a hot segment are kept.  Dropped hits touch no state that is
+// ever read, so the result is unchanged (the filter only ever errs towards keeping: hash collisions and counter
+// saturation inflate h).  Counters: 2^15 4-bit fields in LDS (packed 8 per word; a field that would wrap sets a sticky
+// bit instead of losing the count); hot segments are de-duplicated in an LDS hash set.  Output: per k-mer prefix of kept
+// hits (km_rpre), kept hits per strand, the strand's hot list (emit rebuilds the same relevance bitmap from it).
+__global__ __launch_bounds__(SEED_BLOCK) void seed_filter(const mhip_offset_t* __restrict__ roffs, int rid_begin, int rid_stride,
+                                                          const int32_t* __restrict__ offsets, SeedArrays A, int gate, int enable) {
+    __shared__ uint32_t cnt[FLT_M / 8];          // 16 KB; afterwards: relevance bitmap (8 KB) + hot list (6 KB)
+    __shared__ uint32_t sticky[FLT_M / 32];      // 4 KB
+    __shared__ uint32_t tab[HOT_TAB];            // 8 KB
+    __shared__ uint32_t wtot[SEED_WAVES];
+    __shared__ uint32_t s_n[2];
     const int s = blockIdx.x;
     const int rid = rid_begin + (s >> 1) * rid_stride;
-    const int K = kmers_of(roffs[rid].size);
+    const int L = roffs[rid].size;
+    const int K = kmers_of(L);
     const uint32_t kb = A.km_base[s];
-    const uint32_t H = A.strand_hits[s];
-    uint64_t* __restrict__ out = A.keysA + A.hit_base[s];
-    for (int t0 = 0; t0 < K; t0 += SEED_BLOCK) {
-        int km = t0 + threadIdx.x;
+    const uint32_t Hall = A.strand_hits_all[s];
+    bool filtered = enable && Hall > 0;
+    uint32_t nh = 0;
+    uint32_t* rel = cnt;
+    uint32_t* hot = cnt + REL_WORDS;
+    const int reach = sweep_reach(L);
+    if (filtered) {
+        for (int i = threadIdx.x; i < FLT_M / 8; i += SEED_BLOCK) cnt[i] = 0;
+        for (int i = threadIdx.x; i < FLT_M / 32; i += SEED_BLOCK) sticky[i] = 0;
+        for (int i = threadIdx.x; i < HOT_TAB; i += SEED_BLOCK) tab[i] = 0xFFFFFFFFu;
+        if (threadIdx.x == 0) { s_n[0] = 0; s_n[1] = 0; }
         __syncthreads();
-        if (km < K) { pre[threadIdx.x] = A.km_hpre[kb + km]; bst[threadIdx.x] = A.km_bstart[kb + km]; }
-        int nk = min(SEED_BLOCK, K - t0);
-        if ((int)threadIdx.x == nk - 1) pre[nk] = (t0 + nk < K) ? A.km_hpre[kb + t0 + nk] : H;
-        __syncthreads();
-        const uint32_t h0 = pre[0], h1 = pre[nk];
-        for (uint32_t h = h0 + threadIdx.x; h < h1; h += SEED_BLOCK) {
-            // last k with pre[k] <= h
-            int lo = 0, hi = nk;   // invariant pre[lo] <= h < pre[hi]
-            while (hi - lo > 1) {
-                int mid = (lo + hi) >> 1;
-                if (pre[mid] <= h) lo = mid; else hi = mid;
+        // pass 1: h(seg)
+        for_each_hit16(A, offsets, kb, K, [&](int, uint32_t, uint32_t pos, bool valid) {
+            if (valid) {
+                const uint32_t e = (pos / ZV) & (FLT_M - 1);
+                const uint32_t sh = (e & 7u) * 4u;
+                const uint32_t old = atomicAdd(&cnt[e >> 3], 1u << sh);
+                if (((old >> sh) & 15u) == 15u) atomicOr(&sticky[e >> 5], 1u << (e & 31u));
             }
-            uint32_t r = h - pre[lo];
-            uint32_t pos = (uint32_t)offsets[bst[lo] + r];
-            uint32_t seg = pos / ZV, so = pos - seg * ZV;
-            out[h] = ((uint64_t)seg << KEY_SEG_SHIFT) | ((uint64_t)(t0 + lo) << KEY_OFF_BITS) | so;
+        });
+        __syncthreads();
+        auto hval = [&](uint32_t seg) -> int {
+            const uint32_t e = seg & (FLT_M - 1);
+            return ((sticky[e >> 5] >> (e & 31u)) & 1u) ? 64 : (int)((cnt[e >> 3] >> ((e & 7u) * 4u)) & 15u);
+        };
+        // pass 2: hot segments into the hash set
+        for_each_hit16(A, offsets, kb, K, [&](int, uint32_t, uint32_t pos, bool valid) {
+            if (valid) {
+                const uint32_t seg = pos / ZV;
+                const int c = hval(seg);
+                if (c + hval(seg + 1) >= gate || c + hval(seg - 1) >= gate) {
+                    uint32_t slot = (seg * 2654435761u) >> (32 - 11);
+                    for (int probe = 0; probe < HOT_TAB; ++probe) {
+                        const uint32_t old = atomicCAS(&tab[slot], 0xFFFFFFFFu, seg);
+                        if (old == 0xFFFFFFFFu) { atomicAdd(&s_n[0], 1u); break; }
+                        if (old == seg) break;
+                        slot = (slot + 1) & (HOT_TAB - 1);
+                    }
+                }
+            }
+        });
+        __syncthreads();
+        nh = s_n[0];
+        if (nh > HOT_CAP) filtered = false;      // too many hot segments for the set: keep everything
+    }
+    if (filtered) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < HOT_TAB; i += SEED_BLOCK) {
+            const uint32_t v = tab[i];
+            if (v != 0xFFFFFFFFu) hot[atomicAdd(&s_n[1], 1u)] = v;
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nh; i += SEED_BLOCK) A.hot_list[(size_t)s * HOT_CAP + i] = hot[i];
+        rel_build(rel, hot, (int)nh, reach);
+    }
+    // pass 3: hits kept per k-mer ...
+    if (!filtered) {
+        for (int km = threadIdx.x; km < K; km += SEED_BLOCK) A.km_rpre[kb + km] = A.km_cnt[kb + km];
+    } else {
+        const int g = threadIdx.x >> 4, sub = threadIdx.x & 15;
+        for (int km = g; km < K; km += SEED_BLOCK / 16) {
+            const uint32_t bs = A.km_bstart[kb + km], c = A.km_cnt[kb + km];
+            uint32_t keep = 0;
+            for (uint32_t r0 = 0; r0 < c; r0 += 16) {
+                const uint32_t r = r0 + sub;
+                const bool k1 = r < c && rel_test(rel, (uint32_t)offsets[bs + r] / ZV);
+                keep += __popc(group_bits(__ballot(k1)));
+            }
+            if (sub == 0) A.km_rpre[kb + km] = keep;
+        }
+    }
+    __syncthreads();
+    // ... -> exclusive prefix inside the strand
+    uint32_t run = 0;
+    for (int t0 = 0; t0 < K; t0 += SEED_BLOCK) {
+        const int km = t0 + threadIdx.x;
+        const uint32_t keep = km < K ? A.km_rpre[kb + km] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan(keep, wtot, &tot);
+        if (km < K) A.km_rpre[kb + km] = run + ex;
+        run += tot;
+    }
+    if (threadIdx.x == 0) { A.strand_hits[s] = run; A.hot_count[s] = filtered ? (int32_t)nh : -1; }
+}
+
+// ------------------------------------------------------------------------------------------------ emit
+// keys of the kept hits in (km, position) order = the order the reference visits them: key = seg:21 | km:16 | off:11
+__global__ __launch_bounds__(SEED_BLOCK) void seed_emit(const mhip_offset_t* __restrict__ roffs, int rid_begin, int rid_stride,
+                                                        const int32_t* __restrict__ offsets, SeedArrays A) {
+    __shared__ uint32_t rel[REL_WORDS];
+    __shared__ uint32_t hot[HOT_CAP];
+    const int s = blockIdx.x;
+    const int rid = rid_begin + (s >> 1) * rid_stride;
+    const int L = roffs[rid].size;
+    const int K = kmers_of(L);
+    const uint32_t kb = A.km_base[s];
+    if (A.strand_hits[s] == 0) return;
+    uint64_t* __restrict__ out = A.keysA + A.hit_base[s];
+    const int nh = A.hot_count[s];
+    if (nh >= 0) {
+        for (int i = threadIdx.x; i < nh; i += SEED_BLOCK) hot[i] = A.hot_list[(size_t)s * HOT_CAP + i];
+        __syncthreads();
+        rel_build(rel, hot, nh, sweep_reach(L));
+    }
+    const int g = threadIdx.x >> 4, sub = threadIdx.x & 15;
+    for (int km = g; km < K; km += SEED_BLOCK / 16) {
+        const uint32_t bs = A.km_bstart[kb + km], c = A.km_cnt[kb + km];
+        uint32_t at = A.km_rpre[kb + km];
+        for (uint32_t r0 = 0; r0 < c; r0 += 16) {
+            const uint32_t r = r0 + sub;
+            const uint32_t pos = r < c ? (uint32_t)offsets[bs + r] : 0u;
+            const uint32_t seg = pos / ZV, so = pos - seg * ZV;
+            const bool k1 = r < c && (nh < 0 || rel_test(rel, seg));
+            const uint32_t bits = group_bits(__ballot(k1));
+            if (k1) out[at + __popc(bits & ((1u << sub) - 1u))] = ((uint64_t)seg << KEY_SEG_SHIFT) | ((uint64_t)km << KEY_OFF_BITS) | so;
+            at += __popc(bits);
         }
     }
 }
@@ -711,8 +872,12 @@ static int seed_batch(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref
     uint32_t* d_kmb;
     if (c->scratch("sd_kmbase", sizeof(uint32_t) * (size_t)ns, (void**)&d_kmb)) return -1;
     if (c->scratch("sd_kmbstart", sizeof(uint32_t) * (size_t)(sumK + 1), (void**)&A.km_bstart)) return -1;
-    if (c->scratch("sd_kmhpre", sizeof(uint32_t) * (size_t)(sumK + 1), (void**)&A.km_hpre)) return -1;
+    if (c->scratch("sd_kmcnt", sizeof(uint32_t) * (size_t)(sumK + 1), (void**)&A.km_cnt)) return -1;
+    if (c->scratch("sd_kmrpre", sizeof(uint32_t) * (size_t)(sumK + 1), (void**)&A.km_rpre)) return -1;
     if (c->scratch("sd_hits", sizeof(uint32_t) * (size_t)ns, (void**)&A.strand_hits)) return -1;
+    if (c->scratch("sd_hitsall", sizeof(uint32_t) * (size_t)ns, (void**)&A.strand_hits_all)) return -1;
+    if (c->scratch("sd_hotcnt", sizeof(int32_t) * (size_t)ns, (void**)&A.hot_count)) return -1;
+    if (c->scratch("sd_hotlist", sizeof(uint32_t) * (size_t)ns * HOT_CAP, (void**)&A.hot_list)) return -1;
     if (c->scratch("sd_hbase", sizeof(uint64_t) * (size_t)(ns + 1), (void**)&A.hit_base)) return -1;
     if (c->scratch("sd_nseg", sizeof(uint32_t) * (size_t)ns, (void**)&A.nseg)) return -1;
     if (c->scratch("sd_nrec", sizeof(uint32_t) * (size_t)ns, (void**)&A.nrec)) return -1;
@@ -721,6 +886,14 @@ static int seed_batch(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref
     HIPCHK(hipMemcpyAsync(d_kmb, kmb.data(), sizeof(uint32_t) * (size_t)ns, hipMemcpyHostToDevice, c->stream));
     LAUNCH(c, "seed_probe", seed_probe, ns, SEED_BLOCK, 0, (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs, rb, stride,
            (const uint32_t*)idx->d_starts, A, (unsigned long long*)c->d_counters);
+    {
+        // the filter needs a gate high enough to separate signal from random hits; below that every hit is kept
+        const int gate = 2 * P->min_kmer_match;
+        const char* fe = getenv("MECAT_SEED_FILTER");      // debug knob: 0 disables the relevance filter
+        const int enable = (gate >= 6 && !(fe && atoi(fe) == 0)) ? 1 : 0;
+        LAUNCH(c, "seed_filter", seed_filter, ns, SEED_BLOCK, 0, (const mhip_offset_t*)reads->d_offs, rb, stride,
+               (const int32_t*)idx->d_offsets, A, gate, enable);
+    }
     LAUNCH(c, "seed_scan", seed_scan, 1, 1024, 0, (const uint32_t*)A.strand_hits, ns, A.hit_base);
     uint64_t Htot = 0;
     HIPCHK(hipMemcpyAsync(&Htot, A.hit_base + ns, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));

@@ -16,6 +16,11 @@
 //               one wave per 64 consecutive buckets, each non-trivial bucket sorted by a 64-/128-wide
 //               bitonic network in registers (wave shuffles), contiguous loads/stores.
 // Algorithmic bytes: 2*(N/4) + 3*4*4^13 + 4*N_kept.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <algorithm>
+
 #include "common.h"
 
 #define IDX_BLOCK 256
@@ -223,11 +228,343 @@ __global__ __launch_bounds__(IDX_BLOCK) void idx_sort(const uint32_t* __restrict
     }
 }
 
+// ==================================================================================================================
+// Binned build (default).  The direct-address table is 268 MB, so the count/fill walks above are 1.6e9 read-modify-write
+// round trips to memory-side atomics plus 4-byte scattered stores (r01 profile: ~100 GB of HBM traffic each for 6 GB of
+// algorithmic bytes).  Here the (k-mer, position) pairs are first partitioned by the top 12 k-mer bits in two LDS-staged
+// 64-way scatter passes (runs of ~512 bytes per bin and tile), after which every fine bin covers 2^14 k-mer ids: one
+// workgroup per bin counts in LDS, drops > 128, scans, writes its slice of starts[] and fills its (L2-sized) slice of
+// offsets[] with LDS cursors, then sorts its buckets.  All global traffic is sequential or run-coalesced.
+#define FINE_BITS 12
+#define NFINE (1 << FINE_BITS)            // 4096 fine bins
+#define NCOARSE 64
+#define IDS_PER_FINE (NKMER >> FINE_BITS) // 16384 k-mer ids per fine bin
+#define TILE_POS 4096                     // positions (level 1) / entries (level 2) per scatter tile
+#define HIST_TILES 64                     // tiles per block in the histogram pass
+#define BIN_THREADS 1024
+
+// the 16 k-mer start positions of aligned window t (positions 16t .. 16t+15): f(j, kmer, pos) for each valid one (j = slot 0..15)
+template <typename F>
+__device__ __forceinline__ void walk16(const uint32_t* __restrict__ pac, const mhip_offset_t* __restrict__ offs, int num_reads,
+                                       int num_bases, int64_t t, F f) {
+    const int64_t p0 = t << 4;
+    if (p0 >= num_bases || num_reads == 0) return;
+    const uint64_t W = ((uint64_t)pac_word(pac, t) << 32) | pac_word(pac, t + 1);
+    int r = find_read(offs, num_reads, (int)p0);
+    int rend = r >= 0 ? offs[r].offset + offs[r].size : -1;
+    int next_off = (r + 1 < num_reads) ? offs[r + 1].offset : 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int p = (int)p0 + j;
+        if (p >= next_off) {
+            ++r;
+            rend = offs[r].offset + offs[r].size;
+            next_off = (r + 1 < num_reads) ? offs[r + 1].offset : 0x7fffffff;
+        }
+        if (p + MHIP_KMER_SIZE <= rend) f(j, (uint32_t)(W >> (64 - 26 - 2 * j)) & KMER_MASK, p);
+    }
+}
+
+// occurrences per fine bin
+__global__ __launch_bounds__(IDX_BLOCK) void idx_hist(const uint32_t* __restrict__ pac, const mhip_offset_t* __restrict__ offs,
+                                                      int num_reads, int num_bases, uint32_t* __restrict__ fine_hist) {
+    __shared__ uint32_t h[NFINE];
+    for (int i = threadIdx.x; i < NFINE; i += IDX_BLOCK) h[i] = 0;
+    __syncthreads();
+    for (int tile = 0; tile < HIST_TILES; ++tile) {
+        const int64_t t = ((int64_t)blockIdx.x * HIST_TILES + tile) * IDX_BLOCK + threadIdx.x;
+        walk16(pac, offs, num_reads, num_bases, t, [&](int, uint32_t k, int) { atomicAdd(&h[k >> (26 - FINE_BITS)], 1u); });
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NFINE; i += IDX_BLOCK)
+        if (h[i]) atomicAdd(&fine_hist[i], h[i]);
+}
+
+// exclusive scan of 4096 values (one block of 1024 threads, 4 items each); out[4096] = total
+__global__ __launch_bounds__(1024) void idx_scan4096(const uint32_t* __restrict__ in, uint32_t* __restrict__ out) {
+    __shared__ uint32_t wtot[16];
+    uint32_t v[4], s = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = in[threadIdx.x * 4 + i]; s += v[i]; }
+    uint32_t incl = s;
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t n = __shfl_up(incl, o);
+        if (lane_id() >= o) incl += n;
+    }
+    if (lane_id() == 63) wtot[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += wtot[w];
+    uint32_t run = base + incl - s;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { out[threadIdx.x * 4 + i] = run; run += v[i]; }
+    if (threadIdx.x == 1023) out[NFINE] = run;
+}
+
+// cursors of a scatter level: cur[b] = base of bin b's region
+__global__ void idx_init_cursors(const uint32_t* __restrict__ fine_base, uint32_t* __restrict__ cur1, uint32_t* __restrict__ cur2) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < NFINE) cur2[i] = fine_base[i];
+    if (i < NCOARSE) cur1[i] = fine_base[i * (NFINE / NCOARSE)];
+}
+
+// LDS-staged 64-way scatter of up to TILE_POS entries held 16 per thread (slot j valid iff bit j of vmask, bins in binv[]):
+// rank inside the tile by LDS atomics, one global reservation per bin and tile, then run-coalesced copy out.
+__device__ __forceinline__ void scatter_tile64(const uint64_t* ent, const uint32_t* binv, uint32_t vmask, uint32_t* __restrict__ cursors,
+                                               uint64_t* __restrict__ out, uint32_t* hist /*[64]*/, uint32_t* lbase /*[65]*/,
+                                               uint32_t* gbase /*[64]*/, uint64_t* stage /*[TILE_POS]*/, uint8_t* sbin /*[TILE_POS]*/) {
+    if (threadIdx.x < NCOARSE) hist[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t rank[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) rank[j] = ((vmask >> j) & 1u) ? atomicAdd(&hist[binv[j]], 1u) : 0u;
+    __syncthreads();
+    if (threadIdx.x < 64) {     // exclusive scan of the 64 counts by the first wave + global reservation
+        const uint32_t c = hist[threadIdx.x];
+        uint32_t incl = c;
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t n = __shfl_up(incl, o);
+            if ((int)threadIdx.x >= o) incl += n;
+        }
+        lbase[threadIdx.x] = incl - c;
+        if (threadIdx.x == 63) lbase[64] = incl;
+        gbase[threadIdx.x] = c ? atomicAdd(&cursors[threadIdx.x], c) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        if ((vmask >> j) & 1u) {
+            const uint32_t at = lbase[binv[j]] + rank[j];
+            stage[at] = ent[j];
+            sbin[at] = (uint8_t)binv[j];
+        }
+    __syncthreads();
+    const uint32_t total = lbase[64];
+    for (uint32_t i = threadIdx.x; i < total; i += IDX_BLOCK) {
+        const uint32_t b = sbin[i];
+        out[(size_t)gbase[b] + (i - lbase[b])] = stage[i];
+    }
+    __syncthreads();
+}
+
+// level 1: volume walk -> entries (kmer << 32 | pos) partitioned by the top 6 k-mer bits
+__global__ __launch_bounds__(IDX_BLOCK) void idx_scatter1(const uint32_t* __restrict__ pac, const mhip_offset_t* __restrict__ offs,
+                                                          int num_reads, int num_bases, uint32_t* __restrict__ cur1,
+                                                          uint64_t* __restrict__ ent1) {
+    __shared__ uint32_t hist[NCOARSE], lbase[NCOARSE + 1], gbase[NCOARSE];
+    __shared__ uint64_t stage[TILE_POS];
+    __shared__ uint8_t sbin[TILE_POS];
+    uint64_t ent[16];
+    uint32_t binv[16];
+    uint32_t vmask = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { ent[j] = 0; binv[j] = 0; }
+    const int64_t t = (int64_t)blockIdx.x * IDX_BLOCK + threadIdx.x;
+    walk16(pac, offs, num_reads, num_bases, t, [&](int j, uint32_t k, int p) {
+        ent[j] = ((uint64_t)k << 32) | (uint32_t)p;
+        binv[j] = k >> 20;
+        vmask |= 1u << j;
+    });
+    scatter_tile64(ent, binv, vmask, cur1, ent1, hist, lbase, gbase, stage, sbin);
+}
+
+// level 2: inside coarse bin c (its own 64 fine cursors), by the next 6 k-mer bits.  blockIdx.y = coarse bin.
+__global__ __launch_bounds__(IDX_BLOCK) void idx_scatter2(const uint64_t* __restrict__ ent1, const uint32_t* __restrict__ fine_base,
+                                                          uint32_t* __restrict__ cur2, uint64_t* __restrict__ ent2) {
+    __shared__ uint32_t hist[NCOARSE], lbase[NCOARSE + 1], gbase[NCOARSE];
+    __shared__ uint64_t stage[TILE_POS];
+    __shared__ uint8_t sbin[TILE_POS];
+    const int c = blockIdx.y;
+    const uint32_t cb = fine_base[c * 64], ce = fine_base[(c + 1) * 64];
+    const uint64_t first = (uint64_t)cb + (uint64_t)blockIdx.x * TILE_POS;
+    if (first >= ce) return;
+    uint64_t ent[16];
+    uint32_t binv[16];
+    uint32_t vmask = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint64_t i = first + (uint64_t)j * IDX_BLOCK + threadIdx.x;      // coalesced reads
+        const bool ok = i < ce;
+        const uint64_t e = ok ? ent1[i] : 0ull;
+        ent[j] = e;
+        binv[j] = (uint32_t)(e >> (32 + 14)) & 63u;
+        vmask |= ok ? (1u << j) : 0u;
+    }
+    scatter_tile64(ent, binv, vmask, cur2 + c * 64, ent2, hist, lbase, gbase, stage, sbin);
+}
+
+// one workgroup per fine bin: kept occurrence counts of its 2^14 k-mer ids -> starts[] slice (temporarily counts), bin total
+__global__ __launch_bounds__(BIN_THREADS) void idx_bin_count(const uint64_t* __restrict__ ent2, const uint32_t* __restrict__ fine_base,
+                                                             uint32_t* __restrict__ starts, uint32_t* __restrict__ bintot) {
+    __shared__ uint32_t cnt[IDS_PER_FINE];     // 64 KB
+    __shared__ uint32_t wtot[BIN_THREADS / WAVE];
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < IDS_PER_FINE; i += BIN_THREADS) cnt[i] = 0;
+    __syncthreads();
+    const uint32_t eb = fine_base[b], ee = fine_base[b + 1];
+    for (uint32_t i = eb + threadIdx.x; i < ee; i += BIN_THREADS) atomicAdd(&cnt[(uint32_t)(ent2[i] >> 32) & (IDS_PER_FINE - 1)], 1u);
+    __syncthreads();
+    uint32_t s = 0;
+    for (int i = threadIdx.x; i < IDS_PER_FINE; i += BIN_THREADS) {
+        const uint32_t k = kept(cnt[i]);
+        starts[(size_t)b * IDS_PER_FINE + i] = k;
+        s += k;
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane_id() == 0) wtot[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int w = 0; w < BIN_THREADS / WAVE; ++w) tot += wtot[w];
+        bintot[b] = tot;
+    }
+}
+
+// one workgroup per fine bin: absolute starts[] slice, fill of the bin's offsets[] slice with LDS cursors, bucket sort
+__global__ __launch_bounds__(BIN_THREADS) void idx_bin_fill(const uint64_t* __restrict__ ent2, const uint32_t* __restrict__ fine_base,
+                                                            const uint32_t* __restrict__ binout, uint32_t* __restrict__ starts,
+                                                            int32_t* __restrict__ offsets) {
+    __shared__ uint32_t cur[IDS_PER_FINE];     // 64 KB: kept count -> absolute start -> running cursor
+    __shared__ uint32_t keptbits[IDS_PER_FINE / 32];
+    __shared__ uint32_t wtot[BIN_THREADS / WAVE];
+    const int b = blockIdx.x;
+    const int per = IDS_PER_FINE / BIN_THREADS;     // 16 consecutive ids per thread
+    uint32_t v[per], s = 0;
+    for (int i = threadIdx.x; i < IDS_PER_FINE / 32; i += BIN_THREADS) keptbits[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < per; ++i) { v[i] = starts[(size_t)b * IDS_PER_FINE + threadIdx.x * per + i]; s += v[i]; }
+    uint32_t incl = s;
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t n = __shfl_up(incl, o);
+        if (lane_id() >= o) incl += n;
+    }
+    if (lane_id() == 63) wtot[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t run = binout[b] + incl - s;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) run += wtot[w];
+    uint32_t kb = 0;
+#pragma unroll
+    for (int i = 0; i < per; ++i) {
+        const int id = threadIdx.x * per + i;
+        starts[(size_t)b * IDS_PER_FINE + id] = run;
+        cur[id] = run;
+        if (v[i]) kb |= 1u << (id & 31);
+        run += v[i];
+    }
+    // 16 consecutive ids of a thread share one 32-bit word with the neighbouring thread
+    if (kb) atomicOr(&keptbits[(threadIdx.x * per) >> 5], kb);
+    __syncthreads();
+    const uint32_t eb = fine_base[b], ee = fine_base[b + 1];
+    for (uint32_t i = eb + threadIdx.x; i < ee; i += BIN_THREADS) {
+        const uint64_t e = ent2[i];
+        const uint32_t id = (uint32_t)(e >> 32) & (IDS_PER_FINE - 1);
+        if ((keptbits[id >> 5] >> (id & 31)) & 1u) offsets[atomicAdd(&cur[id], 1u)] = (int32_t)(uint32_t)e;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // bucket order must be ascending position (the reference's fill order): sort every bucket with >= 2 entries.
+    // after the fill cur[id] == end of bucket id == start of bucket id + 1
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    for (int g0 = wv * 64; g0 < IDS_PER_FINE; g0 += (BIN_THREADS / WAVE) * 64) {
+        const int id = g0 + lane;
+        const uint32_t e1 = cur[id];
+        const uint32_t s0 = id == 0 ? binout[b] : cur[id - 1];
+        uint64_t todo = __ballot(e1 - s0 >= 2u);
+        while (todo) {
+            const int bb = __ffsll((unsigned long long)todo) - 1;
+            todo &= todo - 1;
+            const uint32_t st = __shfl(s0, bb), en = __shfl(e1, bb);
+            const int n = (int)(en - st);
+            if (n <= 64) {
+                int x = lane < n ? offsets[st + lane] : 0x7fffffff;
+                x = bitonic64(x);
+                if (lane < n) offsets[st + lane] = x;
+            } else {
+                int a = offsets[st + lane];
+                int c2 = lane + 64 < n ? offsets[st + 64 + lane] : 0x7fffffff;
+                bitonic128(a, c2);
+                offsets[st + lane] = a;
+                if (lane + 64 < n) offsets[st + 64 + lane] = c2;
+            }
+        }
+    }
+}
+
+#include <chrono>
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#define TRACE(tag) do { if (trace) { (void)hipStreamSynchronize(c->stream); double t_ = now_ms(); fprintf(stderr, "[idx trace] %-14s %.2f ms\n", tag, t_ - t0); t0 = t_; } } while (0)
+
+static int index_build_binned(mhip_ctx* c, const mhip_volume* v, mhip_index* idx) {
+    const bool trace = getenv("MECAT_TRACE") != nullptr;
+    double t0 = now_ms();
+    uint32_t *d_hist, *d_fbase, *d_cur1, *d_cur2, *d_bintot, *d_binout;
+    if (c->scratch("ix_hist", sizeof(uint32_t) * (NFINE + 1), (void**)&d_hist)) return -1;
+    if (c->scratch("ix_fbase", sizeof(uint32_t) * (NFINE + 1), (void**)&d_fbase)) return -1;
+    if (c->scratch("ix_cur1", sizeof(uint32_t) * NCOARSE, (void**)&d_cur1)) return -1;
+    if (c->scratch("ix_cur2", sizeof(uint32_t) * NFINE, (void**)&d_cur2)) return -1;
+    if (c->scratch("ix_bintot", sizeof(uint32_t) * (NFINE + 1), (void**)&d_bintot)) return -1;
+    if (c->scratch("ix_binout", sizeof(uint32_t) * (NFINE + 1), (void**)&d_binout)) return -1;
+    HIPCHK(hipMemsetAsync(d_hist, 0, sizeof(uint32_t) * (NFINE + 1), c->stream));
+    const int64_t nthreads = ((int64_t)v->num_bases + 15) / 16;
+    const unsigned tiles = (unsigned)((nthreads + IDX_BLOCK - 1) / IDX_BLOCK);
+    if (tiles == 0) {
+        HIPCHK(hipMemsetAsync(idx->d_starts, 0, sizeof(uint32_t) * ((size_t)NKMER + 1), c->stream));
+        idx->num_kmers = 0;
+        return 0;
+    }
+    LAUNCH(c, "idx_hist", idx_hist, (tiles + HIST_TILES - 1) / HIST_TILES, IDX_BLOCK, 0, (const uint32_t*)v->d_pac, (const mhip_offset_t*)v->d_offs,
+           v->num_reads, v->num_bases, d_hist);
+    LAUNCH(c, "idx_scan4096", idx_scan4096, 1, 1024, 0, (const uint32_t*)d_hist, d_fbase);
+    TRACE("hist+scan");
+    uint32_t nent = 0;
+    HIPCHK(hipMemcpyAsync(&nent, d_fbase + NFINE, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    uint64_t *d_e1, *d_e2;
+    if (c->scratch("ix_ent1", sizeof(uint64_t) * ((size_t)nent + 64), (void**)&d_e1)) return -1;
+    if (c->scratch("ix_ent2", sizeof(uint64_t) * ((size_t)nent + 64), (void**)&d_e2)) return -1;
+    TRACE("scratch");
+    LAUNCH(c, "idx_init_cursors", idx_init_cursors, NFINE / 256, 256, 0, (const uint32_t*)d_fbase, d_cur1, d_cur2);
+    LAUNCH(c, "idx_scatter1", idx_scatter1, tiles, IDX_BLOCK, 0, (const uint32_t*)v->d_pac, (const mhip_offset_t*)v->d_offs, v->num_reads,
+           v->num_bases, d_cur1, d_e1);
+    {
+        // grid.x covers the largest coarse bin; blocks past a bin's end exit immediately
+        std::vector<uint32_t> fb(NFINE + 1);
+        HIPCHK(hipMemcpyAsync(fb.data(), d_fbase, sizeof(uint32_t) * (NFINE + 1), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        uint32_t mx = 0;
+        for (int cc = 0; cc < NCOARSE; ++cc) mx = std::max(mx, fb[(size_t)(cc + 1) * 64] - fb[(size_t)cc * 64]);
+        const unsigned gx = (mx + TILE_POS - 1) / TILE_POS;
+        if (gx) LAUNCH(c, "idx_scatter2", idx_scatter2, dim3(gx, NCOARSE), IDX_BLOCK, 0, (const uint64_t*)d_e1, (const uint32_t*)d_fbase, d_cur2, d_e2);
+    }
+    TRACE("scatter");
+    LAUNCH(c, "idx_bin_count", idx_bin_count, NFINE, BIN_THREADS, 0, (const uint64_t*)d_e2, (const uint32_t*)d_fbase, idx->d_starts, d_bintot);
+    LAUNCH(c, "idx_scan4096", idx_scan4096, 1, 1024, 0, (const uint32_t*)d_bintot, d_binout);
+    uint32_t total = 0;
+    HIPCHK(hipMemcpyAsync(&total, d_binout + NFINE, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    idx->num_kmers = total;
+    TRACE("bin_count");
+    if (hipMalloc((void**)&idx->d_offsets, sizeof(int32_t) * ((size_t)total + 64)) != hipSuccess) {
+        mhip_set_error("hipMalloc of %zu bytes for k-mer positions failed", sizeof(int32_t) * (size_t)total);
+        return -1;
+    }
+    TRACE("malloc offsets");
+    LAUNCH(c, "idx_bin_fill", idx_bin_fill, NFINE, BIN_THREADS, 0, (const uint64_t*)d_e2, (const uint32_t*)d_fbase, (const uint32_t*)d_binout,
+           idx->d_starts, idx->d_offsets);
+    HIPCHK(hipMemcpyAsync(idx->d_starts + NKMER, d_binout + NFINE, sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    TRACE("bin_fill");
+    return 0;
+}
+
 extern "C" {
 
 int mhip_index_build(mhip_ctx* c, const mhip_volume* v, mhip_index** out) {
     *out = nullptr;
     HIPCHK(hipSetDevice(c->device));
+    const double tb0 = now_ms();
     mhip_index* idx = new mhip_index();
     idx->device = c->device;
     idx->num_bases = v->num_bases;
@@ -239,6 +576,15 @@ int mhip_index_build(mhip_ctx* c, const mhip_volume* v, mhip_index** out) {
         mhip_set_error("hipMalloc starts failed");
         delete idx;
         return -1;
+    }
+    {
+        const char* e = getenv("MECAT_IDX_BUILD");       // debug knob: 1 = direct atomic walks, default = binned build
+        if (!(e && atoi(e) == 1)) {
+            if (getenv("MECAT_TRACE")) fprintf(stderr, "[idx trace] pre-alloc      %.2f ms\n", now_ms() - tb0);
+            if (index_build_binned(c, v, idx)) { mhip_index_free(idx); return -1; }
+            *out = idx;
+            return 0;
+        }
     }
     HIPCHK(hipMemsetAsync(d_counts, 0, sizeof(uint32_t) * (size_t)NKMER, c->stream));
     int64_t nthreads = ((int64_t)v->num_bases + 15) / 16;

@@ -166,15 +166,41 @@ __global__ __launch_bounds__(1024) void seed_scan(const uint32_t* __restrict__ h
 // 16 lanes per query k-mer: a bucket (<= 128 ascending positions, ~22 on average) is read in 64-byte pieces, lane `sub`
 // takes entries sub, sub + 16, ...  `f(km, r, pos, valid)` is called by all 16 lanes of the group together (group-uniform
 // control flow), so it may use the group's 16 bits of a wave ballot.
-template <typename F>
-__device__ __forceinline__ void for_each_hit16(const SeedArrays& A, const int32_t* __restrict__ offsets, const uint32_t kb, const int K, F f) {
+// Four buckets per group are in flight at once (their (start, size) and first two 64-byte pieces are loaded before any is
+// consumed): the walk is a gather of ~88-byte runs, so throughput comes from outstanding loads, not from arithmetic.
+// `begin(slot, km)`, `f(slot, km, r, pos, valid)`, `end(slot, km)`; slot 0..3 is a compile-time index for per-bucket state.
+template <typename B, typename F, typename E>
+__device__ __forceinline__ void for_each_hit16(const SeedArrays& A, const int32_t* __restrict__ offsets, const uint32_t kb, const int K,
+                                               B begin, F f, E end) {
     const int g = threadIdx.x >> 4, sub = threadIdx.x & 15;
-    for (int km = g; km < K; km += SEED_BLOCK / 16) {
-        const uint32_t bs = A.km_bstart[kb + km], cnt = A.km_cnt[kb + km];
-        for (uint32_t r0 = 0; r0 < cnt; r0 += 16) {
-            const uint32_t r = r0 + sub;
-            const bool valid = r < cnt;
-            f(km, r, valid ? (uint32_t)offsets[bs + r] : 0u, valid);
+    constexpr int G = SEED_BLOCK / 16;
+    for (int km0 = g; km0 < K; km0 += 4 * G) {
+        uint32_t bs[4], cnt[4], p0[4], p1[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int km = km0 + q * G;
+            bs[q] = km < K ? A.km_bstart[kb + km] : 0u;
+            cnt[q] = km < K ? A.km_cnt[kb + km] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            p0[q] = (uint32_t)sub < cnt[q] ? (uint32_t)offsets[bs[q] + sub] : 0u;
+            p1[q] = (uint32_t)sub + 16u < cnt[q] ? (uint32_t)offsets[bs[q] + 16 + sub] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int km = km0 + q * G;
+            if (km < K) {
+                begin(q, km);
+                if (cnt[q] > 0) f(q, km, (uint32_t)sub, p0[q], (uint32_t)sub < cnt[q]);
+                if (cnt[q] > 16) f(q, km, (uint32_t)sub + 16u, p1[q], (uint32_t)sub + 16u < cnt[q]);
+                for (uint32_t r0 = 32; r0 < cnt[q]; r0 += 16) {
+                    const uint32_t r = r0 + sub;
+                    const bool valid = r < cnt[q];
+                    f(q, km, r, valid ? (uint32_t)offsets[bs[q] + r] : 0u, valid);
+                }
+                end(q, km);
+            }
         }
     }
 }
@@ -240,21 +266,22 @@ __global__ __launch_bounds__(SEED_BLOCK) void seed_filter(const mhip_offset_t* _
         if (threadIdx.x == 0) { s_n[0] = 0; s_n[1] = 0; }
         __syncthreads();
         // pass 1: h(seg)
-        for_each_hit16(A, offsets, kb, K, [&](int, uint32_t, uint32_t pos, bool valid) {
+        auto nop = [](int, int) {};
+        for_each_hit16(A, offsets, kb, K, nop, [&](int, int, uint32_t, uint32_t pos, bool valid) {
             if (valid) {
                 const uint32_t e = (pos / ZV) & (FLT_M - 1);
                 const uint32_t sh = (e & 7u) * 4u;
                 const uint32_t old = atomicAdd(&cnt[e >> 3], 1u << sh);
                 if (((old >> sh) & 15u) == 15u) atomicOr(&sticky[e >> 5], 1u << (e & 31u));
             }
-        });
+        }, nop);
         __syncthreads();
         auto hval = [&](uint32_t seg) -> int {
             const uint32_t e = seg & (FLT_M - 1);
             return ((sticky[e >> 5] >> (e & 31u)) & 1u) ? 64 : (int)((cnt[e >> 3] >> ((e & 7u) * 4u)) & 15u);
         };
         // pass 2: hot segments into the hash set
-        for_each_hit16(A, offsets, kb, K, [&](int, uint32_t, uint32_t pos, bool valid) {
+        for_each_hit16(A, offsets, kb, K, nop, [&](int, int, uint32_t, uint32_t pos, bool valid) {
             if (valid) {
                 const uint32_t seg = pos / ZV;
                 const int c = hval(seg);
@@ -268,7 +295,7 @@ __global__ __launch_bounds__(SEED_BLOCK) void seed_filter(const mhip_offset_t* _
                     }
                 }
             }
-        });
+        }, nop);
         __syncthreads();
         nh = s_n[0];
         if (nh > HOT_CAP) filtered = false;      // too many hot segments for the set: keep everything
@@ -287,17 +314,14 @@ __global__ __launch_bounds__(SEED_BLOCK) void seed_filter(const mhip_offset_t* _
     if (!filtered) {
         for (int km = threadIdx.x; km < K; km += SEED_BLOCK) A.km_rpre[kb + km] = A.km_cnt[kb + km];
     } else {
-        const int g = threadIdx.x >> 4, sub = threadIdx.x & 15;
-        for (int km = g; km < K; km += SEED_BLOCK / 16) {
-            const uint32_t bs = A.km_bstart[kb + km], c = A.km_cnt[kb + km];
-            uint32_t keep = 0;
-            for (uint32_t r0 = 0; r0 < c; r0 += 16) {
-                const uint32_t r = r0 + sub;
-                const bool k1 = r < c && rel_test(rel, (uint32_t)offsets[bs + r] / ZV);
-                keep += __popc(group_bits(__ballot(k1)));
-            }
-            if (sub == 0) A.km_rpre[kb + km] = keep;
-        }
+        uint32_t keep[4];
+        for_each_hit16(A, offsets, kb, K,
+            [&](int q, int) { keep[q] = 0; },
+            [&](int q, int, uint32_t, uint32_t pos, bool valid) {
+                const bool k1 = valid && rel_test(rel, pos / ZV);
+                keep[q] += __popc(group_bits(__ballot(k1)));
+            },
+            [&](int q, int km) { if ((threadIdx.x & 15) == 0) A.km_rpre[kb + km] = keep[q]; });
     }
     __syncthreads();
     // ... -> exclusive prefix inside the strand
@@ -332,20 +356,18 @@ __global__ __launch_bounds__(SEED_BLOCK) void seed_emit(const mhip_offset_t* __r
         __syncthreads();
         rel_build(rel, hot, nh, sweep_reach(L));
     }
-    const int g = threadIdx.x >> 4, sub = threadIdx.x & 15;
-    for (int km = g; km < K; km += SEED_BLOCK / 16) {
-        const uint32_t bs = A.km_bstart[kb + km], c = A.km_cnt[kb + km];
-        uint32_t at = A.km_rpre[kb + km];
-        for (uint32_t r0 = 0; r0 < c; r0 += 16) {
-            const uint32_t r = r0 + sub;
-            const uint32_t pos = r < c ? (uint32_t)offsets[bs + r] : 0u;
+    const uint32_t sub = threadIdx.x & 15;
+    uint32_t at[4];
+    for_each_hit16(A, offsets, kb, K,
+        [&](int q, int km) { at[q] = A.km_rpre[kb + km]; },
+        [&](int q, int km, uint32_t, uint32_t pos, bool valid) {
             const uint32_t seg = pos / ZV, so = pos - seg * ZV;
-            const bool k1 = r < c && (nh < 0 || rel_test(rel, seg));
+            const bool k1 = valid && (nh < 0 || rel_test(rel, seg));
             const uint32_t bits = group_bits(__ballot(k1));
-            if (k1) out[at + __popc(bits & ((1u << sub) - 1u))] = ((uint64_t)seg << KEY_SEG_SHIFT) | ((uint64_t)km << KEY_OFF_BITS) | so;
-            at += __popc(bits);
-        }
-    }
+            if (k1) out[at[q] + __popc(bits & ((1u << sub) - 1u))] = ((uint64_t)seg << KEY_SEG_SHIFT) | ((uint64_t)km << KEY_OFF_BITS) | so;
+            at[q] += __popc(bits);
+        },
+        [](int, int) {});
 }
 
 // ------------------------------------------------------------------------------------------------ sort (one LSD pass)

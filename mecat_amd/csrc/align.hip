@@ -481,9 +481,7 @@ struct HalfLds {
     uint32_t Qp[SEQ_WORDS];
     uint32_t Tp[SEQ_WORDS];
     uint16_t ring[RCAP];
-    uint32_t rlin[RROWS];
-    int16_t rmin[RROWS];
-    int16_t rmax[RROWS];
+    uint2 rrec[RROWS];          // per d-row: x = min_k | max_k << 16, y = linear ring position of the row
 };
 static_assert(offsetof(HalfLds, Qp) == offsetof(AlnWaveLds, Qp) && offsetof(HalfLds, Tp) == offsetof(AlnWaveLds, Tp),
               "the spill fallback reuses V/Qp/Tp in place");
@@ -573,12 +571,14 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
         for (int i = sl; i < 2 * max_d + 4 && i < VU_LEN; i += 32) S.V[i] = 0;
         __builtin_amdgcn_wave_barrier();
 
-        // ---- 3. rows (Align, diff_gapalign.cpp:107-219)
-        int best_m = -1, best_x = -1, best_d = 0, best_k = 0;
+        // ---- 3. rows (Align, diff_gapalign.cpp:107-219).  Only the running maximum of x + y is tracked here; a block that
+        // ends without reaching an end of either sequence (0.06 % of blocks) needs the position of that maximum and is
+        // handed to the one-unit code path below, like a block whose traceback outran the ring.
+        int best_m = -1;
         int min_k = 0, max_k = 0;
         int aligned = 0, end_x = 0, end_k = 0, end_d = 0, last_row = -1;
         unsigned int lin = 0;
-        bool rowing = live;
+        bool rowing = live, ran = false;
         for (int d = 0;; ++d) {
             rowing = rowing && d < max_d && (max_k - min_k <= band_size);
             const unsigned long long rmask = __ballot(rowing);
@@ -588,11 +588,15 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
             const int nslot = rowing ? (max_k - min_k) / 2 + 1 : 0;
             unsigned int pos0 = lin & (RCAP - 1);
             if (pos0 + (unsigned)nslot > RCAP) { lin += RCAP - pos0; pos0 = 0; }
-            if (rowing && sl == 0) { S.rmin[d & (RROWS - 1)] = (int16_t)min_k; S.rmax[d & (RROWS - 1)] = (int16_t)max_k; S.rlin[d & (RROWS - 1)] = lin; }
-            if (rowing) last_row = d;
+            if (rowing && sl == 0) {        // row record: band limits + linear ring position, one 64-bit store
+                S.rrec[d & (RROWS - 1)] = make_uint2(((uint32_t)(uint16_t)(int16_t)min_k) | ((uint32_t)(uint16_t)(int16_t)max_k << 16), lin);
+            }
+            if (rowing) { last_row = d; ran = true; }
             const int ns_a = __builtin_amdgcn_readlane(nslot, 0), ns_b = __builtin_amdgcn_readlane(nslot, 32);
             const int NJ = (max(ns_a, ns_b) + 31) >> 5;
-            int bm = -1, hk = 0x7fffffff, m0 = -1;
+            int mmax = -1, m0 = -1;
+            int hx = 0, hkk = 0;
+            bool reached = false;
             for (int j = 0; j < NJ; ++j) {
                 const int tt = sl + 32 * j;
                 const bool act = rowing && tt < nslot;
@@ -608,34 +612,29 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
                     const int n0 = match32(S.Qp, x, S.Tp, min(max(y, 0), MAX_BLK));
                     const int nn = act ? max(0, min(n0, lim)) : 0;
                     x += nn; y += nn;
-                    usnake += (unsigned int)nn;
-                    more = act & (nn == 32) & (lim > 32);
+                    more = (nn == 32) & (lim > 32);
                 } while (__ballot(more));
                 if (act) {
                     S.V[kk] = (int16_t)x;
                     S.ring[pos0 + tt] = (uint16_t)x;
-                    bm = max(bm, ((x + y) << 10) | (1023 - kk));
-                    if (x >= q_len || y >= t_len) hk = min(hk, (kk << 10) | x);
+                    mmax = max(mmax, x + y);
+                    if (!reached && (x >= q_len || y >= t_len)) { reached = true; hx = x; hkk = kk; }     // lowest k of this lane
                 }
                 if (j == 0) m0 = act ? x + y : -1;
             }
             lin += (unsigned)nslot;
             cells += (unsigned long long)(ns_a + ns_b);
             __builtin_amdgcn_wave_barrier();
-            // first maximum of x + y in k order (:160-167); lowest diagonal that reached an end (:168-169)
-            const int bkey = half_max(bm);
+            // running maximum of x + y (:160-167); lowest diagonal that reached an end (:168-169)
+            const int rm = half_max(mmax);
+            if (rowing && rm > best_m) best_m = rm;
             int hkey = 0x7fffffff;
-            if (__ballot(hk != 0x7fffffff)) hkey = half_min(hk);
-            if (rowing) {
-                const int rm = bkey >> 10, rk = 1023 - (bkey & 1023) - k_offset;
-                if (rm > best_m) { best_m = rm; best_x = (rm + rk) / 2; best_d = d; best_k = rk; }
-            }
+            if (__ballot(reached)) hkey = half_min(reached ? ((hkk << 10) | hx) : 0x7fffffff);
             // band update (:172-179)
             int nmin = max_k, nmax = min_k;
             if (NJ == 1) {
-                const unsigned long long qb = __ballot(rowing && sl < nslot && m0 >= best_m - band_tol);
-                const unsigned int qa = (unsigned int)qb, qbh = (unsigned int)(qb >> 32);
-                const unsigned int mine = hh ? qbh : qa;
+                const unsigned long long qb = __ballot(m0 >= best_m - band_tol && m0 >= 0);
+                const unsigned int mine = hh ? (unsigned int)(qb >> 32) : (unsigned int)qb;
                 if (mine) { nmin = min_k + 2 * (__ffs((int)mine) - 1); nmax = min_k + 2 * (31 - __clz((int)mine)); }
             } else {
                 int lo = 0x7fffffff, hi = -0x7fffffff;
@@ -661,25 +660,24 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
         }
 
         // ---- 4. tail traceback == trim_mismatch_end(.., 4, ..) (gapalign.cpp:47-68)
-        bool has_aln = live && (aligned || best_x > 0);
-        if (!aligned) { end_x = best_x; end_k = best_k; end_d = best_d; }
+        bool has_aln = live && aligned;
+        bool fallback = live && ran && !aligned;        // needs the best point: one-unit path
         const int end_y = end_x - end_k;
         const int aln_size = (end_x + end_y + end_d) / 2;
         int cd = end_d, ck = end_k, cx2 = end_x;
         int qcnt = 0, tcnt = 0, acnt = 0, found = 0;
-        bool fallback = false;
         bool tracing = has_aln;
         while (__ballot(tracing)) {
             if (tracing) {
                 int x1 = 0, pre_k = 0, takes_q = 0;
                 if (cd > 0) {
                     const int r = cd - 1;
-                    const unsigned int rl = S.rlin[r & (RROWS - 1)];
-                    if (last_row - r >= RROWS || lin - rl > RCAP) { fallback = true; tracing = false; }
+                    const uint2 pr = S.rrec[r & (RROWS - 1)], cr = S.rrec[cd & (RROWS - 1)];
+                    if (last_row - r >= RROWS || lin - pr.y > RCAP) { fallback = true; tracing = false; }
                     else {
-                        const int pmin = S.rmin[r & (RROWS - 1)], pmax = S.rmax[r & (RROWS - 1)];
-                        const int cmin = S.rmin[cd & (RROWS - 1)], cmax = S.rmax[cd & (RROWS - 1)];
-                        const unsigned int pb = rl & (RCAP - 1);
+                        const int pmin = (int)(int16_t)(pr.x & 0xFFFFu), pmax = (int)(int16_t)(pr.x >> 16);
+                        const int cmin = (int)(int16_t)(cr.x & 0xFFFFu), cmax = (int)(int16_t)(cr.x >> 16);
+                        const unsigned int pb = pr.y & (RCAP - 1);
                         const int kl = ck - 1, kr = ck + 1;
                         int vl = 0, vr = 0;
                         if (kl >= pmin && kl <= pmax) vl = S.ring[pb + ((kl - pmin) >> 1)];

@@ -191,6 +191,9 @@ int split_raw_dataset(const char* reads, const char* wrk_dir) {
     const std::string idx_name = index_file_name(wrk_dir);
     FILE* idx_file = fopen(idx_name.c_str(), "w");
     if (!idx_file) DIE("cannot open '%s' for writing", idx_name.c_str());
+    // testing knob (additive, environment only): smaller volumes so the multi-volume grid can be exercised on small inputs
+    long max_volume_bases = kMaxVolumeBases;
+    if (const char* e = getenv("MECAT_HIP_MCS")) { long v2 = atol(e); if (v2 > 0 && v2 < kMaxVolumeBases) max_volume_bases = v2; }
     LineReader lr(reads);
     std::string seq;
     long long num_reads = 0, num_nucls = 0;
@@ -214,7 +217,7 @@ int split_raw_dataset(const char* reads, const char* wrk_dir) {
         if (rsize == -1) break;
         ++num_reads;
         num_nucls += rsize;
-        if (curr + rsize + 1 > kMaxVolumeBases) flush();
+        if (curr + rsize + 1 > max_volume_bases) flush();
         mhip_offset_t o;
         o.offset = (int)curr;
         o.size = (int)rsize;

@@ -864,6 +864,259 @@ int orc_dw_go(orc_aligner* A, const char* query, int qstart, int qsize, const ch
     return out->ok;
 }
 
+/* ------------------------------------------------------------------ A13: X-drop aligner (xdrop_gapalign.cpp) */
+
+#define X_MIN_SCORE (-100000000)
+enum { X_SUB = 3, X_GAP_IN_A = 0, X_GAP_IN_B = 6, X_OP_MASK = 0x07, X_EXT_A = 0x10, X_EXT_B = 0x40 };   /* xdrop_gapalign.h:13-34 */
+typedef struct { int best, best_gap; } gapdp;                 /* BlastGapDP, xdrop_gapalign.h:37-40 */
+
+struct orc_xaligner {                                         /* xdrop_gapalign.h:117-212, parameters :85-115 */
+    int reward, penalty, gap_open, gap_extend, x_dropoff, block_size;
+    uint8_t* state_array;
+    gapdp* score_array;
+    uint8_t** edit_script;
+    int* edit_start_offset;
+    int* op_type; int* op_num; int num_ops, last_op;           /* GapPrelimEditBlock */
+    int matrix[4][4];
+    char *lq, *lt, *rq, *rt, *tq, *tt;                         /* left/right/tmp aligned strings (codes 0..4) */
+    int lsize, rsize;
+};
+
+orc_xaligner* orc_xaligner_new(void)
+{
+    orc_xaligner* a = (orc_xaligner*)xcalloc(sizeof(*a));
+    a->reward = 1; a->penalty = -1; a->gap_open = 0; a->gap_extend = 1; a->x_dropoff = 30; a->block_size = 500;
+    a->state_array = (uint8_t*)xmalloc(5000000);
+    a->score_array = (gapdp*)xmalloc(sizeof(gapdp) * 4096);
+    a->edit_script = (uint8_t**)xmalloc(sizeof(uint8_t*) * 4096);
+    a->edit_start_offset = (int*)xmalloc(sizeof(int) * 4096);
+    a->op_type = (int*)xmalloc(sizeof(int) * ORC_MAX_SEQ_SIZE);
+    a->op_num = (int*)xmalloc(sizeof(int) * ORC_MAX_SEQ_SIZE);
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) a->matrix[i][j] = i == j ? a->reward : a->penalty;
+    a->lq = (char*)xmalloc(ORC_MAX_SEQ_SIZE); a->lt = (char*)xmalloc(ORC_MAX_SEQ_SIZE);
+    a->rq = (char*)xmalloc(ORC_MAX_SEQ_SIZE); a->rt = (char*)xmalloc(ORC_MAX_SEQ_SIZE);
+    a->tq = (char*)xmalloc(8192); a->tt = (char*)xmalloc(8192);
+    return a;
+}
+
+void orc_xaligner_free(orc_xaligner* a)
+{
+    if (!a) return;
+    free(a->state_array); free(a->score_array); free(a->edit_script); free(a->edit_start_offset); free(a->op_type);
+    free(a->op_num); free(a->lq); free(a->lt); free(a->rq); free(a->rt); free(a->tq); free(a->tt); free(a);
+}
+
+static void xblock_add(orc_xaligner* a, int op, int n)        /* GapPrelimEditBlock::add, xdrop_gapalign.h:70-81 */
+{
+    if (n == 0) return;
+    if (a->last_op == op) a->op_num[a->num_ops - 1] += n;
+    else { a->last_op = op; a->op_type[a->num_ops] = op; a->op_num[a->num_ops] = n; ++a->num_ops; }
+}
+
+/* xdrop_gapalign.cpp:10-213 */
+static int xdrop_align(orc_xaligner* X, const char* A, int M, const char* B, int N, int forward, int* ae, int* be)
+{
+    const int gap_open = X->gap_open, gap_extend = X->gap_extend;
+    int x_dropoff = X->x_dropoff;
+    uint8_t* state_array = X->state_array;
+    gapdp* score_array = X->score_array;
+    uint8_t** edit_script = X->edit_script;
+    int* edit_start_offset = X->edit_start_offset;
+    *ae = 0; *be = 0;
+    X->last_op = 8; X->num_ops = 0;                            /* edit_block->clear() */
+    if (M <= 0 || N <= 0) return 0;
+    int i, a_index, b_index, b_size, first_b_index, last_b_index;
+    const int gap_open_extend = gap_open + gap_extend;
+    int best_score, score, score_gap_row, score_gap_col, next_score, orig_b_index, states_used = 0;
+    const int* matrix_row;
+    uint8_t* edit_script_row;
+    uint8_t script, next_script, script_row, script_col;
+    if (x_dropoff < gap_open_extend) x_dropoff = gap_open_extend;
+    edit_script[0] = state_array;
+    edit_start_offset[0] = 0;
+    edit_script_row = state_array;
+    score = -gap_open_extend;
+    score_array[0].best = 0;
+    score_array[0].best_gap = -gap_open_extend;
+    for (i = 1; i <= N; ++i) {
+        if (score < -x_dropoff) break;
+        score_array[i].best = score;
+        score_array[i].best_gap = score - gap_open_extend;
+        score -= gap_extend;
+        edit_script_row[i] = X_GAP_IN_A;
+    }
+    states_used = N < i + 1 ? N : i + 1;
+    b_size = i;
+    best_score = 0;
+    first_b_index = 0;
+    for (a_index = 1; a_index <= M; ++a_index) {
+        const uint8_t AC = (uint8_t)extract_char(A, a_index - 1, forward);
+        edit_script[a_index] = state_array + states_used + 1;
+        edit_start_offset[a_index] = first_b_index;
+        edit_script_row = edit_script[a_index] - first_b_index;
+        orig_b_index = first_b_index;
+        matrix_row = X->matrix[AC];
+        score = X_MIN_SCORE;
+        score_gap_row = X_MIN_SCORE;
+        last_b_index = first_b_index;
+        for (b_index = first_b_index; b_index < b_size; ++b_index) {
+            const uint8_t BC = (uint8_t)extract_char(B, b_index, forward);
+            score_gap_col = score_array[b_index].best_gap;
+            next_score = score_array[b_index].best + matrix_row[BC];
+            script = X_SUB;
+            script_row = X_EXT_B;
+            script_col = X_EXT_A;
+            if (score < score_gap_col) { script = X_GAP_IN_B; score = score_gap_col; }
+            if (score < score_gap_row) { script = X_GAP_IN_A; score = score_gap_row; }
+            if (best_score - score > x_dropoff) {
+                if (first_b_index == b_index) ++first_b_index;
+                else score_array[b_index].best = X_MIN_SCORE;
+            } else {
+                last_b_index = b_index;
+                if (score > best_score) { best_score = score; *ae = a_index; *be = b_index; }
+                score_gap_col -= gap_extend;
+                if (score_gap_col < (score - gap_open_extend)) score_array[b_index].best_gap = score - gap_open_extend;
+                else { score_array[b_index].best_gap = score_gap_col; script += script_col; }
+                score_gap_row -= gap_extend;
+                if (score_gap_row < (score - gap_open_extend)) score_gap_row = score - gap_open_extend;
+                else script += script_row;
+                score_array[b_index].best = score;
+            }
+            score = next_score;
+            edit_script_row[b_index] = script;
+        }
+        if (first_b_index == b_size) break;
+        if (last_b_index < b_size - 1) b_size = last_b_index + 1;
+        else {
+            while (score_gap_row >= (best_score - x_dropoff) && b_size < N) {
+                score_array[b_size].best = score_gap_row;
+                score_array[b_size].best_gap = score_gap_row - gap_open_extend;
+                score_gap_row -= gap_extend;
+                edit_script_row[b_size] = X_GAP_IN_A;
+                ++b_size;
+            }
+        }
+        states_used += (b_index > b_size ? b_index : b_size) - orig_b_index + 1;
+        if (b_size < N) {
+            score_array[b_size].best = X_MIN_SCORE;
+            score_array[b_size].best_gap = X_MIN_SCORE;
+            ++b_size;
+        }
+    }
+    a_index = *ae;
+    b_index = *be;
+    script = X_SUB;
+    while (a_index > 0 || b_index > 0) {
+        next_script = edit_script[a_index][b_index - edit_start_offset[a_index]];
+        switch (script) {
+        case X_GAP_IN_A:
+            script = next_script & X_OP_MASK;
+            if (next_script & X_EXT_A) script = X_GAP_IN_A;
+            break;
+        case X_GAP_IN_B:
+            script = next_script & X_OP_MASK;
+            if (next_script & X_EXT_B) script = X_GAP_IN_B;
+            break;
+        default:
+            script = next_script & X_OP_MASK;
+            break;
+        }
+        if (script == X_GAP_IN_A) --b_index;
+        else if (script == X_GAP_IN_B) --a_index;
+        else { --a_index; --b_index; }
+        xblock_add(X, script, 1);
+    }
+    return best_score;
+}
+
+int orc_xdrop_align(orc_xaligner* a, const char* A, int M, const char* B, int N, int forward, int* res, int* ops)
+{
+    const char* AA = forward ? A : A + M - 1;
+    const char* BB = forward ? B : B + N - 1;
+    int ae, be;
+    int sc = xdrop_align(a, AA, M, BB, N, forward, &ae, &be);
+    res[0] = ae; res[1] = be; res[2] = a->num_ops;
+    for (int i = 0; i < a->num_ops; ++i) { ops[2 * i] = a->op_type[i]; ops[2 * i + 1] = a->op_num[i]; }
+    return sc;
+}
+
+/* script_to_aligned_string, xdrop_gapalign.cpp:215-261 ; returns the string length */
+static int script_to_aligned_string(orc_xaligner* X, const char* query, const char* target, int forward, char* qaln, char* taln)
+{
+    const char *q = query, *t = target;
+    const int inc = forward ? 1 : -1;
+    int n = 0;
+    for (int i = X->num_ops - 1; i >= 0; --i) {
+        const int op = X->op_type[i], cnt = X->op_num[i];
+        for (int j = 0; j < cnt; ++j) {
+            if (op == X_SUB) { qaln[n] = *q; taln[n] = *t; q += inc; t += inc; }
+            else if (op == X_GAP_IN_A) { qaln[n] = ORC_GAP_CODE; taln[n] = *t; t += inc; }
+            else { qaln[n] = *q; taln[n] = ORC_GAP_CODE; q += inc; }
+            ++n;
+        }
+    }
+    return n;
+}
+
+/* align_ex, xdrop_gapalign.cpp:263-357 ; appends to (qaln, taln), returns the new length */
+static int align_ex(orc_xaligner* X, const char* query, int query_size, const char* target, int target_size, int forward,
+                    char* qaln, char* taln)
+{
+    const int kTailMatchBP = 4;
+    int qidx = 0, tidx = 0, qblk, tblk, aln_qe, aln_te, len = 0;
+    const char *Q, *T;
+    while (1) {
+        int last_block = retrieve_next_aln_block(query, qidx, query_size, target, tidx, target_size, X->block_size, forward, &Q, &T, &qblk, &tblk);
+        xdrop_align(X, Q, qblk, T, tblk, forward, &aln_qe, &aln_te);
+        int n = script_to_aligned_string(X, Q, T, forward, X->tq, X->tt);
+        int full_map = 0;
+        if (qblk - aln_qe <= 20 || tblk - aln_te <= 20) full_map = 1;
+        if ((!full_map) || last_block) {
+            memcpy(qaln + len, X->tq, (size_t)n); memcpy(taln + len, X->tt, (size_t)n);
+            len += n;
+            break;
+        }
+        int qcnt = 0, tcnt = 0, acnt = 0;
+        int trim = trim_mismatch_end(X->tq, X->tt, n, kTailMatchBP, &qcnt, &tcnt, &acnt);
+        if (!trim) break;
+        n -= acnt;
+        memcpy(qaln + len, X->tq, (size_t)n); memcpy(taln + len, X->tt, (size_t)n);
+        len += n;
+        qidx += (aln_qe - qcnt);
+        tidx += (aln_te - tcnt);
+    }
+    return len;
+}
+
+/* XdropAligner::go, xdrop_gapalign.cpp:359-439 (the left half skips its last column: `n = size() - 1; k = n - 1`) */
+int orc_xdrop_go(orc_xaligner* X, const char* query, int qstart, int qsize, const char* target, int tstart, int tsize,
+                 int min_aln_size, orc_aln_result* out)
+{
+    X->lsize = align_ex(X, query + qstart - 1, qstart, target + tstart - 1, tstart, 0, X->lq, X->lt);
+    X->rsize = align_ex(X, query + qstart, qsize - qstart, target + tstart, tsize - tstart, 1, X->rq, X->rt);
+    int i = 0, j = 0, k, n, idx = 0, ident = 0;
+    n = X->lsize - 1;
+    for (k = n - 1; k >= 0; --k, ++idx) {
+        if (X->lq[k] != ORC_GAP_CODE) ++i;
+        if (X->lt[k] != ORC_GAP_CODE) ++j;
+        if (X->lq[k] == X->lt[k]) ++ident;
+    }
+    out->query_start = qstart - i;
+    out->target_start = tstart - j;
+    n = X->rsize;
+    for (i = 0, j = 0, k = 0; k < n; ++k, ++idx) {
+        if (X->rq[k] != ORC_GAP_CODE) ++i;
+        if (X->rt[k] != ORC_GAP_CODE) ++j;
+        if (X->rq[k] == X->rt[k]) ++ident;
+    }
+    out->query_end = qstart + i;
+    out->target_end = tstart + j;
+    out->matches = ident;
+    out->columns = idx;
+    out->ok = out->query_end - out->query_start >= min_aln_size;
+    return out->ok;
+}
+
 /* ------------------------------------------------------------------ A14: m4 */
 
 /* pw_impl.cpp:467-506 ; ident = 100.0 * n / out_store_size, 0.0 when empty (diff_gapalign.h:90-97) */
@@ -942,9 +1195,15 @@ int orc_m4_line(const orc_m4* m, int gapped, char* buf)
     return n;
 }
 
-/* pairwise_mapping pw_impl.cpp:651-700 for one read (PacBio / DiffAligner only; XdropAligner is SURVEY row A13, next) */
 int orc_map_read(const orc_volume* ref, const orc_volume* reads, const orc_index* ridx, orc_seeding_bk* bk,
                  orc_aligner* al, int rid, const orc_params* p, orc_m4* out)
+{
+    return orc_map_read_x(ref, reads, ridx, bk, al, NULL, rid, p, out);
+}
+
+/* pairwise_mapping pw_impl.cpp:651-700 for one read; aligner by tech (:638-644) */
+int orc_map_read_x(const orc_volume* ref, const orc_volume* reads, const orc_index* ridx, orc_seeding_bk* bk,
+                   orc_aligner* al, orc_xaligner* xal, int rid, const orc_params* p, orc_m4* out)
 {
     orc_candidate* cands = (orc_candidate*)xmalloc(sizeof(orc_candidate) * (size_t)p->maxc);
     orc_m4* m4v = (orc_m4*)xmalloc(sizeof(orc_m4) * (size_t)p->maxc);
@@ -964,7 +1223,9 @@ int orc_map_read(const orc_volume* ref, const orc_volume* reads, const orc_index
         if (qstart && sstart) { qstart += ORC_KMER / 2; sstart += ORC_KMER / 2; }
         int ssize = ref->offs[lid].size;
         orc_aln_result r;
-        if (orc_dw_go(al, read, qstart, rsize, subject, sstart, ssize, p->min_align_size, &r)) {
+        int okk = (p->tech == 1 && xal) ? orc_xdrop_go(xal, read, qstart, rsize, subject, sstart, ssize, p->min_align_size, &r)
+                                       : orc_dw_go(al, read, qstart, rsize, subject, sstart, ssize, p->min_align_size, &r);
+        if (okk) {
             orc_m4_fill(&r, rid + reads->start_read_id, cands[s].readno, cands[s].chain, rsize, ssize, qstart, sstart,
                         cands[s].score, m4v + num_m4);
             ++num_m4;

@@ -141,6 +141,17 @@ int orc_dw_go(orc_aligner* a, const char* query, int qstart, int qsize, const ch
 /* work counters of the last orc_dw_go call: blocks, d-path cells, snake bases */
 void orc_dw_counters(const orc_aligner* a, int64_t* blocks, int64_t* cells, int64_t* snake);
 
+/* ---- A13: X-drop aligner (nanopore mode, -x 1 -j 1) ---- */
+typedef struct orc_xaligner orc_xaligner;                    /* XdropAligner, xdrop_gapalign.h:117-212 */
+orc_xaligner* orc_xaligner_new(void);
+void orc_xaligner_free(orc_xaligner* a);
+/* xdrop_align (xdrop_gapalign.cpp:10-213) on forward-ordered code arrays (left extension reads them backwards from the
+   last element like align_ex does); returns the best score; res = {ae, be, num_ops}; ops receives num_ops pairs
+   (op_type, count) in edit_block order (i.e. from the alignment end towards its start) */
+int orc_xdrop_align(orc_xaligner* a, const char* A, int M, const char* B, int N, int forward, int* res, int* ops);
+int orc_xdrop_go(orc_xaligner* a, const char* query, int qstart, int qsize, const char* target, int tstart, int tsize,
+                 int min_aln_size, orc_aln_result* out);     /* xdrop_gapalign.cpp:359-439 */
+
 /* ---- A14: m4 records ---- */
 void orc_m4_fill(const orc_aln_result* r, int qid, int sid, char qchain, int qsize, int ssize,
                  int qstart, int sstart, int vscore, orc_m4* m);                          /* pw_impl.cpp:467-506 */
@@ -149,6 +160,9 @@ int orc_m4_line(const orc_m4* m, int gapped, char* buf);     /* output_m4record 
 /* whole `-j 1` body for one read (pairwise_mapping :651-700): candidates -> dw -> m4 -> post-filter */
 int orc_map_read(const orc_volume* ref, const orc_volume* reads, const orc_index* ridx, orc_seeding_bk* bk,
                  orc_aligner* al, int rid, const orc_params* p, orc_m4* out);
+/* same with the X-drop aligner when p->tech == 1 (xal may be NULL for tech 0) */
+int orc_map_read_x(const orc_volume* ref, const orc_volume* reads, const orc_index* ridx, orc_seeding_bk* bk,
+                   orc_aligner* al, orc_xaligner* xal, int rid, const orc_params* p, orc_m4* out);
 
 #ifdef __cplusplus
 }

@@ -13,6 +13,10 @@
 
 #include <cstring>
 
+/* defined (non-static) in common/xdrop_gapalign.cpp:10 */
+int xdrop_align(const char* A, const int M, const char* B, const int N, int matrix[][4], int gap_open, int gap_extend,
+                int x_dropoff, u8* state_array, BlastGapDP* score_array, u8** edit_script, int* edit_start_offset,
+                GapPrelimEditBlock* edit_block, const bool forward, int& ae, int& be);
 /* defined (non-static) in common/diff_gapalign.cpp:107 */
 int Align(const char* query, const int q_len, const char* target, const int t_len,
           const int band_tolerance, const int get_aln_str, Alignment* align,
@@ -132,6 +136,34 @@ int refh_dw_go(const char* q, int qstart, int qsize, const char* t, int tstart, 
     res[5] = n; res[6] = r->out_store_size;
     *ident = r->calc_ident();
     return ok;
+}
+
+/* XdropAligner::go (xdrop_gapalign.cpp:359). res = {ok, qoff, qend, toff, tend, matches, columns} */
+static XdropAligner* g_xa = NULL;
+int refh_xdrop_go(const char* q, int qstart, int qsize, const char* t, int tstart, int tsize, int min_aln, int* res, double* ident)
+{
+    if (!g_xa) g_xa = new XdropAligner(0);
+    bool ok = g_xa->go(q, qstart, qsize, t, tstart, tsize, min_aln);
+    int n = 0;
+    for (int i = 0; i < g_xa->aln_size; ++i) if (g_xa->qaln[i] == g_xa->taln[i]) ++n;
+    res[0] = ok; res[1] = g_xa->qoff; res[2] = g_xa->qend; res[3] = g_xa->toff; res[4] = g_xa->tend; res[5] = n; res[6] = g_xa->aln_size;
+    *ident = g_xa->calc_ident();
+    return ok;
+}
+
+/* xdrop_align on one block (xdrop_gapalign.cpp:10); res = {ae, be, num_ops}, ops = (type, count) pairs in edit_block order */
+int refh_xdrop_align(const char* A, int M, const char* B, int N, int forward, int* res, int* ops)
+{
+    if (!g_xa) g_xa = new XdropAligner(0);
+    const char* AA = forward ? A : A + M - 1;
+    const char* BB = forward ? B : B + N - 1;
+    int ae, be;
+    int sc = xdrop_align(AA, M, BB, N, g_xa->score_matrix, g_xa->param.gap_open, g_xa->param.gap_extend, g_xa->param.x_dropoff,
+                         g_xa->state_array, g_xa->score_array, g_xa->edit_script, g_xa->edit_start_offset, &g_xa->edit_block,
+                         forward, ae, be);
+    res[0] = ae; res[1] = be; res[2] = g_xa->edit_block.num_ops;
+    for (int i = 0; i < g_xa->edit_block.num_ops; ++i) { ops[2 * i] = g_xa->edit_block.edit_ops[i].op_type; ops[2 * i + 1] = g_xa->edit_block.edit_ops[i].num; }
+    return sc;
 }
 
 int refh_sizeof(int what)

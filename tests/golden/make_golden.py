@@ -98,6 +98,11 @@ def main():
                 cs["cands_maxc%d" % maxc] = np.concatenate(rows) if rows else np.zeros((0, 12), np.int32)
                 cs["counts_maxc%d" % maxc] = np.array(cnts, dtype=np.int32)
             np.savez_compressed(os.path.join(OUT, name + "_cands.npz"), **cs)
+        if ont:
+            m4, _ = run_ref(fa, d, ["-j", "1", "-x", "1", "-g", "1"], "%s.g1.m4" % name)
+            m["m4_g1_sorted_sha256"] = sha(("\n".join(m4) + "\n").encode())
+            m["m4_g1_lines"] = len(m4)
+            open(os.path.join(OUT, "%s.g1.m4.sorted" % name), "w").write("\n".join(m4) + "\n")
         if not ont:
             for g in (0, 1):
                 if name == "config1" and g == 0:
@@ -220,6 +225,29 @@ def main():
         dres.append(list(res))
     kat["dw_q"] = np.concatenate(dq); kat["dw_t"] = np.concatenate(dt)
     kat["dw_par"] = np.array(dpar, np.int32); kat["dw_res"] = np.array(dres, np.int32)
+    # XdropAligner::go (nanopore mode)
+    xq, xt, xpar, xres = [], [], [], []
+    for it in range(40):
+        n = int(rng.integers(600, 5000))
+        g = rng.integers(0, 4, size=n + 2000).astype(np.int8)
+        a0, b0 = int(rng.integers(0, 1000)), int(rng.integers(0, 1000))
+        q = mutate(rng, g[a0: a0 + n], 0.12)
+        t = mutate(rng, g[b0: b0 + n], 0.12)
+        mid = max(a0, b0) + n // 3
+        qs = int((mid - a0) * 1.04) if it % 5 else int(rng.integers(0, len(q)))
+        ts = int((mid - b0) * 1.04) if it % 5 else int(rng.integers(0, len(t)))
+        qs = min(max(qs, 0), len(q) - 1)
+        ts = min(max(ts, 0), len(t) - 1)
+        if it % 11 == 0:
+            qs = 0
+        res = np.zeros(7, np.int32)
+        ident = C.c_double()
+        R.refh_xdrop_go(q.ctypes.data, qs, len(q), t.ctypes.data, ts, len(t), 500, res.ctypes.data, C.byref(ident))
+        xq.append(q); xt.append(t)
+        xpar.append([len(q), len(t), qs, ts, 500])
+        xres.append(list(res))
+    kat["xd_q"] = np.concatenate(xq); kat["xd_t"] = np.concatenate(xt)
+    kat["xd_par"] = np.array(xpar, np.int32); kat["xd_res"] = np.array(xres, np.int32)
     np.savez_compressed(os.path.join(OUT, "kats.npz"), **kat)
     json.dump(meta, open(os.path.join(OUT, "golden.json"), "w"), indent=1, sort_keys=True)
     print("wrote", OUT, file=sys.stderr)

@@ -136,6 +136,12 @@ def orc():
         L.orc_align.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]
         L.orc_dw_go.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.POINTER(OrcAlnResult)]
         L.orc_dw_counters.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.orc_xaligner_new.restype = vp
+        L.orc_xaligner_free.argtypes = [vp]
+        L.orc_xdrop_align.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp]
+        L.orc_xdrop_go.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.POINTER(OrcAlnResult)]
+        L.orc_map_read_x.argtypes = [C.POINTER(OrcVolume), C.POINTER(OrcVolume), C.POINTER(OrcIndex), vp, vp, vp, C.c_int,
+                                     C.POINTER(OrcParams), vp]
         L.orc_m4_fill.argtypes = [C.POINTER(OrcAlnResult), C.c_int, C.c_int, C.c_char, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_int, C.POINTER(OrcM4)]
         L.orc_m4_postfilter.argtypes = [vp, C.c_int, vp]
@@ -254,5 +260,7 @@ def ref():
         L.refh_find_location.argtypes = [vp, vp, vp, vp, C.c_int, C.POINTER(C.c_int), C.c_float, C.c_int]
         L.refh_align.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]
         L.refh_dw_go.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, C.POINTER(C.c_double)]
+        L.refh_xdrop_go.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, C.POINTER(C.c_double)]
+        L.refh_xdrop_align.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp]
         _ref = L
     return _ref

@@ -67,3 +67,41 @@ def test_cli_resume_skips_finished_volume(tmp_path):
     r = subprocess.run([BIN, "-j", "0", "-d", fa, "-o", out, "-w", str(wrk)], capture_output=True, text=True)
     assert r.returncode == 0 and "volume 0 has been finished" in r.stderr
     assert open(out).read() == "sentinel\n"
+
+
+def test_cli_multi_volume_grid(tmp_path):
+    """three volumes (MECAT_HIP_MCS test knob) -> 6 grid cells (i, j >= i), r_<i> files, cat merge.  Expected output:
+    the oracle run cell by cell on the same volumes (the reference's MCS is a compile-time constant, so the reference
+    binary itself cannot be made to split a small input)."""
+    import ctypes as C
+    g = G["sets"]["tiny"]["gen"]
+    codes, lens = H.synth_reads(g["nreads"], g["L"], g["err"], g["genome"], g["seed"], g["ont"])
+    fa = str(tmp_path / "tiny.fa")
+    H.write_fasta(fa, codes, lens)
+    wrk = tmp_path / "w_mv"
+    out = str(tmp_path / "mv.can")
+    env = dict(os.environ, MECAT_HIP_MCS="250000")
+    r = subprocess.run([BIN, "-j", "0", "-d", fa, "-o", out, "-w", str(wrk)], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    names = open(os.path.join(str(wrk), "fileindex.txt")).read().split()
+    assert len(names) == 3
+    O = H.orc()
+    vols = [O.orc_volume_load(n.encode()) for n in names]
+    assert sum(v.contents.num_reads for v in vols) == len(lens)
+    assert [v.contents.start_read_id for v in vols][0] == 0
+    want = []
+    p = H.orc_params(tech=0)
+    for i, ref in enumerate(vols):
+        oidx = O.orc_index_build(ref)
+        ro, _ = H.vol_arrays(ref)
+        for j in range(i, len(vols)):
+            rd = vols[j]
+            cands = H.orc_seed_all(ref, rd, oidx, p)
+            qo, _ = H.vol_arrays(rd)
+            want += H.can_lines_from_cands(cands, qo, ro, rd.contents.start_read_id, ref.contents.start_read_id)
+        O.orc_index_free(oidx)
+    got = sorted(open(out).read().splitlines())
+    assert got == sorted(want)
+    assert len(got) > 300
+    for i in range(3):
+        assert os.path.exists(os.path.join(str(wrk), "r_%d" % i))

@@ -169,3 +169,36 @@ def test_dw_go_kats():
         O.orc_dw_go(al, q.ctypes.data, qs, nq, t.ctypes.data, ts, nt, mn, C.byref(o))
         assert [o.ok, o.query_start, o.query_end, o.target_start, o.target_end, o.matches, o.columns] == list(want)
     O.orc_aligner_free(al)
+
+
+def test_xdrop_go_kats():
+    """XdropAligner::go known answers (nanopore mode)"""
+    O = H.orc()
+    xa = O.orc_xaligner_new()
+    qo = to = 0
+    for par, want in zip(KAT["xd_par"], KAT["xd_res"]):
+        nq, nt, qs, ts, mn = [int(x) for x in par]
+        q = KAT["xd_q"][qo: qo + nq].copy(); qo += nq
+        t = KAT["xd_t"][to: to + nt].copy(); to += nt
+        o = H.OrcAlnResult()
+        O.orc_xdrop_go(xa, q.ctypes.data, qs, nq, t.ctypes.data, ts, nt, mn, C.byref(o))
+        assert [o.ok, o.query_start, o.query_end, o.target_start, o.target_end, o.matches, o.columns] == list(want)
+    O.orc_xaligner_free(xa)
+
+
+def test_m4_lines_tiny_ont():
+    """-x 1 -j 1 -g 1 (X-drop aligner) against the reference's sorted output"""
+    codes, lens, v, idx = dataset("tiny_ont")
+    O = H.orc()
+    p = H.orc_params(tech=1)
+    bk = O.orc_bk_new(v.contents.num_bases)
+    al, xa = O.orc_aligner_new(), O.orc_xaligner_new()
+    out = (H.OrcM4 * 100)()
+    buf = C.create_string_buffer(512)
+    lines = []
+    for rid in range(len(lens)):
+        k = O.orc_map_read_x(v, v, idx, bk, al, xa, rid, C.byref(p), out)
+        for i in range(k):
+            n = O.orc_m4_line(C.byref(out[i]), 1, buf)
+            lines.append(buf.raw[:n].decode().rstrip("\n"))
+    assert sorted(lines) == open(os.path.join(H.GOLDEN, "tiny_ont.g1.m4.sorted")).read().splitlines()

@@ -246,3 +246,94 @@ def test_m4_output_identical(tiny, gapped):
     O.orc_aligner_free(al)
     assert len(want) > 50
     assert sorted(lines) == want
+
+
+def _mutate_ont(rng, s, e):
+    out = []
+    for b in s:
+        u = rng.random()
+        if u < 0.35 * e:
+            continue
+        out.append(int(rng.integers(0, 4)) if u < 0.70 * e else int(b))
+        if rng.random() < 0.30 * e:
+            out.append(int(rng.integers(0, 4)))
+    return np.array(out, dtype=np.int8)
+
+
+def test_xdrop_align_random():
+    R, O = H.ref(), H.orc()
+    xa = O.orc_xaligner_new()
+    rng = np.random.default_rng(21)
+    for it in range(200):
+        n = int(rng.integers(1, 700))
+        q = rng.integers(0, 4, size=n).astype(np.int8)
+        e = [0.0, 0.05, 0.12, 0.3, 0.7][it % 5]
+        t = _mutate_ont(rng, q, e) if it % 9 else rng.integers(0, 4, size=int(rng.integers(1, 700))).astype(np.int8)
+        if len(t) == 0:
+            continue
+        fwd = it % 2
+        outs = []
+        for fn, pre in ((R.refh_xdrop_align, ()), (O.orc_xdrop_align, (xa,))):
+            res = np.zeros(3, np.int32)
+            ops = np.zeros(2 * 4096, np.int32)
+            sc = fn(*pre, q.ctypes.data, len(q), t.ctypes.data, len(t), fwd, res.ctypes.data, ops.ctypes.data)
+            outs.append((sc, tuple(res), tuple(ops[: 2 * res[2]])))
+        assert outs[0] == outs[1], it
+    O.orc_xaligner_free(xa)
+
+
+def test_xdrop_go_random():
+    R, O = H.ref(), H.orc()
+    xa = O.orc_xaligner_new()
+    rng = np.random.default_rng(23)
+    oks = 0
+    for it in range(60):
+        n = int(rng.integers(600, 6000))
+        g = rng.integers(0, 4, size=n + 2000).astype(np.int8)
+        a0, b0 = int(rng.integers(0, 1000)), int(rng.integers(0, 1000))
+        q = _mutate_ont(rng, g[a0: a0 + n], 0.12)
+        t = _mutate_ont(rng, g[b0: b0 + n], 0.12)
+        mid = max(a0, b0) + n // 3
+        qs = int((mid - a0) * 0.995) if it % 5 else int(rng.integers(0, len(q)))
+        ts = int((mid - b0) * 0.995) if it % 5 else int(rng.integers(0, len(t)))
+        qs = min(max(qs, 0), len(q) - 1)
+        ts = min(max(ts, 0), len(t) - 1)
+        if it % 11 == 0:
+            qs = 0
+        res_r = np.zeros(7, dtype=np.int32)
+        ident = C.c_double()
+        R.refh_xdrop_go(q.ctypes.data, qs, len(q), t.ctypes.data, ts, len(t), 500, res_r.ctypes.data, C.byref(ident))
+        o = H.OrcAlnResult()
+        O.orc_xdrop_go(xa, q.ctypes.data, qs, len(q), t.ctypes.data, ts, len(t), 500, C.byref(o))
+        got = (o.ok, o.query_start, o.query_end, o.target_start, o.target_end, o.matches, o.columns)
+        assert got == tuple(res_r), it
+        oks += o.ok
+    assert oks > 10
+    O.orc_xaligner_free(xa)
+
+
+def test_m4_nanopore_output_identical(tmp_path):
+    """-x 1 -j 1 -g 1: XdropAligner end to end"""
+    codes, lens = H.synth_reads(150, 4000, 0.12, 40000, 12, 1)
+    fa = str(tmp_path / "ont.fa")
+    H.write_fasta(fa, codes, lens)
+    out = str(tmp_path / "ont.m4")
+    subprocess.run([H.ref_bin(), "-j", "1", "-x", "1", "-g", "1", "-d", fa, "-o", out, "-w", str(tmp_path / "w"), "-t", "2"], check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    want = sorted(open(out).read().splitlines())
+    O = H.orc()
+    ov = H.orc_pack(codes, lens)
+    oidx = O.orc_index_build(ov)
+    p = H.orc_params(tech=1)
+    bk = O.orc_bk_new(ov.contents.num_bases)
+    al, xa = O.orc_aligner_new(), O.orc_xaligner_new()
+    outm = (H.OrcM4 * 100)()
+    buf = C.create_string_buffer(512)
+    lines = []
+    for rid in range(len(lens)):
+        k = O.orc_map_read_x(ov, ov, oidx, bk, al, xa, rid, C.byref(p), outm)
+        for i in range(k):
+            n = O.orc_m4_line(C.byref(outm[i]), 1, buf)
+            lines.append(buf.raw[:n].decode().rstrip("\n"))
+    assert len(want) > 100
+    assert sorted(lines) == want

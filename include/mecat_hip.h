@@ -9,6 +9,7 @@
  *   mhip_seed_reads       <- seeding + get_candidates, both strands     mecat2pw/pw_impl.cpp:241, :288, loop at :752-765
  *   mhip_align_candidates <- GapAligner::go + accessors (DiffAligner)   common/gapalign.h:4-25, diff_gapalign.cpp:294,
  *                                                                       called at mecat2pw/pw_impl.cpp:688-697
+ *   mhip_xalign_candidates<- GapAligner::go + accessors (XdropAligner)  common/xdrop_gapalign.cpp:359 (nanopore, -x 1)
  *   mhip_volume_upload    <- load_volume's in-memory volume_t           common/split_database.h:18-24, split_database.cpp:155
  *   mhip_params           <- the file-static tuning values              mecat2pw/pw_impl.cpp:18-26, set at :838-851
  *
@@ -135,6 +136,14 @@ int  mhip_align_candidates(mhip_ctx* ctx, const mhip_volume* ref, const mhip_vol
                            int n, int min_align_size, mhip_aln_result* out);
 int  mhip_align_candidates_dev(mhip_ctx* ctx, const mhip_volume* ref, const mhip_volume* reads, const void* d_jobs,
                                int n, int min_align_size, void* d_out);
+
+/* the same contract with XdropAligner semantics (nanopore mode, common/xdrop_gapalign.cpp:359-439: reward 1, penalty -1,
+   gap_open 0, gap_extend 1, X = 30; ok = query_end - query_start >= min_align_size; `columns`/`matches` count the
+   reference's aligned strings, whose left half is emitted without its last column) */
+int  mhip_xalign_candidates(mhip_ctx* ctx, const mhip_volume* ref, const mhip_volume* reads, const mhip_aln_job* jobs,
+                            int n, int min_align_size, mhip_aln_result* out);
+int  mhip_xalign_candidates_dev(mhip_ctx* ctx, const mhip_volume* ref, const mhip_volume* reads, const void* d_jobs,
+                                int n, int min_align_size, void* d_out);
 
 #ifdef __cplusplus
 }

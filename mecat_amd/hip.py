@@ -83,6 +83,8 @@ def lib():
     L.mhip_jobs_from_candidates_dev.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, C.POINTER(i32)]
     L.mhip_align_candidates.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     L.mhip_align_candidates_dev.argtypes = [vp, vp, vp, vp, i32, i32, vp]
+    L.mhip_xalign_candidates.argtypes = [vp, vp, vp, vp, i32, i32, vp]
+    L.mhip_xalign_candidates_dev.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     assert L.mhip_abi_version() == 1
     _lib = L
     return L
@@ -219,11 +221,13 @@ def jobs_from_candidates_dev(ctx, d_cands, d_counts, n_reads, maxc, rid_begin, r
     return n.value
 
 
-def align_candidates(ctx, ref, reads, jobs, min_align_size):
+def align_candidates(ctx, ref, reads, jobs, min_align_size, tech=0):
+    """tech 0: dw / DiffAligner, tech 1: X-drop aligner (nanopore mode)"""
     jobs = np.ascontiguousarray(jobs, dtype=JOB_DTYPE)
     out = np.zeros(len(jobs), dtype=ALN_DTYPE)
     if len(jobs):
-        _chk(lib().mhip_align_candidates(ctx.h, ref.h, reads.h, jobs.ctypes.data, len(jobs), min_align_size, out.ctypes.data))
+        fn = lib().mhip_xalign_candidates if tech == 1 else lib().mhip_align_candidates
+        _chk(fn(ctx.h, ref.h, reads.h, jobs.ctypes.data, len(jobs), min_align_size, out.ctypes.data))
     return out
 
 

@@ -95,8 +95,6 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
     P.maxc = opt.num_candidates;
     P.min_align_size = opt.min_align_size;
     P.min_kmer_match = opt.min_kmer_match;
-    if (opt.task == TASK_ALN && opt.tech == TECH_NANOPORE)
-        DIE("-x 1 -j 1 needs the X-drop aligner (SURVEY.md row A13), which is not available in this build; use -j 0 or -x 0");
 
     HostVolume ref;
     load_volume(vn[svid], &ref);
@@ -169,7 +167,9 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
                     jobs.push_back(j);
                 }
             res.resize(jobs.size());
-            MCHK(mhip_align_candidates(ctx, dref, dreads, jobs.data(), (int)jobs.size(), P.min_align_size, res.data()));
+            // aligner by technology (pw_impl.cpp:638-644): DiffAligner (dw) for PacBio, XdropAligner for nanopore
+            if (opt.tech == TECH_NANOPORE) MCHK(mhip_xalign_candidates(ctx, dref, dreads, jobs.data(), (int)jobs.size(), P.min_align_size, res.data()));
+            else MCHK(mhip_align_candidates(ctx, dref, dreads, jobs.data(), (int)jobs.size(), P.min_align_size, res.data()));
             size_t ji = 0;
             for (int r = 0; r < nr; ++r) {
                 const int qsize = rd->offs[(size_t)(rb + r)].size, qid = rb + r + rd->start_read_id;
@@ -183,7 +183,7 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
                     M4Record m;     // fill_m4record, pw_impl.cpp:467-506
                     m.qid = c.readno;
                     m.sid = qid;
-                    m.ident = a.columns == 0 ? 0.0 : 100.0 * a.matches / a.columns;   // OutputStore::calc_ident
+                    m.ident = a.columns == 0 ? 0.0 : 100.0 * a.matches / a.columns;   // OutputStore::calc_ident / XdropAligner::calc_ident
                     m.vscore = c.score;
                     m.qdir = 0;
                     m.qoff = a.target_start;

@@ -1,0 +1,121 @@
+"""GPU parity of the X-drop aligner (nanopore mode): mhip_xalign_candidates against the oracle's
+XdropAligner restatement, the reference's known answers, and the golden `-x 1 -j 1 -g 1` output."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+KAT = np.load(os.path.join(H.GOLDEN, "kats.npz"))
+BIN = os.path.join(H.ROOT, "mecat_amd", "bin", "mecat2pw")
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import mecat_amd.hip as M
+    return M
+
+
+@pytest.fixture(scope="module")
+def ctx(hip):
+    c = hip.Context(0)
+    yield c
+    c.close()
+
+
+def _vol(hip, ctx, seqs):
+    lens = np.array([len(s) for s in seqs], dtype=np.int32)
+    ov = H.orc_pack(np.concatenate(seqs).astype(np.uint8), lens)
+    offs, pac = H.vol_arrays(ov)
+    return hip.Volume(ctx, pac, offs, ov.contents.num_bases, 0)
+
+
+def _t(r):
+    return tuple(int(r[f]) for f in ("ok", "query_start", "query_end", "target_start", "target_end", "matches", "columns"))
+
+
+def test_xdrop_golden_kats(hip, ctx):
+    seqs, jobs, want = [], [], []
+    qo = to = 0
+    for i, (par, res) in enumerate(zip(KAT["xd_par"], KAT["xd_res"])):
+        nq, nt, qs, ts, mn = [int(x) for x in par]
+        seqs.append(KAT["xd_q"][qo: qo + nq]); qo += nq
+        seqs.append(KAT["xd_t"][to: to + nt]); to += nt
+        jobs.append((2 * i, 2 * i + 1, 0, qs, ts))
+        want.append(tuple(int(x) for x in res))
+    gv = _vol(hip, ctx, seqs)
+    out = hip.align_candidates(ctx, gv, gv, np.array(jobs, dtype=hip.JOB_DTYPE), 500, tech=1)
+    bad = [(i, _t(out[i]), want[i]) for i in range(len(jobs)) if _t(out[i]) != want[i]]
+    assert not bad, bad[:5]
+    gv.free()
+
+
+def _mut(rng, s, e):
+    out = []
+    for b in s:
+        u = rng.random()
+        if u < 0.35 * e:
+            continue
+        out.append(int(rng.integers(0, 4)) if u < 0.70 * e else int(b))
+        if rng.random() < 0.30 * e:
+            out.append(int(rng.integers(0, 4)))
+    return np.array(out, dtype=np.int8)
+
+
+def test_xdrop_random_pairs_both_strands(hip, ctx):
+    rng = np.random.default_rng(99)
+    O = H.orc()
+    xa = O.orc_xaligner_new()
+    seqs, jobs, want = [], [], []
+    for it in range(120):
+        n = int(rng.integers(200, 6000))
+        g = rng.integers(0, 4, size=n + 2000).astype(np.int8)
+        a0, b0 = int(rng.integers(0, 1000)), int(rng.integers(0, 1000))
+        e = [0.12, 0.12, 0.04, 0.0, 0.3][it % 5]
+        q = _mut(rng, g[a0: a0 + n], e)
+        t = _mut(rng, g[b0: b0 + n], e) if it % 13 else rng.integers(0, 4, size=n).astype(np.int8)
+        if len(q) < 20 or len(t) < 20:
+            continue
+        mid = max(a0, b0) + n // 3
+        qs = int((mid - a0) * (1 - 0.05 * e)) if it % 7 else int(rng.integers(0, len(q)))
+        ts = int((mid - b0) * (1 - 0.05 * e)) if it % 7 else int(rng.integers(0, len(t)))
+        qs = min(max(qs, 0), len(q) - 1)
+        ts = min(max(ts, 0), len(t) - 1)
+        if it % 17 == 0:
+            qs = 0
+        if it % 19 == 0:
+            ts = len(t) - 1
+        chain = it % 2
+        i = len(seqs)
+        seqs.append((3 - q[::-1]).astype(np.int8) if chain else q)
+        seqs.append(t)
+        jobs.append((i, i + 1, chain, qs, ts))
+        o = H.OrcAlnResult()
+        qc, tc = np.ascontiguousarray(q), np.ascontiguousarray(t)
+        O.orc_xdrop_go(xa, qc.ctypes.data, qs, len(qc), tc.ctypes.data, ts, len(tc), 500, C.byref(o))
+        want.append((o.ok, o.query_start, o.query_end, o.target_start, o.target_end, o.matches, o.columns))
+    gv = _vol(hip, ctx, seqs)
+    out = hip.align_candidates(ctx, gv, gv, np.array(jobs, dtype=hip.JOB_DTYPE), 500, tech=1)
+    bad = [(i, jobs[i], _t(out[i]), want[i]) for i in range(len(jobs)) if _t(out[i]) != want[i]]
+    assert not bad, "%d/%d differ: %s" % (len(bad), len(jobs), bad[:4])
+    assert sum(w[0] for w in want) > 30
+    O.orc_xaligner_free(xa)
+    gv.free()
+
+
+def test_cli_m4_nanopore_mode(tmp_path):
+    """mecat2pw -x 1 -j 1 -g 1 end to end against the reference's golden output"""
+    import json
+    G = json.load(open(os.path.join(H.GOLDEN, "golden.json")))
+    g = G["sets"]["tiny_ont"]["gen"]
+    codes, lens = H.synth_reads(g["nreads"], g["L"], g["err"], g["genome"], g["seed"], g["ont"])
+    fa = str(tmp_path / "ont.fa")
+    H.write_fasta(fa, codes, lens)
+    out = str(tmp_path / "ont.m4")
+    r = subprocess.run([BIN, "-j", "1", "-x", "1", "-g", "1", "-d", fa, "-o", out, "-w", str(tmp_path / "w")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert sorted(open(out).read().splitlines()) == open(os.path.join(H.GOLDEN, "tiny_ont.g1.m4.sorted")).read().splitlines()

@@ -130,6 +130,14 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
             rd = &rd_store;
             MCHK(mhip_volume_upload(ctx, rd->pac.data(), rd->offs.data(), rd->num_reads, rd->num_bases, rd->start_read_id, &dreads));
         }
+        // candidate_detect aborts on a read of MAX_SEQ_SIZE bases or more (pw_impl.cpp:743-746); pairwise_mapping would
+        // overrun its MAX_SEQ_SIZE buffers there.  Same limit, same message, for both tasks.
+        for (int r = 0; r < rd->num_reads; ++r)
+            if (rd->offs[(size_t)r].size >= MHIP_MAX_SEQ_SIZE) {
+                printf("rsize = %d\t%d\n", rd->offs[(size_t)r].size, MHIP_MAX_SEQ_SIZE);
+                fflush(stdout);
+                abort();
+            }
         for (int rb = 0; rb < rd->num_reads; rb += slab) {
             const int re = std::min(rd->num_reads, rb + slab), nr = re - rb;
             cands.resize((size_t)nr * P.maxc);

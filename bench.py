@@ -141,8 +141,11 @@ def main():
     d_jobs = torch.empty((n_pad * world * maxc // world + maxc, 5), dtype=torch.int32, device=dev)
     d_res = torch.empty((d_jobs.shape[0], 8), dtype=torch.int32, device=dev)
 
-    def one_step(collect=False):
+    keep = {}
+
+    def one_step():
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        h0 = time.perf_counter()
         ev[0].record(stream)
         idx = M.Index(ctx, vol)
         ev[1].record(stream)
@@ -162,14 +165,11 @@ def main():
         ev[3].record(stream)
         idx_handle = idx
         stream.synchronize()
-        out = {"ncand": int(full_counts.sum().item()), "njobs": njobs,
-               "ms": [ev[i].elapsed_time(ev[i + 1]) for i in range(3)]}
-        if collect and not args.no_align:
-            r = d_res[:njobs]
-            ok = r[:, 0] != 0
-            out["aln_ok"] = int(ok.sum().item())
-            out["aligned_bases"] = int((r[:, 2] - r[:, 1])[ok].sum().item())
+        h1 = time.perf_counter()
+        out = {"njobs": njobs, "ms": [ev[i].elapsed_time(ev[i + 1]) for i in range(3)]}
+        keep["full_counts"], keep["njobs"] = full_counts, njobs
         idx_handle.free()
+        out["host_ms"] = [(h1 - h0) * 1e3, (time.perf_counter() - h1) * 1e3]
         return out
 
     ctx.set_profiling(True)         # on during warm-up too, so the event pool exists before the timed region
@@ -180,7 +180,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    outs = [one_step(collect=True) for _ in range(args.steps)]
+    outs = [one_step() for _ in range(args.steps)]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -193,9 +193,14 @@ def main():
     counters = ctx.counters()
     ctx.set_profiling(False)
 
-    last = outs[-1]
-    ncand = last["ncand"]
-    aln = torch.tensor([last.get("aln_ok", 0), last.get("aligned_bases", 0)], dtype=torch.int64, device=dev)
+    # result statistics of the last timed step, read from its output buffers after the timed region
+    ncand = int(keep["full_counts"].sum().item())
+    aln = torch.zeros(2, dtype=torch.int64, device=dev)
+    if not args.no_align:
+        r = d_res[:keep["njobs"]]
+        ok = r[:, 0] != 0
+        aln[0] = ok.sum()
+        aln[1] = ((r[:, 2] - r[:, 1]).to(torch.int64) * ok).sum()
     if world > 1:
         dist.all_reduce(aln, op=dist.ReduceOp.SUM)
     aln_ok, aligned_bases = int(aln[0].item()), int(aln[1].item())
@@ -203,6 +208,7 @@ def main():
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         phase = np.mean([o["ms"] for o in outs], axis=0)
+        print("[bench] host ms/step: submit+wait=%.1f, free=%.1f" % tuple(np.mean([o["host_ms"] for o in outs], axis=0)), file=sys.stderr)
         # dominant kernel by summed HIP-event time on the launch stream
         dom = max(kstats.items(), key=lambda kv: kv[1][1]) if kstats else ("none", (1, 0.0))
         dname, (dl, dms) = dom
@@ -214,7 +220,7 @@ def main():
         idx_obj_kmers = None
         b_idx = 2 * (N / 4) + 3 * 4 * (1 << 26)
         b_seed = (lens.astype(np.int64)[rank::world].sum() * 2) / 4 + 8 * lookups + 4 * hits + 48 * cands_c
-        b_aln = per_step("aligned_bases") * 2 / 4 + 32 * last["njobs"]
+        b_aln = per_step("aligned_bases") * 2 / 4 + 32 * keep["njobs"]
         phase_of = {"idx": b_idx, "seed": b_seed, "dw": b_aln}
         pk = "idx" if dname.startswith("idx") else ("dw" if dname.startswith("dw") else "seed")
         launches_per_step = max(1, dl // args.steps)

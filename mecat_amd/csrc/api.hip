@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include "common.h"
+#include <mutex>
 
 static thread_local char g_err[1024] = "";
 
@@ -73,6 +74,7 @@ void mhip_ctx_destroy(mhip_ctx* c) {
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     for (auto& kv : c->bufs) if (kv.second.p) (void)hipFree(kv.second.p);
     if (c->d_counters) (void)hipFree(c->d_counters);
+    dev_recycler_release(c->device);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -168,6 +170,68 @@ int mhip_volume_num_reads(const mhip_volume* v) { return v->num_reads; }
 int mhip_volume_num_bases(const mhip_volume* v) { return v->num_bases; }
 
 }  // extern "C"
+
+namespace {
+struct Parked { int device; void* p; size_t cap; };
+std::mutex g_park_mu;
+std::vector<Parked> g_parked;
+}  // namespace
+
+int dev_alloc_recycled(int device, size_t bytes, void** p, size_t* cap) {
+    {
+        std::lock_guard<std::mutex> lk(g_park_mu);
+        for (size_t i = 0; i < g_parked.size(); ++i) {
+            Parked& k = g_parked[i];
+            if (k.device == device && k.cap >= bytes && k.cap / 2 <= bytes) {
+                *p = k.p;
+                *cap = k.cap;
+                g_parked.erase(g_parked.begin() + i);
+                return 0;
+            }
+        }
+    }
+    size_t want = bytes + bytes / 16 + 4096;
+    hipError_t e = hipMalloc(p, want);
+    if (e != hipSuccess) {
+        dev_recycler_release(device);            // give parked blocks back and retry at the exact size
+        want = bytes;
+        e = hipMalloc(p, want);
+    }
+    if (e != hipSuccess) {
+        *p = nullptr;
+        mhip_set_error("hipMalloc of %zu bytes failed: %s", want, hipGetErrorString(e));
+        return -1;
+    }
+    *cap = want;
+    return 0;
+}
+
+void dev_free_recycled(int device, void* p, size_t cap) {
+    if (!p) return;
+    void* drop = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_park_mu);
+        size_t n = 0, smallest = (size_t)-1;
+        for (size_t i = 0; i < g_parked.size(); ++i)
+            if (g_parked[i].device == device) { ++n; if (smallest == (size_t)-1 || g_parked[i].cap < g_parked[smallest].cap) smallest = i; }
+        if (n >= 2) {
+            if (g_parked[smallest].cap < cap) { drop = g_parked[smallest].p; g_parked[smallest] = Parked{device, p, cap}; }
+            else drop = p;
+        } else g_parked.push_back(Parked{device, p, cap});
+    }
+    if (drop) (void)hipFree(drop);
+}
+
+void dev_recycler_release(int device) {
+    std::vector<void*> drop;
+    {
+        std::lock_guard<std::mutex> lk(g_park_mu);
+        for (size_t i = 0; i < g_parked.size();)
+            if (g_parked[i].device == device) { drop.push_back(g_parked[i].p); g_parked.erase(g_parked.begin() + i); }
+            else ++i;
+    }
+    for (void* q : drop) (void)hipFree(q);
+}
 
 int mhip_ctx::scratch(const char* name, size_t bytes, void** out) {
     DevBuf& b = bufs[name];

@@ -545,10 +545,7 @@ static int index_build_binned(mhip_ctx* c, const mhip_volume* v, mhip_index* idx
     HIPCHK(hipStreamSynchronize(c->stream));
     idx->num_kmers = total;
     TRACE("bin_count");
-    if (hipMalloc((void**)&idx->d_offsets, sizeof(int32_t) * ((size_t)total + 64)) != hipSuccess) {
-        mhip_set_error("hipMalloc of %zu bytes for k-mer positions failed", sizeof(int32_t) * (size_t)total);
-        return -1;
-    }
+    if (dev_alloc_recycled(c->device, sizeof(int32_t) * ((size_t)total + 64), (void**)&idx->d_offsets, &idx->cap_offsets)) return -1;
     TRACE("malloc offsets");
     LAUNCH(c, "idx_bin_fill", idx_bin_fill, NFINE, BIN_THREADS, 0, (const uint64_t*)d_e2, (const uint32_t*)d_fbase, (const uint32_t*)d_binout,
            idx->d_starts, idx->d_offsets);
@@ -572,8 +569,7 @@ int mhip_index_build(mhip_ctx* c, const mhip_volume* v, mhip_index** out) {
     uint32_t* d_partial = nullptr;
     if (c->scratch("idx_counts", sizeof(uint32_t) * (size_t)NKMER, (void**)&d_counts)) { delete idx; return -1; }
     if (c->scratch("idx_partial", sizeof(uint32_t) * (SCAN_BLOCKS + 1), (void**)&d_partial)) { delete idx; return -1; }
-    if (hipMalloc((void**)&idx->d_starts, sizeof(uint32_t) * ((size_t)NKMER + 1)) != hipSuccess) {
-        mhip_set_error("hipMalloc starts failed");
+    if (dev_alloc_recycled(c->device, sizeof(uint32_t) * ((size_t)NKMER + 1), (void**)&idx->d_starts, &idx->cap_starts)) {
         delete idx;
         return -1;
     }
@@ -599,8 +595,7 @@ int mhip_index_build(mhip_ctx* c, const mhip_volume* v, mhip_index** out) {
     HIPCHK(hipMemcpyAsync(&total, d_partial + SCAN_BLOCKS, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     idx->num_kmers = total;
-    if (hipMalloc((void**)&idx->d_offsets, sizeof(int32_t) * ((size_t)total + 64)) != hipSuccess) {
-        mhip_set_error("hipMalloc of %zu bytes for k-mer positions failed", sizeof(int32_t) * (size_t)total);
+    if (dev_alloc_recycled(c->device, sizeof(int32_t) * ((size_t)total + 64), (void**)&idx->d_offsets, &idx->cap_offsets)) {
         mhip_index_free(idx);
         return -1;
     }
@@ -618,8 +613,8 @@ int mhip_index_build(mhip_ctx* c, const mhip_volume* v, mhip_index** out) {
 void mhip_index_free(mhip_index* idx) {
     if (!idx) return;
     (void)hipSetDevice(idx->device);
-    if (idx->d_starts) (void)hipFree(idx->d_starts);
-    if (idx->d_offsets) (void)hipFree(idx->d_offsets);
+    dev_free_recycled(idx->device, idx->d_starts, idx->cap_starts);
+    dev_free_recycled(idx->device, idx->d_offsets, idx->cap_offsets);
     delete idx;
 }
 

@@ -114,6 +114,16 @@ __device__ __forceinline__ int match32(const uint32_t* Q, int x, const uint32_t*
     return dh ? nh : nl;
 }
 
+// 16-base version (0..16): two words per side.  Snakes between two 15 %-error reads are ~3 bases long, so one 16-base
+// window settles 99.5 % of the diagonals at two thirds of match32's instruction count.
+__device__ __forceinline__ int match16(const uint32_t* Q, int x, const uint32_t* T, int y) {
+    const int xx = x + 15, yy = y + 15;
+    const int wq = xx >> 4, wt = yy >> 4;
+    const int hq = 30 - ((xx & 15) << 1), ht = 30 - ((yy & 15) << 1);
+    const uint32_t dh = __builtin_amdgcn_alignbit(Q[wq], Q[wq + 1], hq) ^ __builtin_amdgcn_alignbit(T[wt], T[wt + 1], ht);
+    return __clz(dh) >> 1;
+}
+
 // ---- wave64 reductions on the DPP network (no LDS traffic): quad swaps, half-row / row mirrors, row broadcasts.
 // Fused v_<op>_dpp steps in inline asm (hipcc emits mov + nop + mov_dpp + op per step); a DPP source written by the
 // previous VALU instruction needs two wait states, hence the s_nop 1 between steps (cdna_hip_programming.md §5.7).
@@ -474,8 +484,12 @@ __global__ __launch_bounds__(AL_BLOCK) void dw_extend(const uint32_t* __restrict
 // decisions use the two 32-bit halves of a ballot.  d-rows live in a 1024-entry circular buffer per half (rows are
 // packed back to back: the average row is 25 entries, so ~40 rows stay traceable); the rare block whose tail
 // traceback needs an overwritten row is re-run by the one-unit code path with rows spilled to global scratch.
+#ifndef RCAP
 #define RCAP 1024
+#endif
+#ifndef RROWS
 #define RROWS 64
+#endif
 struct HalfLds {
     int16_t V[VU_LEN];
     uint32_t Qp[SEQ_WORDS];
@@ -609,10 +623,10 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
                 bool more;
                 do {
                     const int lim = min(q_len - x, t_len - y);
-                    const int n0 = match32(S.Qp, x, S.Tp, min(max(y, 0), MAX_BLK));
+                    const int n0 = match16(S.Qp, x, S.Tp, min(max(y, 0), MAX_BLK));
                     const int nn = act ? max(0, min(n0, lim)) : 0;
                     x += nn; y += nn;
-                    more = (nn == 32) & (lim > 32);
+                    more = (nn == 16) & (lim > 16);
                 } while (__ballot(more));
                 if (act) {
                     S.V[kk] = (int16_t)x;
@@ -851,7 +865,7 @@ int mhip_align_candidates_dev(mhip_ctx* c, const mhip_volume* ref, const mhip_vo
     HIPCHK(hipSetDevice(c->device));
     if (n <= 0) return 0;
     int waves_per_cu = 16;                              // 4 waves per SIMD (VGPR budget); LDS 9.2 KB per wave
-    if (const char* e = getenv("MECAT_DW_WAVES")) waves_per_cu = std::max(4, std::min(16, atoi(e)));   // tuning/debug knob
+    if (const char* e = getenv("MECAT_DW_WAVES")) waves_per_cu = std::max(4, std::min(32, atoi(e)));   // tuning/debug knob
     const int max_waves = c->num_cus * waves_per_cu;
     int grid = max_waves / AL_WAVES;
     grid = std::min(grid, (2 * n + AL_WAVES - 1) / AL_WAVES);

@@ -875,6 +875,8 @@ static int bits_for(uint32_t maxv) {
     return b < 1 ? 1 : b;
 }
 
+static bool filter_enabled(const mhip_params* P);
+
 // reads rid0 + i * stride for i in [ib, ie)
 static int seed_batch(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref, const mhip_volume* reads, int rid0, int stride,
                       int ib, int ie, const mhip_params* P, mhip_candidate* d_out, int32_t* d_counts) {
@@ -909,10 +911,8 @@ static int seed_batch(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref
     LAUNCH(c, "seed_probe", seed_probe, ns, SEED_BLOCK, 0, (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs, rb, stride,
            (const uint32_t*)idx->d_starts, A, (unsigned long long*)c->d_counters);
     {
-        // the filter needs a gate high enough to separate signal from random hits; below that every hit is kept
         const int gate = 2 * P->min_kmer_match;
-        const char* fe = getenv("MECAT_SEED_FILTER");      // debug knob: 0 disables the relevance filter
-        const int enable = (gate >= 6 && !(fe && atoi(fe) == 0)) ? 1 : 0;
+        const int enable = filter_enabled(P) ? 1 : 0;
         LAUNCH(c, "seed_filter", seed_filter, ns, SEED_BLOCK, 0, (const mhip_offset_t*)reads->d_offs, rb, stride,
                (const int32_t*)idx->d_offsets, A, gate, enable);
     }
@@ -960,10 +960,19 @@ static int seed_batch(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref
     return 0;
 }
 
-// reads per launch: bounded by an estimate of the hits they produce (batch arrays cost ~ 60 bytes per hit)
-static int next_batch_end(const mhip_index* idx, const mhip_volume* reads, int rid0, int stride, int rb, int re) {
+static bool filter_enabled(const mhip_params* P) {
+    // the filter needs a gate high enough to separate signal from random hits; below that every hit is kept
+    const char* fe = getenv("MECAT_SEED_FILTER");      // debug knob: 0 disables the relevance filter
+    return 2 * P->min_kmer_match >= 6 && !(fe && atoi(fe) == 0);
+}
+
+// reads per launch: bounded by an estimate of the bucket hits they produce.  The batch arrays cost ~54 bytes per KEPT
+// hit (about one hit in seven survives the relevance filter); seed_cand runs one wave per read and is latency bound,
+// so larger batches are what fills the chip.
+static int next_batch_end(const mhip_index* idx, const mhip_volume* reads, int rid0, int stride, int rb, int re, const mhip_params* P) {
     const double hits_per_lookup = (double)idx->num_kmers / (double)NKMER + 2.0;
-    const double budget = 160e6;   // hits per launch (~10 GB of batch arrays)
+    double budget = filter_enabled(P) ? 1.6e9 : 200e6;   // ~12 GB of batch arrays either way
+    if (const char* e = getenv("MECAT_SEED_BATCH_HITS")) budget = std::max(1e6, atof(e));   // tuning knob
     double acc = 0;
     int r = rb;
     while (r < re) {
@@ -989,7 +998,7 @@ int mhip_seed_reads_strided_dev(mhip_ctx* c, const mhip_index* idx, const mhip_v
     if (ref->num_reads == 0) { mhip_set_error("empty reference volume"); return -1; }
     int ib = 0;
     while (ib < n) {
-        int ie = next_batch_end(idx, reads, rid_begin, rid_stride, ib, n);
+        int ie = next_batch_end(idx, reads, rid_begin, rid_stride, ib, n, P);
         if (seed_batch(c, idx, ref, reads, rid_begin, rid_stride, ib, ie, P, (mhip_candidate*)d_out + (size_t)ib * P->maxc,
                        (int32_t*)d_out_counts + ib))
             return -1;

@@ -476,9 +476,10 @@ __global__ __launch_bounds__(AL_BLOCK) void dw_extend(const uint32_t* __restrict
 // dw_extend2 — two (candidate, direction) units per wave, one per 32-lane half.
 //
 // The adaptive band keeps ~25 diagonals alive on average (config 2: 6.0e9 rows, 1.5e11 cells), so a whole wave per
-// unit leaves 60 % of the lanes idle and the kernel is VALU-issue bound.  Here each half-wave runs its own unit; the
-// two halves advance in lock step only inside a block (row d of both blocks is one pass over the code, a finished half
-// idles until the other block ends) and fetch new units independently at block boundaries.  Everything that is a
+// unit leaves 60 % of the lanes idle and the kernel is VALU-issue bound.  Here each half-wave runs its own unit with its
+// own block and row counter: one pass over the row code advances both halves by one d-row of their respective blocks; a
+// half whose rows ended does its tail traceback, accounting and next block setup (or pulls a new unit) while the other
+// half is masked off, and rejoins the row code at its row 0.  Everything that is a
 // scalar in the one-unit kernel (band limits, best point, block sizes ...) is a per-half-uniform VGPR value here;
 // per-half row maxima use a 5-step DPP chain (quad swaps, half/row mirrors, row_bcast:15) + two readlanes, first-index
 // decisions use the two 32-bit halves of a ballot.  d-rows live in a 1024-entry circular buffer per half (rows are
@@ -524,82 +525,92 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
     HalfLds& S = lds[threadIdx.x >> 6][hh];
     const int gw = blockIdx.x * AL_WAVES + (threadIdx.x >> 6);
     uint16_t* grow = gscratch + (size_t)gw * GROW_STRIDE;
-    unsigned long long cells = 0, snake = 0, nblocks = 0, nfallback = 0, nrows = 0, nidle = 0;
-    unsigned int usnake = 0;
+    unsigned long long cells = 0, nblocks = 0, nfallback = 0, nrows = 0, nidle = 0;
 
     // per-half unit state (uniform inside a half)
     bool need_unit = true, exhausted = false;
+    bool setup = true;          // the half is between blocks
+    bool inblock = false;       // the half has a block whose rows are running or have just ended
     unsigned int unit = 0;
     SeqView q, t;
     q.pac = qpac; t.pac = rpac; q.off = 0; t.off = 0; q.A = q.B = t.A = t.B = 0; q.comp = t.comp = 0;
     int query_size = 0, target_size = 0, qidx = 0, tidx = 0;
     int Rq = 0, Rt = 0, Rm = 0, Rc = 0, Rb = 0;
+    // per-half block state
+    int qblk = 0, tblk = 0, last_block = 0, band_tol = 0, max_d = 0, band_size = 0;
+    int best_m = -1, min_k = 0, max_k = 0, aligned = 0, end_x = 0, end_k = 0, end_d = 0, last_row = -1, d = 0;
+    unsigned int lin = 0;
+    bool rowing = false, ran = false;
 
     while (true) {
-        // ---- 1. a half without a unit pulls the next one
-        if (need_unit && !exhausted) {
-            unsigned int u = 0;
-            if (sl == 0) u = atomicAdd(cursor, 1u);
-            u = __shfl(u, hh << 5);
-            if (u >= 2u * (unsigned)n) exhausted = true;
-            else {
-                unit = u;
-                const mhip_aln_job jb = jobs[u >> 1];
-                const int right = u & 1;
-                const int qsize = qoffs[jb.qid_local].size, tsize = roffs[jb.sid_local].size;
-                q.off = qoffs[jb.qid_local].offset; q.comp = jb.chain;
-                t.off = roffs[jb.sid_local].offset; t.comp = 0;
-                const int qs0 = right ? jb.qstart : jb.qstart - 1, step = right ? 1 : -1;
-                if (jb.chain) { q.A = qsize - 1 - qs0; q.B = -step; } else { q.A = qs0; q.B = step; }
-                t.A = right ? jb.sstart : jb.sstart - 1; t.B = step;
-                if (right) { query_size = qsize - jb.qstart; target_size = tsize - jb.sstart; }
-                else { query_size = jb.qstart; target_size = jb.sstart; }
-                qidx = tidx = 0;
-                Rq = Rt = Rm = Rc = Rb = 0;
-                need_unit = false;
+        if (__ballot(setup)) {
+            // ---- 1. a half without a unit pulls the next one
+            if (setup && need_unit) {
+                unsigned int u = 0;
+                if (sl == 0) u = atomicAdd(cursor, 1u);
+                u = __shfl(u, hh << 5);
+                if (u >= 2u * (unsigned)n) { exhausted = true; setup = false; }
+                else {
+                    unit = u;
+                    const mhip_aln_job jb = jobs[u >> 1];
+                    const int right = u & 1;
+                    const int qsize = qoffs[jb.qid_local].size, tsize = roffs[jb.sid_local].size;
+                    q.off = qoffs[jb.qid_local].offset; q.comp = jb.chain;
+                    t.off = roffs[jb.sid_local].offset; t.comp = 0;
+                    const int qs0 = right ? jb.qstart : jb.qstart - 1, step = right ? 1 : -1;
+                    if (jb.chain) { q.A = qsize - 1 - qs0; q.B = -step; } else { q.A = qs0; q.B = step; }
+                    t.A = right ? jb.sstart : jb.sstart - 1; t.B = step;
+                    if (right) { query_size = qsize - jb.qstart; target_size = tsize - jb.sstart; }
+                    else { query_size = jb.qstart; target_size = jb.sstart; }
+                    qidx = tidx = 0;
+                    Rq = Rt = Rm = Rc = Rb = 0;
+                    need_unit = false;
+                }
             }
+            // ---- 2. block setup: retrieve_next_aln_block (gapalign.cpp:9-45) + staging
+            if (setup) {
+                const int qleft = query_size - qidx, tleft = target_size - tidx;
+                if (qleft < SEG_BLK + 100 || tleft < SEG_BLK + 100) {
+                    qblk = min(qleft, (int)(tleft + tleft * 0.2));
+                    tblk = min(tleft, (int)(qleft + qleft * 0.2));
+                    last_block = 1;
+                } else { qblk = SEG_BLK; tblk = SEG_BLK; last_block = 0; }
+                qblk = max(qblk, 0);
+                tblk = max(tblk, 0);
+                band_tol = (int)(0.3 * (qblk > tblk ? qblk : tblk));
+                max_d = (int)(.3 * (qblk + tblk));
+                band_size = band_tol * 2;
+                for (int w = sl; w < SEQ_WORDS; w += 32) {
+                    S.Qp[w] = (w > 0 && (w - 1) * 16 < qblk + 32) ? view_word(q, qidx + (w - 1) * 16) : 0u;
+                    S.Tp[w] = (w > 0 && (w - 1) * 16 < tblk + 32) ? view_word(t, tidx + (w - 1) * 16) : 0u;
+                }
+                // The reference zero-fills V per block (:232-233); row d only reads diagonals written by row d - 1, except
+                // row 0, which reads V[k_offset + 1].
+                if (sl == 0) S.V[max_d + 1] = 0;
+                best_m = -1; min_k = 0; max_k = 0;
+                aligned = 0; end_x = 0; end_k = 0; end_d = 0; last_row = -1; d = 0;
+                lin = 0;
+                rowing = true; ran = false; inblock = true;
+                setup = false;
+            }
+            __builtin_amdgcn_wave_barrier();
         }
         if (!__ballot(!exhausted)) break;
-        const bool live = !exhausted;
+        const int q_len = qblk, t_len = tblk, k_offset = max_d;
 
-        // ---- 2. block setup: retrieve_next_aln_block (gapalign.cpp:9-45) + staging
-        const int qleft = query_size - qidx, tleft = target_size - tidx;
-        int qblk, tblk, last_block;
-        if (qleft < SEG_BLK + 100 || tleft < SEG_BLK + 100) {
-            qblk = min(qleft, (int)(tleft + tleft * 0.2));
-            tblk = min(tleft, (int)(qleft + qleft * 0.2));
-            last_block = 1;
-        } else { qblk = SEG_BLK; tblk = SEG_BLK; last_block = 0; }
-        qblk = live ? max(qblk, 0) : 0;
-        tblk = live ? max(tblk, 0) : 0;
-        const int q_len = qblk, t_len = tblk;
-        const int band_tol = (int)(0.3 * (q_len > t_len ? q_len : t_len));
-        const int max_d = (int)(.3 * (q_len + t_len));
-        const int k_offset = max_d;
-        const int band_size = band_tol * 2;
-        __builtin_amdgcn_wave_barrier();
-        for (int w = sl; w < SEQ_WORDS; w += 32) {
-            S.Qp[w] = (live && w > 0 && (w - 1) * 16 < qblk + 32) ? view_word(q, qidx + (w - 1) * 16) : 0u;
-            S.Tp[w] = (live && w > 0 && (w - 1) * 16 < tblk + 32) ? view_word(t, tidx + (w - 1) * 16) : 0u;
-        }
-        for (int i = sl; i < 2 * max_d + 4 && i < VU_LEN; i += 32) S.V[i] = 0;
-        __builtin_amdgcn_wave_barrier();
-
-        // ---- 3. rows (Align, diff_gapalign.cpp:107-219).  Only the running maximum of x + y is tracked here; a block that
-        // ends without reaching an end of either sequence (0.06 % of blocks) needs the position of that maximum and is
-        // handed to the one-unit code path below, like a block whose traceback outran the ring.
-        int best_m = -1;
-        int min_k = 0, max_k = 0;
-        int aligned = 0, end_x = 0, end_k = 0, end_d = 0, last_row = -1;
-        unsigned int lin = 0;
-        bool rowing = live, ran = false;
-        for (int d = 0;; ++d) {
+        // ---- 3. one row per half (Align, diff_gapalign.cpp:107-219); the halves' row counters are independent.  Only the
+        // running maximum of x + y is tracked here; a block that ends without reaching an end of either sequence (0.06 %
+        // of blocks) needs the position of that maximum and is handed to the one-unit code path below, like a block whose
+        // traceback outran the ring.
+        // The inner loop runs while every half that has a block is still rowing.
+        const unsigned long long inmask = __ballot(inblock);
+        while (true) {
             rowing = rowing && d < max_d && (max_k - min_k <= band_size);
             const unsigned long long rmask = __ballot(rowing);
-            if (!rmask) break;
+            if (rmask != inmask) break;
             nrows += 1;
             nidle += (rmask == ~0ull) ? 0u : 1u;
-            const int nslot = rowing ? (max_k - min_k) / 2 + 1 : 0;
+            const int nslot = rowing ? ((max_k - min_k) >> 1) + 1 : 0;
             unsigned int pos0 = lin & (RCAP - 1);
             if (pos0 + (unsigned)nslot > RCAP) { lin += RCAP - pos0; pos0 = 0; }
             if (rowing && sl == 0) {        // row record: band limits + linear ring position, one 64-bit store
@@ -670,12 +681,15 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
                     rowing = false;
                 }
             }
+            d += 1;
             __builtin_amdgcn_wave_barrier();
         }
 
-        // ---- 4. tail traceback == trim_mismatch_end(.., 4, ..) (gapalign.cpp:47-68)
-        bool has_aln = live && aligned;
-        bool fallback = live && ran && !aligned;        // needs the best point: one-unit path
+        const bool fin = inblock && !rowing;
+
+        // ---- 4. tail traceback == trim_mismatch_end(.., 4, ..) (gapalign.cpp:47-68), for the halves whose rows just ended
+        bool has_aln = fin && aligned;
+        bool fallback = fin && ran && !aligned;         // needs the best point: one-unit path
         const int end_y = end_x - end_k;
         const int aln_size = (end_x + end_y + end_d) / 2;
         int cd = end_d, ck = end_k, cx2 = end_x;
@@ -719,7 +733,8 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
         int o_qe = end_x, o_te = end_y, o_dist = end_d;
         int trim_ok = has_aln && found && (aln_size - acnt >= 2);
 
-        // ---- 5. rare: the tail needs a row that left the ring -> re-run that half's block with spilled rows
+        // ---- 5. rare: the tail needs a row that left the ring -> re-run that half's block with spilled rows (whole wave;
+        // only that half's V/Qp/Tp are touched, the other half may be in the middle of its own block)
         const unsigned long long fb = __ballot(fallback);
         if (fb) {
             for (int hx = 0; hx < 2; ++hx) {
@@ -738,34 +753,33 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
         }
 
         // ---- 6. block accounting (dw_in_one_direction, diff_gapalign.cpp:259-290)
-        if (live) {
+        if (fin) {
             nblocks += (sl == 0) ? 1u : 0u;
             Rb += 1;
             bool stop = !has_aln || !trim_ok;
             if (!stop) {
                 const int full_map = (qblk - o_qe <= 20 || tblk - o_te <= 20);
-                const bool fin = last_block || !full_map;
-                if (fin) { qcnt -= 4; tcnt -= 4; acnt -= 4; }
+                const bool last = last_block || !full_map;
+                if (last) { qcnt -= 4; tcnt -= 4; acnt -= 4; }
                 Rc += (o_qe + o_te + o_dist) / 2 - acnt;
                 Rm += (o_qe + o_te - o_dist) / 2 - (qcnt + tcnt - acnt);
                 Rq += o_qe - qcnt;
                 Rt += o_te - tcnt;
-                if (fin) stop = true;
+                if (last) stop = true;
                 else { qidx += o_qe - qcnt; tidx += o_te - tcnt; }
             }
             if (stop) {
                 if (sl == 0) { DirResult R = {Rq, Rt, Rm, Rc, Rb, 0}; dres[unit] = R; }
                 need_unit = true;
             }
+            inblock = false;
+            setup = true;
         }
-        snake += usnake;
-        usnake = 0;
     }
-    for (int off = 32; off > 0; off >>= 1) { snake += __shfl_xor(snake, off); nblocks += __shfl_xor(nblocks, off); }
+    for (int off = 32; off > 0; off >>= 1) nblocks += __shfl_xor(nblocks, off);
     if (lane == 0) {
         atomicAdd(&counters[3], nblocks);
         atomicAdd(&counters[4], cells);
-        atomicAdd(&counters[5], snake);
         atomicAdd(&counters[8], nfallback);
         atomicAdd(&counters[9], nrows);          // dual rows
         atomicAdd(&counters[10], nidle);         // dual rows with one idle half
@@ -794,11 +808,10 @@ __global__ void dw_stitch(const mhip_aln_job* __restrict__ jobs, const DirResult
     }
 }
 
-// candidate table -> job list (pw_impl.cpp:674-686).  Single block: running exclusive scan of the counts over tiles.
-__global__ __launch_bounds__(1024) void dw_make_jobs(const mhip_candidate* __restrict__ cands, const int32_t* __restrict__ counts,
-                                                     int n_reads, int maxc, int rid_begin, int rid_stride, int ref_start_id,
-                                                     int part_index, int part_count, mhip_aln_job* __restrict__ jobs,
-                                                     int* __restrict__ num_jobs) {
+// candidate table -> job list (pw_impl.cpp:674-686): exclusive scan of the per-read counts (one block, running carry
+// over 1024-read tiles), then one thread per (read, slot).
+__global__ __launch_bounds__(1024) void dw_job_scan(const int32_t* __restrict__ counts, int n_reads, int part_index, int part_count,
+                                                    unsigned int* __restrict__ first, int* __restrict__ num_jobs) {
     __shared__ unsigned int wtot[16];
     __shared__ unsigned int carry_all;
     if (threadIdx.x == 0) carry_all = 0;
@@ -815,22 +828,7 @@ __global__ __launch_bounds__(1024) void dw_make_jobs(const mhip_candidate* __res
         __syncthreads();
         unsigned int base = carry_all;
         for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += wtot[w];
-        const unsigned int first = base + incl - c;          // global index of this read's first candidate
-        for (unsigned int j = 0; j < c; ++j) {
-            const unsigned int g = first + j;
-            if (part_count > 1 && (int)(g % (unsigned)part_count) != part_index) continue;
-            const unsigned int slot = part_count > 1 ? g / (unsigned)part_count : g;
-            const mhip_candidate cd = cands[(size_t)i * maxc + j];
-            mhip_aln_job jb;
-            jb.qid_local = rid_begin + i * rid_stride;
-            jb.sid_local = cd.readno - ref_start_id;
-            jb.chain = cd.chain;
-            int qstart = cd.loc2, sstart = cd.loc1;
-            if (qstart && sstart) { qstart += MHIP_KMER_SIZE / 2; sstart += MHIP_KMER_SIZE / 2; }
-            jb.qstart = qstart;
-            jb.sstart = sstart;
-            jobs[slot] = jb;
-        }
+        if (i < n_reads) first[i] = base + incl - c;         // global index of this read's first candidate
         __syncthreads();
         if (threadIdx.x == 1023) carry_all = base + incl;
         __syncthreads();
@@ -843,6 +841,28 @@ __global__ __launch_bounds__(1024) void dw_make_jobs(const mhip_candidate* __res
     }
 }
 
+__global__ __launch_bounds__(256) void dw_make_jobs(const mhip_candidate* __restrict__ cands, const int32_t* __restrict__ counts,
+                                                    const unsigned int* __restrict__ first, int n_reads, int maxc, int rid_begin,
+                                                    int rid_stride, int ref_start_id, int part_index, int part_count,
+                                                    mhip_aln_job* __restrict__ jobs) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = (int)(t / (unsigned)maxc), j = (int)(t % (unsigned)maxc);
+    if (i >= n_reads || j >= counts[i]) return;
+    const unsigned int g = first[i] + (unsigned)j;
+    if (part_count > 1 && (int)(g % (unsigned)part_count) != part_index) return;
+    const unsigned int slot = part_count > 1 ? g / (unsigned)part_count : g;
+    const mhip_candidate cd = cands[(size_t)i * maxc + j];
+    mhip_aln_job jb;
+    jb.qid_local = rid_begin + i * rid_stride;
+    jb.sid_local = cd.readno - ref_start_id;
+    jb.chain = cd.chain;
+    int qstart = cd.loc2, sstart = cd.loc1;
+    if (qstart && sstart) { qstart += MHIP_KMER_SIZE / 2; sstart += MHIP_KMER_SIZE / 2; }
+    jb.qstart = qstart;
+    jb.sstart = sstart;
+    jobs[slot] = jb;
+}
+
 extern "C" {
 
 int mhip_jobs_from_candidates_dev(mhip_ctx* c, const void* d_cands, const void* d_counts, int n_reads, int maxc, int rid_begin,
@@ -853,8 +873,13 @@ int mhip_jobs_from_candidates_dev(mhip_ctx* c, const void* d_cands, const void* 
     if (part_count < 1) part_count = 1;
     int* d_n;
     if (c->scratch("al_njobs", 64, (void**)&d_n)) return -1;
-    LAUNCH(c, "dw_make_jobs", dw_make_jobs, 1, 1024, 0, (const mhip_candidate*)d_cands, (const int32_t*)d_counts, n_reads, maxc,
-           rid_begin, rid_stride, ref_start_read_id, part_index, part_count, (mhip_aln_job*)d_jobs, d_n);
+    unsigned int* d_first;
+    if (c->scratch("al_jobfirst", sizeof(unsigned int) * (size_t)n_reads, (void**)&d_first)) return -1;
+    LAUNCH(c, "dw_job_scan", dw_job_scan, 1, 1024, 0, (const int32_t*)d_counts, n_reads, part_index, part_count, d_first, d_n);
+    const size_t nthreads = (size_t)n_reads * (size_t)maxc;
+    LAUNCH(c, "dw_make_jobs", dw_make_jobs, (unsigned)((nthreads + 255) / 256), 256, 0, (const mhip_candidate*)d_cands,
+           (const int32_t*)d_counts, (const unsigned int*)d_first, n_reads, maxc, rid_begin, rid_stride, ref_start_read_id, part_index,
+           part_count, (mhip_aln_job*)d_jobs);
     HIPCHK(hipMemcpyAsync(num_jobs, d_n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;

@@ -11,10 +11,13 @@
 // hit order.  That state is order dependent (SURVEY.md §7 "hard parts" 1-3), so the GPU formulation is a replay:
 //
 //   seed_probe  (block / strand)  2-bit read -> 13-mers (reverse strand by index arithmetic) -> bucket (start, count)
-//                                 from the starts[] table, exclusive scan -> per-k-mer hit offsets, hits per strand
-//   seed_scan   (one block)       exclusive scan of hits per strand -> region of every strand in the batch arrays
-//   seed_emit   (block / strand)  expand buckets: key = seg:21 | km:16 | off:11 written in (km, position) order,
-//                                 i.e. in the order the reference visits the hits; coalesced by an LDS prefix search
+//                                 from the starts[] table, hits per strand
+//   seed_filter (block / strand)  relevance filter: one walk over the buckets counts hits per (hashed) 2 kb segment in
+//                                 LDS; segments that can reach the index_score gate, +- the sweep reach, form the
+//                                 relevance bitmap; every other hit (6 of 7 at config 2) is never expanded
+//   seed_scan   (one block)       exclusive scan of kept hits per strand -> region of every strand in the batch arrays
+//   seed_emit   (block / strand)  expand the kept hits: key = seg:21 | km:16 | off:11 written in (km, position) order,
+//                                 i.e. in the order the reference visits the hits (64 buckets per step: count, scan, write)
 //   seed_sort   (block / strand)  stable LSD radix sort on the seg bits only (7-8 bits per pass): ranking by
 //                                 wave64 ballot multi-split, per-wave cursors in LDS, no atomics in the scatter loop.
 //                                 Stability keeps (km, position) order inside a segment == the reference's visit order.
@@ -43,21 +46,19 @@
 #define KEY_KM_BITS 16
 #define KEY_SEG_SHIFT (KEY_OFF_BITS + KEY_KM_BITS)   // 27
 #define MAXC_LIMIT 1024
-#define FLT_BITS 15                 // relevance filter: 2^15 4-bit hit counters per strand
+#define FLT_BITS 15                 // relevance filter: 2^15 8-bit hit counters per strand, segment ids hashed by their low bits
 #define FLT_M (1 << FLT_BITS)
-#define HOT_TAB 2048                // hash set of hot segments
-#define HOT_CAP 1536                // more distinct hot segments than this -> the strand is not filtered
+#define REL_WORDS (FLT_M / 32)      // relevance bitmap over the same hashed ids
 
 struct SeedArrays {
     // per batch
     const uint32_t* km_base;     // [ns]   first k-mer slot of the strand
     uint32_t* km_bstart;         // [sumK] bucket start in index offsets[]
     uint32_t* km_cnt;            // [sumK] bucket size
-    uint32_t* km_rpre;           // [sumK] exclusive prefix (inside the strand) of the hits kept per k-mer
     uint32_t* strand_hits_all;   // [ns]   bucket hits of the strand (before the relevance filter)
     uint32_t* strand_hits;       // [ns]   hits kept (emitted, sorted, built)
-    uint32_t* hot_list;          // [ns * HOT_CAP] sorted hot segments of the strand
-    int32_t* hot_count;          // [ns]   number of hot segments, -1 = strand not filtered
+    uint32_t* rel_bits;          // [ns * REL_WORDS] relevance bitmap of the strand (filtered strands only)
+    int32_t* filtered;           // [ns]   1 = only relevant hits are kept, 0 = every hit is kept
     uint64_t* hit_base;          // [ns + 1]
     uint64_t* keysA;             // [Htot]
     uint64_t* keysB;             // [Htot]
@@ -209,45 +210,28 @@ __device__ __forceinline__ uint32_t group_bits(unsigned long long ballot) { retu
 // sweeps of get_candidates reach ceil(num / ZV) segments, num <= read length + 12 (pw_impl.cpp:388-425); +1 for seg - 1
 __device__ __forceinline__ int sweep_reach(int L) { return (L + MHIP_KMER_SIZE - 1 + ZV - 1) / ZV + 1; }
 
-// relevance bitmap over hashed segment ids: bit (seg mod 2^16) is set for every segment within `reach` of a hot segment.
-// A hash collision can only keep an irrelevant hit (5 % at config 2), never drop a relevant one.
-#define REL_BITS 16
-#define REL_WORDS ((1 << REL_BITS) / 32)
-__device__ __forceinline__ void rel_build(uint32_t* rel, const uint32_t* hot, int nh, int reach) {
-    for (int i = threadIdx.x; i < REL_WORDS; i += SEED_BLOCK) rel[i] = 0;
-    __syncthreads();
-    const int span = 2 * reach + 1;
-    for (int i = threadIdx.x; i < nh * span; i += SEED_BLOCK) {
-        const int seg = (int)hot[i / span] - reach + (i % span);
-        if (seg >= 0) {
-            const uint32_t e = (uint32_t)seg & ((1u << REL_BITS) - 1u);
-            atomicOr(&rel[e >> 5], 1u << (e & 31u));
-        }
-    }
-    __syncthreads();
-}
 __device__ __forceinline__ bool rel_test(const uint32_t* rel, uint32_t seg) {
-    const uint32_t e = seg & ((1u << REL_BITS) - 1u);
+    const uint32_t e = seg & (FLT_M - 1);
     return (rel[e >> 5] >> (e & 31u)) & 1u;
 }
 
 // ------------------------------------------------------------------------------------------------ relevance filter
 // Most bucket hits are random 13-mer matches that land alone in their 2 kb segment and can never matter:
 // get_candidates only looks at segments whose index_score (own + left neighbour's seed count) reaches 2 * min_kmer_match
-// (pw_impl.cpp:309) and, from those, at most ceil((L + 12) / 2000) segments to either side (:405-438).  With h(seg) = bucket
-// hits in a segment (an upper bound of its seed count), a segment is HOT when h(seg-1) + h(seg) or h(seg) + h(seg+1) reaches
-// the gate; only hits within `sweep_reach` segments of a hot segment are kept.  Dropped hits touch no state that is
-// ever read, so the result is unchanged (the filter only ever errs towards keeping: hash collisions and counter
-// saturation inflate h).  Counters: 2^15 4-bit fields in LDS (packed 8 per word; a field that would wrap sets a sticky
-// bit instead of losing the count); hot segments are de-duplicated in an LDS hash set.  Output: per k-mer prefix of kept
-// hits (km_rpre), kept hits per strand, the strand's hot list (emit rebuilds the same relevance bitmap from it).
+// (pw_impl.cpp:309) and, from those, at most ceil((L + 12) / 2000) segments to either side (:405-438).  With h(e) = bucket
+// hits whose segment id is e modulo 2^15 (an upper bound of the seed count of every segment hashing to e), slot e is HOT
+// when h(e) > 0 and h(e-1) + h(e) or h(e) + h(e+1) reaches the gate; a hit is kept when its slot lies within `sweep_reach`
+// slots of a hot one.  Dropped hits touch no state that is ever read, so the result is unchanged: the filter only errs
+// towards keeping (collisions inflate h and spread relevance).  One walk over the buckets fills the byte counters in LDS;
+// hot slots, the relevance bitmap and the exact number of kept hits (sum of h over relevant slots: the strand's room in
+// the key arrays) come from passes over the 32 K-entry table.  A counter that would wrap (>= 256 hits in one slot: repeats)
+// turns the filter off for the strand.
 __global__ __launch_bounds__(SEED_BLOCK) void seed_filter(const mhip_offset_t* __restrict__ roffs, int rid_begin, int rid_stride,
                                                           const int32_t* __restrict__ offsets, SeedArrays A, int gate, int enable) {
-    __shared__ uint32_t cnt[FLT_M / 8];          // 16 KB; afterwards: relevance bitmap (8 KB) + hot list (6 KB)
-    __shared__ uint32_t sticky[FLT_M / 32];      // 4 KB
-    __shared__ uint32_t tab[HOT_TAB];            // 8 KB
+    __shared__ uint32_t cnt[FLT_M / 4];          // 32 KB
+    __shared__ uint32_t rel[REL_WORDS];          // 4 KB
     __shared__ uint32_t wtot[SEED_WAVES];
-    __shared__ uint32_t s_n[2];
+    __shared__ uint32_t s_wrap;
     const int s = blockIdx.x;
     const int rid = rid_begin + (s >> 1) * rid_stride;
     const int L = roffs[rid].size;
@@ -255,94 +239,66 @@ __global__ __launch_bounds__(SEED_BLOCK) void seed_filter(const mhip_offset_t* _
     const uint32_t kb = A.km_base[s];
     const uint32_t Hall = A.strand_hits_all[s];
     bool filtered = enable && Hall > 0;
-    uint32_t nh = 0;
-    uint32_t* rel = cnt;
-    uint32_t* hot = cnt + REL_WORDS;
-    const int reach = sweep_reach(L);
+    uint32_t kept = Hall;
     if (filtered) {
-        for (int i = threadIdx.x; i < FLT_M / 8; i += SEED_BLOCK) cnt[i] = 0;
-        for (int i = threadIdx.x; i < FLT_M / 32; i += SEED_BLOCK) sticky[i] = 0;
-        for (int i = threadIdx.x; i < HOT_TAB; i += SEED_BLOCK) tab[i] = 0xFFFFFFFFu;
-        if (threadIdx.x == 0) { s_n[0] = 0; s_n[1] = 0; }
+        for (int i = threadIdx.x; i < FLT_M / 4; i += SEED_BLOCK) cnt[i] = 0;
+        for (int i = threadIdx.x; i < REL_WORDS; i += SEED_BLOCK) rel[i] = 0;
+        if (threadIdx.x == 0) s_wrap = 0;
         __syncthreads();
-        // pass 1: h(seg)
         auto nop = [](int, int) {};
         for_each_hit16(A, offsets, kb, K, nop, [&](int, int, uint32_t, uint32_t pos, bool valid) {
             if (valid) {
                 const uint32_t e = (pos / ZV) & (FLT_M - 1);
-                const uint32_t sh = (e & 7u) * 4u;
-                const uint32_t old = atomicAdd(&cnt[e >> 3], 1u << sh);
-                if (((old >> sh) & 15u) == 15u) atomicOr(&sticky[e >> 5], 1u << (e & 31u));
+                const uint32_t sh = (e & 3u) * 8u;
+                const uint32_t old = atomicAdd(&cnt[e >> 2], 1u << sh);
+                if (((old >> sh) & 255u) == 255u) s_wrap = 1;
             }
         }, nop);
         __syncthreads();
-        auto hval = [&](uint32_t seg) -> int {
-            const uint32_t e = seg & (FLT_M - 1);
-            return ((sticky[e >> 5] >> (e & 31u)) & 1u) ? 64 : (int)((cnt[e >> 3] >> ((e & 7u) * 4u)) & 15u);
-        };
-        // pass 2: hot segments into the hash set
-        for_each_hit16(A, offsets, kb, K, nop, [&](int, int, uint32_t, uint32_t pos, bool valid) {
-            if (valid) {
-                const uint32_t seg = pos / ZV;
-                const int c = hval(seg);
-                if (c + hval(seg + 1) >= gate || c + hval(seg - 1) >= gate) {
-                    uint32_t slot = (seg * 2654435761u) >> (32 - 11);
-                    for (int probe = 0; probe < HOT_TAB; ++probe) {
-                        const uint32_t old = atomicCAS(&tab[slot], 0xFFFFFFFFu, seg);
-                        if (old == 0xFFFFFFFFu) { atomicAdd(&s_n[0], 1u); break; }
-                        if (old == seg) break;
-                        slot = (slot + 1) & (HOT_TAB - 1);
-                    }
-                }
-            }
-        }, nop);
-        __syncthreads();
-        nh = s_n[0];
-        if (nh > HOT_CAP) filtered = false;      // too many hot segments for the set: keep everything
+        if (s_wrap) filtered = false;
     }
     if (filtered) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < HOT_TAB; i += SEED_BLOCK) {
-            const uint32_t v = tab[i];
-            if (v != 0xFFFFFFFFu) hot[atomicAdd(&s_n[1], 1u)] = v;
+        const uint8_t* cb = (const uint8_t*)cnt;
+        const uint32_t reach = (uint32_t)min(sweep_reach(L), FLT_M / 2 - 1);
+        for (int i = 0; i < FLT_M / SEED_BLOCK; ++i) {
+            const uint32_t e = (uint32_t)i * SEED_BLOCK + threadIdx.x;
+            const int c = cb[e];
+            if (c > 0 && (c + (int)cb[(e + 1) & (FLT_M - 1)] >= gate || c + (int)cb[(e - 1) & (FLT_M - 1)] >= gate)) {
+                uint32_t lo = (e - reach) & (FLT_M - 1), left = 2 * reach + 1;      // bits lo .. lo + left - 1, circular
+                while (left > 0) {
+                    const uint32_t b = lo & 31u, take = min(32u - b, left);
+                    const uint32_t m = (take == 32u ? 0xFFFFFFFFu : ((1u << take) - 1u)) << b;
+                    atomicOr(&rel[lo >> 5], m);
+                    lo = (lo + take) & (FLT_M - 1);
+                    left -= take;
+                }
+            }
         }
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < nh; i += SEED_BLOCK) A.hot_list[(size_t)s * HOT_CAP + i] = hot[i];
-        rel_build(rel, hot, (int)nh, reach);
-    }
-    // pass 3: hits kept per k-mer ...
-    if (!filtered) {
-        for (int km = threadIdx.x; km < K; km += SEED_BLOCK) A.km_rpre[kb + km] = A.km_cnt[kb + km];
-    } else {
-        uint32_t keep[4];
-        for_each_hit16(A, offsets, kb, K,
-            [&](int q, int) { keep[q] = 0; },
-            [&](int q, int, uint32_t, uint32_t pos, bool valid) {
-                const bool k1 = valid && rel_test(rel, pos / ZV);
-                keep[q] += __popc(group_bits(__ballot(k1)));
-            },
-            [&](int q, int km) { if ((threadIdx.x & 15) == 0) A.km_rpre[kb + km] = keep[q]; });
-    }
-    __syncthreads();
-    // ... -> exclusive prefix inside the strand
-    uint32_t run = 0;
-    for (int t0 = 0; t0 < K; t0 += SEED_BLOCK) {
-        const int km = t0 + threadIdx.x;
-        const uint32_t keep = km < K ? A.km_rpre[kb + km] : 0u;
+        uint32_t mine = 0;
+        for (int i = 0; i < FLT_M / SEED_BLOCK; ++i) {
+            const uint32_t e = (uint32_t)i * SEED_BLOCK + threadIdx.x;
+            if (rel_test(rel, e)) mine += cb[e];
+        }
         uint32_t tot;
-        const uint32_t ex = block_excl_scan(keep, wtot, &tot);
-        if (km < K) A.km_rpre[kb + km] = run + ex;
-        run += tot;
+        (void)block_excl_scan(mine, wtot, &tot);
+        kept = tot;
+        for (int i = threadIdx.x; i < REL_WORDS; i += SEED_BLOCK) A.rel_bits[(size_t)s * REL_WORDS + i] = rel[i];
     }
-    if (threadIdx.x == 0) { A.strand_hits[s] = run; A.hot_count[s] = filtered ? (int32_t)nh : -1; }
+    if (threadIdx.x == 0) { A.strand_hits[s] = kept; A.filtered[s] = filtered ? 1 : 0; }
 }
 
 // ------------------------------------------------------------------------------------------------ emit
-// keys of the kept hits in (km, position) order = the order the reference visits them: key = seg:21 | km:16 | off:11
+// keys of the kept hits in (km, position) order = the order the reference visits them: key = seg:21 | km:16 | off:11.
+// The strand's k-mers are taken 64 at a time (16 lanes per bucket, four buckets per group as in for_each_hit16): count the
+// kept hits per bucket, scan the 64 counts, write.  The first 32 entries of a bucket stay in registers between the two
+// steps; longer buckets are read again (from cache).
 __global__ __launch_bounds__(SEED_BLOCK) void seed_emit(const mhip_offset_t* __restrict__ roffs, int rid_begin, int rid_stride,
                                                         const int32_t* __restrict__ offsets, SeedArrays A) {
     __shared__ uint32_t rel[REL_WORDS];
-    __shared__ uint32_t hot[HOT_CAP];
+    __shared__ uint32_t ccnt[64];
+    __shared__ uint32_t coff[64];
+    __shared__ uint32_t s_tot;
     const int s = blockIdx.x;
     const int rid = rid_begin + (s >> 1) * rid_stride;
     const int L = roffs[rid].size;
@@ -350,24 +306,76 @@ __global__ __launch_bounds__(SEED_BLOCK) void seed_emit(const mhip_offset_t* __r
     const uint32_t kb = A.km_base[s];
     if (A.strand_hits[s] == 0) return;
     uint64_t* __restrict__ out = A.keysA + A.hit_base[s];
-    const int nh = A.hot_count[s];
-    if (nh >= 0) {
-        for (int i = threadIdx.x; i < nh; i += SEED_BLOCK) hot[i] = A.hot_list[(size_t)s * HOT_CAP + i];
-        __syncthreads();
-        rel_build(rel, hot, nh, sweep_reach(L));
+    const bool flt = A.filtered[s] != 0;
+    if (flt) {
+        for (int i = threadIdx.x; i < REL_WORDS; i += SEED_BLOCK) rel[i] = A.rel_bits[(size_t)s * REL_WORDS + i];
     }
+    __syncthreads();
+    const int g = threadIdx.x >> 4;
     const uint32_t sub = threadIdx.x & 15;
-    uint32_t at[4];
-    for_each_hit16(A, offsets, kb, K,
-        [&](int q, int km) { at[q] = A.km_rpre[kb + km]; },
-        [&](int q, int km, uint32_t, uint32_t pos, bool valid) {
-            const uint32_t seg = pos / ZV, so = pos - seg * ZV;
-            const bool k1 = valid && (nh < 0 || rel_test(rel, seg));
-            const uint32_t bits = group_bits(__ballot(k1));
-            if (k1) out[at[q] + __popc(bits & ((1u << sub) - 1u))] = ((uint64_t)seg << KEY_SEG_SHIFT) | ((uint64_t)km << KEY_OFF_BITS) | so;
-            at[q] += __popc(bits);
-        },
-        [](int, int) {});
+    const uint32_t below = (1u << sub) - 1u;
+    uint32_t run = 0;
+    for (int c0 = 0; c0 < K; c0 += 64) {
+        uint32_t bs[4], cn[4], p0[4], p1[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int km = c0 + q * 16 + g;
+            bs[q] = km < K ? A.km_bstart[kb + km] : 0u;
+            cn[q] = km < K ? A.km_cnt[kb + km] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            p0[q] = sub < cn[q] ? (uint32_t)offsets[bs[q] + sub] : 0u;
+            p1[q] = sub + 16u < cn[q] ? (uint32_t)offsets[bs[q] + 16 + sub] : 0u;
+        }
+        // count
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t kept = 0;
+            if (cn[q] > 0) kept += __popc(group_bits(__ballot(sub < cn[q] && (!flt || rel_test(rel, p0[q] / ZV)))));
+            if (cn[q] > 16) kept += __popc(group_bits(__ballot(sub + 16u < cn[q] && (!flt || rel_test(rel, p1[q] / ZV)))));
+            for (uint32_t r0 = 32; r0 < cn[q]; r0 += 16) {
+                const uint32_t r = r0 + sub;
+                const bool valid = r < cn[q];
+                const uint32_t pos = valid ? (uint32_t)offsets[bs[q] + r] : 0u;
+                kept += __popc(group_bits(__ballot(valid && (!flt || rel_test(rel, pos / ZV)))));
+            }
+            if (sub == 0) ccnt[q * 16 + g] = kept;
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const uint32_t v = ccnt[threadIdx.x];
+            uint32_t incl = v;
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t nb = __shfl_up(incl, o);
+                if ((int)threadIdx.x >= o) incl += nb;
+            }
+            coff[threadIdx.x] = incl - v;
+            if (threadIdx.x == 63) s_tot = incl;
+        }
+        __syncthreads();
+        // write
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int km = c0 + q * 16 + g;
+            uint32_t at = run + coff[q * 16 + g];
+            auto put = [&](uint32_t pos, bool valid) {
+                const uint32_t seg = pos / ZV, so = pos - seg * ZV;
+                const bool k1 = valid && (!flt || rel_test(rel, seg));
+                const uint32_t bits = group_bits(__ballot(k1));
+                if (k1) out[at + __popc(bits & below)] = ((uint64_t)seg << KEY_SEG_SHIFT) | ((uint64_t)km << KEY_OFF_BITS) | so;
+                at += __popc(bits);
+            };
+            if (cn[q] > 0) put(p0[q], sub < cn[q]);
+            if (cn[q] > 16) put(p1[q], sub + 16u < cn[q]);
+            for (uint32_t r0 = 32; r0 < cn[q]; r0 += 16) {
+                const uint32_t r = r0 + sub;
+                const bool valid = r < cn[q];
+                put(valid ? (uint32_t)offsets[bs[q] + r] : 0u, valid);
+            }
+        }
+        run += s_tot;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ sort (one LSD pass)
@@ -897,11 +905,10 @@ static int seed_batch(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref
     if (c->scratch("sd_kmbase", sizeof(uint32_t) * (size_t)ns, (void**)&d_kmb)) return -1;
     if (c->scratch("sd_kmbstart", sizeof(uint32_t) * (size_t)(sumK + 1), (void**)&A.km_bstart)) return -1;
     if (c->scratch("sd_kmcnt", sizeof(uint32_t) * (size_t)(sumK + 1), (void**)&A.km_cnt)) return -1;
-    if (c->scratch("sd_kmrpre", sizeof(uint32_t) * (size_t)(sumK + 1), (void**)&A.km_rpre)) return -1;
     if (c->scratch("sd_hits", sizeof(uint32_t) * (size_t)ns, (void**)&A.strand_hits)) return -1;
     if (c->scratch("sd_hitsall", sizeof(uint32_t) * (size_t)ns, (void**)&A.strand_hits_all)) return -1;
-    if (c->scratch("sd_hotcnt", sizeof(int32_t) * (size_t)ns, (void**)&A.hot_count)) return -1;
-    if (c->scratch("sd_hotlist", sizeof(uint32_t) * (size_t)ns * HOT_CAP, (void**)&A.hot_list)) return -1;
+    if (c->scratch("sd_filtered", sizeof(int32_t) * (size_t)ns, (void**)&A.filtered)) return -1;
+    if (c->scratch("sd_relbits", sizeof(uint32_t) * (size_t)ns * REL_WORDS, (void**)&A.rel_bits)) return -1;
     if (c->scratch("sd_hbase", sizeof(uint64_t) * (size_t)(ns + 1), (void**)&A.hit_base)) return -1;
     if (c->scratch("sd_nseg", sizeof(uint32_t) * (size_t)ns, (void**)&A.nseg)) return -1;
     if (c->scratch("sd_nrec", sizeof(uint32_t) * (size_t)ns, (void**)&A.nrec)) return -1;

@@ -116,12 +116,16 @@ __device__ __forceinline__ int match32(const uint32_t* Q, int x, const uint32_t*
 
 // 16-base version (0..16): two words per side.  Snakes between two 15 %-error reads are ~3 bases long, so one 16-base
 // window settles 99.5 % of the diagonals at two thirds of match32's instruction count.
+// The result for 16 equal bases is 0x7fffffff (v_ffbh_u32 of 0 is -1): callers clamp with min(.., lim, 16), one v_min3.
+// v_alignbit uses the low 5 bits of its shift operand, so 30 - 2 * (xx & 15) is passed as ~xx << 1.
 __device__ __forceinline__ int match16(const uint32_t* Q, int x, const uint32_t* T, int y) {
     const int xx = x + 15, yy = y + 15;
     const int wq = xx >> 4, wt = yy >> 4;
-    const int hq = 30 - ((xx & 15) << 1), ht = 30 - ((yy & 15) << 1);
-    const uint32_t dh = __builtin_amdgcn_alignbit(Q[wq], Q[wq + 1], hq) ^ __builtin_amdgcn_alignbit(T[wt], T[wt + 1], ht);
-    return __clz(dh) >> 1;
+    const uint32_t dh = __builtin_amdgcn_alignbit(Q[wq], Q[wq + 1], (uint32_t)(~xx) << 1) ^
+                        __builtin_amdgcn_alignbit(T[wt], T[wt + 1], (uint32_t)(~yy) << 1);
+    uint32_t lead;
+    asm("v_ffbh_u32 %0, %1" : "=v"(lead) : "v"(dh));
+    return (int)(lead >> 1);
 }
 
 // ---- wave64 reductions on the DPP network (no LDS traffic): quad swaps, half-row / row mirrors, row broadcasts.
@@ -629,13 +633,14 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
                 const int ix = act ? kk : 1;
                 const int vl = S.V[ix - 1], vr = S.V[ix + 1];
                 int x = (k == min_k || (k != max_k && vl < vr)) ? vr : vl + 1;       // :138-142
-                x = act ? x : 0;
+                // 0 <= y <= t_len and x <= q_len on every live diagonal (a diagonal at an end stops the block); idle lanes sit
+                // at (q_len, 0), where lim == 0
+                x = act ? x : q_len;
                 int y = act ? x - k : 0;
                 bool more;
                 do {
                     const int lim = min(q_len - x, t_len - y);
-                    const int n0 = match16(S.Qp, x, S.Tp, min(max(y, 0), MAX_BLK));
-                    const int nn = act ? max(0, min(n0, lim)) : 0;
+                    const int nn = min(min(match16(S.Qp, x, S.Tp, y), lim), 16);
                     x += nn; y += nn;
                     more = (nn == 16) & (lim > 16);
                 } while (__ballot(more));

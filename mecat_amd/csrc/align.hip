@@ -51,9 +51,9 @@ struct DirResult {
 };
 
 struct AlnWaveLds {
-    int16_t V[VU_LEN];
-    uint32_t Qp[SEQ_WORDS];
+    uint32_t Qp[SEQ_WORDS];     // staged block sequences first: their byte offsets fit the ds_read2 offset field
     uint32_t Tp[SEQ_WORDS];
+    int16_t V[VU_LEN];
     uint16_t ring[RING * ROW_W];
     int16_t rmin[RING];
     int16_t rmax[RING];
@@ -116,13 +116,15 @@ __device__ __forceinline__ int match32(const uint32_t* Q, int x, const uint32_t*
 
 // 16-base version (0..16): two words per side.  Snakes between two 15 %-error reads are ~3 bases long, so one 16-base
 // window settles 99.5 % of the diagonals at two thirds of match32's instruction count.
-// The result for 16 equal bases is 0x7fffffff (v_ffbh_u32 of 0 is -1): callers clamp with min(.., lim, 16), one v_min3.
-// v_alignbit uses the low 5 bits of its shift operand, so 30 - 2 * (xx & 15) is passed as ~xx << 1.
+// The result for 16 equal bases is 0x7fffffff (v_ffbh_u32 of 0 is -1): callers clamp with min(.., lim, 16).
+// v_alignbit uses the low 5 bits of its shift operand: 30 - 2 * ((x + 15) & 15) == -2 * x (mod 32), one v_mul_i32_i24
+// (a 32-bit v_mul_lo would be quarter rate).
 __device__ __forceinline__ int match16(const uint32_t* Q, int x, const uint32_t* T, int y) {
-    const int xx = x + 15, yy = y + 15;
-    const int wq = xx >> 4, wt = yy >> 4;
-    const uint32_t dh = __builtin_amdgcn_alignbit(Q[wq], Q[wq + 1], (uint32_t)(~xx) << 1) ^
-                        __builtin_amdgcn_alignbit(T[wt], T[wt + 1], (uint32_t)(~yy) << 1);
+    const int wq = (x + 15) >> 4, wt = (y + 15) >> 4;
+    uint32_t sq, st;            // asm: the optimizer rewrites the multiply as a (quarter rate) v_mul_lo_u32 by 30
+    asm("v_mul_i32_i24 %0, -2, %1" : "=v"(sq) : "v"(x));
+    asm("v_mul_i32_i24 %0, -2, %1" : "=v"(st) : "v"(y));
+    const uint32_t dh = __builtin_amdgcn_alignbit(Q[wq], Q[wq + 1], sq) ^ __builtin_amdgcn_alignbit(T[wt], T[wt + 1], st);
     uint32_t lead;
     asm("v_ffbh_u32 %0, %1" : "=v"(lead) : "v"(dh));
     return (int)(lead >> 1);
@@ -496,13 +498,14 @@ __global__ __launch_bounds__(AL_BLOCK) void dw_extend(const uint32_t* __restrict
 #define RROWS 64
 #endif
 struct HalfLds {
-    int16_t V[VU_LEN];
     uint32_t Qp[SEQ_WORDS];
     uint32_t Tp[SEQ_WORDS];
+    int16_t V[VU_LEN];
     uint16_t ring[RCAP];
     uint2 rrec[RROWS];          // per d-row: x = min_k | max_k << 16, y = linear ring position of the row
 };
-static_assert(offsetof(HalfLds, Qp) == offsetof(AlnWaveLds, Qp) && offsetof(HalfLds, Tp) == offsetof(AlnWaveLds, Tp),
+static_assert(offsetof(HalfLds, Qp) == offsetof(AlnWaveLds, Qp) && offsetof(HalfLds, Tp) == offsetof(AlnWaveLds, Tp) &&
+                  offsetof(HalfLds, V) == offsetof(AlnWaveLds, V),
               "the spill fallback reuses V/Qp/Tp in place");
 
 // max over each 32-lane half, returned in every lane of the half
@@ -630,8 +633,8 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
                 const int tt = sl + 32 * j;
                 const bool act = rowing && tt < nslot;
                 const int k = min_k + 2 * tt, kk = k + k_offset;
-                const int ix = act ? kk : 1;
-                const int vl = S.V[ix - 1], vr = S.V[ix + 1];
+                const int16_t* vp = &S.V[kk - 1];                  // idle lanes read (and ignore) in-range garbage
+                const int vl = vp[0], vr = vp[2];
                 int x = (k == min_k || (k != max_k && vl < vr)) ? vr : vl + 1;       // :138-142
                 // 0 <= y <= t_len and x <= q_len on every live diagonal (a diagonal at an end stops the block); idle lanes sit
                 // at (q_len, 0), where lim == 0
@@ -640,9 +643,10 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
                 bool more;
                 do {
                     const int lim = min(q_len - x, t_len - y);
-                    const int nn = min(min(match16(S.Qp, x, S.Tp, y), lim), 16);
+                    const int m = min(match16(S.Qp, x, S.Tp, y), lim);      // 0..15, or lim when all 16 bases match
+                    const int nn = min(m, 16);
                     x += nn; y += nn;
-                    more = (nn == 16) & (lim > 16);
+                    more = m > 16;
                 } while (__ballot(more));
                 if (act) {
                     S.V[kk] = (int16_t)x;

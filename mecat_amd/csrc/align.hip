@@ -489,7 +489,7 @@ __global__ __launch_bounds__(AL_BLOCK) void dw_extend(const uint32_t* __restrict
 // scalar in the one-unit kernel (band limits, best point, block sizes ...) is a per-half-uniform VGPR value here;
 // per-half row maxima use a 5-step DPP chain (quad swaps, half/row mirrors, row_bcast:15) + two readlanes, first-index
 // decisions use the two 32-bit halves of a ballot.  d-rows live in a 1024-entry circular buffer per half (rows are
-// packed back to back: the average row is 25 entries, so ~40 rows stay traceable); the rare block whose tail
+// packed back to back, wrapping: the average row is 25 entries, so ~40 rows stay traceable); the rare block whose tail
 // traceback needs an overwritten row is re-run by the one-unit code path with rows spilled to global scratch.
 #ifndef RCAP
 #define RCAP 1024
@@ -508,17 +508,22 @@ static_assert(offsetof(HalfLds, Qp) == offsetof(AlnWaveLds, Qp) && offsetof(Half
                   offsetof(HalfLds, V) == offsetof(AlnWaveLds, V),
               "the spill fallback reuses V/Qp/Tp in place");
 
-// max over each 32-lane half, returned in every lane of the half
+// mask of the lanes where p holds, without the bool -> int -> compare round trip of __ballot
+#define BALLOT(p) __builtin_amdgcn_ballot_w64(p)
+
+// max over each 32-lane half, returned in every lane of the half: four mirrored DPP steps leave each 16-lane row with its
+// maximum in every lane; v_permlane16_swap (gfx950) then exchanges rows 1 <-> 0 and 3 <-> 2 between two copies.
 __device__ __forceinline__ int half_max(int v) {
+    int w;
     asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
                  "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
                  "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
                  "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-                 "s_nop 1"
-                 : "+v"(v));
-    const int a = __builtin_amdgcn_readlane(v, 31), b = __builtin_amdgcn_readlane(v, 63);
-    return (lane_id() & 32) ? b : a;
+                 "v_mov_b32 %1, %0\n\t"
+                 "s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\t"
+                 "s_nop 1\n\tv_max_i32 %0, %0, %1"
+                 : "+v"(v), "=&v"(w));
+    return v;
 }
 __device__ __forceinline__ int half_min(int v) { return -half_max(-v); }
 
@@ -550,7 +555,7 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
     bool rowing = false, ran = false;
 
     while (true) {
-        if (__ballot(setup)) {
+        if (BALLOT(setup)) {
             // ---- 1. a half without a unit pulls the next one
             if (setup && need_unit) {
                 unsigned int u = 0;
@@ -602,7 +607,7 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
             }
             __builtin_amdgcn_wave_barrier();
         }
-        if (!__ballot(!exhausted)) break;
+        if (!BALLOT(!exhausted)) break;
         const int q_len = qblk, t_len = tblk, k_offset = max_d;
 
         // ---- 3. one row per half (Align, diff_gapalign.cpp:107-219); the halves' row counters are independent.  Only the
@@ -610,16 +615,14 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
         // of blocks) needs the position of that maximum and is handed to the one-unit code path below, like a block whose
         // traceback outran the ring.
         // The inner loop runs while every half that has a block is still rowing.
-        const unsigned long long inmask = __ballot(inblock);
+        const unsigned long long inmask = BALLOT(inblock);
         while (true) {
             rowing = rowing && d < max_d && (max_k - min_k <= band_size);
-            const unsigned long long rmask = __ballot(rowing);
+            const unsigned long long rmask = BALLOT(rowing);
             if (rmask != inmask) break;
             nrows += 1;
             nidle += (rmask == ~0ull) ? 0u : 1u;
             const int nslot = rowing ? ((max_k - min_k) >> 1) + 1 : 0;
-            unsigned int pos0 = lin & (RCAP - 1);
-            if (pos0 + (unsigned)nslot > RCAP) { lin += RCAP - pos0; pos0 = 0; }
             if (rowing && sl == 0) {        // row record: band limits + linear ring position, one 64-bit store
                 S.rrec[d & (RROWS - 1)] = make_uint2(((uint32_t)(uint16_t)(int16_t)min_k) | ((uint32_t)(uint16_t)(int16_t)max_k << 16), lin);
             }
@@ -647,10 +650,10 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
                     const int nn = min(m, 16);
                     x += nn; y += nn;
                     more = m > 16;
-                } while (__ballot(more));
+                } while (BALLOT(more));
                 if (act) {
                     S.V[kk] = (int16_t)x;
-                    S.ring[pos0 + tt] = (uint16_t)x;
+                    S.ring[(lin + (unsigned)tt) & (RCAP - 1)] = (uint16_t)x;
                     mmax = max(mmax, x + y);
                     if (!reached && (x >= q_len || y >= t_len)) { reached = true; hx = x; hkk = kk; }     // lowest k of this lane
                 }
@@ -663,11 +666,11 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
             const int rm = half_max(mmax);
             if (rowing && rm > best_m) best_m = rm;
             int hkey = 0x7fffffff;
-            if (__ballot(reached)) hkey = half_min(reached ? ((hkk << 10) | hx) : 0x7fffffff);
+            if (BALLOT(reached)) hkey = half_min(reached ? ((hkk << 10) | hx) : 0x7fffffff);
             // band update (:172-179)
             int nmin = max_k, nmax = min_k;
             if (NJ == 1) {
-                const unsigned long long qb = __ballot(m0 >= best_m - band_tol && m0 >= 0);
+                const unsigned long long qb = BALLOT(m0 >= best_m - band_tol && m0 >= 0);
                 const unsigned int mine = hh ? (unsigned int)(qb >> 32) : (unsigned int)qb;
                 if (mine) { nmin = min_k + 2 * (__ffs((int)mine) - 1); nmax = min_k + 2 * (31 - __clz((int)mine)); }
             } else {
@@ -704,7 +707,7 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
         int cd = end_d, ck = end_k, cx2 = end_x;
         int qcnt = 0, tcnt = 0, acnt = 0, found = 0;
         bool tracing = has_aln;
-        while (__ballot(tracing)) {
+        while (BALLOT(tracing)) {
             if (tracing) {
                 int x1 = 0, pre_k = 0, takes_q = 0;
                 if (cd > 0) {
@@ -714,11 +717,10 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
                     else {
                         const int pmin = (int)(int16_t)(pr.x & 0xFFFFu), pmax = (int)(int16_t)(pr.x >> 16);
                         const int cmin = (int)(int16_t)(cr.x & 0xFFFFu), cmax = (int)(int16_t)(cr.x >> 16);
-                        const unsigned int pb = pr.y & (RCAP - 1);
                         const int kl = ck - 1, kr = ck + 1;
                         int vl = 0, vr = 0;
-                        if (kl >= pmin && kl <= pmax) vl = S.ring[pb + ((kl - pmin) >> 1)];
-                        if (kr >= pmin && kr <= pmax) vr = S.ring[pb + ((kr - pmin) >> 1)];
+                        if (kl >= pmin && kl <= pmax) vl = S.ring[(pr.y + (unsigned)((kl - pmin) >> 1)) & (RCAP - 1)];
+                        if (kr >= pmin && kr <= pmax) vr = S.ring[(pr.y + (unsigned)((kr - pmin) >> 1)) & (RCAP - 1)];
                         if (ck == cmin || (ck != cmax && vl < vr)) { x1 = vr; pre_k = kr; takes_q = 0; }
                         else { x1 = vl + 1; pre_k = kl; takes_q = 1; }
                     }
@@ -744,7 +746,7 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
 
         // ---- 5. rare: the tail needs a row that left the ring -> re-run that half's block with spilled rows (whole wave;
         // only that half's V/Qp/Tp are touched, the other half may be in the middle of its own block)
-        const unsigned long long fb = __ballot(fallback);
+        const unsigned long long fb = BALLOT(fallback);
         if (fb) {
             for (int hx = 0; hx < 2; ++hx) {
                 if (!((fb >> (hx * 32)) & 1ull)) continue;

@@ -537,7 +537,7 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
     HalfLds& S = lds[threadIdx.x >> 6][hh];
     const int gw = blockIdx.x * AL_WAVES + (threadIdx.x >> 6);
     uint16_t* grow = gscratch + (size_t)gw * GROW_STRIDE;
-    unsigned long long cells = 0, nblocks = 0, nfallback = 0, nrows = 0, nidle = 0;
+    unsigned long long cells = 0, nblocks = 0, nfallback = 0, nrows = 0, nidle = 0, nwide = 0;
 
     // per-half unit state (uniform inside a half)
     bool need_unit = true, exhausted = false;
@@ -629,6 +629,7 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
             if (rowing) { last_row = d; ran = true; }
             const int ns_a = __builtin_amdgcn_readlane(nslot, 0), ns_b = __builtin_amdgcn_readlane(nslot, 32);
             const int NJ = (max(ns_a, ns_b) + 31) >> 5;
+            nwide += NJ > 1 ? 1u : 0u;
             int mmax = -1, m0 = -1;
             int hx = 0, hkk = 0;
             bool reached = false;
@@ -794,6 +795,7 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
         atomicAdd(&counters[8], nfallback);
         atomicAdd(&counters[9], nrows);          // dual rows
         atomicAdd(&counters[10], nidle);         // dual rows with one idle half
+        atomicAdd(&counters[11], nwide);         // dual rows with more than 32 diagonals in a half
     }
 }
 

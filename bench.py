@@ -232,6 +232,28 @@ def main():
                 "algorithmic_bytes_per_launch": alg_per_launch, "avg_launch_ms": avg_ms, "launches": dl,
                 "phase_bytes_per_step": {k: float(v) for k, v in phase_of.items()},
                 "note": "algorithmic bytes of the kernel's phase (SURVEY.md §8d) / launches; scratch/sort traffic not counted"}
+        # HBM bytes of the same kernel from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command
+        # (PMC counters cannot be read from inside the run); VALU issue rate from the committed SQ_INSTS_VALU pass.
+        prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+        try:
+            tfile = sorted(f for f in os.listdir(prof_dir) if f.endswith("_hbm_traffic.json"))[-1]
+            t = json.load(open(os.path.join(prof_dir, tfile))).get(dname)
+            if t and args.workload == "config2" and world == 1:
+                roof["traffic"] = t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]
+                roof["traffic_source"] = "profiles/" + tfile
+        except (OSError, IndexError, ValueError):
+            pass
+        try:
+            ifile = sorted(f for f in os.listdir(prof_dir) if f.endswith("_instruction_mix.json"))[-1]
+            im = json.load(open(os.path.join(prof_dir, ifile))).get(dname)
+            if im and args.workload == "config2" and world == 1 and avg_ms > 0:
+                peak = 256 * 4 * 2.4e9 / 4 / 1e9          # 1024 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz
+                ach = im["valu_insts_per_launch"] / (avg_ms / 1e3) / 1e9
+                roof["valu_issue"] = {"achieved": ach, "peak": peak, "unit": "G wave-instr/s", "frac": ach / peak,
+                                      "source": "profiles/" + ifile,
+                                      "note": "integer O(ND) rows: the kernel is bound by VALU issue, not by HBM or MFMA"}
+        except (OSError, IndexError, ValueError):
+            pass
         if pk == "dw":
             roof["dw_cells_per_s"] = per_step("dw_cells") / (phase[2] / 1e3) if phase[2] > 0 else None
             roof["dw_snake_bases_per_s"] = per_step("snake_bases") / (phase[2] / 1e3) if phase[2] > 0 else None

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 outputs of one round into the summaries kept under profiles/.
+
+    python profiles/summarize.py r01 gpurun_out/prof_r01c gpurun_out/prof_r01c_FETCH_SIZE gpurun_out/prof_r01c_WRITE_SIZE 2
+
+argv: round tag, kernel-trace/stats dir, FETCH_SIZE pmc dir, WRITE_SIZE pmc dir, hot-path passes in each PMC run
+(warm-up + steps).  Writes <tag>_kernel_stats.csv (copy), <tag>_hbm_counters.md, <tag>_hbm_traffic.json.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+
+def short(name):
+    n = name.split("(")[0]
+    return n.replace("void ", "")[:60]
+
+
+def main():
+    tag, kdir, fdir, wdir, passes = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5])
+    here = os.path.dirname(os.path.abspath(__file__))
+    for f in ("kernel_stats", "agent_info"):
+        src = glob.glob(os.path.join(kdir, "*_%s.csv" % f))
+        if src:
+            shutil.copy(src[0], os.path.join(here, "%s_%s.csv" % (tag, f)))
+    tot = collections.defaultdict(lambda: [0, 0.0, 0.0])
+    for d, col in ((fdir, 1), (wdir, 2)):
+        for r in csv.DictReader(open(glob.glob(os.path.join(d, "*counter_collection.csv"))[0])):
+            k = short(r["Kernel_Name"])
+            if col == 1:
+                tot[k][0] += 1
+            tot[k][col] += float(r["Counter_Value"])
+    rows = sorted(tot.items(), key=lambda kv: -(kv[1][1] + kv[1][2]))
+    traffic = {}
+    with open(os.path.join(here, "%s_hbm_counters.md" % tag), "w") as f:
+        f.write("# %s - HBM traffic counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)\n\n" % tag)
+        f.write("Command: `python bench.py --steps 1 --warmup 1 --no-cpu` (config 2), i.e. %d passes of the hot path per run.\n" % passes)
+        f.write("Counter unit is KiB; bytes = value x 1024.  MI355X_MICROARCH.md (HBM): FETCH_SIZE reports half the bytes of a\n"
+                "16 B/lane coalesced streaming read and is uncalibrated for other widths; none of these kernels issues 16 B/lane\n"
+                "streams (4-8 B/lane gathers and scatters), so the values are reported uncorrected.  Infinity-Cache hits count.\n\n")
+        f.write("| kernel | launches | fetch GB / pass | write GB / pass | fetch+write MB / launch |\n|---|---|---|---|---|\n")
+        for k, (n, fk, wk) in rows:
+            if "at::" in k or "rocclr" in k or "rocprim" in k.lower():
+                continue
+            fb, wb = fk * 1024.0, wk * 1024.0
+            traffic[k] = {"launches_per_pass": n / passes, "fetch_bytes_per_launch": fb / max(n, 1), "write_bytes_per_launch": wb / max(n, 1)}
+            f.write("| %s | %d | %.2f | %.2f | %.1f |\n" % (k, n, fb / passes / 1e9, wb / passes / 1e9, (fb + wb) / max(n, 1) / 1e6))
+    json.dump(traffic, open(os.path.join(here, "%s_hbm_traffic.json" % tag), "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

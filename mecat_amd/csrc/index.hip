@@ -173,6 +173,76 @@ __device__ __forceinline__ int bitonic64(int v) {
     return v;
 }
 
+// ascending bitonic sort inside every aligned group of W lanes (W = 16 or 32), one value per lane
+template <int W>
+__device__ __forceinline__ int bitonic_group(int v) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int k = 2; k <= W; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            int partner = __shfl_xor(v, j);
+            bool up = k == W || (lane & k) == 0;
+            bool lower = (lane & j) == 0;
+            v = cmpswap(v, partner, lower == up);
+        }
+    }
+    return v;
+}
+
+// Sort, in place, the buckets selected by `todo` (one bucket per lane: [s0, e1) of that lane) with G = 64 / W buckets per
+// pass, each in its own group of W lanes (bucket sizes <= W).  `data` may point to LDS or to global memory.
+template <int W>
+__device__ __forceinline__ void sort_small_buckets(unsigned long long todo, uint32_t s0, uint32_t e1, int32_t* data) {
+    constexpr int G = 64 / W;
+    const int lane = lane_id(), grp = lane / W, lig = lane % W;
+    while (todo) {
+        int src = -1;
+        unsigned long long t = todo;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int bb = t ? __ffsll(t) - 1 : -1;
+            if (g == grp) src = bb;
+            t &= t - 1;          // t == 0 stays 0
+        }
+        todo = t;
+        const uint32_t st = __shfl(s0, src < 0 ? 0 : src), en = __shfl(e1, src < 0 ? 0 : src);
+        const int n = src < 0 ? 0 : (int)(en - st);
+        int x = lig < n ? data[st + lig] : 0x7fffffff;
+        x = bitonic_group<W>(x);
+        if (lig < n) data[st + lig] = x;
+    }
+}
+
+__device__ __forceinline__ void bitonic128(int& a, int& b);
+
+// every bucket of the wave's 64 lanes ([s0, e1) per lane, <= 128 entries) ascending: the reference's fill order
+__device__ __forceinline__ void sort_wave_buckets(uint32_t s0, uint32_t e1, int32_t* data) {
+    const int lane = lane_id();
+    const uint32_t nb = e1 - s0;
+    // buckets average ~22 positions: four 16-lane or two 32-lane sorts per pass; whole-wave sorts for the long ones
+    sort_small_buckets<16>(__ballot(nb >= 2u && nb <= 16u), s0, e1, data);
+    sort_small_buckets<32>(__ballot(nb > 16u && nb <= 32u), s0, e1, data);
+    uint64_t todo = __ballot(nb > 32u);
+    while (todo) {
+        const int bb = __ffsll((unsigned long long)todo) - 1;
+        todo &= todo - 1;
+        const uint32_t st = __shfl(s0, bb), en = __shfl(e1, bb);
+        const int n = (int)(en - st);
+        if (n <= 64) {
+            int x = lane < n ? data[st + lane] : 0x7fffffff;
+            x = bitonic64(x);
+            if (lane < n) data[st + lane] = x;
+        } else {
+            int a = data[st + lane];
+            int c2 = lane + 64 < n ? data[st + 64 + lane] : 0x7fffffff;
+            bitonic128(a, c2);
+            data[st + lane] = a;
+            if (lane + 64 < n) data[st + 64 + lane] = c2;
+        }
+    }
+}
+
 // ascending bitonic sort of 128 values: element i in lane i (a) and element 64+i in lane i (b)
 __device__ __forceinline__ void bitonic128(int& a, int& b) {
     const int lane = lane_id();
@@ -230,11 +300,14 @@ __global__ __launch_bounds__(IDX_BLOCK) void idx_sort(const uint32_t* __restrict
 
 // ==================================================================================================================
 // Binned build (default).  The direct-address table is 268 MB, so the count/fill walks above are 1.6e9 read-modify-write
-// round trips to memory-side atomics plus 4-byte scattered stores (r01 profile: ~100 GB of HBM traffic each for 6 GB of
-// algorithmic bytes).  Here the (k-mer, position) pairs are first partitioned by the top 12 k-mer bits in two LDS-staged
-// 64-way scatter passes (runs of ~512 bytes per bin and tile), after which every fine bin covers 2^14 k-mer ids: one
-// workgroup per bin counts in LDS, drops > 128, scans, writes its slice of starts[] and fills its (L2-sized) slice of
-// offsets[] with LDS cursors, then sorts its buckets.  All global traffic is sequential or run-coalesced.
+// round trips to memory-side atomics plus 4-byte scattered stores (~100 GB of HBM traffic each for 6 GB of algorithmic
+// bytes).  Here the (k-mer, position) pairs are partitioned by the top 18 k-mer bits in three LDS-staged 64-way scatter
+// passes (runs of ~512 bytes per bin and tile): 64 coarse bins -> 4096 fine bins (2^14 k-mer ids; one workgroup per fine bin
+// counts occurrences per id in LDS, drops > 128 and scans -> starts[]) -> 262144 sub-bins of 256 ids, whose ~4.5 k kept
+// positions fit LDS: one workgroup per sub-bin gathers them per bucket, sorts every bucket and writes its contiguous slice
+// of offsets[] in one sweep.  (Two levels with the fill done per fine bin straight into global memory kept 512 x 1.5 MB
+// of half-written lines in flight: 58 GB of HBM writes for 4.7 GB of positions.)  All global traffic is sequential or
+// run-coalesced.
 #define FINE_BITS 12
 #define NFINE (1 << FINE_BITS)            // 4096 fine bins
 #define NCOARSE 64
@@ -393,11 +466,19 @@ __global__ __launch_bounds__(IDX_BLOCK) void idx_scatter2(const uint64_t* __rest
     scatter_tile64(ent, binv, vmask, cur2 + c * 64, ent2, hist, lbase, gbase, stage, sbin);
 }
 
-// one workgroup per fine bin: kept occurrence counts of its 2^14 k-mer ids -> starts[] slice (temporarily counts), bin total
+#define NSUB 64                           // sub-bins per fine bin (level 3)
+#define IDS_PER_SUB (IDS_PER_FINE / NSUB)  // 256 k-mer ids per sub-bin
+#define SUB_THREADS 256
+#define SUB_CAP 8192                      // positions a sub-bin may hold in LDS (32 KB); ~4.5 k on average at config 2
+
+// one workgroup per fine bin: kept occurrence counts of its 2^14 k-mer ids -> starts[] slice (temporarily counts), bin
+// total, and the entry ranges of its 64 sub-bins (all occurrences, dropped buckets included) for the level-3 scatter
 __global__ __launch_bounds__(BIN_THREADS) void idx_bin_count(const uint64_t* __restrict__ ent2, const uint32_t* __restrict__ fine_base,
-                                                             uint32_t* __restrict__ starts, uint32_t* __restrict__ bintot) {
+                                                             uint32_t* __restrict__ starts, uint32_t* __restrict__ bintot,
+                                                             uint32_t* __restrict__ sub_base, uint32_t* __restrict__ cur3) {
     __shared__ uint32_t cnt[IDS_PER_FINE];     // 64 KB
     __shared__ uint32_t wtot[BIN_THREADS / WAVE];
+    __shared__ uint32_t subtot[NSUB];
     const int b = blockIdx.x;
     for (int i = threadIdx.x; i < IDS_PER_FINE; i += BIN_THREADS) cnt[i] = 0;
     __syncthreads();
@@ -412,28 +493,73 @@ __global__ __launch_bounds__(BIN_THREADS) void idx_bin_count(const uint64_t* __r
     }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if (lane_id() == 0) wtot[threadIdx.x >> 6] = s;
+    {
+        // sub-bin j = ids [256 j, 256 j + 256): 16 threads per sub-bin, thread u sums ids 256 j + u + 16 v
+        const int j = threadIdx.x >> 4, u = threadIdx.x & 15;
+        uint32_t t = 0;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) t += cnt[j * IDS_PER_SUB + u + 16 * v];
+        for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o);
+        if (u == 0) subtot[j] = t;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t tot = 0;
         for (int w = 0; w < BIN_THREADS / WAVE; ++w) tot += wtot[w];
         bintot[b] = tot;
     }
+    if (threadIdx.x < NSUB) {
+        const uint32_t c = subtot[threadIdx.x];
+        uint32_t incl = c;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t n = __shfl_up(incl, o);
+            if ((int)threadIdx.x >= o) incl += n;
+        }
+        const uint32_t at = eb + incl - c;
+        sub_base[(size_t)b * NSUB + threadIdx.x] = at;
+        cur3[(size_t)b * NSUB + threadIdx.x] = at;
+        if (b == NFINE - 1 && threadIdx.x == NSUB - 1) sub_base[(size_t)NFINE * NSUB] = ee;
+    }
 }
 
-// one workgroup per fine bin: absolute starts[] slice, fill of the bin's offsets[] slice with LDS cursors, bucket sort
-__global__ __launch_bounds__(BIN_THREADS) void idx_bin_fill(const uint64_t* __restrict__ ent2, const uint32_t* __restrict__ fine_base,
-                                                            const uint32_t* __restrict__ binout, uint32_t* __restrict__ starts,
-                                                            int32_t* __restrict__ offsets) {
-    __shared__ uint32_t cur[IDS_PER_FINE];     // 64 KB: kept count -> absolute start -> running cursor
-    __shared__ uint32_t keptbits[IDS_PER_FINE / 32];
+// level 3: inside fine bin b (its own 64 sub-bin cursors), by k-mer bits 13..8.  blockIdx.y = fine bin.
+__global__ __launch_bounds__(IDX_BLOCK) void idx_scatter3(const uint64_t* __restrict__ ent2, const uint32_t* __restrict__ fine_base,
+                                                          uint32_t* __restrict__ cur3, uint64_t* __restrict__ ent3) {
+    __shared__ uint32_t hist[NCOARSE], lbase[NCOARSE + 1], gbase[NCOARSE];
+    __shared__ uint64_t stage[TILE_POS];
+    __shared__ uint8_t sbin[TILE_POS];
+    const int b = blockIdx.y;
+    const uint32_t cb = fine_base[b], ce = fine_base[b + 1];
+    const uint64_t first = (uint64_t)cb + (uint64_t)blockIdx.x * TILE_POS;
+    if (first >= ce) return;
+    uint64_t ent[16];
+    uint32_t binv[16];
+    uint32_t vmask = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint64_t i = first + (uint64_t)j * IDX_BLOCK + threadIdx.x;      // coalesced reads
+        const bool ok = i < ce;
+        const uint64_t e = ok ? ent2[i] : 0ull;
+        ent[j] = e;
+        binv[j] = (uint32_t)(e >> (32 + 8)) & 63u;
+        vmask |= ok ? (1u << j) : 0u;
+    }
+    scatter_tile64(ent, binv, vmask, cur3 + (size_t)b * NSUB, ent3, hist, lbase, gbase, stage, sbin);
+}
+
+// one workgroup per fine bin: kept counts -> absolute starts[] slice
+__global__ __launch_bounds__(BIN_THREADS) void idx_bin_starts(const uint32_t* __restrict__ binout, uint32_t* __restrict__ starts) {
     __shared__ uint32_t wtot[BIN_THREADS / WAVE];
     const int b = blockIdx.x;
     const int per = IDS_PER_FINE / BIN_THREADS;     // 16 consecutive ids per thread
+    uint4* sp = (uint4*)(starts + (size_t)b * IDS_PER_FINE + (size_t)threadIdx.x * per);
     uint32_t v[per], s = 0;
-    for (int i = threadIdx.x; i < IDS_PER_FINE / 32; i += BIN_THREADS) keptbits[i] = 0;
-    __syncthreads();
 #pragma unroll
-    for (int i = 0; i < per; ++i) { v[i] = starts[(size_t)b * IDS_PER_FINE + threadIdx.x * per + i]; s += v[i]; }
+    for (int i = 0; i < per / 4; ++i) {
+        const uint4 q = sp[i];
+        v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w;
+        s += q.x + q.y + q.z + q.w;
+    }
     uint32_t incl = s;
     for (int o = 1; o < 64; o <<= 1) {
         uint32_t n = __shfl_up(incl, o);
@@ -443,51 +569,58 @@ __global__ __launch_bounds__(BIN_THREADS) void idx_bin_fill(const uint64_t* __re
     __syncthreads();
     uint32_t run = binout[b] + incl - s;
     for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) run += wtot[w];
-    uint32_t kb = 0;
 #pragma unroll
-    for (int i = 0; i < per; ++i) {
-        const int id = threadIdx.x * per + i;
-        starts[(size_t)b * IDS_PER_FINE + id] = run;
-        cur[id] = run;
-        if (v[i]) kb |= 1u << (id & 31);
-        run += v[i];
+    for (int i = 0; i < per / 4; ++i) {
+        uint4 o;
+        o.x = run; run += v[4 * i];
+        o.y = run; run += v[4 * i + 1];
+        o.z = run; run += v[4 * i + 2];
+        o.w = run; run += v[4 * i + 3];
+        sp[i] = o;
     }
-    // 16 consecutive ids of a thread share one 32-bit word with the neighbouring thread
-    if (kb) atomicOr(&keptbits[(threadIdx.x * per) >> 5], kb);
+}
+
+// one workgroup per sub-bin (256 k-mer ids, one contiguous slice of offsets[]): the kept positions are gathered per bucket
+// in LDS (cursors handed out by LDS atomics), every bucket is sorted ascending (atomics hand out slots in arbitrary order;
+// the reference's fill order is ascending position and is load-bearing), and the slice is written out in one coalesced
+// sweep.  A sub-bin with more kept positions than SUB_CAP (possible up to 256 x 128) does the same directly in global memory.
+__global__ __launch_bounds__(SUB_THREADS) void idx_sub_fill(const uint64_t* __restrict__ ent3, const uint32_t* __restrict__ sub_base,
+                                                            const uint32_t* __restrict__ starts, int32_t* __restrict__ offsets) {
+    __shared__ uint32_t lstart[IDS_PER_SUB + 1];
+    __shared__ uint32_t cursor[IDS_PER_SUB];
+    __shared__ int32_t buf[SUB_CAP];
+    const uint32_t sb = blockIdx.x;
+    const size_t id0 = (size_t)sb * IDS_PER_SUB;
+    const uint32_t first = starts[id0];
+    const uint32_t mine = starts[id0 + threadIdx.x] - first;
+    lstart[threadIdx.x] = mine;
+    cursor[threadIdx.x] = mine;
+    if (threadIdx.x == 0) lstart[IDS_PER_SUB] = starts[id0 + IDS_PER_SUB] - first;
     __syncthreads();
-    const uint32_t eb = fine_base[b], ee = fine_base[b + 1];
-    for (uint32_t i = eb + threadIdx.x; i < ee; i += BIN_THREADS) {
-        const uint64_t e = ent2[i];
-        const uint32_t id = (uint32_t)(e >> 32) & (IDS_PER_FINE - 1);
-        if ((keptbits[id >> 5] >> (id & 31)) & 1u) offsets[atomicAdd(&cur[id], 1u)] = (int32_t)(uint32_t)e;
+    const uint32_t total = lstart[IDS_PER_SUB];
+    if (total == 0) return;
+    const bool in_lds = total <= SUB_CAP;
+    int32_t* gdst = offsets + first;
+    const uint32_t eb = sub_base[sb], ee = sub_base[sb + 1];
+    for (uint32_t i = eb + threadIdx.x; i < ee; i += SUB_THREADS) {
+        const uint64_t e = ent3[i];
+        const uint32_t id = (uint32_t)(e >> 32) & (IDS_PER_SUB - 1);
+        if (lstart[id + 1] != lstart[id]) {
+            const uint32_t slot = atomicAdd(&cursor[id], 1u);
+            if (in_lds) buf[slot] = (int32_t)(uint32_t)e;
+            else gdst[slot] = (int32_t)(uint32_t)e;
+        }
     }
     __threadfence_block();
     __syncthreads();
-    // bucket order must be ascending position (the reference's fill order): sort every bucket with >= 2 entries.
-    // after the fill cur[id] == end of bucket id == start of bucket id + 1
-    const int lane = lane_id(), wv = threadIdx.x >> 6;
-    for (int g0 = wv * 64; g0 < IDS_PER_FINE; g0 += (BIN_THREADS / WAVE) * 64) {
-        const int id = g0 + lane;
-        const uint32_t e1 = cur[id];
-        const uint32_t s0 = id == 0 ? binout[b] : cur[id - 1];
-        uint64_t todo = __ballot(e1 - s0 >= 2u);
-        while (todo) {
-            const int bb = __ffsll((unsigned long long)todo) - 1;
-            todo &= todo - 1;
-            const uint32_t st = __shfl(s0, bb), en = __shfl(e1, bb);
-            const int n = (int)(en - st);
-            if (n <= 64) {
-                int x = lane < n ? offsets[st + lane] : 0x7fffffff;
-                x = bitonic64(x);
-                if (lane < n) offsets[st + lane] = x;
-            } else {
-                int a = offsets[st + lane];
-                int c2 = lane + 64 < n ? offsets[st + 64 + lane] : 0x7fffffff;
-                bitonic128(a, c2);
-                offsets[st + lane] = a;
-                if (lane + 64 < n) offsets[st + 64 + lane] = c2;
-            }
-        }
+    {
+        const int id = threadIdx.x;      // wave w sorts the buckets of ids 64 w .. 64 w + 63
+        if (in_lds) sort_wave_buckets(lstart[id], lstart[id + 1], buf);
+        else sort_wave_buckets(lstart[id], lstart[id + 1], gdst);
+    }
+    if (in_lds) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < total; i += SUB_THREADS) gdst[i] = buf[i];
     }
 }
 
@@ -524,6 +657,7 @@ static int index_build_binned(mhip_ctx* c, const mhip_volume* v, mhip_index* idx
     if (c->scratch("ix_ent1", sizeof(uint64_t) * ((size_t)nent + 64), (void**)&d_e1)) return -1;
     if (c->scratch("ix_ent2", sizeof(uint64_t) * ((size_t)nent + 64), (void**)&d_e2)) return -1;
     TRACE("scratch");
+    unsigned gx3 = 0;
     LAUNCH(c, "idx_init_cursors", idx_init_cursors, NFINE / 256, 256, 0, (const uint32_t*)d_fbase, d_cur1, d_cur2);
     LAUNCH(c, "idx_scatter1", idx_scatter1, tiles, IDX_BLOCK, 0, (const uint32_t*)v->d_pac, (const mhip_offset_t*)v->d_offs, v->num_reads,
            v->num_bases, d_cur1, d_e1);
@@ -535,21 +669,30 @@ static int index_build_binned(mhip_ctx* c, const mhip_volume* v, mhip_index* idx
         uint32_t mx = 0;
         for (int cc = 0; cc < NCOARSE; ++cc) mx = std::max(mx, fb[(size_t)(cc + 1) * 64] - fb[(size_t)cc * 64]);
         const unsigned gx = (mx + TILE_POS - 1) / TILE_POS;
+        uint32_t mx3 = 0;
+        for (int f = 0; f < NFINE; ++f) mx3 = std::max(mx3, fb[(size_t)f + 1] - fb[(size_t)f]);
+        gx3 = (mx3 + TILE_POS - 1) / TILE_POS;
         if (gx) LAUNCH(c, "idx_scatter2", idx_scatter2, dim3(gx, NCOARSE), IDX_BLOCK, 0, (const uint64_t*)d_e1, (const uint32_t*)d_fbase, d_cur2, d_e2);
     }
     TRACE("scatter");
-    LAUNCH(c, "idx_bin_count", idx_bin_count, NFINE, BIN_THREADS, 0, (const uint64_t*)d_e2, (const uint32_t*)d_fbase, idx->d_starts, d_bintot);
+    uint32_t *d_subbase, *d_cur3;
+    if (c->scratch("ix_subbase", sizeof(uint32_t) * ((size_t)NFINE * NSUB + 1), (void**)&d_subbase)) return -1;
+    if (c->scratch("ix_cur3", sizeof(uint32_t) * (size_t)NFINE * NSUB, (void**)&d_cur3)) return -1;
+    LAUNCH(c, "idx_bin_count", idx_bin_count, NFINE, BIN_THREADS, 0, (const uint64_t*)d_e2, (const uint32_t*)d_fbase, idx->d_starts, d_bintot,
+           d_subbase, d_cur3);
     LAUNCH(c, "idx_scan4096", idx_scan4096, 1, 1024, 0, (const uint32_t*)d_bintot, d_binout);
+    if (gx3) LAUNCH(c, "idx_scatter3", idx_scatter3, dim3(gx3, NFINE), IDX_BLOCK, 0, (const uint64_t*)d_e2, (const uint32_t*)d_fbase, d_cur3, d_e1);
+    LAUNCH(c, "idx_bin_starts", idx_bin_starts, NFINE, BIN_THREADS, 0, (const uint32_t*)d_binout, idx->d_starts);
     uint32_t total = 0;
     HIPCHK(hipMemcpyAsync(&total, d_binout + NFINE, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     idx->num_kmers = total;
-    TRACE("bin_count");
+    TRACE("count+scatter3");
     if (dev_alloc_recycled(c->device, sizeof(int32_t) * ((size_t)total + 64), (void**)&idx->d_offsets, &idx->cap_offsets)) return -1;
     TRACE("malloc offsets");
-    LAUNCH(c, "idx_bin_fill", idx_bin_fill, NFINE, BIN_THREADS, 0, (const uint64_t*)d_e2, (const uint32_t*)d_fbase, (const uint32_t*)d_binout,
-           idx->d_starts, idx->d_offsets);
     HIPCHK(hipMemcpyAsync(idx->d_starts + NKMER, d_binout + NFINE, sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    LAUNCH(c, "idx_sub_fill", idx_sub_fill, NFINE * NSUB, SUB_THREADS, 0, (const uint64_t*)d_e1, (const uint32_t*)d_subbase,
+           (const uint32_t*)idx->d_starts, idx->d_offsets);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     TRACE("bin_fill");

@@ -445,6 +445,12 @@ __device__ __forceinline__ bool ddf_find(int dloc, int dseed, double cutoff) {
     return (double)fabsf(r) < cutoff;
 }
 
+// ddf_find for cutoff == 0.25 (the reference's value in every mode) without the division.  dloc, dseed > 0 are small
+// integers, so x = dloc / (10 dseed) is never within a rounding error of 0.75 or 1.25 unless it equals them
+// (|x - 1.25| >= 1 / (40 dseed) >= 7.6e-7 for dseed < 32768, half an f32 ulp there is 6e-8): q = RN(x) satisfies
+// 0.75 < q < 1.25 exactly when x does; q - 1 is exact for q in [0.5, 2] (Sterbenz) and |RN(q - 1)| >= 0.5 outside.
+__device__ __forceinline__ bool ddf_find_quarter(int dloc, int dseed) { return 2 * dloc > 15 * dseed && 2 * dloc < 25 * dseed; }
+
 // insert_loc replay for one overflowed segment by one wave.  Events e = 40.. c-1 (0-based) arrive one by one.
 // lane i (< 40) holds list entry i.  Writes the final 40 entries to fin[] and the score after each event to esc[].
 __device__ void replay_overflow(const uint32_t* __restrict__ ev, int c, uint32_t* __restrict__ fin, uint16_t* __restrict__ esc,
@@ -697,16 +703,28 @@ __global__ __launch_bounds__(WAVE) void seed_cand(SeedArrays A, const mhip_offse
             const int l0 = i0 < k ? T->t_loc[i0] : 0, d0 = i0 < k ? T->t_seed[i0] : 0;
             const int l1 = i1 < k ? T->t_loc[i1] : 0, d1 = i1 < k ? T->t_seed[i1] : 0;
             int temp0 = d0, temp1 = d1, sc0 = 0, sc1 = 0;
-            for (int j = 1; j < k; ++j) {
-                const int lj = T->t_loc[j], dj = T->t_seed[j];
-                bool v0 = i0 < j && temp0 != dj && dj - d0 > 0 && lj - l0 > 0 && lj - l0 < read_size && ddf_find(lj - l0, dj - d0, cutoff);
-                bool v1 = i1 < j && i1 < k && temp1 != dj && dj - d1 > 0 && lj - l1 > 0 && lj - l1 < read_size && ddf_find(lj - l1, dj - d1, cutoff);
-                if (v0) { ++sc0; temp0 = dj; }
-                if (v1) { ++sc1; temp1 = dj; }
-                int votes = __popcll(__ballot(v0)) + __popcll(__ballot(v1));
-                if (j < 64) { if (lane == j) sc0 += votes; }
-                else if (lane == j - 64) sc1 += votes;
-            }
+            // entries 64.. exist only when both lists are long (k <= 80); most segment pairs fit one entry per lane
+            const int k0 = min(k, 64);
+            auto vote_loops = [&](auto ddf) {
+                for (int j = 1; j < k0; ++j) {
+                    const int lj = T->t_loc[j], dj = T->t_seed[j];
+                    bool v0 = i0 < j && temp0 != dj && dj - d0 > 0 && lj - l0 > 0 && lj - l0 < read_size && ddf(lj - l0, dj - d0);
+                    if (v0) { ++sc0; temp0 = dj; }
+                    const int votes = __popcll(__ballot(v0));
+                    if (lane == j) sc0 += votes;
+                }
+                for (int j = 64; j < k; ++j) {
+                    const int lj = T->t_loc[j], dj = T->t_seed[j];
+                    bool v0 = temp0 != dj && dj - d0 > 0 && lj - l0 > 0 && lj - l0 < read_size && ddf(lj - l0, dj - d0);
+                    bool v1 = i1 < j && temp1 != dj && dj - d1 > 0 && lj - l1 > 0 && lj - l1 < read_size && ddf(lj - l1, dj - d1);
+                    if (v0) { ++sc0; temp0 = dj; }
+                    if (v1) { ++sc1; temp1 = dj; }
+                    const int votes = __popcll(__ballot(v0)) + __popcll(__ballot(v1));
+                    if (lane == j - 64) sc1 += votes;
+                }
+            };
+            if (cutoff == 0.25) vote_loops([](int dloc, int dseed) { return ddf_find_quarter(dloc, dseed); });
+            else vote_loops([&](int dloc, int dseed) { return ddf_find(dloc, dseed, cutoff); });
             int mv = max(i0 < k ? sc0 : -1, i1 < k ? sc1 : -1);
             for (int o = 32; o > 0; o >>= 1) mv = max(mv, __shfl_xor(mv, o));
             const int maxval = mv;

@@ -6,7 +6,7 @@
 // (mecat2pw/pw_impl.cpp:509-531).  What the reference does in its pthread workers (pw_impl.cpp:623-818) is done by three
 // calls into libmecat_hip.so per (reference volume, query volume) grid cell: index build, seed_reads, align_candidates.
 // Record assembly, the per-read m4 post-filter (std::sort + containment, pw_impl.cpp:539-610) and text output stay on
-// the host.  There is no CPU fallback for the kernels: any failure aborts with the library's message.
+// the host (`-t` threads; the same option sizes the FASTA reader's thread pool).  There is no CPU fallback for the kernels: any failure aborts with the library's message.
 //
 // Additive, environment-only knobs:  MECAT_HIP_DEVICE=<n> (default 0),  MECAT_HIP_SLAB=<reads per seed call>.
 #include <stdint.h>
@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "mecat_hip.h"
@@ -80,14 +81,13 @@ static void check_records_containment(const M4Record* v, int s, int e, std::vect
     }
 }
 
-struct OutBuf {
-    FILE* f;
-    std::vector<char> buf;
-    size_t n = 0;
-    explicit OutBuf(FILE* file) : f(file), buf(8u << 20) {}
-    void room(size_t need) { if (n + need > buf.size()) flush(); }
-    void flush() { if (n && fwrite(buf.data(), 1, n, f) != n) DIE("write error!"); n = 0; }
-};
+template <typename F>
+static void run_threads(int nt, F f) {
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(f, t);
+    f(0);
+    for (auto& x : th) x.join();
+}
 
 static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, const std::vector<std::string>& vn, FILE* out) {
     mhip_params P;
@@ -109,13 +109,11 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
 
     const char* slab_env = getenv("MECAT_HIP_SLAB");
     const int slab = slab_env ? std::max(1, atoi(slab_env)) : 20000;
-    OutBuf ob(out);
     std::vector<mhip_candidate> cands;
     std::vector<int32_t> counts;
     std::vector<mhip_aln_job> jobs;
+    std::vector<size_t> jfirst;
     std::vector<mhip_aln_result> res;
-    std::vector<M4Record> m4v;
-    std::vector<int> valid;
 
     for (int vid = svid; vid < (int)vn.size(); ++vid) {
         char info[64];
@@ -143,26 +141,40 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
             cands.resize((size_t)nr * P.maxc);
             counts.resize((size_t)nr);
             MCHK(mhip_seed_reads(ctx, idx, dref, dreads, rb, re, &P, cands.data(), counts.data()));
+            // text assembly is per read and order preserving: thread t formats a contiguous range of the slab's reads
+            const int nt = std::max(1, std::min(opt.num_threads, 64));
+            std::vector<std::string> text((size_t)nt);
+            auto range_of = [&](int t, int* lo, int* hi) { *lo = (int)((long long)nr * t / nt); *hi = (int)((long long)nr * (t + 1) / nt); };
             if (opt.task == TASK_SEED) {
                 // candidate_detect, pw_impl.cpp:767-801 ; line format alignment.cpp:18-32
-                for (int r = 0; r < nr; ++r) {
-                    const int qsize = rd->offs[(size_t)(rb + r)].size, qid = rb + r + rd->start_read_id;
-                    for (int k = 0; k < counts[(size_t)r]; ++k) {
-                        const mhip_candidate& c = cands[(size_t)r * P.maxc + k];
-                        int qext = c.loc2, sext = c.loc1;
-                        if (qext && sext) { qext += MHIP_KMER_SIZE / 2; sext += MHIP_KMER_SIZE / 2; }
-                        const int ssize = ref.offs[(size_t)(c.readno - ref.start_read_id)].size;
-                        if (c.chain == 1) qext = qsize - 1 - qext;
-                        ob.room(160);
-                        ob.n += (size_t)snprintf(&ob.buf[ob.n], 160, "%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\n", qid, c.readno, c.chain, 0,
-                                                 qext, sext, c.score, qsize, ssize);
+                run_threads(nt, [&](int t) {
+                    int lo, hi;
+                    range_of(t, &lo, &hi);
+                    std::string& o = text[(size_t)t];
+                    char line[160];
+                    for (int r = lo; r < hi; ++r) {
+                        const int qsize = rd->offs[(size_t)(rb + r)].size, qid = rb + r + rd->start_read_id;
+                        for (int k = 0; k < counts[(size_t)r]; ++k) {
+                            const mhip_candidate& c = cands[(size_t)r * P.maxc + k];
+                            int qext = c.loc2, sext = c.loc1;
+                            if (qext && sext) { qext += MHIP_KMER_SIZE / 2; sext += MHIP_KMER_SIZE / 2; }
+                            const int ssize = ref.offs[(size_t)(c.readno - ref.start_read_id)].size;
+                            if (c.chain == 1) qext = qsize - 1 - qext;
+                            const int w = snprintf(line, sizeof(line), "%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\n", qid, c.readno, c.chain, 0, qext,
+                                                   sext, c.score, qsize, ssize);
+                            o.append(line, (size_t)w);
+                        }
                     }
-                }
+                });
+                for (const std::string& o : text)
+                    if (!o.empty() && fwrite(o.data(), 1, o.size(), out) != o.size()) DIE("write error!");
                 continue;
             }
             // pairwise_mapping, pw_impl.cpp:674-700
             jobs.clear();
-            for (int r = 0; r < nr; ++r)
+            jfirst.assign((size_t)nr + 1, 0);
+            for (int r = 0; r < nr; ++r) {
+                jfirst[(size_t)r] = jobs.size();
                 for (int k = 0; k < counts[(size_t)r]; ++k) {
                     const mhip_candidate& c = cands[(size_t)r * P.maxc + k];
                     mhip_aln_job j;
@@ -174,60 +186,69 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
                     if (j.qstart && j.sstart) { j.qstart += MHIP_KMER_SIZE / 2; j.sstart += MHIP_KMER_SIZE / 2; }
                     jobs.push_back(j);
                 }
+            }
+            jfirst[(size_t)nr] = jobs.size();
             res.resize(jobs.size());
             // aligner by technology (pw_impl.cpp:638-644): DiffAligner (dw) for PacBio, XdropAligner for nanopore
             if (opt.tech == TECH_NANOPORE) MCHK(mhip_xalign_candidates(ctx, dref, dreads, jobs.data(), (int)jobs.size(), P.min_align_size, res.data()));
             else MCHK(mhip_align_candidates(ctx, dref, dreads, jobs.data(), (int)jobs.size(), P.min_align_size, res.data()));
-            size_t ji = 0;
-            for (int r = 0; r < nr; ++r) {
-                const int qsize = rd->offs[(size_t)(rb + r)].size, qid = rb + r + rd->start_read_id;
-                m4v.clear();
-                for (int k = 0; k < counts[(size_t)r]; ++k, ++ji) {
-                    const mhip_aln_result& a = res[ji];
-                    if (!a.ok) continue;
-                    const mhip_candidate& c = cands[(size_t)r * P.maxc + k];
-                    const mhip_aln_job& j = jobs[ji];
-                    const int ssize = ref.offs[(size_t)j.sid_local].size;
-                    M4Record m;     // fill_m4record, pw_impl.cpp:467-506
-                    m.qid = c.readno;
-                    m.sid = qid;
-                    m.ident = a.columns == 0 ? 0.0 : 100.0 * a.matches / a.columns;   // OutputStore::calc_ident / XdropAligner::calc_ident
-                    m.vscore = c.score;
-                    m.qdir = 0;
-                    m.qoff = a.target_start;
-                    m.qend = a.target_end;
-                    m.qsize = ssize;
-                    m.ssize = qsize;
-                    m.qext = j.sstart;
-                    if (c.chain == 0) { m.sdir = 0; m.soff = a.query_start; m.send = a.query_end; m.sext = j.qstart; }
-                    else { m.sdir = 1; m.soff = qsize - a.query_end; m.send = qsize - a.query_start; m.sext = qsize - 1 - j.qstart; }
-                    m4v.push_back(m);
+            run_threads(nt, [&](int t) {
+                int lo, hi;
+                range_of(t, &lo, &hi);
+                std::string& o = text[(size_t)t];
+                std::vector<M4Record> m4v;
+                std::vector<int> valid;
+                char line[320];
+                for (int r = lo; r < hi; ++r) {
+                    const int qsize = rd->offs[(size_t)(rb + r)].size, qid = rb + r + rd->start_read_id;
+                    size_t ji = jfirst[(size_t)r];
+                    m4v.clear();
+                    for (int k = 0; k < counts[(size_t)r]; ++k, ++ji) {
+                        const mhip_aln_result& a = res[ji];
+                        if (!a.ok) continue;
+                        const mhip_candidate& c = cands[(size_t)r * P.maxc + k];
+                        const mhip_aln_job& j = jobs[ji];
+                        const int ssize = ref.offs[(size_t)j.sid_local].size;
+                        M4Record m;     // fill_m4record, pw_impl.cpp:467-506
+                        m.qid = c.readno;
+                        m.sid = qid;
+                        m.ident = a.columns == 0 ? 0.0 : 100.0 * a.matches / a.columns;   // OutputStore::calc_ident / XdropAligner::calc_ident
+                        m.vscore = c.score;
+                        m.qdir = 0;
+                        m.qoff = a.target_start;
+                        m.qend = a.target_end;
+                        m.qsize = ssize;
+                        m.ssize = qsize;
+                        m.qext = j.sstart;
+                        if (c.chain == 0) { m.sdir = 0; m.soff = a.query_start; m.send = a.query_end; m.sext = j.qstart; }
+                        else { m.sdir = 1; m.soff = qsize - a.query_end; m.send = qsize - a.query_start; m.sext = qsize - 1 - j.qstart; }
+                        m4v.push_back(m);
+                    }
+                    // append_m4v, pw_impl.cpp:576-610
+                    std::sort(m4v.begin(), m4v.end(), CmpM4ByQidAndOvlpSize());
+                    const int n = (int)m4v.size();
+                    valid.assign((size_t)n, 1);
+                    for (int i = 0; i < n;) {
+                        int e = i + 1;
+                        while (e < n && m4v[(size_t)e].qid == m4v[(size_t)i].qid) ++e;
+                        if (e - i > 1) check_records_containment(m4v.data(), i, e, valid);
+                        i = e;
+                    }
+                    for (int i = 0; i < n; ++i) {
+                        if (!valid[(size_t)i]) continue;
+                        const M4Record& m = m4v[(size_t)i];
+                        int w = snprintf(line, 256, "%lld\t%lld\t%g\t%d\t%d\t%lld\t%lld\t%lld\t%d\t%lld\t%lld\t%lld", (long long)m.qid,
+                                         (long long)m.sid, m.ident, m.vscore, m.qdir, (long long)m.qoff, (long long)m.qend,
+                                         (long long)m.qsize, m.sdir, (long long)m.soff, (long long)m.send, (long long)m.ssize);
+                        if (opt.output_gapped_start_point) w += snprintf(line + w, 64, "\t%lld\t%lld", (long long)m.qext, (long long)m.sext);
+                        line[w++] = '\n';
+                        o.append(line, (size_t)w);
+                    }
                 }
-                // append_m4v, pw_impl.cpp:576-610
-                std::sort(m4v.begin(), m4v.end(), CmpM4ByQidAndOvlpSize());
-                const int n = (int)m4v.size();
-                valid.assign((size_t)n, 1);
-                for (int i = 0; i < n;) {
-                    int e = i + 1;
-                    while (e < n && m4v[(size_t)e].qid == m4v[(size_t)i].qid) ++e;
-                    if (e - i > 1) check_records_containment(m4v.data(), i, e, valid);
-                    i = e;
-                }
-                for (int i = 0; i < n; ++i) {
-                    if (!valid[(size_t)i]) continue;
-                    const M4Record& m = m4v[(size_t)i];
-                    ob.room(320);
-                    char* p = &ob.buf[ob.n];
-                    int w = snprintf(p, 256, "%lld\t%lld\t%g\t%d\t%d\t%lld\t%lld\t%lld\t%d\t%lld\t%lld\t%lld", (long long)m.qid,
-                                     (long long)m.sid, m.ident, m.vscore, m.qdir, (long long)m.qoff, (long long)m.qend,
-                                     (long long)m.qsize, m.sdir, (long long)m.soff, (long long)m.send, (long long)m.ssize);
-                    if (opt.output_gapped_start_point) w += snprintf(p + w, 64, "\t%lld\t%lld", (long long)m.qext, (long long)m.sext);
-                    p[w++] = '\n';
-                    ob.n += (size_t)w;
-                }
-            }
+            });
+            for (const std::string& o : text)
+                if (!o.empty() && fwrite(o.data(), 1, o.size(), out) != o.size()) DIE("write error!");
         }
-        ob.flush();
         if (dreads != dref) mhip_volume_free(dreads);
     }
     mhip_index_free(idx);
@@ -248,7 +269,7 @@ int main(int argc, char* argv[]) {
         print_usage(argv[0]);
         return 1;
     }
-    const int num_vols = split_raw_dataset(opt.reads, opt.wrk_dir);
+    const int num_vols = split_raw_dataset(opt.reads, opt.wrk_dir, opt.num_threads);
     const std::string idx_name = index_file_name(opt.wrk_dir);
     printf("%s\n", idx_name.c_str());
     const std::vector<std::string> vn = load_volume_names(idx_name);

@@ -13,10 +13,16 @@
 #include <ctype.h>
 
 #include <algorithm>
+#include <atomic>
+#include <fcntl.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <sys/time.h>
+#include <thread>
+#include <unistd.h>
 
 #define DIE(...)                                                  \
     do {                                                          \
@@ -165,6 +171,153 @@ void dump_volume(const std::string& path, const HostVolume& v) {
     if (fclose(out) != 0 || !ok) DIE("write error!");
 }
 
+template <typename F>
+void run_threads(int nt, F f) {
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(f, t);
+    f(0);
+    for (auto& x : th) x.join();
+}
+
+struct PlainRec { size_t data; int len; };     // first byte after the header line, number of residues
+
+// Parallel reader for plain FASTA (see volume.h).  Returns false, touching nothing, if the file is anything else.
+bool split_plain_fasta(const char* reads, const char* wrk_dir, long max_volume_bases, int nt, int* out_vols, long long* out_reads,
+                       long long* out_nucls) {
+    const int fd = open(reads, O_RDONLY);
+    if (fd < 0) return false;                       // the sequential reader reports the error
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size <= 1 || !S_ISREG(st.st_mode)) { close(fd); return false; }
+    const size_t size = (size_t)st.st_size;
+    const char* txt = (const char*)mmap(NULL, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (txt == MAP_FAILED) return false;
+    bool ok = txt[0] == '>';
+    nt = std::max(1, std::min(nt, 64));
+    // chunk t = records whose '>' lies in [cut[t], cut[t+1])
+    std::vector<size_t> cut((size_t)nt + 1, size);
+    cut[0] = 0;
+    for (int t = 1; t < nt && ok; ++t) {
+        size_t p = size / (size_t)nt * (size_t)t;
+        const char* q = p < size ? (const char*)memmem(txt + p, size - p, "\n>", 2) : NULL;
+        cut[(size_t)t] = q ? (size_t)(q - txt) + 1 : size;
+    }
+    std::vector<std::vector<PlainRec>> recs((size_t)nt);
+    std::atomic<int> plain(ok ? 1 : 0);
+    if (ok) run_threads(nt, [&](int t) {
+        std::vector<PlainRec>& out = recs[(size_t)t];
+        size_t p = cut[(size_t)t];
+        const size_t end = cut[(size_t)t + 1];
+        while (p < end && plain.load(std::memory_order_relaxed)) {
+            // header line: '>' + at least one character
+            const char* nl = (const char*)memchr(txt + p, '\n', size - p);
+            const size_t hend = nl ? (size_t)(nl - txt) : size;
+            if (txt[p] != '>' || hend - p < 2 || memchr(txt + p, '\r', hend - p)) { plain = 0; return; }
+            p = hend < size ? hend + 1 : size;
+            PlainRec r;
+            r.data = p;
+            long len = 0;
+            while (p < size) {                       // data lines up to the next line starting with '>'
+                const unsigned char c0 = (unsigned char)txt[p];
+                if (c0 == '>') break;
+                if (c0 == '\n') { ++p; continue; }   // empty line
+                if (c0 == '@' || c0 == '+' || c0 == '#' || c0 == '!') { plain = 0; return; }
+                size_t q = p;
+                while (q < size && txt[q] != '\n') {
+                    if (kEnc.t[(unsigned char)txt[q]] >= 16) { plain = 0; return; }     // blanks, digits, ';', '\r', bad residues
+                    ++q;
+                }
+                len += (long)(q - p);
+                p = q < size ? q + 1 : size;
+            }
+            if (len == 0 || len > 0x7fffffffL) { plain = 0; return; }
+            r.len = (int)len;
+            out.push_back(r);
+        }
+    });
+    if (!plain.load()) { munmap((void*)txt, size); return false; }
+
+    // volume layout: the reference's loop (split_database.cpp:240-250)
+    struct Vol { size_t first, count; long bases; };
+    std::vector<PlainRec> all;
+    for (auto& v : recs) { all.insert(all.end(), v.begin(), v.end()); std::vector<PlainRec>().swap(v); }
+    std::vector<long> at(all.size());
+    std::vector<Vol> vols;
+    long curr = 0;
+    size_t first = 0;
+    long long nucls = 0;
+    for (size_t i = 0; i < all.size(); ++i) {
+        const long rsize = all[i].len;
+        nucls += rsize;
+        if (curr + rsize + 1 > max_volume_bases) { vols.push_back(Vol{first, i - first, curr}); first = i; curr = 0; }
+        at[i] = curr;
+        curr += rsize + 1;
+    }
+    if (curr > 0) vols.push_back(Vol{first, all.size() - first, curr});
+
+    const std::string idx_name = index_file_name(wrk_dir);
+    FILE* idx_file = fopen(idx_name.c_str(), "w");
+    if (!idx_file) DIE("cannot open '%s' for writing", idx_name.c_str());
+    int rid = 0;
+    HostVolume v;
+    for (size_t k = 0; k < vols.size(); ++k) {
+        const Vol& vo = vols[k];
+        v.num_bases = (int)vo.bases;
+        v.num_reads = (int)vo.count;
+        v.start_read_id = rid;
+        rid += v.num_reads;
+        v.offs.resize(vo.count);
+        v.pac.assign(((size_t)vo.bases + 3) / 4, 0);
+        // thread t packs a contiguous range of reads holding ~1/nt of the volume's bases
+        std::vector<size_t> rcut((size_t)nt + 1, vo.count);
+        rcut[0] = 0;
+        for (int t = 1; t < nt; ++t) {
+            const long want = vo.bases / nt * t;
+            rcut[(size_t)t] = (size_t)(std::lower_bound(at.begin() + (long)vo.first, at.begin() + (long)(vo.first + vo.count), want) -
+                                       (at.begin() + (long)vo.first));
+        }
+        run_threads(nt, [&](int t) {
+            uint8_t* pac = v.pac.data();
+            for (size_t i = rcut[(size_t)t]; i < rcut[(size_t)t + 1]; ++i) {
+                const PlainRec& r = all[vo.first + i];
+                long pos = at[vo.first + i];
+                v.offs[i].offset = (int)pos;
+                v.offs[i].size = r.len;
+                const long last = pos + r.len - 1;
+                const size_t b_first = (size_t)(pos >> 2), b_last = (size_t)(last >> 2);
+                size_t bi = b_first;
+                uint8_t acc = 0;
+                auto put = [&]() {
+                    // bytes at a read's ends may be shared with the neighbouring read (another thread's, possibly)
+                    if (bi == b_first || bi == b_last) __atomic_fetch_or(&pac[bi], acc, __ATOMIC_RELAXED);
+                    else pac[bi] = acc;
+                };
+                const char* q = txt + r.data;
+                long left = r.len;
+                while (left > 0) {
+                    const unsigned char ch = (unsigned char)*q++;
+                    if (ch == '\n') continue;
+                    const size_t b = (size_t)(pos >> 2);
+                    if (b != bi) { put(); bi = b; acc = 0; }
+                    acc |= (uint8_t)(kEnc.t[ch] << ((~pos & 3) << 1));       // PackedDB::set_char, unmasked
+                    ++pos;
+                    --left;
+                }
+                put();
+            }
+        });
+        const std::string name = volume_file_name(wrk_dir, (int)k);
+        fprintf(idx_file, "%s\n", name.c_str());
+        dump_volume(name, v);
+    }
+    fclose(idx_file);
+    munmap((void*)txt, size);
+    *out_vols = (int)vols.size();
+    *out_reads = (long long)all.size();
+    *out_nucls = nucls;
+    return true;
+}
+
 }  // namespace
 
 std::string volume_file_name(const char* wrk_dir, int vol) {
@@ -182,18 +335,29 @@ std::string index_file_name(const char* wrk_dir) {
     return s;
 }
 
-int split_raw_dataset(const char* reads, const char* wrk_dir) {
+int split_raw_dataset(const char* reads, const char* wrk_dir, int num_threads) {
     struct timeval t0, t1;
     fprintf(stderr, "[%s] begins.\n", __func__);
     gettimeofday(&t0, NULL);
+    // testing knob (additive, environment only): smaller volumes so the multi-volume grid can be exercised on small inputs
+    long max_volume_bases = kMaxVolumeBases;
+    if (const char* e = getenv("MECAT_HIP_MCS")) { long v2 = atol(e); if (v2 > 0 && v2 < kMaxVolumeBases) max_volume_bases = v2; }
+    {
+        const char* mode = getenv("MECAT_HIP_SPLIT");
+        int pv = 0;
+        long long pr = 0, pn = 0;
+        if (!(mode && strcmp(mode, "seq") == 0) && split_plain_fasta(reads, wrk_dir, max_volume_bases, num_threads, &pv, &pr, &pn)) {
+            gettimeofday(&t1, NULL);
+            fprintf(stderr, "[%s, %u] split '%s' (%lld reads, %lld nucls) into %d volumes.\n", __func__, __LINE__, reads, pr, pn, pv);
+            fprintf(stderr, "[%s] takes %.2f secs.\n", __func__, t1.tv_sec - t0.tv_sec + 1e-6 * (t1.tv_usec - t0.tv_usec));
+            return pv;
+        }
+    }
     HostVolume v;
     int vol = 0, rid = 0;
     const std::string idx_name = index_file_name(wrk_dir);
     FILE* idx_file = fopen(idx_name.c_str(), "w");
     if (!idx_file) DIE("cannot open '%s' for writing", idx_name.c_str());
-    // testing knob (additive, environment only): smaller volumes so the multi-volume grid can be exercised on small inputs
-    long max_volume_bases = kMaxVolumeBases;
-    if (const char* e = getenv("MECAT_HIP_MCS")) { long v2 = atol(e); if (v2 > 0 && v2 < kMaxVolumeBases) max_volume_bases = v2; }
     LineReader lr(reads);
     std::string seq;
     long long num_reads = 0, num_nucls = 0;

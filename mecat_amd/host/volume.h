@@ -21,8 +21,11 @@ struct HostVolume {
 };
 
 // Splits `reads` into volumes inside `wrk_dir`; returns the number of volumes.  Aborts with the reference's messages on
-// malformed input (FastaReader, common/fasta_reader.cpp:6-130).
-int split_raw_dataset(const char* reads, const char* wrk_dir);
+// malformed input (FastaReader, common/fasta_reader.cpp:6-130).  Plain FASTA ('>' records, '\n' line ends, residue
+// letters only) is scanned and packed by `num_threads` threads over the mapped file; anything else (FASTQ, comments,
+// '\r', blanks inside lines, invalid residues ...) goes through the sequential reader that reproduces the reference's
+// grammar and error messages.  Both produce the same bytes.  MECAT_HIP_SPLIT=seq forces the sequential reader.
+int split_raw_dataset(const char* reads, const char* wrk_dir, int num_threads = 1);
 
 std::string volume_file_name(const char* wrk_dir, int vol);      // generate_vol_file_name, split_database.cpp:183-192
 std::string index_file_name(const char* wrk_dir);                // generate_idx_file_name, split_database.cpp:194-200

@@ -114,3 +114,35 @@ def test_cli_rejects_malformed_input(tmp_path):
     assert r.returncode != 0 and "sequence data is missing" in r.stderr
     r, _ = _run_split(tmp_path, b">a\nACGT@ACGT\n", "bad.fa")
     assert r.returncode != 0 and "invalid residue" in r.stderr
+
+
+def test_cli_threaded_reader_equals_sequential_reader(tmp_path):
+    """plain FASTA goes through the threaded mmap reader; its volumes must equal the sequential (reference-grammar) reader's:
+    ragged multi-line records, empty lines, ambiguity codes (unmasked OR quirk), lower case, no final newline, several
+    volumes, more threads than records"""
+    rng = np.random.default_rng(7)
+    recs = []
+    for i in range(137):
+        n = int(rng.integers(1, 400))
+        seq = "".join(rng.choice(list("ACGTacgtNnRYKM-"), size=n, p=[.2, .2, .2, .2, .03, .03, .03, .03, .02, .01, .01, .01, .01, .01, .01]))
+        w = int(rng.integers(1, 80))
+        lines = [seq[j:j + w] for j in range(0, n, w)]
+        if i % 5 == 0:
+            lines.insert(len(lines) // 2, "")
+        recs.append(">r%d some text > with a bracket\n" % i + "\n".join(lines))
+    text = ("\n".join(recs)).encode()            # no trailing newline
+    fa = tmp_path / "ragged.fa"
+    fa.write_bytes(text)
+    outs = {}
+    for tag, env, threads in (("seq", {"MECAT_HIP_SPLIT": "seq"}, "1"), ("t1", {}, "1"), ("t7", {}, "7"), ("t64", {}, "64")):
+        wrk = tmp_path / ("w_" + tag)
+        e = dict(os.environ, MECAT_HIP_MCS="3000", **env)
+        r = subprocess.run([BIN, "-j", "0", "-d", str(fa), "-o", str(tmp_path / "o"), "-w", str(wrk), "-t", threads], capture_output=True,
+                           text=True, env=e)
+        assert "split '" in r.stderr, r.stderr
+        names = [ln.strip() for ln in open(wrk / "fileindex.txt")]
+        outs[tag] = (r.stderr.split("split '")[1].split("\n")[0].split("(")[1], [open(n, "rb").read() for n in names])
+        assert len(names) > 5
+    for tag in ("t1", "t7", "t64"):
+        assert outs[tag][0] == outs["seq"][0], tag            # "(N reads, M nucls) into V volumes."
+        assert outs[tag][1] == outs["seq"][1], tag

@@ -77,6 +77,7 @@ struct SeedArrays {
 };
 
 #define OVF_FLAG 0x40000000
+#define GATE_LDS 2048                // gated segments whose first-touch times fit the LDS stage of seed_build
 
 __device__ __forceinline__ int kmers_of(int L) { return L < MHIP_KMER_SIZE ? 0 : (L - MHIP_KMER_SIZE) / BC + 1; }
 
@@ -504,6 +505,7 @@ __device__ void replay_overflow(const uint32_t* __restrict__ ev, int c, uint32_t
 __global__ __launch_bounds__(SEED_BLOCK) void seed_build(SeedArrays A, int sorted_in_b, int min_kmer_match, double cutoff) {
     __shared__ uint32_t wtot[SEED_WAVES];
     __shared__ uint32_t s_cnt[4];          // 0: overflow count, 1: gated count
+    __shared__ uint64_t s_tf[GATE_LDS];    // first-touch times of the gated segments (phase E)
     const int s = blockIdx.x;
     const uint32_t H = A.strand_hits[s];
     const uint64_t hb = A.hit_base[s];
@@ -605,12 +607,23 @@ __global__ __launch_bounds__(SEED_BLOCK) void seed_build(SeedArrays A, int sorte
     // ---- phase E: order gated segments by first-touch time (rank sort; first-touch times are unique)
     {
         const uint32_t ng = s_cnt[1];
-        for (uint32_t a = threadIdx.x; a < ng; a += SEED_BLOCK) {
-            uint32_t ga = (uint32_t)gate_tmp[a];
-            uint64_t ta = seg_tfirst[ga];
-            uint32_t rank = 0;
-            for (uint32_t b = 0; b < ng; ++b) rank += seg_tfirst[(uint32_t)gate_tmp[b]] < ta ? 1u : 0u;
-            gated[rank] = ga;
+        if (ng <= GATE_LDS) {       // the usual case (~250 gated segments): times staged in LDS, ranks from broadcast reads
+            for (uint32_t a = threadIdx.x; a < ng; a += SEED_BLOCK) s_tf[a] = seg_tfirst[(uint32_t)gate_tmp[a]];
+            __syncthreads();
+            for (uint32_t a = threadIdx.x; a < ng; a += SEED_BLOCK) {
+                const uint64_t ta = s_tf[a];
+                uint32_t rank = 0;
+                for (uint32_t b = 0; b < ng; ++b) rank += s_tf[b] < ta ? 1u : 0u;
+                gated[rank] = (uint32_t)gate_tmp[a];
+            }
+        } else {
+            for (uint32_t a = threadIdx.x; a < ng; a += SEED_BLOCK) {
+                uint32_t ga = (uint32_t)gate_tmp[a];
+                uint64_t ta = seg_tfirst[ga];
+                uint32_t rank = 0;
+                for (uint32_t b = 0; b < ng; ++b) rank += seg_tfirst[(uint32_t)gate_tmp[b]] < ta ? 1u : 0u;
+                gated[rank] = ga;
+            }
         }
         if (threadIdx.x == 0) A.ngated[s] = ng;
     }

@@ -192,3 +192,61 @@ def test_empty_and_short_reads(hip, ctx):
     assert cnt[6] >= 1     # the duplicate read finds its twin
     gi.free()
     gv.free()
+
+
+def test_tandem_repeats_match_oracle(hip, ctx):
+    """two reads share a 420-bp period-7 tandem repeat: every repeat k-mer has a kept bucket (120 <= 128 occurrences) and one
+    query strand puts ~2500 bucket hits into one 2 kb segment (the relevance filter's byte counters wrap -> that strand is
+    processed unfiltered), the segment collects more than 40 seeds (insert_loc overflow replay on non-self hits)"""
+    rng = np.random.default_rng(11)
+    G0 = rng.integers(0, 4, size=30000).astype(np.uint8)
+    unit = np.array([0, 1, 2, 3, 3, 2, 0], dtype=np.uint8)
+    G0[5000:5420] = np.tile(unit, 60)
+    spans = [(3000, 7000), (4000, 8000)]                       # the only two reads covering the repeat
+    for i in range(40):
+        L = int(rng.integers(2500, 4000))
+        st = int(rng.integers(5500, len(G0) - L)) if i % 4 else int(rng.integers(0, 4900 - L))
+        spans.append((st, st + L))
+    reads = []
+    for i, (a0, b0) in enumerate(spans):
+        r = G0[a0:b0].copy()
+        if i >= 2:
+            m = rng.random(len(r)) < 0.05
+            r[m] = (r[m] + rng.integers(1, 4, size=int(m.sum()))) % 4
+        if i % 3 == 2:
+            r = (3 - r)[::-1].copy()
+        reads.append(r.astype(np.uint8))
+    lens = np.array([len(r) for r in reads], dtype=np.int32)
+    codes = np.concatenate(reads)
+    ov = H.orc_pack(codes, lens)
+    oidx = H.orc().orc_index_build(ov)
+    offs, pac = H.vol_arrays(ov)
+    gv = hip.Volume(ctx, pac, offs, ov.contents.num_bases, 0)
+    gi = hip.Index(ctx, gv)
+    counts, offsets = gi.download()
+    starts = np.concatenate([[0], np.cumsum(counts, dtype=np.int64)])
+    # the test's premise, checked on the index itself: hits of read 1's forward strand per hashed 2 kb segment
+    r1 = reads[1]
+    slot_hits = np.zeros(1 << 15, dtype=np.int64)
+    for i in range(0, len(r1) - 12, 10):
+        km = 0
+        for c in r1[i:i + 13]:
+            km = (km << 2) | int(c)
+        pos = offsets[starts[km]:starts[km + 1]]
+        np.add.at(slot_hits, (pos // 2000) & 0x7FFF, 1)
+    assert slot_hits.max() >= 256, slot_hits.max()
+    for maxc in (100, 7):
+        p = hip.default_params(0, maxc=maxc)
+        got, cnt = hip.seed_reads(ctx, gi, gv, gv, 0, len(lens), p)
+        want = H.orc_seed_all(ov, ov, oidx, H.orc_params(tech=0, maxc=maxc))
+        bad = _cmp_cands(got, cnt, want)
+        assert not bad, "reads %s differ" % bad[:5]
+        assert int(cnt.sum()) > 20
+        os.environ["MECAT_SEED_FILTER"] = "0"
+        try:
+            got2, cnt2 = hip.seed_reads(ctx, gi, gv, gv, 0, len(lens), p)
+        finally:
+            del os.environ["MECAT_SEED_FILTER"]
+        assert np.array_equal(cnt, cnt2) and not _cmp_cands(got2, cnt2, want)
+    gi.free()
+    gv.free()

@@ -34,6 +34,12 @@ def main():
             if col == 1:
                 tot[k][0] += 1
             tot[k][col] += float(r["Counter_Value"])
+    # average launch duration per kernel from the kernel-trace stats of the same command
+    dur = {}
+    ks = glob.glob(os.path.join(kdir, "*_kernel_stats.csv"))
+    if ks:
+        for r in csv.DictReader(open(ks[0])):
+            dur[short(r["Name"])] = float(r["AverageNs"])
     rows = sorted(tot.items(), key=lambda kv: -(kv[1][1] + kv[1][2]))
     traffic = {}
     with open(os.path.join(here, "%s_hbm_counters.md" % tag), "w") as f:
@@ -42,13 +48,18 @@ def main():
         f.write("Counter unit is KiB; bytes = value x 1024.  MI355X_MICROARCH.md (HBM): FETCH_SIZE reports half the bytes of a\n"
                 "16 B/lane coalesced streaming read and is uncalibrated for other widths; none of these kernels issues 16 B/lane\n"
                 "streams (4-8 B/lane gathers and scatters), so the values are reported uncorrected.  Infinity-Cache hits count.\n\n")
-        f.write("| kernel | launches | fetch GB / pass | write GB / pass | fetch+write MB / launch |\n|---|---|---|---|---|\n")
+        f.write("Achieved = (fetch + write) per launch / average launch duration of the kernel-trace run; peak 8 TB/s (6.3 TB/s achievable).\n\n")
+        f.write("| kernel | launches | fetch GB / pass | write GB / pass | fetch+write MB / launch | avg launch ms | achieved TB/s | of 8 TB/s |\n|---|---|---|---|---|---|---|---|\n")
         for k, (n, fk, wk) in rows:
             if "at::" in k or "rocclr" in k or "rocprim" in k.lower():
                 continue
             fb, wb = fk * 1024.0, wk * 1024.0
             traffic[k] = {"launches_per_pass": n / passes, "fetch_bytes_per_launch": fb / max(n, 1), "write_bytes_per_launch": wb / max(n, 1)}
-            f.write("| %s | %d | %.2f | %.2f | %.1f |\n" % (k, n, fb / passes / 1e9, wb / passes / 1e9, (fb + wb) / max(n, 1) / 1e6))
+            ms = dur.get(k, 0.0) / 1e6
+            tbs = ((fb + wb) / max(n, 1)) / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            traffic[k]["avg_launch_ms"] = ms
+            f.write("| %s | %d | %.2f | %.2f | %.1f | %.3f | %.2f | %.0f %% |\n" % (k, n, fb / passes / 1e9, wb / passes / 1e9, (fb + wb) / max(n, 1) / 1e6, ms,
+                                                                  tbs, 100.0 * tbs / 8.0))
     json.dump(traffic, open(os.path.join(here, "%s_hbm_traffic.json" % tag), "w"), indent=1, sort_keys=True)
 
 

@@ -550,9 +550,9 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
     int Rq = 0, Rt = 0, Rm = 0, Rc = 0, Rb = 0;
     // per-half block state
     int qblk = 0, tblk = 0, last_block = 0, band_tol = 0, max_d = 0, band_size = 0;
-    int best_m = -1, min_k = 0, max_k = 0, aligned = 0, end_x = 0, end_k = 0, end_d = 0, last_row = -1, d = 0;
+    int best_m = -1, min_k = 0, max_k = 0, aligned = 0, end_x = 0, end_k = 0, end_d = 0, d = 0;      // d = rows done
     unsigned int lin = 0;
-    bool rowing = false, ran = false;
+    bool rowing = false;
 
     while (true) {
         if (BALLOT(setup)) {
@@ -600,9 +600,9 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
                 // row 0, which reads V[k_offset + 1].
                 if (sl == 0) S.V[max_d + 1] = 0;
                 best_m = -1; min_k = 0; max_k = 0;
-                aligned = 0; end_x = 0; end_k = 0; end_d = 0; last_row = -1; d = 0;
+                aligned = 0; end_x = 0; end_k = 0; end_d = 0; d = 0;
                 lin = 0;
-                rowing = true; ran = false; inblock = true;
+                rowing = true; inblock = true;
                 setup = false;
             }
             __builtin_amdgcn_wave_barrier();
@@ -626,7 +626,6 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
             if (rowing && sl == 0) {        // row record: band limits + linear ring position, one 64-bit store
                 S.rrec[d & (RROWS - 1)] = make_uint2(((uint32_t)(uint16_t)(int16_t)min_k) | ((uint32_t)(uint16_t)(int16_t)max_k << 16), lin);
             }
-            if (rowing) { last_row = d; ran = true; }
             const int ns_a = __builtin_amdgcn_readlane(nslot, 0), ns_b = __builtin_amdgcn_readlane(nslot, 32);
             const int NJ = (max(ns_a, ns_b) + 31) >> 5;
             nwide += NJ > 1 ? 1u : 0u;
@@ -661,7 +660,6 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
                 if (j == 0) m0 = act ? x + y : -1;
             }
             lin += (unsigned)nslot;
-            cells += (unsigned long long)(ns_a + ns_b);
             __builtin_amdgcn_wave_barrier();
             // running maximum of x + y (:160-167); lowest diagonal that reached an end (:168-169)
             const int rm = half_max(mmax);
@@ -702,7 +700,7 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
 
         // ---- 4. tail traceback == trim_mismatch_end(.., 4, ..) (gapalign.cpp:47-68), for the halves whose rows just ended
         bool has_aln = fin && aligned;
-        bool fallback = fin && ran && !aligned;         // needs the best point: one-unit path
+        bool fallback = fin && d > 0 && !aligned;       // rows ran without reaching an end: needs the best point (one-unit path)
         const int end_y = end_x - end_k;
         const int aln_size = (end_x + end_y + end_d) / 2;
         int cd = end_d, ck = end_k, cx2 = end_x;
@@ -714,7 +712,7 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
                 if (cd > 0) {
                     const int r = cd - 1;
                     const uint2 pr = S.rrec[r & (RROWS - 1)], cr = S.rrec[cd & (RROWS - 1)];
-                    if (last_row - r >= RROWS || lin - pr.y > RCAP) { fallback = true; tracing = false; }
+                    if (d - 1 - r >= RROWS || lin - pr.y > RCAP) { fallback = true; tracing = false; }
                     else {
                         const int pmin = (int)(int16_t)(pr.x & 0xFFFFu), pmax = (int)(int16_t)(pr.x >> 16);
                         const int cmin = (int)(int16_t)(cr.x & 0xFFFFu), cmax = (int)(int16_t)(cr.x >> 16);
@@ -767,6 +765,7 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
         // ---- 6. block accounting (dw_in_one_direction, diff_gapalign.cpp:259-290)
         if (fin) {
             nblocks += (sl == 0) ? 1u : 0u;
+            cells += (sl == 0) ? lin : 0u;              // lin = diagonals visited in this block
             Rb += 1;
             bool stop = !has_aln || !trim_ok;
             if (!stop) {
@@ -788,7 +787,7 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
             setup = true;
         }
     }
-    for (int off = 32; off > 0; off >>= 1) nblocks += __shfl_xor(nblocks, off);
+    for (int off = 32; off > 0; off >>= 1) { nblocks += __shfl_xor(nblocks, off); cells += __shfl_xor(cells, off); }
     if (lane == 0) {
         atomicAdd(&counters[3], nblocks);
         atomicAdd(&counters[4], cells);

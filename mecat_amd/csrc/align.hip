@@ -561,7 +561,7 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
                 unsigned int u = 0;
                 if (sl == 0) u = atomicAdd(cursor, 1u);
                 u = __shfl(u, hh << 5);
-                if (u >= 2u * (unsigned)n) { exhausted = true; setup = false; }
+                if (u >= 2u * (unsigned)n) { exhausted = true; setup = false; min_k = 0; max_k = -2; }      // nslot == 0 from now on
                 else {
                     unit = u;
                     const mhip_aln_job jb = jobs[u >> 1];
@@ -622,7 +622,7 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
             if (rmask != inmask) break;
             nrows += 1;
             nidle += (rmask == ~0ull) ? 0u : 1u;
-            const int nslot = rowing ? ((max_k - min_k) >> 1) + 1 : 0;
+            const int nslot = ((max_k - min_k) >> 1) + 1;        // every half with a block is rowing here; exhausted halves: 0
             if (rowing && sl == 0) {        // row record: band limits + linear ring position, one 64-bit store
                 S.rrec[d & (RROWS - 1)] = make_uint2(((uint32_t)(uint16_t)(int16_t)min_k) | ((uint32_t)(uint16_t)(int16_t)max_k << 16), lin);
             }
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
             bool reached = false;
             for (int j = 0; j < NJ; ++j) {
                 const int tt = sl + 32 * j;
-                const bool act = rowing && tt < nslot;
+                const bool act = tt < nslot;
                 const int k = min_k + 2 * tt, kk = k + k_offset;
                 const int16_t* vp = &S.V[kk - 1];                  // idle lanes read (and ignore) in-range garbage
                 const int vl = vp[0], vr = vp[2];
@@ -663,7 +663,7 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
             __builtin_amdgcn_wave_barrier();
             // running maximum of x + y (:160-167); lowest diagonal that reached an end (:168-169)
             const int rm = half_max(mmax);
-            if (rowing && rm > best_m) best_m = rm;
+            best_m = max(best_m, rm);
             int hkey = 0x7fffffff;
             if (BALLOT(reached)) hkey = half_min(reached ? ((hkk << 10) | hx) : 0x7fffffff);
             // band update (:172-179)

@@ -158,18 +158,22 @@ def main():
         idx = M.Index(ctx, vol)
         ev[1].record(stream)
         M.seed_reads_strided_dev(ctx, idx, vol, vol, rank, world, n_local, params, d_cands.data_ptr(), d_counts.data_ptr())
-        # exchange step: RCCL all-gather of the per-read candidate slabs (48-byte candidate_save records)
-        full_cands, full_counts = S.all_gather_candidates(d_cands, d_counts, n, world)
+        # exchange step: RCCL all-gather of the per-read candidate slabs (48-byte candidate_save records); with more than one
+        # rank it runs on RCCL's stream while this rank extends the candidates of its own reads
+        pending = S.start_all_gather_candidates(d_cands, d_counts, world) if world > 1 else None
         ev[2].record(stream)
         njobs = 0
         if not args.no_align:
-            njobs = M.jobs_from_candidates_dev(ctx, full_cands.data_ptr(), full_counts.data_ptr(), n, maxc, 0, 1, 0, rank, world,
+            njobs = M.jobs_from_candidates_dev(ctx, d_cands.data_ptr(), d_counts.data_ptr(), n_local, maxc, rank, world, 0, 0, 1,
                                                d_jobs.data_ptr())
             M.align_candidates_dev(ctx, vol, vol, d_jobs.data_ptr(), njobs, params.min_align_size, d_res.data_ptr())
-            if world > 1:
-                total_jobs = int(full_counts.sum().item())
-                all_res = S.all_gather_results(d_res, njobs, total_jobs, world)   # rank 0 holds the complete overlap set
-                assert all_res.shape[0] == total_jobs
+        if world > 1:
+            full_cands, full_counts, per_rank = S.finish_all_gather_candidates(pending, n)
+            if not args.no_align:
+                all_res = S.all_gather_results_by_rank(d_res, per_rank)          # every rank holds the complete overlap set
+                assert all_res.shape[0] == int(per_rank.sum().item()) and int(per_rank[rank].item()) == njobs
+        else:
+            full_cands, full_counts = d_cands[:n], d_counts[:n]
         ev[3].record(stream)
         idx_handle = idx
         stream.synchronize()

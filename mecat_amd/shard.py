@@ -5,8 +5,10 @@ CPU tests); no compute.
 Shard: rank r of P owns query reads r, r+P, r+2P, ... (cyclic: candidates with sid > qid are dropped,
 pw_impl.cpp:370 of the reference, so work per read grows with the read id inside a diagonal cell).
 Exchange: one all-gather of the fixed-size per-read candidate slabs [ceil(n/P)][MAXC] x 48-byte candidate_save records
-plus the per-read counts; afterwards every rank holds the complete read-major table, so the extension stage can be
-re-sharded (every P-th candidate) without a second exchange of inputs.
+plus the per-read counts; afterwards every rank holds the complete read-major table.  The gather is started
+asynchronously (start_all_gather_candidates) and runs on RCCL's stream while the rank extends the candidates of its own
+reads (the cyclic read shard balances that work to ~1 %), then the per-rank result slabs are gathered
+(all_gather_results_by_rank).  The blocking variants re-shard the extension stage by candidate instead.
 """
 import torch
 import torch.distributed as dist
@@ -54,3 +56,40 @@ def all_gather_results(local_res, n_local, total_jobs, world):
     g = torch.empty((world, m, local_res.shape[1]), dtype=local_res.dtype, device=local_res.device)
     dist.all_gather_into_tensor(g.view(-1), slab.view(-1))
     return g.transpose(0, 1).reshape(m * world, local_res.shape[1])[:total_jobs].contiguous()
+
+
+def start_all_gather_candidates(local_cands, local_counts, world):
+    """Asynchronous form of all_gather_candidates: returns a pending object for finish_all_gather_candidates.  The
+    collective waits for the work already queued on the current stream and then proceeds on the backend's own stream."""
+    n_pad, maxc, w = local_cands.shape
+    g_counts = torch.empty((world, n_pad), dtype=local_counts.dtype, device=local_counts.device)
+    g_cands = torch.empty((world, n_pad, maxc, w), dtype=local_cands.dtype, device=local_cands.device)
+    h1 = dist.all_gather_into_tensor(g_counts.view(-1), local_counts.contiguous().view(-1), async_op=True)
+    h2 = dist.all_gather_into_tensor(g_cands.view(-1), local_cands.contiguous().view(-1), async_op=True)
+    return (h1, h2, g_counts, g_cands)
+
+
+def finish_all_gather_candidates(pending, n_reads):
+    """-> (cands [n_reads, maxc, 12], counts [n_reads]) read-major, and the per-rank candidate totals [world]"""
+    h1, h2, g_counts, g_cands = pending
+    h1.wait()
+    h2.wait()
+    world, n_pad = g_counts.shape
+    maxc, w = g_cands.shape[2], g_cands.shape[3]
+    counts = g_counts.transpose(0, 1).reshape(-1)[:n_reads].contiguous()
+    cands = g_cands.transpose(0, 1).reshape(n_pad * world, maxc, w)[:n_reads].contiguous()
+    return cands, counts, g_counts.sum(dim=1)
+
+
+def all_gather_results_by_rank(local_res, per_rank_jobs):
+    """local_res [cap, 8] with the first per_rank_jobs[rank] rows valid (the rank's own reads, read-major).  Returns the
+    rows of all ranks, rank-major, [sum(per_rank_jobs), 8] on every rank.  per_rank_jobs: 1-D tensor or list, length world."""
+    per = [int(x) for x in per_rank_jobs]
+    world = len(per)
+    rank = dist.get_rank()
+    m = max(max(per), 1)
+    slab = torch.zeros((m, local_res.shape[1]), dtype=local_res.dtype, device=local_res.device)
+    slab[: per[rank]] = local_res[: per[rank]]
+    g = torch.empty((world, m, local_res.shape[1]), dtype=local_res.dtype, device=local_res.device)
+    dist.all_gather_into_tensor(g.view(-1), slab.view(-1))
+    return torch.cat([g[r, : per[r]] for r in range(world)], dim=0)

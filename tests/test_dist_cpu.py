@@ -59,7 +59,20 @@ def _worker(rank, world, port, out_dir):
     res[: len(my_jobs), 0] = my_jobs.int()
     res[: len(my_jobs), 1] = read_of_job[my_jobs].int()
     allres = S.all_gather_results(res, len(my_jobs), total, world)
-    torch.save({"cands": full_cands, "counts": full_counts, "res": allres}, os.path.join(out_dir, "r%d.pt" % rank))
+    # overlapped form used by bench.py: asynchronous gather, the rank extends its own reads, results gathered rank-major
+    pending = S.start_all_gather_candidates(cands, counts, world)
+    n_mine = int(counts.sum())
+    res2 = torch.zeros((n_mine + 5, 8), dtype=torch.int32)
+    k = 0
+    for i in range(n_local):
+        for j in range(int(counts[i])):
+            res2[k, 0], res2[k, 1], res2[k, 2] = rank, rank + i * world, j      # (rank, read id, slot)
+            k += 1
+    fc2, fn2, per_rank = S.finish_all_gather_candidates(pending, N_READS)
+    assert torch.equal(fc2, full_cands) and torch.equal(fn2, full_counts) and int(per_rank[rank]) == n_mine
+    allres2 = S.all_gather_results_by_rank(res2, per_rank)
+    torch.save({"cands": full_cands, "counts": full_counts, "res": allres, "res2": allres2, "per_rank": per_rank},
+               os.path.join(out_dir, "r%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -81,5 +94,9 @@ def test_two_rank_shard_exchange_equals_single_process(tmp_path):
         assert [int(x) for x in o["res"][:, 0]] == list(range(total))          # global job order restored
         rid_of = [rid for rid, a in enumerate(want) for _ in range(len(a))]
         assert [int(x) for x in o["res"][:, 1]] == rid_of
+        # rank-major result table: rank r's reads r, r + world, ... with their slots in order
+        exp2 = [(r, rid, j) for r in range(world) for rid in range(r, N_READS, world) for j in range(len(want[rid]))]
+        assert [tuple(int(v) for v in row[:3]) for row in o["res2"]] == exp2
+        assert [int(x) for x in o["per_rank"]] == [sum(len(want[rid]) for rid in range(r, N_READS, world)) for r in range(world)]
     assert torch.equal(outs[0]["cands"], outs[1]["cands"])
     assert sum(len(a) for a in want) > 50

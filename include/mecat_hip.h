@@ -24,6 +24,7 @@
 #ifndef MECAT_HIP_H
 #define MECAT_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -74,6 +75,12 @@ typedef struct {
 int  mhip_abi_version(void);
 const char* mhip_last_error(void);
 int  mhip_device_count(void);
+
+/* Page-locked host memory for the buffers handed to the host-pointer entry points (mhip_seed_reads,
+ * mhip_align_candidates ...): optional, any host pointer works, but pageable memory moves at a fraction of the link rate.
+ * Additive (the reference has no counterpart: its buffers never leave the host). */
+int  mhip_host_alloc(size_t bytes, void** out);
+void mhip_host_free(void* p);
 
 /* `stream` may be NULL (the context creates its own) or a hipStream_t the caller owns (e.g. torch's current stream). */
 int  mhip_ctx_create(int device, void* stream, mhip_ctx** out);

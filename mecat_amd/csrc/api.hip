@@ -79,6 +79,17 @@ void mhip_ctx_destroy(mhip_ctx* c) {
     delete c;
 }
 
+int mhip_host_alloc(size_t bytes, void** out) {
+    *out = nullptr;
+    if (bytes == 0) bytes = 1;
+    HIPCHK(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return 0;
+}
+
+void mhip_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
 int mhip_ctx_sync(mhip_ctx* c) {
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));

@@ -81,6 +81,29 @@ static void check_records_containment(const M4Record* v, int s, int e, std::vect
     }
 }
 
+// growable array in page-locked host memory (contents are not preserved across a grow: every user refills it)
+template <typename T>
+struct PinnedBuf {
+    T* p = nullptr;
+    size_t cap = 0, n = 0;
+    ~PinnedBuf() { mhip_host_free(p); }
+    void resize(size_t want) {
+        if (want > cap) {
+            mhip_host_free(p);
+            p = nullptr;
+            cap = want + want / 8 + 1024;
+            void* q = nullptr;
+            MCHK(mhip_host_alloc(cap * sizeof(T), &q));
+            p = (T*)q;
+        }
+        n = want;
+    }
+    T* data() { return p; }
+    size_t size() const { return n; }
+    T& operator[](size_t i) { return p[i]; }
+    const T& operator[](size_t i) const { return p[i]; }
+};
+
 template <typename F>
 static void run_threads(int nt, F f) {
     std::vector<std::thread> th;
@@ -109,11 +132,11 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
 
     const char* slab_env = getenv("MECAT_HIP_SLAB");
     const int slab = slab_env ? std::max(1, atoi(slab_env)) : 20000;
-    std::vector<mhip_candidate> cands;
-    std::vector<int32_t> counts;
-    std::vector<mhip_aln_job> jobs;
+    PinnedBuf<mhip_candidate> cands;      // buffers that cross the PCIe link: page-locked
+    PinnedBuf<int32_t> counts;
+    PinnedBuf<mhip_aln_job> jobs;
     std::vector<size_t> jfirst;
-    std::vector<mhip_aln_result> res;
+    PinnedBuf<mhip_aln_result> res;
 
     for (int vid = svid; vid < (int)vn.size(); ++vid) {
         char info[64];
@@ -171,10 +194,11 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
                 continue;
             }
             // pairwise_mapping, pw_impl.cpp:674-700
-            jobs.clear();
             jfirst.assign((size_t)nr + 1, 0);
+            for (int r = 0; r < nr; ++r) jfirst[(size_t)r + 1] = jfirst[(size_t)r] + (size_t)counts[(size_t)r];
+            jobs.resize(jfirst[(size_t)nr]);
             for (int r = 0; r < nr; ++r) {
-                jfirst[(size_t)r] = jobs.size();
+                size_t jn = jfirst[(size_t)r];
                 for (int k = 0; k < counts[(size_t)r]; ++k) {
                     const mhip_candidate& c = cands[(size_t)r * P.maxc + k];
                     mhip_aln_job j;
@@ -184,10 +208,9 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
                     j.qstart = c.loc2;
                     j.sstart = c.loc1;
                     if (j.qstart && j.sstart) { j.qstart += MHIP_KMER_SIZE / 2; j.sstart += MHIP_KMER_SIZE / 2; }
-                    jobs.push_back(j);
+                    jobs[jn++] = j;
                 }
             }
-            jfirst[(size_t)nr] = jobs.size();
             res.resize(jobs.size());
             // aligner by technology (pw_impl.cpp:638-644): DiffAligner (dw) for PacBio, XdropAligner for nanopore
             if (opt.tech == TECH_NANOPORE) MCHK(mhip_xalign_candidates(ctx, dref, dreads, jobs.data(), (int)jobs.size(), P.min_align_size, res.data()));

@@ -48,6 +48,20 @@ struct ScopedTimer {   // DynamicTimer, common/defs.h:175-191
     }
 };
 
+// extra phase timings on stderr, only with MECAT_TRACE set (the reference prints none of these)
+struct TraceTimer {
+    const char* name;
+    struct timeval t0;
+    bool on;
+    explicit TraceTimer(const char* n) : name(n), on(getenv("MECAT_TRACE") != NULL) { if (on) gettimeofday(&t0, NULL); }
+    ~TraceTimer() {
+        if (!on) return;
+        struct timeval t1;
+        gettimeofday(&t1, NULL);
+        fprintf(stderr, "[trace] %-16s %.3f s\n", name, t1.tv_sec - t0.tv_sec + 1e-6 * (t1.tv_usec - t0.tv_usec));
+    }
+};
+
 struct M4Record {      // common/alignment.h:21-37
     int64_t qid, sid;
     double ident;
@@ -120,9 +134,9 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
     P.min_kmer_match = opt.min_kmer_match;
 
     HostVolume ref;
-    load_volume(vn[svid], &ref);
+    { TraceTimer tt("load_volume"); load_volume(vn[svid], &ref); }
     mhip_volume* dref = NULL;
-    MCHK(mhip_volume_upload(ctx, ref.pac.data(), ref.offs.data(), ref.num_reads, ref.num_bases, ref.start_read_id, &dref));
+    { TraceTimer tt("volume_upload"); MCHK(mhip_volume_upload(ctx, ref.pac.data(), ref.offs.data(), ref.num_reads, ref.num_bases, ref.start_read_id, &dref)); }
     mhip_index* idx = NULL;
     {
         ScopedTimer t("create_ref_index");
@@ -300,7 +314,10 @@ int main(int argc, char* argv[]) {
 
     mhip_ctx* ctx = NULL;
     const char* dev_env = getenv("MECAT_HIP_DEVICE");
-    if (mhip_ctx_create(dev_env ? atoi(dev_env) : 0, NULL, &ctx) != 0) DIE("cannot use the GPU: %s", mhip_last_error());
+    {
+        TraceTimer tt("ctx_create");
+        if (mhip_ctx_create(dev_env ? atoi(dev_env) : 0, NULL, &ctx) != 0) DIE("cannot use the GPU: %s", mhip_last_error());
+    }
 
     for (int i = 0; i < num_vols; ++i) {
         const std::string fin = results_name(opt.wrk_dir, i, false);
@@ -318,6 +335,7 @@ int main(int argc, char* argv[]) {
     mhip_ctx_destroy(ctx);
 
     // merge_results, pw.cpp:34-46
+    TraceTimer tt_merge("merge_results");
     for (int i = 0; i < num_vols; ++i) {
         const std::string cmd = std::string("cat ") + results_name(opt.wrk_dir, i, false) + (i == 0 ? " >" : " >> ") + opt.output;
         if (system(cmd.c_str()) != 0) DIE("'%s' failed", cmd.c_str());

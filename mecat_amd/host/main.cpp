@@ -8,7 +8,8 @@
 // Record assembly, the per-read m4 post-filter (std::sort + containment, pw_impl.cpp:539-610) and text output stay on
 // the host (`-t` threads; the same option sizes the FASTA reader's thread pool).  There is no CPU fallback for the kernels: any failure aborts with the library's message.
 //
-// Additive, environment-only knobs:  MECAT_HIP_DEVICE=<n> (default 0),  MECAT_HIP_SLAB=<reads per seed call>.
+// Additive, environment-only knobs:  MECAT_HIP_DEVICE=<n> (default 0),  MECAT_HIP_SLAB=<reads per seed call>,
+// WORLD_SIZE / RANK / LOCAL_RANK (or MECAT_HIP_WORLD / MECAT_HIP_RANK): one process per GPU, grid rows dealt out cyclically.
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -300,26 +301,71 @@ static std::string results_name(const char* wrk_dir, int vid, bool working) {
     return s;
 }
 
+static int env_int(const char* a, const char* b, int dflt) {
+    const char* e = getenv(a);
+    if (!e && b) e = getenv(b);
+    return e ? atoi(e) : dflt;
+}
+
+static double now_s() {
+    struct timeval t;
+    gettimeofday(&t, NULL);
+    return t.tv_sec + 1e-6 * t.tv_usec;
+}
+
+// Multi-GPU mode (additive): P processes, one per GPU, started with WORLD_SIZE / RANK / LOCAL_RANK in the environment (e.g.
+// `python -m torch.distributed.run --no-python --nproc-per-node 8 mecat2pw ...`) or MECAT_HIP_WORLD / MECAT_HIP_RANK.  The
+// rows of the volume x volume grid (one r_<i> file each) are dealt out cyclically; no data moves between the processes.  Rank
+// 0 splits the input and merges the r_<i> files; the hand-offs are files in wrk_dir, like the resume protocol itself.
 int main(int argc, char* argv[]) {
     Options opt;
     if (parse_arguments(argc, argv, &opt)) {
         print_usage(argv[0]);
         return 1;
     }
-    const int num_vols = split_raw_dataset(opt.reads, opt.wrk_dir, opt.num_threads);
+    const int world = std::max(1, env_int("MECAT_HIP_WORLD", "WORLD_SIZE", 1));
+    const int rank = std::min(world - 1, std::max(0, env_int("MECAT_HIP_RANK", "RANK", 0)));
+    const double t_start = now_s();
+    std::string marker(opt.wrk_dir);
+    if (marker.empty() || marker[marker.size() - 1] != '/') marker += '/';
+    marker += "split_done";
+    int num_vols = 0;
+    if (rank == 0) {
+        if (world > 1) unlink(marker.c_str());
+        num_vols = split_raw_dataset(opt.reads, opt.wrk_dir, opt.num_threads);
+        if (world > 1) {
+            FILE* m = fopen((marker + ".tmp").c_str(), "w");
+            if (!m) DIE("cannot write '%s'", marker.c_str());
+            fprintf(m, "%.3f %d\n", t_start, num_vols);
+            fclose(m);
+            if (rename((marker + ".tmp").c_str(), marker.c_str()) != 0) DIE("cannot rename %s", marker.c_str());
+        }
+    } else {
+        // wait for THIS run's split: the marker carries rank 0's start time (a stale one is much older than our own start)
+        usleep(300 * 1000);
+        for (;;) {
+            FILE* m = fopen(marker.c_str(), "r");
+            double t0 = 0;
+            int nv = 0;
+            const bool ok = m && fscanf(m, "%lf %d", &t0, &nv) == 2;
+            if (m) fclose(m);
+            if (ok && t0 > t_start - 120.0) { num_vols = nv; break; }
+            usleep(50 * 1000);
+        }
+    }
     const std::string idx_name = index_file_name(opt.wrk_dir);
-    printf("%s\n", idx_name.c_str());
+    if (rank == 0) printf("%s\n", idx_name.c_str());
     const std::vector<std::string> vn = load_volume_names(idx_name);
     if ((int)vn.size() != num_vols) DIE("assertion 'num_vols == vn->num_vols' failed");
 
     mhip_ctx* ctx = NULL;
-    const char* dev_env = getenv("MECAT_HIP_DEVICE");
+    const int device = env_int("MECAT_HIP_DEVICE", world > 1 ? "LOCAL_RANK" : NULL, 0);
     {
         TraceTimer tt("ctx_create");
-        if (mhip_ctx_create(dev_env ? atoi(dev_env) : 0, NULL, &ctx) != 0) DIE("cannot use the GPU: %s", mhip_last_error());
+        if (mhip_ctx_create(device, NULL, &ctx) != 0) DIE("cannot use the GPU: %s", mhip_last_error());
     }
 
-    for (int i = 0; i < num_vols; ++i) {
+    for (int i = rank; i < num_vols; i += world) {
         const std::string fin = results_name(opt.wrk_dir, i, false);
         if (access(fin.c_str(), F_OK) == 0) {
             fprintf(stderr, "[%s, %u] volume %d has been finished\n\n", __func__, __LINE__, i);
@@ -333,11 +379,14 @@ int main(int argc, char* argv[]) {
         if (rename(wrk.c_str(), fin.c_str()) != 0) DIE("cannot rename %s", wrk.c_str());
     }
     mhip_ctx_destroy(ctx);
+    if (rank != 0) return 0;
 
-    // merge_results, pw.cpp:34-46
+    // merge_results, pw.cpp:34-46 (rank 0; waits for the rows of the other ranks)
     TraceTimer tt_merge("merge_results");
     for (int i = 0; i < num_vols; ++i) {
-        const std::string cmd = std::string("cat ") + results_name(opt.wrk_dir, i, false) + (i == 0 ? " >" : " >> ") + opt.output;
+        const std::string fin = results_name(opt.wrk_dir, i, false);
+        while (world > 1 && access(fin.c_str(), F_OK) != 0) usleep(50 * 1000);
+        const std::string cmd = std::string("cat ") + fin + (i == 0 ? " >" : " >> ") + opt.output;
         if (system(cmd.c_str()) != 0) DIE("'%s' failed", cmd.c_str());
     }
     return 0;

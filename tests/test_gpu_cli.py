@@ -105,3 +105,27 @@ def test_cli_multi_volume_grid(tmp_path):
     assert len(got) > 300
     for i in range(3):
         assert os.path.exists(os.path.join(str(wrk), "r_%d" % i))
+
+
+@pytest.mark.parametrize("task", ["0", "1"])
+def test_cli_two_processes_share_the_grid_rows(tmp_path, task):
+    """multi-GPU mode of the driver: two processes (here both on GPU 0) deal out the rows of a 3-volume grid; the merged
+    output is byte-identical to the single-process run (rows are merged in volume order)"""
+    fa = _fasta(tmp_path, "tiny")
+    env = dict(os.environ, MECAT_HIP_MCS="250000")
+    one = str(tmp_path / "one.out")
+    r = subprocess.run([BIN, "-j", task, "-d", fa, "-o", one, "-w", str(tmp_path / "w_one"), "-t", "4"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    two = str(tmp_path / "two.out")
+    wrk = str(tmp_path / "w_two")
+    procs = []
+    for rank in (1, 0):          # rank 1 first: it has to wait for rank 0's split
+        e = dict(env, MECAT_HIP_WORLD="2", MECAT_HIP_RANK=str(rank), MECAT_HIP_DEVICE="0")
+        procs.append(subprocess.Popen([BIN, "-j", task, "-d", fa, "-o", two, "-w", wrk, "-t", "4"], stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True, env=e))
+    for p in procs:
+        out, err = p.communicate(timeout=300)
+        assert p.returncode == 0, err[-2000:]
+    assert open(two).read() == open(one).read()
+    assert len(open(two).read().splitlines()) > 300
+    assert sorted(f for f in os.listdir(wrk) if f.startswith("r_")) == ["r_0", "r_1", "r_2"]

@@ -1235,3 +1235,211 @@ int orc_map_read_x(const orc_volume* ref, const orc_volume* reads, const orc_ind
     free(cands); free(m4v); free(read1); free(read2); free(subject);
     return kept;
 }
+
+
+/* ================================================================================================================
+ * N1: the mecat2cns re-aligner (reference src/mecat2cns/dw.cpp).  Same O(ND) core as A9-A12 with different rules:
+ * max_d from an error rate, square blocks, no partial-best fallback, full alignment strings, the 4-match anchor of a
+ * block is re-aligned by the next block, extra end trimming in GetAlignment.
+ * ================================================================================================================ */
+#define CNS_SEG 500            /* get_sw_parameters_small, dw.cpp:8-22 */
+#define CNS_VSIZE 4096         /* row_size / column_size */
+#define CNS_MAX_ALN 100000     /* max_aln_size */
+
+struct orc_cns {
+    int* V;                 /* furthest x per diagonal (index k + k_offset) */
+    int* U;                 /* x + y per diagonal */
+    int* row_first;         /* per d: index of the row's first cell in cell_x2 / cell_k */
+    int* cell_k;            /* per computed cell: its diagonal */
+    int* cell_x1;           /* snake start */
+    int* cell_x2;           /* snake end */
+    int* cell_pre;          /* diagonal the cell was entered from */
+    int cap_cells, cap_rows;
+    uint8_t *lops, *rops, *bops;   /* left / right direction ops, one block's ops */
+};
+
+orc_cns* orc_cns_new(void) {
+    orc_cns* a = (orc_cns*)xcalloc(sizeof(orc_cns));
+    a->V = (int*)xmalloc(sizeof(int) * CNS_VSIZE);
+    a->U = (int*)xmalloc(sizeof(int) * CNS_VSIZE);
+    a->cap_rows = 2048;
+    a->cap_cells = 1 << 20;
+    a->row_first = (int*)xmalloc(sizeof(int) * (size_t)(a->cap_rows + 1));
+    a->cell_k = (int*)xmalloc(sizeof(int) * (size_t)a->cap_cells);
+    a->cell_x1 = (int*)xmalloc(sizeof(int) * (size_t)a->cap_cells);
+    a->cell_x2 = (int*)xmalloc(sizeof(int) * (size_t)a->cap_cells);
+    a->cell_pre = (int*)xmalloc(sizeof(int) * (size_t)a->cap_cells);
+    a->lops = (uint8_t*)xmalloc(CNS_MAX_ALN);
+    a->rops = (uint8_t*)xmalloc(CNS_MAX_ALN);
+    a->bops = (uint8_t*)xmalloc(8192);
+    return a;
+}
+
+void orc_cns_free(orc_cns* a) {
+    if (!a) return;
+    free(a->V); free(a->U); free(a->row_first); free(a->cell_k); free(a->cell_x1); free(a->cell_x2); free(a->cell_pre);
+    free(a->lops); free(a->rops); free(a->bops);
+    free(a);
+}
+
+int orc_cns_align_block(orc_cns* a, const char* q, const char* t, int len, int right, double error_rate,
+                        int* qe, int* te, int* dist, uint8_t* ops, int* ncols) {
+    const int q_len = len, t_len = len;
+    const int band_tol = (int)(0.3 * len);                       /* the call site passes 0.3 * seg_size to an int, dw.cpp:332 */
+    const int max_d = (int)(2.0 * error_rate * (q_len + t_len));  /* :163 */
+    const int koff = max_d, band_size = band_tol * 2;
+    int best_m = -1, min_k = 0, max_k = 0, ncell = 0;
+    *qe = *te = *dist = 0; *ncols = 0;
+    memset(a->U, 0, sizeof(int) * CNS_VSIZE);                     /* the caller zeroes both per block, :329-330 */
+    memset(a->V, 0, sizeof(int) * CNS_VSIZE);
+    for (int d = 0; d < max_d; ++d) {
+        if (max_k - min_k > band_size) break;
+        if (d >= a->cap_rows) { fprintf(stderr, "oracle: cns row capacity\n"); abort(); }
+        a->row_first[d] = ncell;
+        int hit = 0, hit_k = 0, hx = 0, hy = 0;
+        for (int k = min_k; k <= max_k; k += 2) {
+            int pre_k, x;
+            if (k == min_k || (k != max_k && a->V[k - 1 + koff] < a->V[k + 1 + koff])) { pre_k = k + 1; x = a->V[k + 1 + koff]; }
+            else { pre_k = k - 1; x = a->V[k - 1 + koff] + 1; }
+            int y = x - k;
+            const int x1 = x;
+            if (right) while (x < q_len && y < t_len && q[x] == t[y]) { ++x; ++y; }
+            else while (x < q_len && y < t_len && q[-x] == t[-y]) { ++x; ++y; }
+            if (ncell >= a->cap_cells) { fprintf(stderr, "oracle: cns cell capacity\n"); abort(); }
+            a->cell_k[ncell] = k; a->cell_x1[ncell] = x1; a->cell_x2[ncell] = x; a->cell_pre[ncell] = pre_k;
+            ++ncell;
+            a->V[k + koff] = x;
+            a->U[k + koff] = x + y;
+            if (x + y > best_m) best_m = x + y;
+            if (x >= q_len || y >= t_len) { hit = 1; hit_k = k; hx = x; hy = y; break; }   /* first diagonal in k order */
+        }
+        a->row_first[d + 1] = ncell;
+        /* band for the next row (:202-209); after a hit the diagonals above hit_k still hold the values of row d - 2 */
+        int nmin = max_k, nmax = min_k;
+        for (int k2 = min_k; k2 <= max_k; k2 += 2)
+            if (a->U[k2 + koff] >= best_m - band_tol) { if (k2 < nmin) nmin = k2; if (k2 > nmax) nmax = k2; }
+        max_k = nmax + 1;
+        min_k = nmin - 1;
+        if (hit) {
+            /* walk the path back: cell (cd, ck) -> its predecessor diagonal in row cd - 1 (:222-240) */
+            static int px1[4100], px2[4100], pk[4100];
+            int ck = hit_k;
+            for (int cd = d; cd >= 0; --cd) {
+                int lo = a->row_first[cd], hi = a->row_first[cd + 1], at = -1;
+                for (int c = lo; c < hi; ++c) if (a->cell_k[c] == ck) { at = c; break; }
+                if (at < 0) { fprintf(stderr, "oracle: cns path lost\n"); abort(); }
+                px1[cd] = a->cell_x1[at]; px2[cd] = a->cell_x2[at]; pk[cd] = ck;
+                ck = a->cell_pre[at];
+            }
+            /* forward: one indel per row after the first, then the row's snake (:241-297) */
+            int n = 0;
+            for (int cd = 0; cd <= d; ++cd) {
+                if (cd > 0) ops[n++] = (uint8_t)(pk[cd] < pk[cd - 1] ? 1 : 2);   /* from k + 1: target base only; from k - 1: query base only */
+                for (int i = px1[cd]; i < px2[cd]; ++i) ops[n++] = 0;
+            }
+            *ncols = n; *qe = hx; *te = hy; *dist = d;
+            return (hx == q_len || hy == t_len) ? 1 : 0;
+        }
+    }
+    return (0 == q_len || 0 == t_len) ? 1 : 0;       /* Alignment::init leaves aln_q_e = aln_t_e = 0 (:302-303) */
+}
+
+int orc_cns_one_direction(orc_cns* a, const char* q, int qsize, const char* t, int tsize, int right, double error_rate,
+                          uint8_t* ops, int* qbases, int* tbases) {
+    int extend1 = 0, extend2 = 0, total = 0;
+    int extend_size = qsize < tsize ? qsize : tsize;
+    int more = 1;
+    while (more) {
+        int seg;
+        if (extend_size > CNS_SEG + 100) seg = CNS_SEG;
+        else { seg = extend_size; more = 0; }
+        const char* s1 = right ? q + extend1 : q - extend1;
+        const char* s2 = right ? t + extend2 : t - extend2;
+        int qe, te, dist, n;
+        int ok = orc_cns_align_block(a, s1, s2, seg, right, error_rate, &qe, &te, &dist, a->bops, &n);
+        if (!ok) break;
+        /* bases and columns of the tail through the last run of four matches (:336-343) */
+        int k, i = 0, j = 0, nm = 0;
+        for (k = n - 1; k > -1 && nm < 4; --k) {
+            if (a->bops[k] != 1) ++i;
+            if (a->bops[k] != 2) ++j;
+            if (a->bops[k] == 0) ++nm; else nm = 0;
+        }
+        if (more) {
+            i = CNS_SEG - qe + i;
+            j = CNS_SEG - te + j;
+            if (i == CNS_SEG) ok = 0;
+            extend1 += CNS_SEG - i; extend2 += CNS_SEG - j;
+        } else {
+            i = extend_size - qe;
+            j = extend_size - te;
+            if (i == extend_size) ok = 0;
+            extend1 += extend_size - i; extend2 += extend_size - j;
+            k = n - 1;
+        }
+        if (!ok) break;
+        memcpy(ops + total, a->bops, (size_t)(k + 1));
+        total += k + 1;
+        extend_size = (qsize - extend1) < (tsize - extend2) ? (qsize - extend1) : (tsize - extend2);
+    }
+    int qb = 0, tb = 0;
+    for (int c = 0; c < total; ++c) { if (ops[c] != 1) ++qb; if (ops[c] != 2) ++tb; }
+    *qbases = qb; *tbases = tb;
+    return total;
+}
+
+int orc_cns_dw(orc_cns* a, const char* q, int qstart, int qsize, const char* t, int tstart, int tsize, double error_rate,
+               int min_aln_size, int* res, char* out1, char* out2) {
+    static const char dec[] = "ACGT-";
+    int lq, lt, rq, rt;
+    const int nl = orc_cns_one_direction(a, q + qstart - 1, qstart, t + tstart - 1, tstart, 0, error_rate, a->lops, &lq, &lt);
+    const int nr = orc_cns_one_direction(a, q + qstart, qsize - qstart, t + tstart, tsize - tstart, 1, error_rate, a->rops, &rq, &rt);
+    const int n = nl + nr;
+    res[0] = qstart - lq; res[1] = qstart + rq; res[2] = tstart - lt; res[3] = tstart + rt; res[4] = n;
+    res[5] = res[6] = res[7] = res[8] = 0;
+    /* merged strings: the left part reversed, then the right part (:397-437) */
+    int qi = res[0], ti = res[2], mat = 0, ins = 0, del = 0;
+    for (int c = 0; c < n; ++c) {
+        const int op = c < nl ? a->lops[nl - 1 - c] : a->rops[c - nl];
+        const char c1 = op == 1 ? '-' : dec[(int)q[qi]], c2 = op == 2 ? '-' : dec[(int)t[ti]];
+        if (op != 1) ++qi;
+        if (op != 2) ++ti;
+        if (out1) out1[c] = c1;
+        if (out2) out2[c] = c2;
+        if (op == 0) ++mat; else if (op == 1) ++ins; else ++del;
+    }
+    if (out1) out1[n] = 0;
+    if (out2) out2[n] = 0;
+    if (n >= min_aln_size) { res[5] = mat; res[7] = ins; res[8] = del; return 1; }
+    return 0;
+}
+
+int orc_cns_get_alignment(orc_cns* a, const char* q, int qstart, int qsize, const char* t, int tstart, int tsize,
+                          double error_rate, int min_aln_size, int* res, char* qaln, char* saln) {
+    static char s1[CNS_MAX_ALN + 1], s2[CNS_MAX_ALN + 1];
+    int r[9];
+    res[0] = res[1] = res[2] = res[3] = res[4] = 0;
+    if (!orc_cns_dw(a, q, qstart, qsize, t, tstart, tsize, error_rate, min_aln_size, r, s1, s2)) return 0;
+    const int n = r[4], run = 4;
+    int qrb = 0, trb = 0, qre = 0, tre = 0, eit = 0, k;
+    for (k = 0; k < n && eit < run; ++k) {           /* first run of four matches (:495-505) */
+        if (s1[k] != '-') ++qrb;
+        if (s2[k] != '-') ++trb;
+        if (s1[k] == s2[k]) ++eit; else eit = 0;
+    }
+    if (eit < run) return 0;
+    k -= run; qrb -= run; trb -= run;
+    const int first = k;
+    for (k = n - 1, eit = 0; k >= 0 && eit < run; --k) {   /* last run of four matches (:513-523) */
+        if (s1[k] != '-') ++qre;
+        if (s2[k] != '-') ++tre;
+        if (s1[k] == s2[k]) ++eit; else eit = 0;
+    }
+    if (eit < run) return 0;
+    k += run; qre -= run; tre -= run;
+    const int last = k + 1;
+    res[0] = r[0] + qrb; res[1] = r[1] - qre; res[2] = r[2] + trb; res[3] = r[3] - tre; res[4] = last - first;
+    if (qaln) { memcpy(qaln, s1 + first, (size_t)(last - first)); qaln[last - first] = 0; }
+    if (saln) { memcpy(saln, s2 + first, (size_t)(last - first)); saln[last - first] = 0; }
+    return 1;
+}

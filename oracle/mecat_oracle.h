@@ -164,6 +164,28 @@ int orc_map_read(const orc_volume* ref, const orc_volume* reads, const orc_index
 int orc_map_read_x(const orc_volume* ref, const orc_volume* reads, const orc_index* ridx, orc_seeding_bk* bk,
                    orc_aligner* al, orc_xaligner* xal, int rid, const orc_params* p, orc_m4* out);
 
+/* ---- N1: the mecat2cns re-aligner, src/mecat2cns/dw.cpp.  Sequences are code arrays (0..3). ----
+   Columns are reported as ops: 0 = both bases (always equal: O(ND) paths have no mismatch columns), 1 = gap in the
+   query (target base only), 2 = gap in the target (query base only). */
+typedef struct orc_cns orc_cns;
+orc_cns* orc_cns_new(void);
+void orc_cns_free(orc_cns* a);
+/* Align (dw.cpp:146-305) on a square block of `len` bases per side; q / t point at the first base of the block and are
+   read forwards (right != 0) or backwards.  Returns 1 when an end of either sequence was reached; then *qe, *te are the
+   consumed bases, *dist the edit distance and ops[0 .. *ncols) the columns. */
+int orc_cns_align_block(orc_cns* a, const char* q, const char* t, int len, int right, double error_rate,
+                        int* qe, int* te, int* dist, uint8_t* ops, int* ncols);
+/* dw_in_one_direction (dw.cpp:307-376): ops of one direction in extension order, bases covered by them */
+int orc_cns_one_direction(orc_cns* a, const char* q, int qsize, const char* t, int tsize, int right, double error_rate,
+                          uint8_t* ops, int* qbases, int* tbases);
+/* dw (dw.cpp:378-480): res = {query_start, query_end, target_start, target_end, columns, mat, mis, ins, del};
+   out1 / out2 (may be NULL) receive the merged "ACGT-" strings, NUL terminated.  Returns the reference's flag. */
+int orc_cns_dw(orc_cns* a, const char* q, int qstart, int qsize, const char* t, int tstart, int tsize, double error_rate,
+               int min_aln_size, int* res, char* out1, char* out2);
+/* GetAlignment (dw.cpp:482-553): res = {qoff, qend, soff, send, aligned length}; qaln / saln may be NULL */
+int orc_cns_get_alignment(orc_cns* a, const char* q, int qstart, int qsize, const char* t, int tstart, int tsize,
+                          double error_rate, int min_aln_size, int* res, char* qaln, char* saln);
+
 #ifdef __cplusplus
 }
 #endif

@@ -148,6 +148,11 @@ def orc():
         L.orc_m4_line.argtypes = [C.POINTER(OrcM4), C.c_int, C.c_char_p]
         L.orc_map_read.argtypes = [C.POINTER(OrcVolume), C.POINTER(OrcVolume), C.POINTER(OrcIndex), vp, vp, C.c_int,
                                    C.POINTER(OrcParams), vp]
+        L.orc_cns_new.restype = vp
+        L.orc_cns_free.argtypes = [vp]
+        L.orc_cns_one_direction.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_double, vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_cns_dw.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_double, C.c_int, vp, vp, vp]
+        L.orc_cns_get_alignment.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_double, C.c_int, vp, vp, vp]
         _orc = L
     return _orc
 
@@ -264,3 +269,53 @@ def ref():
         L.refh_xdrop_align.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp]
         _ref = L
     return _ref
+
+
+_ref_cns = None
+
+
+def ref_cns_available():
+    return os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libref_cns.so"))
+
+
+def ref_cns():
+    """harness around the unmodified mecat2cns aligner (oracle/ref_harness_cns.cpp)"""
+    global _ref_cns
+    if _ref_cns is None:
+        L = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_cns.so"))
+        vp = C.c_void_p
+        L.refc_dw.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_double, C.c_int, vp, vp, vp]
+        L.refc_get_alignment.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_double, C.c_int, vp, vp, vp]
+        _ref_cns = L
+    return _ref_cns
+
+
+def cns_pair(rng, n, err, it):
+    """two noisy copies of a random sequence and a seed point near their shared diagonal (code arrays, int8)"""
+    g = rng.integers(0, 4, size=n + 1200).astype(np.int8)
+    a0, b0 = int(rng.integers(0, 600)), int(rng.integers(0, 600))
+
+    def mutate(x):
+        out = []
+        for c in x:
+            r = rng.random()
+            if r < err * 0.4:
+                continue
+            if r < err * 0.7:
+                out.append(int(rng.integers(0, 4)))
+            elif r < err:
+                out.append(int((c + rng.integers(1, 4)) % 4))
+                continue
+            out.append(int(c))
+        return np.array(out, dtype=np.int8)
+
+    q, t = mutate(g[a0: a0 + n]), mutate(g[b0: b0 + n])
+    mid = max(a0, b0) + n // 3
+    qs = int((mid - a0) * 1.02) if it % 5 else int(rng.integers(0, len(q)))
+    ts = int((mid - b0) * 1.02) if it % 5 else int(rng.integers(0, len(t)))
+    qs, ts = min(max(qs, 0), len(q) - 1), min(max(ts, 0), len(t) - 1)
+    if it % 11 == 0:
+        qs = 0
+    if it % 13 == 0:
+        ts = len(t) - 1
+    return q, t, qs, ts

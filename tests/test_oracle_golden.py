@@ -202,3 +202,28 @@ def test_m4_lines_tiny_ont():
             n = O.orc_m4_line(C.byref(out[i]), 1, buf)
             lines.append(buf.raw[:n].decode().rstrip("\n"))
     assert sorted(lines) == open(os.path.join(H.GOLDEN, "tiny_ont.g1.m4.sorted")).read().splitlines()
+
+
+def test_cns_aligner_kats():
+    """N1: known answers of the mecat2cns re-aligner (ns_banded_sw::dw, GetAlignment) from the unmodified reference"""
+    import hashlib
+    K = np.load(os.path.join(H.GOLDEN, "cns_kats.npz"))
+    O = H.orc()
+    a = O.orc_cns_new()
+    qo = to = 0
+    for par, dw_want, ga_want, dig in zip(K["par"], K["dw_res"], K["ga_res"], K["digests"]):
+        nq, nt, qs, ts, mn, er100 = [int(x) for x in par]
+        q = K["q"][qo: qo + nq].copy(); qo += nq
+        t = K["t"][to: to + nt].copy(); to += nt
+        res = np.zeros(9, np.int32)
+        s1 = np.zeros(100001, np.int8)
+        s2 = np.zeros(100001, np.int8)
+        ok = O.orc_cns_dw(a, q.ctypes.data, qs, nq, t.ctypes.data, ts, nt, er100 / 100.0, mn, res.ctypes.data, s1.ctypes.data, s2.ctypes.data)
+        assert [ok] + list(res) == list(dw_want)
+        d1 = hashlib.sha256(s1[: res[4]].tobytes() + b"|" + s2[: res[4]].tobytes()).hexdigest()
+        res2 = np.zeros(5, np.int32)
+        ok2 = O.orc_cns_get_alignment(a, q.ctypes.data, qs, nq, t.ctypes.data, ts, nt, er100 / 100.0, mn, res2.ctypes.data, s1.ctypes.data, s2.ctypes.data)
+        assert [ok2] + list(res2) == list(ga_want)
+        d2 = hashlib.sha256(s1[: res2[4]].tobytes() + b"|" + s2[: res2[4]].tobytes()).hexdigest() if ok2 else ""
+        assert d1 + ":" + d2 == str(dig)
+    O.orc_cns_free(a)

@@ -337,3 +337,36 @@ def test_m4_nanopore_output_identical(tmp_path):
             lines.append(buf.raw[:n].decode().rstrip("\n"))
     assert len(want) > 100
     assert sorted(lines) == want
+
+
+@pytest.mark.skipif(not H.ref_cns_available(), reason="mecat2cns reference harness not built (oracle/_ref)")
+@pytest.mark.parametrize("error_rate", [0.15, 0.20])
+def test_cns_aligner_random(error_rate):
+    """N1: ns_banded_sw::dw and GetAlignment of mecat2cns (reference) vs orc_cns_dw / orc_cns_get_alignment"""
+    R, O = H.ref_cns(), H.orc()
+    a = O.orc_cns_new()
+    rng = np.random.default_rng(17)
+    oks = 0
+    for it in range(80):
+        n = int(rng.integers(300, 7000))
+        q, t, qs, ts = H.cns_pair(rng, n, [0.0, 0.05, 0.12, 0.15, 0.3][it % 5], it)
+        min_aln = 500 if it % 3 else 50
+        outs = []
+        for fn, pre in ((R.refc_dw, ()), (O.orc_cns_dw, (a,))):
+            res = np.zeros(9, dtype=np.int32)
+            s1 = np.zeros(100001, dtype=np.int8)
+            s2 = np.zeros(100001, dtype=np.int8)
+            r = fn(*pre, q.ctypes.data, qs, len(q), t.ctypes.data, ts, len(t), error_rate, min_aln, res.ctypes.data, s1.ctypes.data, s2.ctypes.data)
+            outs.append((r, tuple(res), s1[: res[4]].tobytes(), s2[: res[4]].tobytes()))
+        assert outs[0] == outs[1], it
+        outs = []
+        for fn, pre in ((R.refc_get_alignment, ()), (O.orc_cns_get_alignment, (a,))):
+            res = np.zeros(5, dtype=np.int32)
+            s1 = np.zeros(100001, dtype=np.int8)
+            s2 = np.zeros(100001, dtype=np.int8)
+            r = fn(*pre, q.ctypes.data, qs, len(q), t.ctypes.data, ts, len(t), error_rate, min_aln, res.ctypes.data, s1.ctypes.data, s2.ctypes.data)
+            outs.append((r, tuple(res), s1[: res[4]].tobytes(), s2[: res[4]].tobytes()))
+        assert outs[0] == outs[1], it
+        oks += outs[0][0]
+    assert oks > 20
+    O.orc_cns_free(a)

@@ -152,6 +152,30 @@ int  mhip_xalign_candidates(mhip_ctx* ctx, const mhip_volume* ref, const mhip_vo
 int  mhip_xalign_candidates_dev(mhip_ctx* ctx, const mhip_volume* ref, const mhip_volume* reads, const void* d_jobs,
                                 int n, int min_align_size, void* d_out);
 
+/* ---- mecat2cns re-aligner: ns_banded_sw::GetAlignment of src/mecat2cns/dw.cpp:482-553, which
+ * mecat2cns calls for up to 200 candidates per template read (mecat_correction.cpp:286, 347, 431, 494) -------------------
+ * Jobs are mhip_aln_job records: qid_local = the candidate read in `reads`, taken reverse-complemented when chain != 0;
+ * sid_local = the template read in `ref`; qstart / sstart = the extension start (qext, sext).  error_rate is 0.15 (PacBio)
+ * or 0.20 (nanopore), <= 0.20.  An O(ND) alignment has no mismatch columns, so a column is 0 = both bases (equal),
+ * 1 = target base only (gap in the query string), 2 = query base only (gap in the target string): 2 bits per column,
+ * 16 columns per uint32 from the least significant bits, dir_cols_cap columns (a multiple of 16) per direction:
+ *   ops[(2 * i    ) * dir_cols_cap / 16 ...]  left  direction of job i, in extension order (outwards from the start point)
+ *   ops[(2 * i + 1) * dir_cols_cap / 16 ...]  right direction
+ * The reference's merged strings are reverse(left) + right; GetAlignment keeps merged columns [first_col, last_col). */
+typedef struct mhip_cns_result {
+    int32_t ok;                                  /* GetAlignment's return value */
+    int32_t qoff, qend, soff, send;              /* m5qoff / m5qend / m5soff / m5send */
+    int32_t left_cols, right_cols;               /* columns stored per direction */
+    int32_t first_col, last_col;                 /* the aligned strings are merged columns [first_col, last_col) */
+    int32_t mat, ins, del;                       /* OutputStore counts over the untrimmed string (dw.cpp:441-470) */
+    int32_t query_start, query_end, target_start, target_end;    /* OutputStore coordinates before GetAlignment's trimming */
+} mhip_cns_result;
+
+int mhip_cns_align_candidates(mhip_ctx* ctx, const mhip_volume* ref, const mhip_volume* reads, const mhip_aln_job* jobs, int n,
+                              double error_rate, int min_align_size, int dir_cols_cap, mhip_cns_result* results, uint32_t* ops);
+int mhip_cns_align_candidates_dev(mhip_ctx* ctx, const mhip_volume* ref, const mhip_volume* reads, const void* d_jobs, int n,
+                                  double error_rate, int min_align_size, int dir_cols_cap, void* d_results, void* d_ops);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,343 @@
+// cns_align.hip — the mecat2cns re-aligner on the device.
+//
+// Replaces ns_banded_sw::Align / dw_in_one_direction / dw / GetAlignment of the reference's src/mecat2cns/dw.cpp
+// (:146-553), which mecat2cns calls for up to 200 candidates per template read (mecat_correction.cpp:419-443).  Same
+// O(ND) core as align.hip, different rules around it:
+//   * max_d = int(2 * error_rate * (q_len + t_len)) (:163), square blocks: 500 x 500, or the rest when <= 600 (:322-326);
+//   * no best-point fallback: a block that does not reach an end of its square ends the direction (:302-304, :333);
+//   * the whole path is needed: the consensus stage consumes the aligned strings.  O(ND) paths have no mismatch columns,
+//     so a column is one of {both bases, target base only, query base only}; the kernel emits 2 bits per column and the
+//     host rebuilds "ACGT-" strings from the reads (cns_expand in hip.py / INTEGRATION.md);
+//   * a block's tail is cut in front of its last run of four matches and the next block starts there (:336-351);
+//   * GetAlignment trims the merged string to its first and last run of four matches (:495-531).
+//
+// One wave per (candidate, direction); lanes are the diagonals of a d-row.  Every row's furthest-x values are kept (LDS
+// while the block's cells fit CN_RING, always in a per-wave global scratch) because the traceback walks all of them.
+#include <algorithm>
+
+#include "dw_helpers.h"
+
+#define CN_BLOCK 256
+#define CN_WAVES (CN_BLOCK / WAVE)
+#define CN_SEG 500
+#define CN_MAXLEN 600              // a last block is at most CN_SEG + 100 bases per side
+#define CN_MAX_D 480               // int(2 * 0.20 * 1200)
+#define CN_VLEN (2 * CN_MAX_D + 8)
+#define CN_ROW_W 192               // diagonals per row: band of 2 * int(0.3 * 600) = 360 -> 181 + 2
+#define CN_SEQ_WORDS 44            // 600 bases + 32 of window slack = 40 words, one leading pad word, slack
+#define CN_RING 4096               // cells of a block kept in LDS (a 500 x 500 block at 15 % visits ~4 k)
+#define CN_GROW ((size_t)CN_MAX_D * CN_ROW_W)
+
+struct CnsLds {
+    uint32_t Qp[CN_SEQ_WORDS];
+    uint32_t Tp[CN_SEQ_WORDS];
+    int16_t V[CN_VLEN];
+    int16_t rmin[CN_MAX_D], rmax[CN_MAX_D];
+    uint32_t roff[CN_MAX_D];       // forward: linear cell index of the row's first cell; afterwards: columns before the row's snake
+    uint16_t ring[CN_RING];
+    uint16_t tx1[CN_MAX_D], tx2[CN_MAX_D];   // the path: snake start / end (x) per row
+    int16_t tk[CN_MAX_D];                    // the path: diagonal per row
+};
+
+struct CnsDir {                    // one direction of one candidate
+    int32_t cols, qbases, tbases, ins, del, pad;
+};
+
+__device__ __forceinline__ int cns_cell(const CnsLds& S, const uint16_t* __restrict__ grow, int r, int k) {
+    const int idx = (k - (int)S.rmin[r]) >> 1;
+    const uint32_t lin = S.roff[r] + (uint32_t)idx;
+    return lin < CN_RING ? (int)S.ring[lin] : (int)grow[(size_t)r * CN_ROW_W + idx];
+}
+
+__global__ __launch_bounds__(CN_BLOCK) void cns_extend(const uint32_t* __restrict__ rpac, const mhip_offset_t* __restrict__ roffs,
+                                                       const uint32_t* __restrict__ qpac, const mhip_offset_t* __restrict__ qoffs,
+                                                       const mhip_aln_job* __restrict__ jobs, int n, double error_rate, int dir_cols_cap,
+                                                       uint32_t* __restrict__ ops, CnsDir* __restrict__ dres, uint16_t* __restrict__ gscratch,
+                                                       unsigned int* __restrict__ cursor, int* __restrict__ err_flag) {
+    __shared__ CnsLds lds[CN_WAVES];
+    CnsLds& S = lds[threadIdx.x >> 6];
+    const int lane = lane_id();
+    uint16_t* grow = gscratch + (size_t)(blockIdx.x * CN_WAVES + (threadIdx.x >> 6)) * CN_GROW;
+    const size_t dir_words = ((size_t)dir_cols_cap + 15) / 16;
+    while (true) {
+        unsigned int unit = 0;
+        if (lane == 0) unit = atomicAdd(cursor, 1u);
+        unit = __shfl(unit, 0);
+        if (unit >= 2u * (unsigned)n) break;
+        const mhip_aln_job jb = jobs[unit >> 1];
+        const int right = unit & 1;
+        const int qsize = qoffs[jb.qid_local].size, tsize = roffs[jb.sid_local].size;
+        SeqView q, t;
+        q.pac = qpac; q.off = qoffs[jb.qid_local].offset; q.comp = jb.chain;
+        t.pac = rpac; t.off = roffs[jb.sid_local].offset; t.comp = 0;
+        const int qs0 = right ? jb.qstart : jb.qstart - 1, step = right ? 1 : -1;
+        if (jb.chain) { q.A = qsize - 1 - qs0; q.B = -step; } else { q.A = qs0; q.B = step; }
+        t.A = right ? jb.sstart : jb.sstart - 1; t.B = step;
+        const int query_size = right ? qsize - jb.qstart : jb.qstart;
+        const int target_size = right ? tsize - jb.sstart : jb.sstart;
+        uint32_t* uops = ops + (size_t)unit * dir_words;
+
+        int extend1 = 0, extend2 = 0, cols = 0, n_ins = 0, n_del = 0;
+        int extend_size = min(query_size, target_size);
+        bool more = true;
+        while (more) {      // dw_in_one_direction, dw.cpp:319-375
+            int seg;
+            if (extend_size > CN_SEG + 100) seg = CN_SEG;
+            else { seg = extend_size; more = false; }
+            if (seg <= 0) break;                         // Align "succeeds" on an empty block, then i == extend_size ends it (:356)
+            const int band_tol = (int)(0.3 * seg);
+            const int max_d = (int)(2.0 * error_rate * (seg + seg));
+            const int koff = max_d, band_size = band_tol * 2;
+            __builtin_amdgcn_wave_barrier();
+            for (int w = lane; w < CN_SEQ_WORDS; w += 64) {
+                const bool in = w > 0 && (w - 1) * 16 < seg + 32;
+                S.Qp[w] = in ? view_word(q, extend1 + (w - 1) * 16) : 0u;
+                S.Tp[w] = in ? view_word(t, extend2 + (w - 1) * 16) : 0u;
+            }
+            for (int i = lane; i < 2 * max_d + 4 && i < CN_VLEN; i += 64) S.V[i] = 0;     // :329-330
+            __builtin_amdgcn_wave_barrier();
+
+            // ---- Align, forward rows (:172-210)
+            int best_m = -1, min_k = 0, max_k = 0;
+            uint32_t lin = 0;
+            int end_d = -1, end_k = 0, end_x = 0;
+            for (int d = 0; d < max_d; ++d) {
+                if (max_k - min_k > band_size) break;
+                const int nslot = max_k >= min_k ? ((max_k - min_k) >> 1) + 1 : 0;
+                if (lane == 0) { S.rmin[d] = (int16_t)min_k; S.rmax[d] = (int16_t)max_k; S.roff[d] = lin; }
+                int mmax = -1, hkey = 0x7fffffff, lo = 0x7fffffff, hi = -0x7fffffff;
+                constexpr int MAXJ = (CN_ROW_W + 63) / 64;
+                int us[MAXJ];
+                const int NJ = (nslot + 63) >> 6;
+#pragma unroll
+                for (int j = 0; j < MAXJ; ++j) {
+                    us[j] = -0x40000000;
+                    if (j >= NJ) continue;
+                    const int tt = lane + 64 * j;
+                    const bool act = tt < nslot;
+                    const int k = min_k + 2 * tt, kk = k + koff;
+                    const int16_t* vp = &S.V[act ? kk - 1 : 0];
+                    const int vl = vp[0], vr = vp[2];
+                    int x = (k == min_k || (k != max_k && vl < vr)) ? vr : vl + 1;       // :176-179
+                    x = act ? x : seg;
+                    int y = act ? x - k : 0;
+                    bool again;
+                    do {
+                        const int lim = min(seg - x, seg - y);
+                        const int m = min(match16(S.Qp, x, S.Tp, y), lim);
+                        const int nn = min(m, 16);
+                        x += nn; y += nn;
+                        again = m > 16;
+                    } while (__ballot(again));
+                    us[j] = act ? x + y : -0x40000000;
+                    if (act) {
+                        grow[(size_t)d * CN_ROW_W + tt] = (uint16_t)x;
+                        if (lin + (uint32_t)tt < CN_RING) S.ring[lin + tt] = (uint16_t)x;
+                        mmax = max(mmax, x + y);
+                        if (x >= seg || y >= seg) hkey = min(hkey, (kk << 10) | x);           // lowest diagonal first (:198-199)
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                // V is updated after every diagonal of the row has read its neighbours (they have the other parity anyway)
+#pragma unroll
+                for (int j = 0; j < MAXJ; ++j) {
+                    const int tt = lane + 64 * j;
+                    if (tt < nslot) { const int k = min_k + 2 * tt; S.V[k + koff] = (int16_t)((us[j] + k) >> 1); }
+                }
+                lin += (uint32_t)nslot;
+                best_m = max(best_m, wave_max(mmax));
+                hkey = wave_min(hkey);
+                if (hkey != 0x7fffffff) { end_d = d; end_k = (hkey >> 10) - koff; end_x = hkey & 1023; break; }
+#pragma unroll
+                for (int j = 0; j < MAXJ; ++j) {                                               // band (:202-209)
+                    const int tt = lane + 64 * j;
+                    if (tt < nslot && us[j] >= best_m - band_tol) { const int k = min_k + 2 * tt; lo = min(lo, k); hi = max(hi, k); }
+                }
+                lo = wave_min(lo); hi = wave_max(hi);
+                const int nmin = lo != 0x7fffffff ? lo : max_k, nmax = lo != 0x7fffffff ? hi : min_k;
+                max_k = nmax + 1;
+                min_k = nmin - 1;
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (end_d < 0) break;                        // no end reached: Align returns 0
+
+            // ---- the path, end to start (:222-240): one scalar walk, every lane the same
+            __threadfence_block();
+            __builtin_amdgcn_wave_barrier();
+            {
+                int ck = end_k, x2 = end_x;
+                for (int cd = end_d; cd >= 0; --cd) {
+                    int x1 = 0, pre = ck, px2 = 0;
+                    if (cd > 0) {
+                        const int cmin = S.rmin[cd], cmax = S.rmax[cd], pmin = S.rmin[cd - 1], pmax = S.rmax[cd - 1];
+                        const int kl = ck - 1, kr = ck + 1;
+                        const int vl = (kl >= pmin && kl <= pmax) ? cns_cell(S, grow, cd - 1, kl) : 0;
+                        const int vr = (kr >= pmin && kr <= pmax) ? cns_cell(S, grow, cd - 1, kr) : 0;
+                        if (ck == cmin || (ck != cmax && vl < vr)) { pre = kr; x1 = vr; px2 = vr; }
+                        else { pre = kl; x1 = vl + 1; px2 = vl; }
+                    }
+                    if (lane == 0) { S.tk[cd] = (int16_t)ck; S.tx2[cd] = (uint16_t)x2; S.tx1[cd] = (uint16_t)x1; }
+                    ck = pre;
+                    x2 = px2;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+
+            // ---- columns before each row's snake; the last row with a snake of >= 4 (:336-343)
+            int carry = 0, rstar = -1;
+            for (int r0 = 0; r0 <= end_d; r0 += 64) {
+                const int r = r0 + lane;
+                const bool in = r <= end_d;
+                const int len = in ? (int)S.tx2[r] - (int)S.tx1[r] : 0;
+                int incl = len + (in && r > 0 ? 1 : 0);          // the row's indel column + its snake
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int v = __shfl_up(incl, o);
+                    if (lane >= o) incl += v;
+                }
+                if (in) S.roff[r] = (uint32_t)(carry + incl - len);     // columns before the snake of row r (its indel included)
+                const unsigned long long big = __ballot(in && len >= 4);
+                if (big) rstar = r0 + 63 - __clzll((long long)big);
+                carry += __shfl(incl, 63);
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int ncols = carry, end_y = end_x - end_k;
+            int kept_cols, kept_q, kept_t;
+            if (more) {
+                if (rstar < 0) break;
+                const int x2s = (int)S.tx2[rstar], ks = (int)S.tk[rstar], lens = x2s - (int)S.tx1[rstar];
+                kept_cols = (int)S.roff[rstar] + lens - 4;
+                kept_q = x2s - 4;
+                kept_t = x2s - ks - 4;
+                if (kept_q == 0) break;                  // "i == ALN_SIZE" (:350)
+            } else {
+                kept_cols = ncols; kept_q = end_x; kept_t = end_y;
+                if (end_x == 0) break;                   // "i == extend_size" (:356)
+            }
+            if (cols + kept_cols > dir_cols_cap) { if (lane == 0) atomicExch(err_flag, 1); break; }
+            // ---- emit: 0 = both bases (the buffer is zero-filled), 1 = target base only, 2 = query base only
+            for (int r0 = 1; r0 <= end_d; r0 += 64) {
+                const int r = r0 + lane;
+                const bool in = r <= end_d;
+                const int c = in ? (int)S.roff[r] - 1 : 0x7fffffff;          // column of the row's indel
+                const bool put = in && c < kept_cols;
+                const int op = put ? ((int)S.tk[r] < (int)S.tk[r - 1] ? 1 : 2) : 0;
+                if (put) {
+                    const int gc = cols + c;
+                    atomicOr(&uops[gc >> 4], (uint32_t)op << ((gc & 15) << 1));
+                }
+                n_ins += __popcll(__ballot(op == 1));
+                n_del += __popcll(__ballot(op == 2));
+            }
+            cols += kept_cols;
+            extend1 += kept_q;
+            extend2 += kept_t;
+            extend_size = min(query_size - extend1, target_size - extend2);
+        }
+        if (lane == 0) { CnsDir D = {cols, extend1, extend2, n_ins, n_del, 0}; dres[unit] = D; }
+    }
+}
+
+__device__ __forceinline__ int cns_op(const uint32_t* __restrict__ w, int c) { return (int)((w[c >> 4] >> ((c & 15) << 1)) & 3u); }
+
+// dw's merge + GetAlignment's trimming (dw.cpp:397-480, 495-531).  Merged column c: c < L.cols -> left op L.cols - 1 - c, else
+// right op c - L.cols.  One thread per candidate; the scans stop at the first run of four matches from either end.
+__global__ void cns_stitch(const mhip_aln_job* __restrict__ jobs, const CnsDir* __restrict__ dres, const uint32_t* __restrict__ ops,
+                           int dir_cols_cap, int n, int min_aln, mhip_cns_result* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t dir_words = ((size_t)dir_cols_cap + 15) / 16;
+    const CnsDir L = dres[2 * i], R = dres[2 * i + 1];
+    const uint32_t* lw = ops + (size_t)(2 * i) * dir_words;
+    const uint32_t* rw = lw + dir_words;
+    mhip_cns_result r;
+    memset(&r, 0, sizeof(r));
+    r.left_cols = L.cols; r.right_cols = R.cols;
+    r.query_start = jobs[i].qstart - L.qbases; r.query_end = jobs[i].qstart + R.qbases;
+    r.target_start = jobs[i].sstart - L.tbases; r.target_end = jobs[i].sstart + R.tbases;
+    const int size = L.cols + R.cols;
+    r.ins = L.ins + R.ins; r.del = L.del + R.del; r.mat = size - r.ins - r.del;
+    bool ok = size >= min_aln;
+    int first = 0, last = 0, qrb = 0, trb = 0, qre = 0, tre = 0;
+    if (ok) {
+        int eit = 0, k;
+        for (k = 0; k < size && eit < 4; ++k) {
+            const int op = k < L.cols ? cns_op(lw, L.cols - 1 - k) : cns_op(rw, k - L.cols);
+            if (op != 1) ++qrb;
+            if (op != 2) ++trb;
+            if (op == 0) ++eit; else eit = 0;
+        }
+        if (eit < 4) ok = false;
+        first = k - 4; qrb -= 4; trb -= 4;
+        if (ok) {
+            for (k = size - 1, eit = 0; k >= 0 && eit < 4; --k) {
+                const int op = k < L.cols ? cns_op(lw, L.cols - 1 - k) : cns_op(rw, k - L.cols);
+                if (op != 1) ++qre;
+                if (op != 2) ++tre;
+                if (op == 0) ++eit; else eit = 0;
+            }
+            if (eit < 4) ok = false;
+            last = k + 4 + 1; qre -= 4; tre -= 4;
+        }
+    }
+    r.ok = ok ? 1 : 0;
+    if (ok) {
+        r.qoff = r.query_start + qrb; r.qend = r.query_end - qre;
+        r.soff = r.target_start + trb; r.send = r.target_end - tre;
+        r.first_col = first; r.last_col = last;
+    }
+    out[i] = r;
+}
+
+extern "C" {
+
+int mhip_cns_align_candidates_dev(mhip_ctx* c, const mhip_volume* ref, const mhip_volume* reads, const void* d_jobs, int n, double error_rate,
+                                  int min_align_size, int dir_cols_cap, void* d_results, void* d_ops) {
+    HIPCHK(hipSetDevice(c->device));
+    if (n <= 0) return 0;
+    if (dir_cols_cap < 16 || (dir_cols_cap & 15)) { mhip_set_error("dir_cols_cap must be a positive multiple of 16"); return -1; }
+    if (!(error_rate > 0.0) || error_rate > 0.20) { mhip_set_error("error_rate %.3f outside (0, 0.20]", error_rate); return -1; }
+    const int waves_per_cu = 8;                       // 17 KB of LDS per wave
+    const int max_waves = c->num_cus * waves_per_cu;
+    const int grid = std::min(max_waves / CN_WAVES, (2 * n + CN_WAVES - 1) / CN_WAVES);
+    CnsDir* d_dres;
+    uint16_t* d_g;
+    unsigned int* d_cur;
+    int* d_err;
+    if (c->scratch("cn_dres", sizeof(CnsDir) * 2 * (size_t)n, (void**)&d_dres)) return -1;
+    if (c->scratch("cn_rows", sizeof(uint16_t) * CN_GROW * (size_t)max_waves, (void**)&d_g)) return -1;
+    if (c->scratch("cn_cursor", 64, (void**)&d_cur)) return -1;
+    d_err = (int*)(d_cur + 8);
+    HIPCHK(hipMemsetAsync(d_cur, 0, 64, c->stream));
+    const size_t dir_words = (size_t)dir_cols_cap / 16;
+    HIPCHK(hipMemsetAsync(d_ops, 0, sizeof(uint32_t) * dir_words * 2 * (size_t)n, c->stream));
+    LAUNCH(c, "cns_extend", cns_extend, grid, CN_BLOCK, 0, (const uint32_t*)ref->d_pac, (const mhip_offset_t*)ref->d_offs,
+           (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs, (const mhip_aln_job*)d_jobs, n, error_rate, dir_cols_cap,
+           (uint32_t*)d_ops, d_dres, d_g, d_cur, d_err);
+    LAUNCH(c, "cns_stitch", cns_stitch, (n + 255) / 256, 256, 0, (const mhip_aln_job*)d_jobs, (const CnsDir*)d_dres, (const uint32_t*)d_ops,
+           dir_cols_cap, n, min_align_size, (mhip_cns_result*)d_results);
+    int err = 0;
+    HIPCHK(hipMemcpyAsync(&err, d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipGetLastError());
+    if (err) { mhip_set_error("mecat2cns aligner: a direction needed more than dir_cols_cap = %d columns", dir_cols_cap); return -1; }
+    return 0;
+}
+
+int mhip_cns_align_candidates(mhip_ctx* c, const mhip_volume* ref, const mhip_volume* reads, const mhip_aln_job* jobs, int n, double error_rate,
+                              int min_align_size, int dir_cols_cap, mhip_cns_result* results, uint32_t* ops) {
+    HIPCHK(hipSetDevice(c->device));
+    if (n <= 0) return 0;
+    void *d_jobs, *d_res, *d_ops;
+    const size_t ops_bytes = sizeof(uint32_t) * ((size_t)dir_cols_cap / 16) * 2 * (size_t)n;
+    if (c->scratch("cn_jobs", sizeof(mhip_aln_job) * (size_t)n, &d_jobs)) return -1;
+    if (c->scratch("cn_res", sizeof(mhip_cns_result) * (size_t)n, &d_res)) return -1;
+    if (c->scratch("cn_ops", ops_bytes, &d_ops)) return -1;
+    HIPCHK(hipMemcpyAsync(d_jobs, jobs, sizeof(mhip_aln_job) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    if (mhip_cns_align_candidates_dev(c, ref, reads, d_jobs, n, error_rate, min_align_size, dir_cols_cap, d_res, d_ops)) return -1;
+    HIPCHK(hipMemcpyAsync(results, d_res, sizeof(mhip_cns_result) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    if (ops) HIPCHK(hipMemcpyAsync(ops, d_ops, ops_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+}  // extern "C"

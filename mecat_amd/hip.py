@@ -39,6 +39,12 @@ class AlnJob(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("qid_local", "sid_local", "chain", "qstart", "sstart")]
 
 
+class CnsResult(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("ok", "qoff", "qend", "soff", "send", "left_cols", "right_cols", "first_col", "last_col",
+                                         "mat", "ins", "dele", "query_start", "query_end", "target_start", "target_end")]
+
+
+CNS_DTYPE = np.dtype([(n, np.int32) for n, _ in CnsResult._fields_])
 CAND_DTYPE = np.dtype([(n, np.int32) for n, _ in Candidate._fields_])
 ALN_DTYPE = np.dtype([(n, np.int32) for n, _ in AlnResult._fields_])
 JOB_DTYPE = np.dtype([(n, np.int32) for n, _ in AlnJob._fields_])
@@ -85,6 +91,10 @@ def lib():
     L.mhip_align_candidates_dev.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     L.mhip_xalign_candidates.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     L.mhip_xalign_candidates_dev.argtypes = [vp, vp, vp, vp, i32, i32, vp]
+    L.mhip_cns_align_candidates.argtypes = [vp, vp, vp, vp, i32, C.c_double, i32, i32, vp, vp]
+    L.mhip_cns_align_candidates_dev.argtypes = [vp, vp, vp, vp, i32, C.c_double, i32, i32, vp, vp]
+    L.mhip_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    L.mhip_host_free.argtypes = [vp]
     assert L.mhip_abi_version() == 1
     _lib = L
     return L
@@ -233,3 +243,35 @@ def align_candidates(ctx, ref, reads, jobs, min_align_size, tech=0):
 
 def align_candidates_dev(ctx, ref, reads, d_jobs, n, min_align_size, d_out):
     _chk(lib().mhip_align_candidates_dev(ctx.h, ref.h, reads.h, d_jobs, n, min_align_size, d_out))
+
+
+def cns_align_candidates(ctx, ref, reads, jobs, error_rate, min_align_size, dir_cols_cap):
+    """mecat2cns re-aligner (GetAlignment).  -> (results [n] CNS_DTYPE, ops [n, 2, dir_cols_cap / 16] uint32)"""
+    jobs = np.ascontiguousarray(jobs, dtype=JOB_DTYPE)
+    n = len(jobs)
+    res = np.zeros(n, dtype=CNS_DTYPE)
+    ops = np.zeros((n, 2, dir_cols_cap // 16), dtype=np.uint32)
+    if n:
+        _chk(lib().mhip_cns_align_candidates(ctx.h, ref.h, reads.h, jobs.ctypes.data, n, float(error_rate), min_align_size, dir_cols_cap,
+                                             res.ctypes.data, ops.ctypes.data))
+    return res, ops
+
+
+def cns_expand(res, ops_row, qcodes, tcodes):
+    """Rebuild the aligned strings of one result from its ops (the host side of the 2-bit column format): qcodes = the
+    query read as the aligner saw it (reverse-complemented when chain != 0), tcodes = the template.  -> (qaln, saln) over
+    "ACGT-", i.e. m5qaln / m5saln."""
+    def unpack(words, ncols):
+        w = np.asarray(words[: (ncols + 15) // 16], dtype=np.uint32)
+        cols = ((w[:, None] >> (2 * np.arange(16, dtype=np.uint32))[None, :]) & 3).reshape(-1)
+        return cols[:ncols].astype(np.uint8)
+    left = unpack(ops_row[0], int(res["left_cols"]))[::-1]
+    right = unpack(ops_row[1], int(res["right_cols"]))
+    ops = np.concatenate([left, right])
+    dec = np.frombuffer(b"ACGT", dtype=np.uint8)
+    qi = int(res["query_start"]) + np.cumsum(ops != 1) - (ops != 1)
+    ti = int(res["target_start"]) + np.cumsum(ops != 2) - (ops != 2)
+    qs = np.where(ops == 1, ord("-"), dec[np.asarray(qcodes)[np.minimum(qi, len(qcodes) - 1)]]).astype(np.uint8)
+    ts = np.where(ops == 2, ord("-"), dec[np.asarray(tcodes)[np.minimum(ti, len(tcodes) - 1)]]).astype(np.uint8)
+    a, b = int(res["first_col"]), int(res["last_col"])
+    return qs[a:b].tobytes(), ts[a:b].tobytes()

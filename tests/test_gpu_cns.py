@@ -1,0 +1,127 @@
+"""GPU parity of the mecat2cns re-aligner (mhip_cns_align_candidates) against the known answers of
+the unmodified reference (tests/golden/cns_kats.npz) and against the oracle restatement on random pairs, both strands.
+Coordinates, counts and the aligned strings (rebuilt from the 2-bit columns) are bit-exact."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+CAP = 32768
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import mecat_amd.hip as M
+    return M
+
+
+@pytest.fixture(scope="module")
+def ctx(hip):
+    c = hip.Context(0)
+    yield c
+    c.close()
+
+
+def _volume(hip, ctx, seqs):
+    lens = np.array([len(s) for s in seqs], dtype=np.int32)
+    codes = np.concatenate(seqs).astype(np.uint8)
+    ov = H.orc_pack(codes, lens)
+    offs, pac = H.vol_arrays(ov)
+    return hip.Volume(ctx, pac, offs, ov.contents.num_bases, 0)
+
+
+def _orc(a, q, qs, t, ts, er, mn):
+    O = H.orc()
+    res = np.zeros(9, np.int32)
+    s1 = np.zeros(100001, np.int8)
+    s2 = np.zeros(100001, np.int8)
+    ok = O.orc_cns_dw(a, q.ctypes.data, qs, len(q), t.ctypes.data, ts, len(t), er, mn, res.ctypes.data, s1.ctypes.data, s2.ctypes.data)
+    res2 = np.zeros(5, np.int32)
+    ok2 = O.orc_cns_get_alignment(a, q.ctypes.data, qs, len(q), t.ctypes.data, ts, len(t), er, mn, res2.ctypes.data, s1.ctypes.data, s2.ctypes.data)
+    return ok, res, ok2, res2, s1[: res2[4]].tobytes(), s2[: res2[4]].tobytes()
+
+
+def _check(hip, r, ops_row, q, t, want):
+    ok, res, ok2, res2, qaln, saln = want
+    # dw level: coordinates, column count, indel counts of the untrimmed string (the reference only fills the counts on success)
+    assert (int(r["query_start"]), int(r["query_end"]), int(r["target_start"]), int(r["target_end"])) == tuple(int(x) for x in res[:4])
+    assert int(r["left_cols"]) + int(r["right_cols"]) == int(res[4])
+    if ok:
+        assert (int(r["mat"]), int(r["ins"]), int(r["dele"])) == (int(res[5]), int(res[7]), int(res[8]))
+    # GetAlignment level
+    assert int(r["ok"]) == int(ok2)
+    if ok2:
+        assert (int(r["qoff"]), int(r["qend"]), int(r["soff"]), int(r["send"])) == tuple(int(x) for x in res2[:4])
+        assert int(r["last_col"]) - int(r["first_col"]) == int(res2[4])
+        gq, gs = hip.cns_expand(r, ops_row, q, t)
+        assert gq == qaln and gs == saln
+
+
+def test_cns_golden_kats(hip, ctx):
+    K = np.load(os.path.join(H.GOLDEN, "cns_kats.npz"))
+    seqs, cases = [], []
+    qo = to = 0
+    for par in K["par"]:
+        nq, nt, qs, ts, mn, er100 = [int(x) for x in par]
+        seqs += [K["q"][qo: qo + nq], K["t"][to: to + nt]]
+        qo += nq; to += nt
+        cases.append((qs, ts, mn, er100))
+    vol = _volume(hip, ctx, seqs)
+    for er100 in (15, 20):
+        for mn in (50, 500):
+            sel = [i for i, c in enumerate(cases) if c[3] == er100 and c[2] == mn]
+            jobs = np.zeros(len(sel), dtype=hip.JOB_DTYPE)
+            for j, i in enumerate(sel):
+                jobs[j] = (2 * i, 2 * i + 1, 0, cases[i][0], cases[i][1])
+            res, ops = hip.cns_align_candidates(ctx, vol, vol, jobs, er100 / 100.0, mn, CAP)
+            for j, i in enumerate(sel):
+                want_dw, want_ga = K["dw_res"][i], K["ga_res"][i]
+                r = res[j]
+                assert [int(r["query_start"]), int(r["query_end"]), int(r["target_start"]), int(r["target_end"]),
+                        int(r["left_cols"]) + int(r["right_cols"])] == [int(x) for x in want_dw[1:6]], i
+                assert int(r["ok"]) == int(want_ga[0]), i
+                if want_ga[0]:
+                    assert [int(r["qoff"]), int(r["qend"]), int(r["soff"]), int(r["send"]), int(r["last_col"]) - int(r["first_col"])] == \
+                        [int(x) for x in want_ga[1:6]], i
+                    gq, gs = hip.cns_expand(r, ops[j], seqs[2 * i], seqs[2 * i + 1])
+                    # digests: "<untrimmed>:<trimmed>" of "qaln|saln"
+                    assert hashlib.sha256(gq + b"|" + gs).hexdigest() == str(K["digests"][i]).split(":")[1], i
+    vol.free()
+
+
+@pytest.mark.parametrize("error_rate", [0.15, 0.20])
+def test_cns_random_pairs_both_strands(hip, ctx, error_rate):
+    rng = np.random.default_rng(23)
+    O = H.orc()
+    a = O.orc_cns_new()
+    seqs, metas = [], []
+    for it in range(120):
+        n = int(rng.integers(200, 12000))
+        q, t, qs, ts = H.cns_pair(rng, n, [0.0, 0.05, 0.12, 0.15, 0.18, 0.3][it % 6], it)
+        chain = it % 2
+        # the volume holds the read as sequenced; chain 1 means the aligner sees its reverse complement
+        stored_q = (3 - q)[::-1].copy() if chain else q
+        seqs += [stored_q.astype(np.int8), t]
+        metas.append((q, t, qs, ts, chain))
+    vol = _volume(hip, ctx, seqs)
+    for mn in (50, 500):
+        jobs = np.zeros(len(metas), dtype=hip.JOB_DTYPE)
+        for i, (q, t, qs, ts, chain) in enumerate(metas):
+            jobs[i] = (2 * i, 2 * i + 1, chain, qs, ts)
+        res, ops = hip.cns_align_candidates(ctx, vol, vol, jobs, error_rate, mn, CAP)
+        oks = 0
+        for i, (q, t, qs, ts, chain) in enumerate(metas):
+            want = _orc(a, q, qs, t, ts, error_rate, mn)
+            try:
+                _check(hip, res[i], ops[i], q, t, want)
+            except AssertionError:
+                print("case", i, "n", len(q), len(t), "qs", qs, "ts", ts, "chain", chain, "gpu", res[i], "orc", want[:4])
+                raise
+            oks += int(want[2])
+        assert oks > 30
+    O.orc_cns_free(a)
+    vol.free()

@@ -125,3 +125,37 @@ def test_cns_random_pairs_both_strands(hip, ctx, error_rate):
         assert oks > 30
     O.orc_cns_free(a)
     vol.free()
+
+
+def test_cns_argument_checks_and_tiny_reads(hip, ctx):
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 4, size=3000).astype(np.int8)
+    tiny = [rng.integers(0, 4, size=n).astype(np.int8) for n in (1, 2, 3, 5, 9)]
+    seqs = [base, base.copy()] + tiny
+    vol = _volume(hip, ctx, seqs)
+    jobs = np.zeros(1, dtype=hip.JOB_DTYPE)
+    jobs[0] = (0, 1, 0, 1500, 1500)
+    with pytest.raises(hip.MhipError, match="columns"):
+        hip.cns_align_candidates(ctx, vol, vol, jobs, 0.15, 500, 16)          # 3000 identical columns do not fit 16
+    with pytest.raises(hip.MhipError, match="error_rate"):
+        hip.cns_align_candidates(ctx, vol, vol, jobs, 0.25, 500, CAP)
+    with pytest.raises(hip.MhipError, match="multiple of 16"):
+        hip.cns_align_candidates(ctx, vol, vol, jobs, 0.15, 500, 1000)
+    res, ops = hip.cns_align_candidates(ctx, vol, vol, jobs, 0.15, 500, CAP)
+    assert int(res[0]["ok"]) == 1 and (int(res[0]["qoff"]), int(res[0]["qend"])) == (0, 3000) and int(res[0]["mat"]) == 3000
+    # reads shorter than the four-match anchor never align; every start position is legal
+    O = H.orc()
+    a = O.orc_cns_new()
+    js, metas = [], []
+    for i, s in enumerate(tiny):
+        for qs in range(len(s)):
+            js.append((2 + i, 0, 0, qs, 7))
+            metas.append((s, base, qs, 7))
+            js.append((0, 2 + i, 0, 11, qs))
+            metas.append((base, s, 11, qs))
+    jobs = np.array(js, dtype=hip.JOB_DTYPE)
+    res, ops = hip.cns_align_candidates(ctx, vol, vol, jobs, 0.15, 1, CAP)
+    for r, o, (q, t, qs, ts) in zip(res, ops, metas):
+        _check(hip, r, o, q, t, _orc(a, q, qs, t, ts, 0.15, 1))
+    O.orc_cns_free(a)
+    vol.free()

@@ -55,9 +55,6 @@ struct mhip_ctx {
     std::map<std::string, DevBuf> bufs;   // named scratch buffers, grown on demand, freed with the context
     int64_t* d_counters = nullptr;        // 8 work counters (see mecat_hip.h)
     int num_cus = 256;
-    int dbg_flags = 0;                    // bit 0: mhip_seed_reads stops after seed_build (tests/debug only)
-    std::vector<char> dbg_blob;           // SeedArrays of the last seed batch
-    int dbg_ns = 0;
 
     // returns a device buffer of at least `bytes` (contents undefined)
     int scratch(const char* name, size_t bytes, void** out);

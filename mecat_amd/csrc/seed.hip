@@ -985,12 +985,6 @@ static int seed_batch(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref
         }
     }
     LAUNCH(c, "seed_build", seed_build, ns, SEED_BLOCK, 0, A, in_b, (int)P->min_kmer_match, P->ddfs_cutoff);
-    c->dbg_blob.assign((const char*)&A, (const char*)&A + sizeof(A));
-    c->dbg_ns = ns;
-    if (c->dbg_flags & 1) {
-        HIPCHK(hipMemsetAsync(d_counts, 0, sizeof(int32_t) * (size_t)nr, c->stream));
-        return 0;
-    }
     const size_t lds = sizeof(int) * 12 * (size_t)P->maxc + sizeof(CandLds);
     LAUNCH(c, "seed_cand", seed_cand, nr, WAVE, lds, A, (const mhip_offset_t*)ref->d_offs, ref->num_reads, ref->start_read_id,
            (const mhip_offset_t*)reads->d_offs, rb, stride, reads->start_read_id, *P, d_out, d_counts, (unsigned long long*)c->d_counters);
@@ -1064,42 +1058,6 @@ int mhip_seed_reads(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref, 
     HIPCHK(hipMemcpyAsync(out_counts, d_cnt, sizeof(int32_t) * n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(out, d_out, sizeof(mhip_candidate) * n * (size_t)P->maxc, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    return 0;
-}
-
-// ---- debug / test access to the per-strand state of the last seed batch (not part of the product ABI) ----
-int mhip_debug_set_flags(mhip_ctx* c, int flags) { c->dbg_flags = flags; return 0; }
-
-// what: 0 header {H, nseg, nrec, ngated}, 1 seg_id, 2 seg_score, 3 seg_start, 4 ent, 5 ent_fin, 6 gated, 7 sorted keys (u64)
-int mhip_debug_strand(mhip_ctx* c, int strand, int what, void* out, int64_t cap_bytes, int sorted_in_b) {
-    HIPCHK(hipSetDevice(c->device));
-    if (c->dbg_blob.size() != sizeof(SeedArrays) || strand < 0 || strand >= c->dbg_ns) { mhip_set_error("no debug state"); return -1; }
-    SeedArrays A;
-    memcpy(&A, c->dbg_blob.data(), sizeof(A));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    uint32_t H, nseg, nrec, ng;
-    uint64_t hb;
-    HIPCHK(hipMemcpy(&H, A.strand_hits + strand, 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(&nseg, A.nseg + strand, 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(&nrec, A.nrec + strand, 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(&ng, A.ngated + strand, 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(&hb, A.hit_base + strand, 8, hipMemcpyDeviceToHost));
-    const void* src = nullptr;
-    size_t bytes = 0;
-    uint32_t hdr[4] = {H, nseg, nrec, ng};
-    switch (what) {
-    case 0: if (cap_bytes < 16) return -1; memcpy(out, hdr, 16); return 0;
-    case 1: src = A.seg_id + hb; bytes = 4ull * nseg; break;
-    case 2: src = A.seg_score + hb; bytes = 4ull * nseg; break;
-    case 3: src = A.seg_start + hb; bytes = 4ull * nseg; break;
-    case 4: src = A.ent + hb; bytes = 4ull * nrec; break;
-    case 5: src = A.ent_fin + hb; bytes = 4ull * nrec; break;
-    case 6: src = A.gated + hb; bytes = 4ull * ng; break;
-    case 7: src = (sorted_in_b ? A.keysB : A.keysA) + hb; bytes = 8ull * H; break;
-    default: mhip_set_error("bad what"); return -1;
-    }
-    if ((int64_t)bytes > cap_bytes) { mhip_set_error("debug buffer too small"); return -1; }
-    if (bytes) HIPCHK(hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));
     return 0;
 }
 

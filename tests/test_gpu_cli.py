@@ -129,3 +129,43 @@ def test_cli_two_processes_share_the_grid_rows(tmp_path, task):
     assert open(two).read() == open(one).read()
     assert len(open(two).read().splitlines()) > 300
     assert sorted(f for f in os.listdir(wrk) if f.startswith("r_")) == ["r_0", "r_1", "r_2"]
+
+
+def test_cli_multi_volume_grid_m4(tmp_path):
+    """-j 1 over a 3-volume grid: off-diagonal cells align reads of volume j against volume i (local ids, start_read_id
+    offsets in every record).  Expected output: the oracle's whole `-j 1` body (orc_map_read) run cell by cell."""
+    import ctypes as C
+    g = G["sets"]["tiny"]["gen"]
+    codes, lens = H.synth_reads(g["nreads"], g["L"], g["err"], g["genome"], g["seed"], g["ont"])
+    fa = str(tmp_path / "tiny.fa")
+    H.write_fasta(fa, codes, lens)
+    wrk = tmp_path / "w_mv4"
+    out = str(tmp_path / "mv.m4")
+    env = dict(os.environ, MECAT_HIP_MCS="250000")
+    r = subprocess.run([BIN, "-j", "1", "-g", "1", "-d", fa, "-o", out, "-w", str(wrk), "-t", "4"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    names = open(os.path.join(str(wrk), "fileindex.txt")).read().split()
+    assert len(names) == 3
+    O = H.orc()
+    vols = [O.orc_volume_load(n.encode()) for n in names]
+    p = H.orc_params(tech=0)
+    want = []
+    outm = (H.OrcM4 * 200)()
+    buf = C.create_string_buffer(512)
+    al = O.orc_aligner_new()
+    for i, ref in enumerate(vols):
+        oidx = O.orc_index_build(ref)
+        bk = O.orc_bk_new(ref.contents.num_bases)
+        for j in range(i, len(vols)):
+            rd = vols[j]
+            for rid in range(rd.contents.num_reads):
+                k = O.orc_map_read(ref, rd, oidx, bk, al, rid, C.byref(p), outm)
+                for x in range(k):
+                    n = O.orc_m4_line(C.byref(outm[x]), 1, buf)
+                    want.append(buf.raw[:n].decode().rstrip("\n"))
+        O.orc_bk_free(bk)
+        O.orc_index_free(oidx)
+    O.orc_aligner_free(al)
+    got = sorted(open(out).read().splitlines())
+    assert got == sorted(want)
+    assert len(got) > 300

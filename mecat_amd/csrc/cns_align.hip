@@ -11,8 +11,9 @@
 //   * a block's tail is cut in front of its last run of four matches and the next block starts there (:336-351);
 //   * GetAlignment trims the merged string to its first and last run of four matches (:495-531).
 //
-// One wave per (candidate, direction); lanes are the diagonals of a d-row.  Every row's furthest-x values are kept (LDS
-// while the block's cells fit CN_RING, always in a per-wave global scratch) because the traceback walks all of them.
+// One wave per (candidate, direction); lanes are the diagonals of a d-row.  Every row's furthest-x values go to a per-wave
+// global scratch because the traceback walks all of them; the walk pulls them back into LDS a window of rows at a time
+// (coalesced copies), which keeps the LDS footprint at 9 KB per wave = 16 waves per CU.
 #include <algorithm>
 
 #include "dw_helpers.h"
@@ -25,7 +26,7 @@
 #define CN_VLEN (2 * CN_MAX_D + 8)
 #define CN_ROW_W 192               // diagonals per row: band of 2 * int(0.3 * 600) = 360 -> 181 + 2
 #define CN_SEQ_WORDS 44            // 600 bases + 32 of window slack = 40 words, one leading pad word, slack
-#define CN_RING 4096               // cells of a block kept in LDS (a 500 x 500 block at 15 % visits ~4 k)
+#define CN_RING 1536               // cells of the traceback's row window in LDS (~60 rows at 15 %)
 #define CN_GROW ((size_t)CN_MAX_D * CN_ROW_W)
 
 struct CnsLds {
@@ -33,20 +34,37 @@ struct CnsLds {
     uint32_t Tp[CN_SEQ_WORDS];
     int16_t V[CN_VLEN];
     int16_t rmin[CN_MAX_D], rmax[CN_MAX_D];
-    uint32_t roff[CN_MAX_D];       // forward: linear cell index of the row's first cell; afterwards: columns before the row's snake
-    uint16_t ring[CN_RING];
-    uint16_t tx1[CN_MAX_D], tx2[CN_MAX_D];   // the path: snake start / end (x) per row
-    int16_t tk[CN_MAX_D];                    // the path: diagonal per row
+    uint16_t woff[CN_MAX_D];       // traceback: offset of the row in the window; afterwards: columns before the row's snake
+    uint16_t ring[CN_RING];        // the row window
+    uint16_t tlen[CN_MAX_D];       // the path: snake length of the row, bit 15 = the row's indel is a query-only column
 };
 
 struct CnsDir {                    // one direction of one candidate
     int32_t cols, qbases, tbases, ins, del, pad;
 };
 
-__device__ __forceinline__ int cns_cell(const CnsLds& S, const uint16_t* __restrict__ grow, int r, int k) {
-    const int idx = (k - (int)S.rmin[r]) >> 1;
-    const uint32_t lin = S.roff[r] + (uint32_t)idx;
-    return lin < CN_RING ? (int)S.ring[lin] : (int)grow[(size_t)r * CN_ROW_W + idx];
+__device__ __forceinline__ int cns_cell(const CnsLds& S, int r, int k) {
+    return (int)S.ring[(int)S.woff[r] + ((k - (int)S.rmin[r]) >> 1)];
+}
+
+// rows in the window ending at row r (going down): as many of r, r - 1, ... (at most 64) as fit CN_RING cells.  Copies them
+// from the global scratch into the ring, sets woff[]; returns the lowest row loaded.
+__device__ __forceinline__ int cns_load_window(CnsLds& S, const volatile uint16_t* grow, int r, int lane) {
+    const int rr = r - lane;
+    const int ns = rr >= 0 && S.rmax[rr] >= S.rmin[rr] ? (((int)S.rmax[rr] - (int)S.rmin[rr]) >> 1) + 1 : 0;
+    int incl = ns;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    const unsigned long long fits = __ballot(rr >= 0 && incl <= CN_RING);
+    const int count = __popcll(fits);                      // a prefix of the lanes: incl is non-decreasing; >= 1 (a row has <= 181 cells)
+    if (lane < count) S.woff[rr] = (uint16_t)(incl - ns);
+    for (int i = 0; i < count; ++i) {
+        const int n_i = __shfl(ns, i), off_i = __shfl(incl - ns, i), row = r - i;
+        for (int c = lane; c < n_i; c += 64) S.ring[off_i + c] = grow[(size_t)row * CN_ROW_W + c];
+    }
+    return r - count + 1;
 }
 
 __global__ __launch_bounds__(CN_BLOCK) void cns_extend(const uint32_t* __restrict__ rpac, const mhip_offset_t* __restrict__ roffs,
@@ -99,12 +117,11 @@ __global__ __launch_bounds__(CN_BLOCK) void cns_extend(const uint32_t* __restric
 
             // ---- Align, forward rows (:172-210)
             int best_m = -1, min_k = 0, max_k = 0;
-            uint32_t lin = 0;
             int end_d = -1, end_k = 0, end_x = 0;
             for (int d = 0; d < max_d; ++d) {
                 if (max_k - min_k > band_size) break;
                 const int nslot = max_k >= min_k ? ((max_k - min_k) >> 1) + 1 : 0;
-                if (lane == 0) { S.rmin[d] = (int16_t)min_k; S.rmax[d] = (int16_t)max_k; S.roff[d] = lin; }
+                if (lane == 0) { S.rmin[d] = (int16_t)min_k; S.rmax[d] = (int16_t)max_k; }
                 int mmax = -1, hkey = 0x7fffffff, lo = 0x7fffffff, hi = -0x7fffffff;
                 constexpr int MAXJ = (CN_ROW_W + 63) / 64;
                 int us[MAXJ];
@@ -132,7 +149,6 @@ __global__ __launch_bounds__(CN_BLOCK) void cns_extend(const uint32_t* __restric
                     us[j] = act ? x + y : -0x40000000;
                     if (act) {
                         grow[(size_t)d * CN_ROW_W + tt] = (uint16_t)x;
-                        if (lin + (uint32_t)tt < CN_RING) S.ring[lin + tt] = (uint16_t)x;
                         mmax = max(mmax, x + y);
                         if (x >= seg || y >= seg) hkey = min(hkey, (kk << 10) | x);           // lowest diagonal first (:198-199)
                     }
@@ -144,7 +160,6 @@ __global__ __launch_bounds__(CN_BLOCK) void cns_extend(const uint32_t* __restric
                     const int tt = lane + 64 * j;
                     if (tt < nslot) { const int k = min_k + 2 * tt; S.V[k + koff] = (int16_t)((us[j] + k) >> 1); }
                 }
-                lin += (uint32_t)nslot;
                 best_m = max(best_m, wave_max(mmax));
                 hkey = wave_min(hkey);
                 if (hkey != 0x7fffffff) { end_d = d; end_k = (hkey >> 10) - koff; end_x = hkey & 1023; break; }
@@ -161,42 +176,49 @@ __global__ __launch_bounds__(CN_BLOCK) void cns_extend(const uint32_t* __restric
             }
             if (end_d < 0) break;                        // no end reached: Align returns 0
 
-            // ---- the path, end to start (:222-240): one scalar walk, every lane the same
-            __threadfence_block();
+            // ---- the path, end to start (:222-240): one scalar walk, every lane the same.  Row cd needs its two neighbours in
+            // row cd - 1; the rows come back from the global scratch a window at a time.
+            __threadfence();
             __builtin_amdgcn_wave_barrier();
+            int rstar = -1, x2s = 0, ks = 0;             // the last row (highest d) whose snake has >= 4 matches (:336-343)
             {
-                int ck = end_k, x2 = end_x;
+                int ck = end_k, x2 = end_x, w_lo = end_d;        // rows [w_lo, ...] are in the window
                 for (int cd = end_d; cd >= 0; --cd) {
                     int x1 = 0, pre = ck, px2 = 0;
                     if (cd > 0) {
+                        if (cd - 1 < w_lo) {
+                            __builtin_amdgcn_wave_barrier();
+                            w_lo = cns_load_window(S, grow, cd - 1, lane);
+                            __builtin_amdgcn_wave_barrier();
+                        }
                         const int cmin = S.rmin[cd], cmax = S.rmax[cd], pmin = S.rmin[cd - 1], pmax = S.rmax[cd - 1];
                         const int kl = ck - 1, kr = ck + 1;
-                        const int vl = (kl >= pmin && kl <= pmax) ? cns_cell(S, grow, cd - 1, kl) : 0;
-                        const int vr = (kr >= pmin && kr <= pmax) ? cns_cell(S, grow, cd - 1, kr) : 0;
+                        const int vl = (kl >= pmin && kl <= pmax) ? cns_cell(S, cd - 1, kl) : 0;
+                        const int vr = (kr >= pmin && kr <= pmax) ? cns_cell(S, cd - 1, kr) : 0;
                         if (ck == cmin || (ck != cmax && vl < vr)) { pre = kr; x1 = vr; px2 = vr; }
                         else { pre = kl; x1 = vl + 1; px2 = vl; }
                     }
-                    if (lane == 0) { S.tk[cd] = (int16_t)ck; S.tx2[cd] = (uint16_t)x2; S.tx1[cd] = (uint16_t)x1; }
+                    const int len = x2 - x1;
+                    if (rstar < 0 && len >= 4) { rstar = cd; x2s = x2; ks = ck; }
+                    if (lane == 0) S.tlen[cd] = (uint16_t)(len | (cd > 0 && ck > pre ? 0x8000 : 0));   // from k - 1: query base only
                     ck = pre;
                     x2 = px2;
                 }
             }
             __builtin_amdgcn_wave_barrier();
 
-            // ---- columns before each row's snake; the last row with a snake of >= 4 (:336-343)
-            int carry = 0, rstar = -1;
+            // ---- columns before each row's snake
+            int carry = 0;
             for (int r0 = 0; r0 <= end_d; r0 += 64) {
                 const int r = r0 + lane;
                 const bool in = r <= end_d;
-                const int len = in ? (int)S.tx2[r] - (int)S.tx1[r] : 0;
+                const int len = in ? (int)(S.tlen[r] & 0x7FFF) : 0;
                 int incl = len + (in && r > 0 ? 1 : 0);          // the row's indel column + its snake
                 for (int o = 1; o < 64; o <<= 1) {
                     const int v = __shfl_up(incl, o);
                     if (lane >= o) incl += v;
                 }
-                if (in) S.roff[r] = (uint32_t)(carry + incl - len);     // columns before the snake of row r (its indel included)
-                const unsigned long long big = __ballot(in && len >= 4);
-                if (big) rstar = r0 + 63 - __clzll((long long)big);
+                if (in) S.woff[r] = (uint16_t)(carry + incl - len);     // columns before the snake of row r (its indel included)
                 carry += __shfl(incl, 63);
             }
             __builtin_amdgcn_wave_barrier();
@@ -204,8 +226,8 @@ __global__ __launch_bounds__(CN_BLOCK) void cns_extend(const uint32_t* __restric
             int kept_cols, kept_q, kept_t;
             if (more) {
                 if (rstar < 0) break;
-                const int x2s = (int)S.tx2[rstar], ks = (int)S.tk[rstar], lens = x2s - (int)S.tx1[rstar];
-                kept_cols = (int)S.roff[rstar] + lens - 4;
+                const int lens = (int)(S.tlen[rstar] & 0x7FFF);
+                kept_cols = (int)S.woff[rstar] + lens - 4;
                 kept_q = x2s - 4;
                 kept_t = x2s - ks - 4;
                 if (kept_q == 0) break;                  // "i == ALN_SIZE" (:350)
@@ -218,9 +240,9 @@ __global__ __launch_bounds__(CN_BLOCK) void cns_extend(const uint32_t* __restric
             for (int r0 = 1; r0 <= end_d; r0 += 64) {
                 const int r = r0 + lane;
                 const bool in = r <= end_d;
-                const int c = in ? (int)S.roff[r] - 1 : 0x7fffffff;          // column of the row's indel
+                const int c = in ? (int)S.woff[r] - 1 : 0x7fffffff;          // column of the row's indel
                 const bool put = in && c < kept_cols;
-                const int op = put ? ((int)S.tk[r] < (int)S.tk[r - 1] ? 1 : 2) : 0;
+                const int op = put ? ((S.tlen[r] & 0x8000) ? 2 : 1) : 0;
                 if (put) {
                     const int gc = cols + c;
                     atomicOr(&uops[gc >> 4], (uint32_t)op << ((gc & 15) << 1));
@@ -296,7 +318,7 @@ int mhip_cns_align_candidates_dev(mhip_ctx* c, const mhip_volume* ref, const mhi
     if (n <= 0) return 0;
     if (dir_cols_cap < 16 || (dir_cols_cap & 15)) { mhip_set_error("dir_cols_cap must be a positive multiple of 16"); return -1; }
     if (!(error_rate > 0.0) || error_rate > 0.20) { mhip_set_error("error_rate %.3f outside (0, 0.20]", error_rate); return -1; }
-    const int waves_per_cu = 8;                       // 17 KB of LDS per wave
+    const int waves_per_cu = 16;                      // 9 KB of LDS per wave
     const int max_waves = c->num_cus * waves_per_cu;
     const int grid = std::min(max_waves / CN_WAVES, (2 * n + CN_WAVES - 1) / CN_WAVES);
     CnsDir* d_dres;

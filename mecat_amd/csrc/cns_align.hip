@@ -122,7 +122,7 @@ __global__ __launch_bounds__(CN_BLOCK) void cns_extend(const uint32_t* __restric
                 if (max_k - min_k > band_size) break;
                 const int nslot = max_k >= min_k ? ((max_k - min_k) >> 1) + 1 : 0;
                 if (lane == 0) { S.rmin[d] = (int16_t)min_k; S.rmax[d] = (int16_t)max_k; }
-                int mmax = -1, hkey = 0x7fffffff, lo = 0x7fffffff, hi = -0x7fffffff;
+                int mmax = -1, hkey = 0x7fffffff;
                 constexpr int MAXJ = (CN_ROW_W + 63) / 64;
                 int us[MAXJ];
                 const int NJ = (nslot + 63) >> 6;
@@ -161,15 +161,27 @@ __global__ __launch_bounds__(CN_BLOCK) void cns_extend(const uint32_t* __restric
                     if (tt < nslot) { const int k = min_k + 2 * tt; S.V[k + koff] = (int16_t)((us[j] + k) >> 1); }
                 }
                 best_m = max(best_m, wave_max(mmax));
-                hkey = wave_min(hkey);
-                if (hkey != 0x7fffffff) { end_d = d; end_k = (hkey >> 10) - koff; end_x = hkey & 1023; break; }
-#pragma unroll
-                for (int j = 0; j < MAXJ; ++j) {                                               // band (:202-209)
-                    const int tt = lane + 64 * j;
-                    if (tt < nslot && us[j] >= best_m - band_tol) { const int k = min_k + 2 * tt; lo = min(lo, k); hi = max(hi, k); }
+                if (__ballot(hkey != 0x7fffffff)) {      // some diagonal reached an end: the lowest one ends the block
+                    hkey = wave_min(hkey);
+                    end_d = d; end_k = (hkey >> 10) - koff; end_x = hkey & 1023;
+                    break;
                 }
-                lo = wave_min(lo); hi = wave_max(hi);
-                const int nmin = lo != 0x7fffffff ? lo : max_k, nmax = lo != 0x7fffffff ? hi : min_k;
+                // band (:202-209): first / last diagonal within band_tol of the best; one ballot per 64 diagonals, bit scans on
+                // the scalar unit
+                int nmin = max_k, nmax = min_k;
+                {
+                    int first = -1, last = -1;
+#pragma unroll
+                    for (int j = 0; j < MAXJ; ++j) {
+                        if (j >= NJ) continue;
+                        const unsigned long long qb = __ballot(lane + 64 * j < nslot && us[j] >= best_m - band_tol);
+                        if (qb) {
+                            if (first < 0) first = 64 * j + __builtin_ctzll(qb);
+                            last = 64 * j + 63 - __builtin_clzll(qb);
+                        }
+                    }
+                    if (first >= 0) { nmin = min_k + 2 * first; nmax = min_k + 2 * last; }
+                }
                 max_k = nmax + 1;
                 min_k = nmin - 1;
                 __builtin_amdgcn_wave_barrier();

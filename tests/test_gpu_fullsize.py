@@ -40,6 +40,9 @@ def full():
     import mecat_amd.hip as M
     from mecat_amd import workload as W
     n, L, err, G, seed, ont = W.CONFIGS["config2"]
+    if os.environ.get("MECAT_FULLSIZE_READS"):       # e.g. 142000: one volume right below the 2.14 Gbase volume limit
+        n = int(os.environ["MECAT_FULLSIZE_READS"])
+        G = int(G * n / 100000)
     codes, lens = W.synth_reads(n, L, err, G, seed, ont)
     pac, offs, nb = W.pack_volume(codes, lens)
     ctx = M.Context(0)
@@ -92,7 +95,7 @@ def test_candidates_full_size(full):
     n = len(lens)
     cands, cnt = M.seed_reads(ctx, idx, vol, vol, 0, n, p)
     full["cands"], full["cnt"] = cands, cnt
-    assert cnt.min() >= 0 and cnt.max() <= p.maxc and int(cnt.sum()) > 2_000_000
+    assert cnt.min() >= 0 and cnt.max() <= p.maxc and int(cnt.sum()) > 20 * n
     mask = np.arange(p.maxc)[None, :] < cnt[:, None]
     qid = np.broadcast_to(np.arange(n)[:, None], mask.shape)[mask]
     c = cands[mask]

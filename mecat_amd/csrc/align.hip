@@ -417,7 +417,7 @@ struct HalfLds {
     uint32_t Tp[SEQ_WORDS];
     int16_t V[VU_LEN];
     uint16_t ring[RCAP];
-    uint2 rrec[RROWS];          // per d-row: x = min_k | max_k << 16, y = linear ring position of the row
+    int4 rrec[RROWS];           // per d-row: x = min_k, y = max_k, z = linear ring position of the row (unpacked: no VALU to build it)
 };
 static_assert(offsetof(HalfLds, Qp) == offsetof(AlnWaveLds, Qp) && offsetof(HalfLds, Tp) == offsetof(AlnWaveLds, Tp) &&
                   offsetof(HalfLds, V) == offsetof(AlnWaveLds, V),
@@ -539,14 +539,14 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
             nidle += (rmask == ~0ull) ? 0u : 1u;
             const int nslot = ((max_k - min_k) >> 1) + 1;        // every half with a block is rowing here; exhausted halves: 0
             if (rowing && sl == 0) {        // row record: band limits + linear ring position, one 64-bit store
-                S.rrec[d & (RROWS - 1)] = make_uint2(((uint32_t)(uint16_t)(int16_t)min_k) | ((uint32_t)(uint16_t)(int16_t)max_k << 16), lin);
+                int4* rr = &S.rrec[d & (RROWS - 1)];
+                rr->x = min_k; rr->y = max_k; rr->z = (int)lin;
             }
             const int ns_a = __builtin_amdgcn_readlane(nslot, 0), ns_b = __builtin_amdgcn_readlane(nslot, 32);
             const int NJ = (max(ns_a, ns_b) + 31) >> 5;
             nwide += NJ > 1 ? 1u : 0u;
             int mmax = -1, m0 = -1;
-            int hx = 0, hkk = 0;
-            bool reached = false;
+            int hx = -1, hkk = 0;            // hx >= 0: this lane holds a diagonal that reached an end of the block
             for (int j = 0; j < NJ; ++j) {
                 const int tt = sl + 32 * j;
                 const bool act = tt < nslot;
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
                     S.V[kk] = (int16_t)x;
                     S.ring[(lin + (unsigned)tt) & (RCAP - 1)] = (uint16_t)x;
                     mmax = max(mmax, x + y);
-                    if (!reached && (x >= q_len || y >= t_len)) { reached = true; hx = x; hkk = kk; }     // lowest k of this lane
+                    if (hx < 0 && (x >= q_len || y >= t_len)) { hx = x; hkk = kk; }     // lowest k of this lane
                 }
                 if (j == 0) m0 = act ? x + y : -1;
             }
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
             const int rm = half_max(mmax);
             best_m = max(best_m, rm);
             int hkey = 0x7fffffff;
-            if (BALLOT(reached)) hkey = half_min(reached ? ((hkk << 10) | hx) : 0x7fffffff);
+            if (BALLOT(hx >= 0)) hkey = half_min(hx >= 0 ? ((hkk << 10) | hx) : 0x7fffffff);
             // band update (:172-179)
             int nmin = max_k, nmax = min_k;
             if (NJ == 1) {
@@ -626,15 +626,15 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
                 int x1 = 0, pre_k = 0, takes_q = 0;
                 if (cd > 0) {
                     const int r = cd - 1;
-                    const uint2 pr = S.rrec[r & (RROWS - 1)], cr = S.rrec[cd & (RROWS - 1)];
-                    if (d - 1 - r >= RROWS || lin - pr.y > RCAP) { fallback = true; tracing = false; }
+                    const int4 pr = S.rrec[r & (RROWS - 1)], cr = S.rrec[cd & (RROWS - 1)];
+                    const unsigned int plin = (unsigned int)pr.z;
+                    if (d - 1 - r >= RROWS || lin - plin > RCAP) { fallback = true; tracing = false; }
                     else {
-                        const int pmin = (int)(int16_t)(pr.x & 0xFFFFu), pmax = (int)(int16_t)(pr.x >> 16);
-                        const int cmin = (int)(int16_t)(cr.x & 0xFFFFu), cmax = (int)(int16_t)(cr.x >> 16);
+                        const int pmin = pr.x, pmax = pr.y, cmin = cr.x, cmax = cr.y;
                         const int kl = ck - 1, kr = ck + 1;
                         int vl = 0, vr = 0;
-                        if (kl >= pmin && kl <= pmax) vl = S.ring[(pr.y + (unsigned)((kl - pmin) >> 1)) & (RCAP - 1)];
-                        if (kr >= pmin && kr <= pmax) vr = S.ring[(pr.y + (unsigned)((kr - pmin) >> 1)) & (RCAP - 1)];
+                        if (kl >= pmin && kl <= pmax) vl = S.ring[(plin + (unsigned)((kl - pmin) >> 1)) & (RCAP - 1)];
+                        if (kr >= pmin && kr <= pmax) vr = S.ring[(plin + (unsigned)((kr - pmin) >> 1)) & (RCAP - 1)];
                         if (ck == cmin || (ck != cmax && vl < vr)) { x1 = vr; pre_k = kr; takes_q = 0; }
                         else { x1 = vl + 1; pre_k = kl; takes_q = 1; }
                     }

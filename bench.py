@@ -294,7 +294,7 @@ def main():
                 v = C.c_int64()
                 M.lib().mhip_debug_counter(ctx.h, slot, C.byref(v))
                 dbg.append(v.value // args.steps)
-            log("[bench] dw debug/step: spills=%d rows=%d fast_rows=%d wide_rows=%d unaligned_blocks=%d" % tuple(dbg))
+            log("[bench] dw debug/step: spills=%d rows=%d idle_rows=%d wide_rows=%d unaligned_blocks=%d (row counters need -DMECAT_DW_STATS)" % tuple(dbg))
         except Exception as e:
             log("[bench] no debug counters: %r" % (e,))
         log("[bench] kernel ms/step: " + ", ".join("%s=%.2f" % (k, v[1] / args.steps) for k, v in sorted(kstats.items(), key=lambda kv: -kv[1][1])))

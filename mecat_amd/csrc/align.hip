@@ -394,7 +394,7 @@ __global__ __launch_bounds__(AL_BLOCK) void dw_extend(const uint32_t* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// dw_extend2 — two (candidate, direction) units per wave, one per 32-lane half.
+// dw_extend2 — two (candidate, direction) units per wave, one per 32-lane half.  (-DMECAT_DW_STATS: per-row debug counters.)
 //
 // The adaptive band keeps ~25 diagonals alive on average (config 2: 6.0e9 rows, 1.5e11 cells), so a whole wave per
 // unit leaves 60 % of the lanes idle and the kernel is VALU-issue bound.  Here each half-wave runs its own unit with its
@@ -535,8 +535,10 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
             rowing = rowing && d < max_d && (max_k - min_k <= band_size);
             const unsigned long long rmask = BALLOT(rowing);
             if (rmask != inmask) break;
+#ifdef MECAT_DW_STATS
             nrows += 1;
             nidle += (rmask == ~0ull) ? 0u : 1u;
+#endif
             const int nslot = ((max_k - min_k) >> 1) + 1;        // every half with a block is rowing here; exhausted halves: 0
             if (rowing && sl == 0) {        // row record: band limits + linear ring position, one 64-bit store
                 int4* rr = &S.rrec[d & (RROWS - 1)];
@@ -544,7 +546,9 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
             }
             const int ns_a = __builtin_amdgcn_readlane(nslot, 0), ns_b = __builtin_amdgcn_readlane(nslot, 32);
             const int NJ = (max(ns_a, ns_b) + 31) >> 5;
+#ifdef MECAT_DW_STATS
             nwide += NJ > 1 ? 1u : 0u;
+#endif
             int mmax = -1, m0 = -1;
             int hx = -1, hkk = 0;            // hx >= 0: this lane holds a diagonal that reached an end of the block
             for (int j = 0; j < NJ; ++j) {

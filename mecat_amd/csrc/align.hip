@@ -540,8 +540,8 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
             nidle += (rmask == ~0ull) ? 0u : 1u;
 #endif
             const int nslot = ((max_k - min_k) >> 1) + 1;        // every half with a block is rowing here; exhausted halves: 0
-            if (rowing && sl == 0) {        // row record: band limits + linear ring position, one 64-bit store
-                int4* rr = &S.rrec[d & (RROWS - 1)];
+            {                                // row record: band limits + linear ring position.  Every lane of the half stores the same
+                int4* rr = &S.rrec[d & (RROWS - 1)];      // three words to the same address (no exec juggling on the scalar unit)
                 rr->x = min_k; rr->y = max_k; rr->z = (int)lin;
             }
             const int ns_a = __builtin_amdgcn_readlane(nslot, 0), ns_b = __builtin_amdgcn_readlane(nslot, 32);
@@ -551,7 +551,8 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
 #endif
             int mmax = -1, m0 = -1;
             int hx = -1, hkk = 0;            // hx >= 0: this lane holds a diagonal that reached an end of the block
-            for (int j = 0; j < NJ; ++j) {
+            int j = 0;
+            do {                                 // at least one pass (a pass over an empty band only moves idle lanes)
                 const int tt = sl + 32 * j;
                 const bool act = tt < nslot;
                 const int k = min_k + 2 * tt, kk = k + k_offset;
@@ -576,8 +577,8 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
                     mmax = max(mmax, x + y);
                     if (hx < 0 && (x >= q_len || y >= t_len)) { hx = x; hkk = kk; }     // lowest k of this lane
                 }
-                if (j == 0) m0 = act ? x + y : -1;
-            }
+                m0 = act ? x + y : -1;              // read by the one-pass band update only (NJ <= 1)
+            } while (++j < NJ);
             lin += (unsigned)nslot;
             __builtin_amdgcn_wave_barrier();
             // running maximum of x + y (:160-167); lowest diagonal that reached an end (:168-169)
@@ -587,7 +588,7 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
             if (BALLOT(hx >= 0)) hkey = half_min(hx >= 0 ? ((hkk << 10) | hx) : 0x7fffffff);
             // band update (:172-179)
             int nmin = max_k, nmax = min_k;
-            if (NJ == 1) {
+            if (NJ <= 1) {
                 const unsigned long long qb = BALLOT(m0 >= best_m - band_tol && m0 >= 0);
                 const unsigned int mine = hh ? (unsigned int)(qb >> 32) : (unsigned int)qb;
                 if (mine) { nmin = min_k + 2 * (__ffs((int)mine) - 1); nmax = min_k + 2 * (31 - __clz((int)mine)); }

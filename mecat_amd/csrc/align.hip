@@ -550,7 +550,7 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
             nwide += NJ > 1 ? 1u : 0u;
 #endif
             int mmax = -1, m0 = -1;
-            int hx = -1, hkk = 0;            // hx >= 0: this lane holds a diagonal that reached an end of the block
+            unsigned long long ended = 0;    // lanes whose diagonal reached an end of the block in some pass (rare: once per block)
             int j = 0;
             do {                                 // at least one pass (a pass over an empty band only moves idle lanes)
                 const int tt = sl + 32 * j;
@@ -564,20 +564,21 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
                 x = act ? x : q_len;
                 int y = act ? x - k : 0;
                 bool more;
+                int lim, nn;
                 do {
-                    const int lim = min(q_len - x, t_len - y);
+                    lim = min(q_len - x, t_len - y);
                     const int m = min(match16(S.Qp, x, S.Tp, y), lim);      // 0..15, or lim when all 16 bases match
-                    const int nn = min(m, 16);
+                    nn = min(m, 16);
                     x += nn; y += nn;
                     more = m > 16;
                 } while (BALLOT(more));
                 if (act) {
                     S.V[kk] = (int16_t)x;
                     S.ring[(lin + (unsigned)tt) & (RCAP - 1)] = (uint16_t)x;
-                    mmax = max(mmax, x + y);
-                    if (hx < 0 && (x >= q_len || y >= t_len)) { hx = x; hkk = kk; }     // lowest k of this lane
                 }
-                m0 = act ? x + y : -1;              // read by the one-pass band update only (NJ <= 1)
+                ended |= BALLOT(act && lim == nn);  // nothing left of the query or of the target on this diagonal
+                m0 = act ? x + y : -1;              // also read by the one-pass band update (NJ <= 1)
+                mmax = max(mmax, m0);
             } while (++j < NJ);
             lin += (unsigned)nslot;
             __builtin_amdgcn_wave_barrier();
@@ -585,7 +586,16 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
             const int rm = half_max(mmax);
             best_m = max(best_m, rm);
             int hkey = 0x7fffffff;
-            if (BALLOT(hx >= 0)) hkey = half_min(hx >= 0 ? ((hkk << 10) | hx) : 0x7fffffff);
+            if (ended) {                     // the lowest diagonal that reached an end, from the values just stored in V
+                for (int jj = 0; jj < NJ; ++jj) {
+                    const int tt = sl + 32 * jj, k = min_k + 2 * tt, kk = k + k_offset;
+                    if (tt < nslot) {
+                        const int x = S.V[kk];
+                        if (x >= q_len || x - k >= t_len) hkey = min(hkey, (kk << 10) | x);
+                    }
+                }
+                hkey = half_min(hkey);
+            }
             // band update (:172-179)
             int nmin = max_k, nmax = min_k;
             if (NJ <= 1) {

@@ -549,7 +549,7 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
 #ifdef MECAT_DW_STATS
             nwide += NJ > 1 ? 1u : 0u;
 #endif
-            int mmax = -1, m0 = -1;
+            int mmax = -1, m0 = -0x40000000;
             unsigned long long ended = 0;    // lanes whose diagonal reached an end of the block in some pass (rare: once per block)
             int j = 0;
             do {                                 // at least one pass (a pass over an empty band only moves idle lanes)
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
                     S.ring[(lin + (unsigned)tt) & (RCAP - 1)] = (uint16_t)x;
                 }
                 ended |= BALLOT(act && lim == nn);  // nothing left of the query or of the target on this diagonal
-                m0 = act ? x + y : -1;              // also read by the one-pass band update (NJ <= 1)
+                m0 = act ? x + y : -0x40000000;     // also read by the one-pass band update (NJ <= 1); idle lanes never qualify
                 mmax = max(mmax, m0);
             } while (++j < NJ);
             lin += (unsigned)nslot;
@@ -599,9 +599,9 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
             // band update (:172-179)
             int nmin = max_k, nmax = min_k;
             if (NJ <= 1) {
-                const unsigned long long qb = BALLOT(m0 >= best_m - band_tol && m0 >= 0);
+                const unsigned long long qb = BALLOT(m0 >= best_m - band_tol);
                 const unsigned int mine = hh ? (unsigned int)(qb >> 32) : (unsigned int)qb;
-                if (mine) { nmin = min_k + 2 * (__ffs((int)mine) - 1); nmax = min_k + 2 * (31 - __clz((int)mine)); }
+                if (mine) { nmin = min_k + 2 * (__ffs((int)mine) - 1); nmax = __mul24(__clz((int)mine), -2) + (min_k + 62); }
             } else {
                 int lo = 0x7fffffff, hi = -0x7fffffff;
                 for (int j = 0; j < NJ; ++j) {

@@ -549,7 +549,7 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
 #ifdef MECAT_DW_STATS
             nwide += NJ > 1 ? 1u : 0u;
 #endif
-            int mmax = -1, m0 = -0x40000000;
+            int mmax = -1, m0 = -0x40000000, mp = -0x40000000;      // x + y of the lane's diagonal in the last / previous pass
             unsigned long long ended = 0;    // lanes whose diagonal reached an end of the block in some pass (rare: once per block)
             int j = 0;
             do {                                 // at least one pass (a pass over an empty band only moves idle lanes)
@@ -577,7 +577,8 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
                     S.ring[(lin + (unsigned)tt) & (RCAP - 1)] = (uint16_t)x;
                 }
                 ended |= BALLOT(act && lim == nn);  // nothing left of the query or of the target on this diagonal
-                m0 = act ? x + y : -0x40000000;     // also read by the one-pass band update (NJ <= 1); idle lanes never qualify
+                mp = m0;
+                m0 = act ? x + y : -0x40000000;     // also read by the band update below (NJ <= 2); idle lanes never qualify
                 mmax = max(mmax, m0);
             } while (++j < NJ);
             lin += (unsigned)nslot;
@@ -598,10 +599,18 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
             }
             // band update (:172-179)
             int nmin = max_k, nmax = min_k;
-            if (NJ <= 1) {
-                const unsigned long long qb = BALLOT(m0 >= best_m - band_tol);
-                const unsigned int mine = hh ? (unsigned int)(qb >> 32) : (unsigned int)qb;
-                if (mine) { nmin = min_k + 2 * (__ffs((int)mine) - 1); nmax = __mul24(__clz((int)mine), -2) + (min_k + 62); }
+            if (NJ <= 2) {
+                // up to 64 diagonals per half: two ballots, the half's 2 x 32 qualification bits, first / last set bit
+                const int thr = best_m - band_tol;
+                const unsigned long long q0 = BALLOT((NJ == 2 ? mp : m0) >= thr), q1 = NJ == 2 ? BALLOT(m0 >= thr) : 0ull;
+                const unsigned int lo32 = hh ? (unsigned int)(q0 >> 32) : (unsigned int)q0;
+                const unsigned int hi32 = hh ? (unsigned int)(q1 >> 32) : (unsigned int)q1;
+                if (lo32 | hi32) {
+                    const int first = lo32 ? __ffs((int)lo32) - 1 : 31 + __ffs((int)hi32);
+                    const int last = hi32 ? 63 - __clz((int)hi32) : 31 - __clz((int)lo32);
+                    nmin = min_k + 2 * first;
+                    nmax = min_k + 2 * last;
+                }
             } else {
                 int lo = 0x7fffffff, hi = -0x7fffffff;
                 for (int j = 0; j < NJ; ++j) {

@@ -464,10 +464,10 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
     int query_size = 0, target_size = 0, qidx = 0, tidx = 0;
     int Rq = 0, Rt = 0, Rm = 0, Rc = 0, Rb = 0;
     // per-half block state
-    int qblk = 0, tblk = 0, last_block = 0, band_tol = 0, max_d = 0, band_size = 0;
+    int qblk = 0, tblk = 0, last_block = 0, band_tol = 0, max_d = 0;
     int best_m = -1, min_k = 0, max_k = 0, aligned = 0, end_x = 0, end_k = 0, end_d = 0, d = 0;      // d = rows done
     unsigned int lin = 0;
-    bool rowing = false;
+    int dlim = 0;               // rows run while d < dlim: max_d of the block, 0 once an end was reached / without a block
 
     while (true) {
         if (BALLOT(setup)) {
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
                 unsigned int u = 0;
                 if (sl == 0) u = atomicAdd(cursor, 1u);
                 u = __shfl(u, hh << 5);
-                if (u >= 2u * (unsigned)n) { exhausted = true; setup = false; min_k = 0; max_k = -2; }      // nslot == 0 from now on
+                if (u >= 2u * (unsigned)n) { exhausted = true; setup = false; min_k = 0; max_k = -2; dlim = 0; }      // nslot == 0, never rowing
                 else {
                     unit = u;
                     const mhip_aln_job jb = jobs[u >> 1];
@@ -506,7 +506,6 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
                 tblk = max(tblk, 0);
                 band_tol = (int)(0.3 * (qblk > tblk ? qblk : tblk));
                 max_d = (int)(.3 * (qblk + tblk));
-                band_size = band_tol * 2;
                 for (int w = sl; w < SEQ_WORDS; w += 32) {
                     S.Qp[w] = (w > 0 && (w - 1) * 16 < qblk + 32) ? view_word(q, qidx + (w - 1) * 16) : 0u;
                     S.Tp[w] = (w > 0 && (w - 1) * 16 < tblk + 32) ? view_word(t, tidx + (w - 1) * 16) : 0u;
@@ -517,7 +516,7 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
                 best_m = -1; min_k = 0; max_k = 0;
                 aligned = 0; end_x = 0; end_k = 0; end_d = 0; d = 0;
                 lin = 0;
-                rowing = true; inblock = true;
+                dlim = max_d; inblock = true;
                 setup = false;
             }
             __builtin_amdgcn_wave_barrier();
@@ -531,15 +530,16 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
         // traceback outran the ring.
         // The inner loop runs while every half that has a block is still rowing.
         const unsigned long long inmask = BALLOT(inblock);
+        bool row_ok;
         while (true) {
-            rowing = rowing && d < max_d && (max_k - min_k <= band_size);
-            const unsigned long long rmask = BALLOT(rowing);
+            const int nslot = ((max_k - min_k) >> 1) + 1;        // min_k and max_k have the same parity; exhausted halves: 0
+            row_ok = d < dlim && nslot <= band_tol + 1;          // :118 "max_k - min_k <= band_size"
+            const unsigned long long rmask = BALLOT(row_ok);
             if (rmask != inmask) break;
 #ifdef MECAT_DW_STATS
             nrows += 1;
             nidle += (rmask == ~0ull) ? 0u : 1u;
 #endif
-            const int nslot = ((max_k - min_k) >> 1) + 1;        // every half with a block is rowing here; exhausted halves: 0
             {                                // row record: band limits + linear ring position.  Every lane of the half stores the same
                 int4* rr = &S.rrec[d & (RROWS - 1)];      // three words to the same address (no exec juggling on the scalar unit)
                 rr->x = min_k; rr->y = max_k; rr->z = (int)lin;
@@ -615,7 +615,7 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
                 int lo = 0x7fffffff, hi = -0x7fffffff;
                 for (int j = 0; j < NJ; ++j) {
                     const int tt = sl + 32 * j;
-                    const bool act = rowing && tt < nslot;
+                    const bool act = inblock && tt < nslot;
                     const int k = min_k + 2 * tt;
                     const int u = act ? 2 * (int)S.V[k + k_offset] - k : -0x40000000;
                     if (act && u >= best_m - band_tol) { lo = min(lo, k); hi = max(hi, k); }
@@ -623,19 +623,19 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
                 lo = half_min(lo); hi = half_max(hi);
                 if (lo != 0x7fffffff) { nmin = lo; nmax = hi; }
             }
-            if (rowing) {
+            if (inblock) {
                 max_k = nmax + 1;
                 min_k = nmin - 1;
                 if (hkey != 0x7fffffff) {
                     aligned = 1; end_k = (hkey >> 10) - k_offset; end_x = hkey & 1023; end_d = d;
-                    rowing = false;
+                    dlim = 0;
                 }
             }
             d += 1;
             __builtin_amdgcn_wave_barrier();
         }
 
-        const bool fin = inblock && !rowing;
+        const bool fin = inblock && !row_ok;
 
         // ---- 4. tail traceback == trim_mismatch_end(.., 4, ..) (gapalign.cpp:47-68), for the halves whose rows just ended
         bool has_aln = fin && aligned;
@@ -724,6 +724,7 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
             }
             inblock = false;
             setup = true;
+            dlim = 0;           // a half without a block must never look like it is rowing (its rows may have ended on the band limit)
         }
     }
     for (int off = 32; off > 0; off >>= 1) { nblocks += __shfl_xor(nblocks, off); cells += __shfl_xor(cells, off); }

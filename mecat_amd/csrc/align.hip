@@ -860,6 +860,11 @@ int mhip_align_candidates_dev(mhip_ctx* c, const mhip_volume* ref, const mhip_vo
                (unsigned long long*)c->d_counters);
     } else {
         grid = std::min(max_waves / AL_WAVES, (n + AL_WAVES - 1) / AL_WAVES);
+        if (getenv("MECAT_TRACE")) {
+            int nb = 0;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dw_extend2, AL_BLOCK, 0);
+            fprintf(stderr, "[dw trace] occupancy query: %d blocks of %d threads per CU; grid %d; HalfLds %zu bytes\n", nb, AL_BLOCK, grid, sizeof(HalfLds));
+        }
         LAUNCH(c, "dw_extend2", dw_extend2, grid, AL_BLOCK, 0, (const uint32_t*)ref->d_pac, (const mhip_offset_t*)ref->d_offs,
                (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs, (const mhip_aln_job*)d_jobs, n, d_dres, d_g, d_cur,
                (unsigned long long*)c->d_counters);

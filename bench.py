@@ -263,7 +263,7 @@ def main():
                 ach = im["valu_insts_per_launch"] / (avg_ms / 1e3) / 1e9
                 roof["valu_issue"] = {"achieved": ach, "peak": peak, "unit": "G wave-instr/s", "frac": ach / peak,
                                       "source": "profiles/" + ifile,
-                                      "note": "integer O(ND) rows: the kernel is bound by VALU issue, not by HBM or MFMA"}
+                                      "note": "integer O(ND) rows: bound by instruction issue (about one instruction per SIMD per cycle, VALU + SALU + LDS), not by HBM or MFMA; peak = nominal 1024 SIMDs x 2.4 GHz / 4"}
         except (OSError, IndexError, ValueError):
             pass
         if pk == "dw":

@@ -586,8 +586,8 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
             // running maximum of x + y (:160-167); lowest diagonal that reached an end (:168-169)
             const int rm = half_max(mmax);
             best_m = max(best_m, rm);
-            int hkey = 0x7fffffff;
-            if (ended) {                     // the lowest diagonal that reached an end, from the values just stored in V
+            if (ended) {                     // once per block: the lowest diagonal that reached an end, from the values just stored in V
+                int hkey = 0x7fffffff;
                 for (int jj = 0; jj < NJ; ++jj) {
                     const int tt = sl + 32 * jj, k = min_k + 2 * tt, kk = k + k_offset;
                     if (tt < nslot) {
@@ -596,6 +596,10 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
                     }
                 }
                 hkey = half_min(hkey);
+                if (inblock && hkey != 0x7fffffff) {
+                    aligned = 1; end_k = (hkey >> 10) - k_offset; end_x = hkey & 1023; end_d = d;
+                    dlim = 0;
+                }
             }
             // band update (:172-179)
             int nmin = max_k, nmax = min_k;
@@ -626,10 +630,6 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
             if (inblock) {
                 max_k = nmax + 1;
                 min_k = nmin - 1;
-                if (hkey != 0x7fffffff) {
-                    aligned = 1; end_k = (hkey >> 10) - k_offset; end_x = hkey & 1023; end_d = d;
-                    dlim = 0;
-                }
             }
             d += 1;
             __builtin_amdgcn_wave_barrier();

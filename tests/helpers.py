@@ -148,6 +148,7 @@ def orc():
         L.orc_m4_line.argtypes = [C.POINTER(OrcM4), C.c_int, C.c_char_p]
         L.orc_map_read.argtypes = [C.POINTER(OrcVolume), C.POINTER(OrcVolume), C.POINTER(OrcIndex), vp, vp, C.c_int,
                                    C.POINTER(OrcParams), vp]
+        L.orc_xdrop_rowpar_selfcheck.argtypes = [vp, C.c_int, vp, C.c_int]
         L.orc_cns_new.restype = vp
         L.orc_cns_free.argtypes = [vp]
         L.orc_cns_one_direction.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_double, vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]

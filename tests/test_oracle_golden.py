@@ -227,3 +227,38 @@ def test_cns_aligner_kats():
         d2 = hashlib.sha256(s1[: res2[4]].tobytes() + b"|" + s2[: res2[4]].tobytes()).hexdigest() if ok2 else ""
         assert d1 + ":" + d2 == str(dig)
     O.orc_cns_free(a)
+
+
+def test_xdrop_row_scan_formulation_equals_sequential_row():
+    """the X-drop row as per-cell work + prefix scans (oracle/xdrop_rowpar.c, what a wave-parallel kernel computes) against
+    the literal sequential row, state by state, on random / unrelated / low-complexity blocks"""
+    O = H.orc()
+    rng = np.random.default_rng(3)
+
+    def mut(s, e):
+        out = []
+        for b in s:
+            u = rng.random()
+            if u < 0.35 * e:
+                continue
+            out.append(int(rng.integers(0, 4)) if u < 0.7 * e else int(b))
+            if rng.random() < 0.3 * e:
+                out.append(int(rng.integers(0, 4)))
+        return np.array(out, dtype=np.int8)
+
+    rows = 0
+    for it in range(600):
+        n = int(rng.integers(5, 740))
+        g = rng.integers(0, 4, size=n).astype(np.int8)
+        e = [0.0, 0.04, 0.12, 0.2, 0.35, 0.6][it % 6]
+        a = mut(g, e)
+        b = mut(g, e) if it % 9 else rng.integers(0, 4, size=n).astype(np.int8)
+        if it % 11 == 0:
+            a = np.tile(rng.integers(0, 4, size=int(rng.integers(1, 5))).astype(np.int8), 300)[:n]
+            b = mut(a, 0.1)
+        a, b = a[:736], b[:736]
+        if len(a) < 2 or len(b) < 2:
+            continue
+        assert O.orc_xdrop_rowpar_selfcheck(a.ctypes.data, len(a), b.ctypes.data, len(b)) == 0, it
+        rows += len(a)
+    assert rows > 100000

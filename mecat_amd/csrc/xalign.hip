@@ -249,6 +249,310 @@ __global__ __launch_bounds__(XB_BLOCK) void xd_extend(const uint32_t* __restrict
     atomicAdd(&counters[3], nblocks);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// xd_extend_w — one WAVE per (candidate, direction).  A row of the dynamic program is per-cell independent work plus two
+// prefix-max scans over the window (oracle/xdrop_rowpar.c states and checks the equivalence with the sequential row):
+//   diag_b = H'[b-1] + s(A_a, B_{b-1}) (MIN for the row's first cell),  M_b = max(diag_b, F'[b]),
+//   E_b = max_{j<b}(M_j + j) - b,  H_b = max(M_b, E_b),  best_b = max(best, max_{j<b} H_j),  dropped <=> best_b - H_b > X;
+// a value carried across a dropped cell is below every later kept cell's score, so it only shows in the op bits of dropped
+// cells (there E = H of the nearest kept cell to the left - 1, no decay).  Lanes = 64 consecutive cells, a second chunk with
+// scalar carries when the window is wider.  Scores live in an LDS ring of XW_RING cells; the op bytes go to a per-wave global
+// scratch with a fixed row stride (coalesced 64-byte stores), plus bit 7 = "the diagonal step into this cell is a match" so
+// that the traceback needs nothing but these bytes.  The traceback is a scalar walk: a row's bytes sit in two registers
+// (one cell per lane), fetched one row ahead from a 4 KB LDS window over the scratch, and are read with v_readlane.
+// A window wider than XW_RING - 2 cells hands the unit over (overflow list) to the WIDE instantiation of the same code:
+// scores in per-wave global arrays instead of the ring, rows of XW_WSTRIDE bytes, traceback reading byte by byte through the
+// LDS window — slower per row, but only a fraction of a percent of the units (low-complexity sequence) need it.
+#define XW_WAVES 4
+#define XW_BLOCK (XW_WAVES * 64)
+#define XW_RING 128
+#define XW_STRIDE 128                    // script bytes per row in the scratch
+#define XW_WIN 4096                      // = 32 rows
+#define XW_STATE_BYTES ((size_t)(X_MAXN + 2) * XW_STRIDE)
+#define XW_WSTRIDE 768                   // WIDE: any window fits a row (N + 1 <= 737 cells)
+#define XW_WIDE_BYTES ((size_t)(X_MAXN + 2) * XW_WSTRIDE + 2 * (size_t)(X_MAXN + 8) * 4)
+#define XW_NEG (-(1 << 30))
+#define XS_MATCH 0x80
+struct XwLds {
+    int Hs[XW_RING], Fs[XW_RING];
+    uint8_t Qb[X_MAXN + 8], Tb[X_MAXN + 8];
+    int16_t rstart[X_MAXN + 2];
+    uint32_t win[XW_WIN / 4];
+};
+
+template <int CTRL, int RMASK> __device__ __forceinline__ int xw_dpp_max(int v) {
+    return max(v, __builtin_amdgcn_update_dpp(v, v, CTRL, RMASK, 0xf, false));
+}
+__device__ __forceinline__ int xw_scan_max(int v) {          // inclusive prefix max over the 64 lanes, all lanes active
+    v = xw_dpp_max<0x111, 0xf>(v);                            // row_shr:1,2,4,8 (lanes without a source keep their value)
+    v = xw_dpp_max<0x112, 0xf>(v);
+    v = xw_dpp_max<0x114, 0xf>(v);
+    v = xw_dpp_max<0x118, 0xf>(v);
+    v = xw_dpp_max<0x142, 0xa>(v);                            // row_bcast:15 into rows 1 and 3
+    v = xw_dpp_max<0x143, 0xc>(v);                            // row_bcast:31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ int xw_shr1(int v, int fill) {    // lane l gets lane l-1, lane 0 gets fill
+    return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false);   // wave_shr:1
+}
+
+template <bool WIDE>
+__device__ void xdrop_block_w(XwLds& S, const XView& q, int qidx, int M, const XView& t, int tidx, int N, uint8_t* __restrict__ st,
+                              XBlockOut& o) {
+    constexpr int STRIDE = WIDE ? XW_WSTRIDE : XW_STRIDE;
+    volatile int* gH = (volatile int*)(st + (size_t)(X_MAXN + 2) * XW_WSTRIDE);      // WIDE only
+    volatile int* gF = gH + (X_MAXN + 8);
+    auto ldH = [&](int b) -> int { return WIDE ? gH[b] : S.Hs[b & (XW_RING - 1)]; };
+    auto ldF = [&](int b) -> int { return WIDE ? gF[b] : S.Fs[b & (XW_RING - 1)]; };
+    auto stH = [&](int b, int v) { if (WIDE) gH[b] = v; else S.Hs[b & (XW_RING - 1)] = v; };
+    auto stF = [&](int b, int v) { if (WIDE) gF[b] = v; else S.Fs[b & (XW_RING - 1)] = v; };
+    o.ae = o.be = 0; o.n = o.nmatch = 0; o.qcnt = o.tcnt = o.acnt = o.mtail = 0; o.trim_ok = 0; o.overflow = 0;
+    o.l0q = o.l0t = o.l0m = o.l1q = o.l1t = o.l1m = 0;
+    if (M <= 0 || N <= 0) return;
+    const int lane = lane_id();
+    const int X = 30;
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < M; i += 64) S.Qb[i] = (uint8_t)xv_at(q, qidx + i);
+    for (int i = lane; i < N; i += 64) S.Tb[i] = (uint8_t)xv_at(t, tidx + i);
+    // row 0 (xdrop_gapalign.cpp:45-57): cells 1.. hold -1, -2, ... while >= -X
+    const int n_init = min(N, X);
+    if (lane == 0) { stH(0, 0); stF(0, -1); S.rstart[0] = 0; }
+    if (lane >= 1 && lane <= n_init) { stH(lane, -lane); stF(lane, -lane - 1); st[lane] = XS_GAP_IN_A; }
+    if (WIDE) __threadfence();
+    int b_size = n_init + 1, best = 0, first_b = 0, ae = 0, be = 0;      // b_size == N + 1 when N <= X, as in the reference
+    __builtin_amdgcn_wave_barrier();
+    for (int a = 1; a <= M; ++a) {
+        const int AC = S.Qb[a - 1];
+        const int f0 = first_b, n0 = b_size;
+        uint8_t* srow = st + (size_t)a * STRIDE;
+        if (lane == 0) S.rstart[a] = (int16_t)f0;
+        int runP = XW_NEG, bb = best, rowmax = X_MIN_SCORE, rowarg = -1, firstkept = -1, lastkept = -1, lastkeptH = 0;
+        int prevHp = 0;
+        for (int c0 = f0; c0 < n0; c0 += 64) {
+            const int b = c0 + lane;
+            const bool in = b < n0;
+            const int Hp = in ? ldH(b) : X_MIN_SCORE, Fp = in ? ldF(b) : X_MIN_SCORE;
+            const int left = xw_shr1(Hp, prevHp);
+            const int tb = b > 0 ? (int)S.Tb[b - 1] : 0;
+            const bool mt = AC == tb;
+            const int diag = b == f0 ? X_MIN_SCORE : left + (mt ? 1 : -1);
+            const int Mv = max(diag, Fp);
+            const int incl = xw_scan_max(in ? Mv + b : XW_NEG);
+            const int pex = max(xw_shr1(incl, XW_NEG), runP);         // max over all earlier cells of the row of M_j + j
+            const int Ec = (b == f0) ? X_MIN_SCORE : pex - b;
+            const int Hc = max(Mv, Ec);
+            const int inclH = xw_scan_max(in ? Hc : XW_NEG);
+            const int bbefore = max(bb, xw_shr1(inclH, XW_NEG));
+            const bool kept = in && !(bbefore - Hc > X);
+            const unsigned long long km = __ballot(kept);
+            // op bits: SUB unless the column gap, then the row gap, is strictly better (:99-107)
+            int sc = diag, script = XS_SUB;
+            if (sc < Fp) { script = XS_GAP_IN_B; sc = Fp; }
+            const unsigned long long lower = km & ((1ull << lane) - 1ull);
+            const int jsrc = lower ? 63 - __clzll((long long)lower) : 0;
+            const int Hj = __shfl(Hc, jsrc);
+            if (kept) {
+                if (sc < Ec) script = XS_GAP_IN_A;
+                if (!(Fp - 1 < Hc - 1)) script += XS_EXT_A;
+                if (!(Ec - 1 < Hc - 1)) script += XS_EXT_B;
+                stH(b, Hc);
+                stF(b, max(Fp - 1, Hc - 1));
+            } else if (in) {
+                const int et = lower ? Hj - 1 : (lastkept >= 0 ? lastkeptH - 1 : X_MIN_SCORE);
+                if (sc < et) script = XS_GAP_IN_A;
+                if (lower || firstkept >= 0) stH(b, X_MIN_SCORE);       // interior; a leading one only moves first_b
+            }
+            if (in) srow[b - f0] = (uint8_t)(script | (mt ? XS_MATCH : 0));
+            // carries
+            const int cmaxH = __builtin_amdgcn_readlane(inclH, 63);
+            runP = max(runP, __builtin_amdgcn_readlane(incl, 63));
+            if (cmaxH > rowmax) {
+                rowmax = cmaxH;
+                rowarg = c0 + __ffsll((long long)__ballot(in && Hc == cmaxH)) - 1;
+            }
+            bb = max(bb, cmaxH);
+            if (km) {
+                if (firstkept < 0) firstkept = c0 + __ffsll((long long)km) - 1;
+                const int lk = 63 - __clzll((long long)km);
+                lastkept = c0 + lk;
+                lastkeptH = __builtin_amdgcn_readlane(Hc, lk);
+            }
+            prevHp = __builtin_amdgcn_readlane(Hp, 63);
+        }
+        if (rowmax > best) { best = rowmax; ae = a; be = rowarg; }
+        if (firstkept < 0) { first_b = n0; break; }
+        first_b = firstkept;
+        if (lastkept < n0 - 1) b_size = lastkept + 1;
+        else {
+            // the row gap keeps the window open while it stays within X of the best (:139-147); H >= E at a kept cell
+            const int e_end = lastkeptH - 1;
+            int cnt = e_end >= best - X ? e_end - (best - X) + 1 : 0;
+            cnt = max(min(cnt, N - b_size), 0);          // b_size is N + 1 in a block with N <= X (row 0 ran off the end)
+            if (lane < cnt) {
+                const int bnew = b_size + lane;
+                stH(bnew, e_end - lane);
+                stF(bnew, e_end - lane - 1);
+                if (bnew - f0 < STRIDE) srow[bnew - f0] = XS_GAP_IN_A;
+            }
+            b_size += cnt;
+        }
+        if (b_size < N) {
+            if (lane == 0) { stH(b_size, X_MIN_SCORE); stF(b_size, X_MIN_SCORE); }
+            ++b_size;
+        }
+        if (!WIDE && (b_size - first_b > XW_RING - 2 || b_size - f0 > XW_STRIDE)) { o.overflow = 2; return; }
+        if (WIDE) __threadfence();
+        __builtin_amdgcn_wave_barrier();
+    }
+    o.ae = ae; o.be = be;
+    // ---- traceback (:165-210) fused with script_to_aligned_string + trim_mismatch_end, as in the lane kernel
+    __threadfence();
+    __builtin_amdgcn_wave_barrier();
+    const volatile uint32_t* stw = (const volatile uint32_t*)st;
+    int wbase = 1 << 30;                                 // first scratch byte in the LDS window; nothing loaded yet
+    // row registers: lane l holds the bytes of cells rstart + l and rstart + 64 + l
+    auto fetch_row = [&](int a, int& r0, int& r1, int& rs) {
+        rs = __builtin_amdgcn_readfirstlane((int)S.rstart[a]);
+        if (WIDE) return;                                // bytes are read one by one below
+        const int off = a * XW_STRIDE;
+        if (off < wbase) {
+            __builtin_amdgcn_wave_barrier();
+            wbase = max(off + XW_STRIDE - XW_WIN, 0);
+            for (int w = lane; w < XW_WIN / 4; w += 64) S.win[w] = stw[wbase / 4 + w];
+            __builtin_amdgcn_wave_barrier();
+        }
+        const uint8_t* wb = (const uint8_t*)S.win + (off - wbase);
+        r0 = wb[lane];
+        r1 = wb[64 + lane];
+    };
+    auto wide_byte = [&](int a, int b, int rs) -> int {
+        const int idx = a * XW_WSTRIDE + (b - rs);
+        if (idx < wbase || idx >= wbase + XW_WIN) {
+            __builtin_amdgcn_wave_barrier();
+            wbase = max(((idx + 4) & ~3) - XW_WIN, 0);
+            for (int w = lane; w < XW_WIN / 4; w += 64) S.win[w] = stw[wbase / 4 + w];
+            __builtin_amdgcn_wave_barrier();
+        }
+        return __builtin_amdgcn_readfirstlane((int)((const uint8_t*)S.win)[idx - wbase]);
+    };
+    int a_index = ae, b_index = be;
+    int c0r = 0, c1r = 0, crs, n0r = 0, n1r = 0, nrs = 0;
+    fetch_row(a_index, c0r, c1r, crs);
+    if (a_index > 0) fetch_row(a_index - 1, n0r, n1r, nrs);
+    int script = XS_SUB;
+    int n = 0, nmatch = 0, m = 0, found = 0;
+    int qcnt = 0, tcnt = 0, acnt = 0, mtail = 0, want_l1 = 0;
+    while (a_index > 0 || b_index > 0) {
+        const int li = b_index - crs;
+        const int next_script = WIDE ? wide_byte(a_index, b_index, crs)
+                                     : (li < 64 ? __builtin_amdgcn_readlane(c0r, li) : __builtin_amdgcn_readlane(c1r, li - 64));
+        switch (script) {
+        case XS_GAP_IN_A:
+            script = next_script & XS_OP_MASK;
+            if (next_script & XS_EXT_A) script = XS_GAP_IN_A;
+            break;
+        case XS_GAP_IN_B:
+            script = next_script & XS_OP_MASK;
+            if (next_script & XS_EXT_B) script = XS_GAP_IN_B;
+            break;
+        default:
+            script = next_script & XS_OP_MASK;
+            break;
+        }
+        int cq, ct, cm;
+        if (script == XS_GAP_IN_A) { --b_index; cq = 0; ct = 1; cm = 0; }
+        else {
+            if (script == XS_GAP_IN_B) { cq = 1; ct = 0; cm = 0; }
+            else { --b_index; cq = 1; ct = 1; cm = (next_script & XS_MATCH) != 0; }
+            --a_index;
+            c0r = n0r; c1r = n1r; crs = nrs;
+            if (a_index > 0) fetch_row(a_index - 1, n0r, n1r, nrs);
+        }
+        if (n == 0) { o.l0q = cq; o.l0t = ct; o.l0m = cm; }
+        if (want_l1) { o.l1q = cq; o.l1t = ct; o.l1m = cm; want_l1 = 0; }
+        if (!found) {
+            ++acnt; qcnt += cq; tcnt += ct; mtail += cm;
+            if (cm) ++m; else m = 0;
+            if (m == 4) { found = 1; want_l1 = 1; }
+        }
+        ++n;
+        nmatch += cm;
+    }
+    o.n = n; o.nmatch = nmatch;
+    o.qcnt = qcnt; o.tcnt = tcnt; o.acnt = acnt; o.mtail = mtail;
+    o.trim_ok = found && (n - acnt >= 2);
+}
+
+template <bool WIDE>
+__global__ __launch_bounds__(XW_BLOCK) void xd_extend_w(const uint32_t* __restrict__ rpac, const mhip_offset_t* __restrict__ roffs,
+                                                        const uint32_t* __restrict__ qpac, const mhip_offset_t* __restrict__ qoffs,
+                                                        const mhip_aln_job* __restrict__ jobs, int n, XDir* __restrict__ dres,
+                                                        uint8_t* __restrict__ scratch, unsigned int* __restrict__ cursor,
+                                                        unsigned int* __restrict__ ovf_list, unsigned long long* __restrict__ counters,
+                                                        const unsigned int* __restrict__ ulist, unsigned int nunits) {
+    __shared__ XwLds lds[WIDE ? 1 : XW_WAVES];
+    XwLds& S = lds[threadIdx.x >> 6];
+    const int lane = lane_id();
+    uint8_t* st = scratch + (size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (WIDE ? XW_WIDE_BYTES : XW_STATE_BYTES);
+    unsigned long long nblocks = 0;
+    while (true) {
+        unsigned int unit = 0;
+        if (lane == 0) unit = atomicAdd(cursor, 1u);
+        unit = __builtin_amdgcn_readfirstlane(unit);
+        if (unit >= nunits) break;
+        if (ulist) unit = ulist[unit];
+        const mhip_aln_job jb = jobs[unit >> 1];
+        const int right = unit & 1;
+        const int qsize = qoffs[jb.qid_local].size, tsize = roffs[jb.sid_local].size;
+        XView q, t;
+        q.pac = qpac; q.off = qoffs[jb.qid_local].offset; q.comp = jb.chain;
+        t.pac = rpac; t.off = roffs[jb.sid_local].offset; t.comp = 0;
+        const int qs0 = right ? jb.qstart : jb.qstart - 1, step = right ? 1 : -1;
+        if (jb.chain) { q.A = qsize - 1 - qs0; q.B = -step; } else { q.A = qs0; q.B = step; }
+        t.A = right ? jb.sstart : jb.sstart - 1; t.B = step;
+        const int query_size = right ? qsize - jb.qstart : jb.qstart;
+        const int target_size = right ? tsize - jb.sstart : jb.sstart;
+        int qidx = 0, tidx = 0;
+        XDir R = {0, 0, 0, 0, 0, 0, 0, 0};
+        bool handed_over = false;
+        while (true) {      // align_ex (xdrop_gapalign.cpp:263-357)
+            const int qleft = query_size - qidx, tleft = target_size - tidx;
+            int qblk, tblk, last_block;
+            if (qleft < X_SEG + 100 || tleft < X_SEG + 100) {
+                qblk = min(qleft, (int)(tleft + tleft * 0.2));
+                tblk = min(tleft, (int)(qleft + qleft * 0.2));
+                last_block = 1;
+            } else { qblk = X_SEG; tblk = X_SEG; last_block = 0; }
+            XBlockOut o;
+            xdrop_block_w<WIDE>(S, q, qidx, qblk, t, tidx, tblk, st, o);
+            ++nblocks;
+            R.blocks += 1;
+            if (o.overflow) { handed_over = true; break; }
+            const int full_map = (qblk - o.ae <= 20 || tblk - o.be <= 20);
+            if (!full_map || last_block) {
+                if (o.n > 0) {
+                    R.columns += o.n; R.matches += o.nmatch; R.qbases += o.ae; R.tbases += o.be;
+                    R.last_q = o.l0q; R.last_t = o.l0t; R.last_m = o.l0m;
+                }
+                break;
+            }
+            if (!o.trim_ok) break;
+            const int kept = o.n - o.acnt;
+            if (kept > 0) {
+                R.columns += kept; R.matches += o.nmatch - o.mtail; R.qbases += o.ae - o.qcnt; R.tbases += o.be - o.tcnt;
+                R.last_q = o.l1q; R.last_t = o.l1t; R.last_m = o.l1m;
+            }
+            qidx += o.ae - o.qcnt;
+            tidx += o.be - o.tcnt;
+        }
+        if (lane == 0) {
+            if (handed_over) ovf_list[1 + atomicAdd(ovf_list, 1u)] = unit;     // the WIDE launch redoes the whole unit
+            else dres[unit] = R;
+        }
+    }
+    if (lane == 0) atomicAdd(&counters[3], nblocks);
+}
+
 // XdropAligner::go tail (xdrop_gapalign.cpp:396-438): the left half is emitted without its last column
 __global__ void xd_stitch(const mhip_aln_job* __restrict__ jobs, const XDir* __restrict__ dres, int n, int min_aln,
                           mhip_aln_result* __restrict__ out, unsigned long long* __restrict__ counters) {
@@ -279,18 +583,43 @@ int mhip_xalign_candidates_dev(mhip_ctx* c, const mhip_volume* ref, const mhip_v
                                int min_align_size, void* d_out) {
     HIPCHK(hipSetDevice(c->device));
     if (n <= 0) return 0;
-    int nthreads = c->num_cus * 4 * XB_BLOCK;
-    nthreads = std::min(nthreads, ((2 * n + XB_BLOCK - 1) / XB_BLOCK) * XB_BLOCK);
     XDir* d_dres;
     uint8_t* d_s;
     unsigned int* d_cur;
     if (c->scratch("xa_dres", sizeof(XDir) * 2 * (size_t)n, (void**)&d_dres)) return -1;
-    if (c->scratch("xa_lanes", X_LANE_BYTES * (size_t)nthreads, (void**)&d_s)) return -1;
+    unsigned int* d_ovf;
     if (c->scratch("xa_cursor", 64, (void**)&d_cur)) return -1;
-    HIPCHK(hipMemsetAsync(d_cur, 0, 8, c->stream));
-    LAUNCH(c, "xd_extend", xd_extend, nthreads / XB_BLOCK, XB_BLOCK, 0, (const uint32_t*)ref->d_pac, (const mhip_offset_t*)ref->d_offs,
-           (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs, (const mhip_aln_job*)d_jobs, n, d_dres, d_s, d_cur,
-           (int*)(d_cur + 1), (unsigned long long*)c->d_counters);
+    if (c->scratch("xa_ovf", sizeof(unsigned int) * (2 * (size_t)n + 4), (void**)&d_ovf)) return -1;
+    HIPCHK(hipMemsetAsync(d_cur, 0, 16, c->stream));
+    const char* kv = getenv("MECAT_XD_KERNEL");      // 1 = the one-lane-per-unit kernel (independent implementation, tests)
+    if (!(kv && atoi(kv) == 1)) {
+        const int waves = c->num_cus * 16;
+        const int grid = std::min(waves / XW_WAVES, (2 * n + XW_WAVES - 1) / XW_WAVES);
+        if (c->scratch("xw_state", XW_STATE_BYTES * (size_t)waves, (void**)&d_s)) return -1;
+        HIPCHK(hipMemsetAsync(d_ovf, 0, sizeof(unsigned int), c->stream));
+        LAUNCH(c, "xd_extend_w", xd_extend_w<false>, grid, XW_BLOCK, 0, (const uint32_t*)ref->d_pac, (const mhip_offset_t*)ref->d_offs,
+               (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs, (const mhip_aln_job*)d_jobs, n, d_dres, d_s, d_cur,
+               d_ovf, (unsigned long long*)c->d_counters, (const unsigned int*)nullptr, 2u * (unsigned)n);
+        unsigned int nwide = 0;
+        HIPCHK(hipMemcpyAsync(&nwide, d_ovf, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (getenv("MECAT_TRACE")) fprintf(stderr, "[mecat_hip] X-drop: %u of %d units need the wide-window path\n", nwide, 2 * n);
+        if (nwide > 0) {
+            const int wgrid = (int)std::min(nwide, 2048u);
+            uint8_t* d_w;
+            if (c->scratch("xw_wide", XW_WIDE_BYTES * (size_t)wgrid, (void**)&d_w)) return -1;
+            LAUNCH(c, "xd_extend_wide", xd_extend_w<true>, wgrid, 64, 0, (const uint32_t*)ref->d_pac, (const mhip_offset_t*)ref->d_offs,
+                   (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs, (const mhip_aln_job*)d_jobs, n, d_dres, d_w, d_cur + 2,
+                   d_ovf + 2 * (size_t)n + 1, (unsigned long long*)c->d_counters, (const unsigned int*)(d_ovf + 1), nwide);
+        }
+    } else {
+        int nthreads = c->num_cus * 4 * XB_BLOCK;
+        nthreads = std::min(nthreads, ((2 * n + XB_BLOCK - 1) / XB_BLOCK) * XB_BLOCK);
+        if (c->scratch("xa_lanes", X_LANE_BYTES * (size_t)nthreads, (void**)&d_s)) return -1;
+        LAUNCH(c, "xd_extend", xd_extend, nthreads / XB_BLOCK, XB_BLOCK, 0, (const uint32_t*)ref->d_pac, (const mhip_offset_t*)ref->d_offs,
+               (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs, (const mhip_aln_job*)d_jobs, n, d_dres, d_s, d_cur,
+               (int*)(d_cur + 1), (unsigned long long*)c->d_counters);
+    }
     LAUNCH(c, "xd_stitch", xd_stitch, (n + 255) / 256, 256, 0, (const mhip_aln_job*)d_jobs, (const XDir*)d_dres, n, min_align_size,
            (mhip_aln_result*)d_out, (unsigned long long*)c->d_counters);
     int err = 0;

@@ -13,5 +13,7 @@ jobs = W.jobs_from_candidates(cands, cnt, 0)
 t2 = time.time(); res = M.align_candidates(ctx, vol, vol, jobs, p.min_align_size, tech=1); t3 = time.time()
 ok = res["ok"] != 0
 print("ONT 5000x10kb: cands %d seed %.3fs ; xalign %d jobs %.3fs ok %d aligned %.3f Gbase -> %.3f Gbase/s" % (cnt.sum(), t1-t0, len(jobs), t3-t2, ok.sum(), (res["query_end"]-res["query_start"])[ok].sum()/1e9, (res["query_end"]-res["query_start"])[ok].sum()/1e9/(t3-t2)))
+
+
 t2 = time.time(); res2 = M.align_candidates(ctx, vol, vol, jobs, p.min_align_size, tech=0); t3 = time.time()
 print("same jobs with dw: %.3fs" % (t3-t2))

@@ -119,3 +119,61 @@ def test_cli_m4_nanopore_mode(tmp_path):
     r = subprocess.run([BIN, "-j", "1", "-x", "1", "-g", "1", "-d", fa, "-o", out, "-w", str(tmp_path / "w")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     assert sorted(open(out).read().splitlines()) == open(os.path.join(H.GOLDEN, "tiny_ont.g1.m4.sorted")).read().splitlines()
+
+
+def test_xdrop_wide_windows_low_complexity(hip, ctx, capfd):
+    """Homopolymer / short-period tandem stretches keep hundreds of cells within X of the best score: those units leave the
+    128-cell fast path for the wide-window instantiation.  Wave kernel == oracle == lane kernel (independent code)."""
+    rng = np.random.default_rng(4242)
+    O = H.orc()
+    xa = O.orc_xaligner_new()
+    seqs, jobs, want = [], [], []
+    for it in range(40):
+        parts = []
+        for _ in range(int(rng.integers(3, 9))):
+            kind = int(rng.integers(0, 3))
+            ln = int(rng.integers(150, 900))
+            if kind == 0:
+                parts.append(rng.integers(0, 4, size=ln).astype(np.int8))
+            elif kind == 1:
+                parts.append(np.full(ln, int(rng.integers(0, 4)), dtype=np.int8))
+            else:
+                unit = rng.integers(0, 4, size=int(rng.integers(2, 6))).astype(np.int8)
+                parts.append(np.tile(unit, ln // len(unit) + 1)[:ln])
+        g = np.concatenate(parts)
+        e = [0.12, 0.05, 0.2][it % 3]
+        q, t = _mut(rng, g, e), _mut(rng, g, e)
+        if len(q) < 600 or len(t) < 600:
+            continue
+        qs = int(rng.integers(0, len(q)))
+        ts = min(max(int(qs * len(t) / len(q)) + int(rng.integers(-20, 20)), 0), len(t) - 1)
+        chain = it % 2
+        i = len(seqs)
+        seqs.append((3 - q[::-1]).astype(np.int8) if chain else q)
+        seqs.append(t)
+        jobs.append((i, i + 1, chain, qs, ts))
+        o = H.OrcAlnResult()
+        qc, tc = np.ascontiguousarray(q), np.ascontiguousarray(t)
+        O.orc_xdrop_go(xa, qc.ctypes.data, qs, len(qc), tc.ctypes.data, ts, len(tc), 500, C.byref(o))
+        want.append((o.ok, o.query_start, o.query_end, o.target_start, o.target_end, o.matches, o.columns))
+    O.orc_xaligner_free(xa)
+    gv = _vol(hip, ctx, seqs)
+    ja = np.array(jobs, dtype=hip.JOB_DTYPE)
+    os.environ["MECAT_TRACE"] = "1"
+    try:
+        out = hip.align_candidates(ctx, gv, gv, ja, 500, tech=1).copy()
+    finally:
+        os.environ.pop("MECAT_TRACE")
+    err = capfd.readouterr().err
+    nwide = int(err.split("X-drop: ")[1].split(" of ")[0])
+    assert nwide > 5, err                                     # the wide path really ran
+    os.environ["MECAT_XD_KERNEL"] = "1"
+    try:
+        lane = hip.align_candidates(ctx, gv, gv, ja, 500, tech=1).copy()
+    finally:
+        os.environ.pop("MECAT_XD_KERNEL")
+    bad = [(i, jobs[i], _t(out[i]), want[i]) for i in range(len(jobs)) if _t(out[i]) != want[i]]
+    assert not bad, "%d/%d differ from the oracle: %s" % (len(bad), len(jobs), bad[:4])
+    assert out.tobytes() == lane.tobytes()
+    assert sum(w[0] for w in want) > 10
+    gv.free()

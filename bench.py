@@ -307,6 +307,26 @@ def main():
                 del c_res, c_ops
             except Exception as e:          # never let the extra measurement break the contract line
                 log("[bench] cns_realign skipped: %r" % (e,))
+        # not part of the metric either: the X-drop aligner (nanopore mode) on the first 100 000 candidates
+        if world == 1 and not args.no_align and keep["njobs"] > 0:
+            try:
+                nj = min(100000, keep["njobs"])
+                x_res = torch.empty((nj, 8), dtype=torch.int32, device=dev)
+                M.lib().mhip_xalign_candidates_dev.restype = C.c_int
+                tx = []
+                for _ in range(2):
+                    torch.cuda.synchronize()
+                    c0 = time.perf_counter()
+                    rc = M.lib().mhip_xalign_candidates_dev(ctx.h, vol.h, vol.h, d_jobs.data_ptr(), nj, params.min_align_size, x_res.data_ptr())
+                    torch.cuda.synchronize()
+                    tx.append(time.perf_counter() - c0)
+                if rc == 0:
+                    okx = x_res[:, 0] != 0
+                    line["xdrop_extend"] = {"jobs": nj, "seconds": tx[-1], "alignments_per_s": nj / tx[-1], "ok": int(okx.sum().item()),
+                                            "aligned_gbase_per_s": float(((x_res[:, 2] - x_res[:, 1]).to(torch.int64) * okx).sum().item()) / 1e9 / tx[-1]}
+                del x_res
+            except Exception as e:
+                log("[bench] xdrop_extend skipped: %r" % (e,))
         if args.stats:
             json.dump({"kernels": {k: {"launches": v[0], "total_ms": v[1]} for k, v in kstats.items()}, "line": line},
                       open(args.stats, "w"), indent=1)

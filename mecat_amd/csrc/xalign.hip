@@ -260,52 +260,57 @@ __global__ __launch_bounds__(XB_BLOCK) void xd_extend(const uint32_t* __restrict
 // scratch with a fixed row stride (coalesced 64-byte stores), plus bit 7 = "the diagonal step into this cell is a match" so
 // that the traceback needs nothing but these bytes.  The traceback is a scalar walk: a row's bytes sit in two registers
 // (one cell per lane), fetched one row ahead from a 4 KB LDS window over the scratch, and are read with v_readlane.
-// A window wider than XW_RING - 2 cells hands the unit over (overflow list) to the WIDE instantiation of the same code:
-// scores in per-wave global arrays instead of the ring, rows of XW_WSTRIDE bytes, traceback reading byte by byte through the
-// LDS window — slower per row, but only a fraction of a percent of the units (low-complexity sequence) need it.
+// A window wider than XW_RING - 2 cells hands the unit over (overflow list) to a second launch with a bigger per-wave
+// scratch, which redoes the unit and runs the WIDE instantiation of the same code for the blocks that overflow: scores in
+// per-wave global arrays instead of the ring, rows of XW_WSTRIDE bytes, traceback reading byte by byte through the LDS
+// window — slower per row, but only a fraction of a percent of the units (low-complexity sequence) have such blocks.
 #define XW_WAVES 4
 #define XW_BLOCK (XW_WAVES * 64)
 #define XW_RING 128
 #define XW_STRIDE 128                    // script bytes per row in the scratch
-#define XW_WIN 4096                      // = 32 rows
+#define XW_WIN 2048                      // = 16 rows
 #define XW_STATE_BYTES ((size_t)(X_MAXN + 2) * XW_STRIDE)
 #define XW_WSTRIDE 768                   // WIDE: any window fits a row (N + 1 <= 737 cells)
-#define XW_WIDE_BYTES ((size_t)(X_MAXN + 2) * XW_WSTRIDE + 2 * (size_t)(X_MAXN + 8) * 4)
+#define XW_WIDE_BYTES ((size_t)(X_MAXN + 2) * XW_WSTRIDE)
+#define XW_WIDE_HF (X_MAXN + 8)
 #define XW_NEG (-(1 << 30))
 #define XS_MATCH 0x80
-struct XwLds {
-    int Hs[XW_RING], Fs[XW_RING];
-    uint8_t Qb[X_MAXN + 8], Tb[X_MAXN + 8];
+template <int HFN> struct XwLds {
+    int2 HF[HFN];                                        // (H, F) of cell b at b mod XW_RING; WIDE blocks: at b
+    uint8_t Qb[X_MAXN + 8], Tb[X_MAXN + 72];             // Tb[b + 1] = target base b (one pad in front, 64 behind for idle lanes)
     int16_t rstart[X_MAXN + 2];
     uint32_t win[XW_WIN / 4];
 };
 
-template <int CTRL, int RMASK> __device__ __forceinline__ int xw_dpp_max(int v) {
-    return max(v, __builtin_amdgcn_update_dpp(v, v, CTRL, RMASK, 0xf, false));
-}
 __device__ __forceinline__ int xw_scan_max(int v) {          // inclusive prefix max over the 64 lanes, all lanes active
-    v = xw_dpp_max<0x111, 0xf>(v);                            // row_shr:1,2,4,8 (lanes without a source keep their value)
-    v = xw_dpp_max<0x112, 0xf>(v);
-    v = xw_dpp_max<0x114, 0xf>(v);
-    v = xw_dpp_max<0x118, 0xf>(v);
-    v = xw_dpp_max<0x142, 0xa>(v);                            // row_bcast:15 into rows 1 and 3
-    v = xw_dpp_max<0x143, 0xc>(v);                            // row_bcast:31 into rows 2 and 3
+    // fused v_max_i32_dpp steps (a lane without a source keeps its value); a DPP source written by the previous VALU
+    // instruction needs two wait states (dw_helpers.h)
+    asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "+v"(v));
     return v;
 }
 __device__ __forceinline__ int xw_shr1(int v, int fill) {    // lane l gets lane l-1, lane 0 gets fill
     return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false);   // wave_shr:1
 }
 
-template <bool WIDE>
-__device__ void xdrop_block_w(XwLds& S, const XView& q, int qidx, int M, const XView& t, int tidx, int N, uint8_t* __restrict__ st,
+template <bool WIDE, int HFN>
+__device__ void xdrop_block_w(XwLds<HFN>& S, const XView& q, int qidx, int M, const XView& t, int tidx, int N, uint8_t* __restrict__ st,
                               XBlockOut& o) {
     constexpr int STRIDE = WIDE ? XW_WSTRIDE : XW_STRIDE;
-    volatile int* gH = (volatile int*)(st + (size_t)(X_MAXN + 2) * XW_WSTRIDE);      // WIDE only
-    volatile int* gF = gH + (X_MAXN + 8);
-    auto ldH = [&](int b) -> int { return WIDE ? gH[b] : S.Hs[b & (XW_RING - 1)]; };
-    auto ldF = [&](int b) -> int { return WIDE ? gF[b] : S.Fs[b & (XW_RING - 1)]; };
-    auto stH = [&](int b, int v) { if (WIDE) gH[b] = v; else S.Hs[b & (XW_RING - 1)] = v; };
-    auto stF = [&](int b, int v) { if (WIDE) gF[b] = v; else S.Fs[b & (XW_RING - 1)] = v; };
+    static_assert(!WIDE || HFN >= XW_WIDE_HF, "WIDE blocks index the score array by b");
+    auto slot = [&](int b) -> int { return WIDE ? min(b, HFN - 1) : b & (XW_RING - 1); };      // (idle lanes read a valid slot)
+    auto ldHF = [&](int b, bool in) -> int2 {
+        const int2 v = S.HF[slot(b)];
+        return in ? v : make_int2(X_MIN_SCORE, X_MIN_SCORE);
+    };
+    auto stH = [&](int b, int v) { S.HF[slot(b)].x = v; };
+    auto stHF = [&](int b, int h, int f) { S.HF[slot(b)] = make_int2(h, f); };
     o.ae = o.be = 0; o.n = o.nmatch = 0; o.qcnt = o.tcnt = o.acnt = o.mtail = 0; o.trim_ok = 0; o.overflow = 0;
     o.l0q = o.l0t = o.l0m = o.l1q = o.l1t = o.l1m = 0;
     if (M <= 0 || N <= 0) return;
@@ -313,12 +318,11 @@ __device__ void xdrop_block_w(XwLds& S, const XView& q, int qidx, int M, const X
     const int X = 30;
     __builtin_amdgcn_wave_barrier();
     for (int i = lane; i < M; i += 64) S.Qb[i] = (uint8_t)xv_at(q, qidx + i);
-    for (int i = lane; i < N; i += 64) S.Tb[i] = (uint8_t)xv_at(t, tidx + i);
+    for (int i = lane; i < N; i += 64) S.Tb[i + 1] = (uint8_t)xv_at(t, tidx + i);
     // row 0 (xdrop_gapalign.cpp:45-57): cells 1.. hold -1, -2, ... while >= -X
     const int n_init = min(N, X);
-    if (lane == 0) { stH(0, 0); stF(0, -1); S.rstart[0] = 0; }
-    if (lane >= 1 && lane <= n_init) { stH(lane, -lane); stF(lane, -lane - 1); st[lane] = XS_GAP_IN_A; }
-    if (WIDE) __threadfence();
+    if (lane == 0) S.rstart[0] = 0;
+    if (lane <= n_init) { stHF(lane, -lane, -lane - 1); if (lane) st[lane] = XS_GAP_IN_A; }
     int b_size = n_init + 1, best = 0, first_b = 0, ae = 0, be = 0;      // b_size == N + 1 when N <= X, as in the reference
     __builtin_amdgcn_wave_barrier();
     for (int a = 1; a <= M; ++a) {
@@ -331,10 +335,10 @@ __device__ void xdrop_block_w(XwLds& S, const XView& q, int qidx, int M, const X
         for (int c0 = f0; c0 < n0; c0 += 64) {
             const int b = c0 + lane;
             const bool in = b < n0;
-            const int Hp = in ? ldH(b) : X_MIN_SCORE, Fp = in ? ldF(b) : X_MIN_SCORE;
+            const int2 hf = ldHF(b, in);
+            const int Hp = hf.x, Fp = hf.y;
             const int left = xw_shr1(Hp, prevHp);
-            const int tb = b > 0 ? (int)S.Tb[b - 1] : 0;
-            const bool mt = AC == tb;
+            const bool mt = AC == (int)S.Tb[b];                         // target base b - 1
             const int diag = b == f0 ? X_MIN_SCORE : left + (mt ? 1 : -1);
             const int Mv = max(diag, Fp);
             const int incl = xw_scan_max(in ? Mv + b : XW_NEG);
@@ -351,17 +355,13 @@ __device__ void xdrop_block_w(XwLds& S, const XView& q, int qidx, int M, const X
             const unsigned long long lower = km & ((1ull << lane) - 1ull);
             const int jsrc = lower ? 63 - __clzll((long long)lower) : 0;
             const int Hj = __shfl(Hc, jsrc);
-            if (kept) {
-                if (sc < Ec) script = XS_GAP_IN_A;
-                if (!(Fp - 1 < Hc - 1)) script += XS_EXT_A;
-                if (!(Ec - 1 < Hc - 1)) script += XS_EXT_B;
-                stH(b, Hc);
-                stF(b, max(Fp - 1, Hc - 1));
-            } else if (in) {
-                const int et = lower ? Hj - 1 : (lastkept >= 0 ? lastkeptH - 1 : X_MIN_SCORE);
-                if (sc < et) script = XS_GAP_IN_A;
-                if (lower || firstkept >= 0) stH(b, X_MIN_SCORE);       // interior; a leading one only moves first_b
-            }
+            // a dropped cell compares with the row gap as the sequential row carries it: H of the nearest kept cell to the left - 1
+            const int et = lower ? Hj - 1 : (lastkept >= 0 ? lastkeptH - 1 : X_MIN_SCORE);
+            if (sc < (kept ? Ec : et)) script = XS_GAP_IN_A;
+            if (kept && Fp >= Hc) script += XS_EXT_A;
+            if (kept && Ec >= Hc) script += XS_EXT_B;
+            if (kept) stHF(b, Hc, max(Fp - 1, Hc - 1));
+            else if (in && (lower || firstkept >= 0)) stH(b, X_MIN_SCORE);   // interior; a leading one only moves first_b
             if (in) srow[b - f0] = (uint8_t)(script | (mt ? XS_MATCH : 0));
             // carries
             const int cmaxH = __builtin_amdgcn_readlane(inclH, 63);
@@ -390,18 +390,16 @@ __device__ void xdrop_block_w(XwLds& S, const XView& q, int qidx, int M, const X
             cnt = max(min(cnt, N - b_size), 0);          // b_size is N + 1 in a block with N <= X (row 0 ran off the end)
             if (lane < cnt) {
                 const int bnew = b_size + lane;
-                stH(bnew, e_end - lane);
-                stF(bnew, e_end - lane - 1);
+                stHF(bnew, e_end - lane, e_end - lane - 1);
                 if (bnew - f0 < STRIDE) srow[bnew - f0] = XS_GAP_IN_A;
             }
             b_size += cnt;
         }
         if (b_size < N) {
-            if (lane == 0) { stH(b_size, X_MIN_SCORE); stF(b_size, X_MIN_SCORE); }
+            if (lane == 0) stHF(b_size, X_MIN_SCORE, X_MIN_SCORE);
             ++b_size;
         }
         if (!WIDE && (b_size - first_b > XW_RING - 2 || b_size - f0 > XW_STRIDE)) { o.overflow = 2; return; }
-        if (WIDE) __threadfence();
         __builtin_amdgcn_wave_barrier();
     }
     o.ae = ae; o.be = be;
@@ -411,7 +409,7 @@ __device__ void xdrop_block_w(XwLds& S, const XView& q, int qidx, int M, const X
     const volatile uint32_t* stw = (const volatile uint32_t*)st;
     int wbase = 1 << 30;                                 // first scratch byte in the LDS window; nothing loaded yet
     // row registers: lane l holds the bytes of cells rstart + l and rstart + 64 + l
-    auto fetch_row = [&](int a, int& r0, int& r1, int& rs) {
+    auto fetch_row = [&](int a, int& r, int& rs) {
         rs = __builtin_amdgcn_readfirstlane((int)S.rstart[a]);
         if (WIDE) return;                                // bytes are read one by one below
         const int off = a * XW_STRIDE;
@@ -422,8 +420,7 @@ __device__ void xdrop_block_w(XwLds& S, const XView& q, int qidx, int M, const X
             __builtin_amdgcn_wave_barrier();
         }
         const uint8_t* wb = (const uint8_t*)S.win + (off - wbase);
-        r0 = wb[lane];
-        r1 = wb[64 + lane];
+        r = (int)wb[lane] | ((int)wb[64 + lane] << 8);
     };
     auto wide_byte = [&](int a, int b, int rs) -> int {
         const int idx = a * XW_WSTRIDE + (b - rs);
@@ -436,51 +433,42 @@ __device__ void xdrop_block_w(XwLds& S, const XView& q, int qidx, int M, const X
         return __builtin_amdgcn_readfirstlane((int)((const uint8_t*)S.win)[idx - wbase]);
     };
     int a_index = ae, b_index = be;
-    int c0r = 0, c1r = 0, crs, n0r = 0, n1r = 0, nrs = 0;
-    fetch_row(a_index, c0r, c1r, crs);
-    if (a_index > 0) fetch_row(a_index - 1, n0r, n1r, nrs);
-    int script = XS_SUB;
-    int n = 0, nmatch = 0, m = 0, found = 0;
-    int qcnt = 0, tcnt = 0, acnt = 0, mtail = 0, want_l1 = 0;
+    int cr = 0, crs, nr = 0, nrs = 0;
+    fetch_row(a_index, cr, crs);
+    if (a_index > 0) fetch_row(a_index - 1, nr, nrs);
+    // One step = one byte: the op is the previous one while its extension bit is set in this byte, else the byte's own
+    // (bit 4 continues GAP_IN_A, bit 6 GAP_IN_B; bit 5 is never set and stands in for "after a substitution").
+    int st_op = XS_SUB;
+    int n = 0, nmatch = 0, m = 0, found = 0, want_l1 = 0, first = 0, l1 = 0;
+    int sn_n = 0, sn_a = 0, sn_b = 0, sn_m = 0;          // the walk's state right after the first run of 4 matches
     while (a_index > 0 || b_index > 0) {
         const int li = b_index - crs;
-        const int next_script = WIDE ? wide_byte(a_index, b_index, crs)
-                                     : (li < 64 ? __builtin_amdgcn_readlane(c0r, li) : __builtin_amdgcn_readlane(c1r, li - 64));
-        switch (script) {
-        case XS_GAP_IN_A:
-            script = next_script & XS_OP_MASK;
-            if (next_script & XS_EXT_A) script = XS_GAP_IN_A;
-            break;
-        case XS_GAP_IN_B:
-            script = next_script & XS_OP_MASK;
-            if (next_script & XS_EXT_B) script = XS_GAP_IN_B;
-            break;
-        default:
-            script = next_script & XS_OP_MASK;
-            break;
-        }
-        int cq, ct, cm;
-        if (script == XS_GAP_IN_A) { --b_index; cq = 0; ct = 1; cm = 0; }
-        else {
-            if (script == XS_GAP_IN_B) { cq = 1; ct = 0; cm = 0; }
-            else { --b_index; cq = 1; ct = 1; cm = (next_script & XS_MATCH) != 0; }
-            --a_index;
-            c0r = n0r; c1r = n1r; crs = nrs;
-            if (a_index > 0) fetch_row(a_index - 1, n0r, n1r, nrs);
-        }
-        if (n == 0) { o.l0q = cq; o.l0t = ct; o.l0m = cm; }
-        if (want_l1) { o.l1q = cq; o.l1t = ct; o.l1m = cm; want_l1 = 0; }
-        if (!found) {
-            ++acnt; qcnt += cq; tcnt += ct; mtail += cm;
-            if (cm) ++m; else m = 0;
-            if (m == 4) { found = 1; want_l1 = 1; }
-        }
+        const int byte = WIDE ? wide_byte(a_index, b_index, crs) : (__builtin_amdgcn_readlane(cr, li & 63) >> ((li >> 6) << 3)) & 0xff;
+        const int sh = 4 + (st_op & 1) + ((st_op >> 2) << 1);
+        const int op = ((byte >> sh) & 1) ? st_op : (byte & XS_OP_MASK);
+        st_op = op;
+        const int cq = op != XS_GAP_IN_A, ct = op != XS_GAP_IN_B;
+        const int cm = cq & ct & (byte >> 7);
+        a_index -= cq;
+        b_index -= ct;
+        const int pk = cq | (ct << 1) | (cm << 2);
+        first = n == 0 ? pk : first;
+        l1 = want_l1 ? pk : l1;
+        want_l1 = 0;
         ++n;
         nmatch += cm;
+        m = cm ? m + 1 : 0;
+        if (m == 4 && !found) { found = 1; want_l1 = 1; sn_n = n; sn_a = a_index; sn_b = b_index; sn_m = nmatch; }
+        if (cq) {
+            cr = nr; crs = nrs;
+            if (a_index > 0) fetch_row(a_index - 1, nr, nrs);
+        }
     }
     o.n = n; o.nmatch = nmatch;
-    o.qcnt = qcnt; o.tcnt = tcnt; o.acnt = acnt; o.mtail = mtail;
-    o.trim_ok = found && (n - acnt >= 2);
+    o.l0q = first & 1; o.l0t = (first >> 1) & 1; o.l0m = first >> 2;
+    o.l1q = l1 & 1; o.l1t = (l1 >> 1) & 1; o.l1m = l1 >> 2;
+    o.acnt = found ? sn_n : n; o.qcnt = found ? ae - sn_a : ae; o.tcnt = found ? be - sn_b : be; o.mtail = found ? sn_m : nmatch;
+    o.trim_ok = found && (n - o.acnt >= 2);
 }
 
 template <bool WIDE>
@@ -490,8 +478,9 @@ __global__ __launch_bounds__(XW_BLOCK) void xd_extend_w(const uint32_t* __restri
                                                         uint8_t* __restrict__ scratch, unsigned int* __restrict__ cursor,
                                                         unsigned int* __restrict__ ovf_list, unsigned long long* __restrict__ counters,
                                                         const unsigned int* __restrict__ ulist, unsigned int nunits) {
-    __shared__ XwLds lds[WIDE ? 1 : XW_WAVES];
-    XwLds& S = lds[threadIdx.x >> 6];
+    constexpr int HFN = WIDE ? XW_WIDE_HF : XW_RING;
+    __shared__ XwLds<HFN> lds[WIDE ? 1 : XW_WAVES];
+    XwLds<HFN>& S = lds[threadIdx.x >> 6];
     const int lane = lane_id();
     uint8_t* st = scratch + (size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (WIDE ? XW_WIDE_BYTES : XW_STATE_BYTES);
     unsigned long long nblocks = 0;
@@ -524,10 +513,13 @@ __global__ __launch_bounds__(XW_BLOCK) void xd_extend_w(const uint32_t* __restri
                 last_block = 1;
             } else { qblk = X_SEG; tblk = X_SEG; last_block = 0; }
             XBlockOut o;
-            xdrop_block_w<WIDE>(S, q, qidx, qblk, t, tidx, tblk, st, o);
+            xdrop_block_w<false, HFN>(S, q, qidx, qblk, t, tidx, tblk, st, o);
             ++nblocks;
             R.blocks += 1;
-            if (o.overflow) { handed_over = true; break; }
+            if (o.overflow) {
+                if (!WIDE) { handed_over = true; break; }
+                if constexpr (WIDE) xdrop_block_w<true, HFN>(S, q, qidx, qblk, t, tidx, tblk, st, o);      // only the blocks that need it
+            }
             const int full_map = (qblk - o.ae <= 20 || tblk - o.be <= 20);
             if (!full_map || last_block) {
                 if (o.n > 0) {
@@ -593,7 +585,7 @@ int mhip_xalign_candidates_dev(mhip_ctx* c, const mhip_volume* ref, const mhip_v
     HIPCHK(hipMemsetAsync(d_cur, 0, 16, c->stream));
     const char* kv = getenv("MECAT_XD_KERNEL");      // 1 = the one-lane-per-unit kernel (independent implementation, tests)
     if (!(kv && atoi(kv) == 1)) {
-        const int waves = c->num_cus * 16;
+        const int waves = c->num_cus * (getenv("MECAT_XW_WAVES") ? atoi(getenv("MECAT_XW_WAVES")) : 24);
         const int grid = std::min(waves / XW_WAVES, (2 * n + XW_WAVES - 1) / XW_WAVES);
         if (c->scratch("xw_state", XW_STATE_BYTES * (size_t)waves, (void**)&d_s)) return -1;
         HIPCHK(hipMemsetAsync(d_ovf, 0, sizeof(unsigned int), c->stream));

@@ -29,10 +29,14 @@ $(LIBDIR)/libmecat_hip.so: $(HIP_OBJS)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(HIP_OBJS) -o $@
 
-host: $(BINDIR)/mecat2pw
+host: $(BINDIR)/mecat2pw $(BINDIR)/mecat2cns_partition
 $(BINDIR)/mecat2pw: $(HOST_SRCS) $(wildcard mecat_amd/host/*.h) include/mecat_hip.h $(LIBDIR)/libmecat_hip.so
 	@mkdir -p $(BINDIR)
 	$(CXX) -O2 -std=c++17 -pthread -Wall -Iinclude $(HOST_SRCS) -L$(LIBDIR) -lmecat_hip -Wl,-rpath,'$$ORIGIN/../lib' -o $@
+
+$(BINDIR)/mecat2cns_partition: mecat_amd/tools/partition_main.cpp mecat_amd/host/partition.cpp mecat_amd/host/partition.h
+	@mkdir -p $(BINDIR)
+	$(CXX) -O2 -std=c++17 -pthread -Wall mecat_amd/tools/partition_main.cpp mecat_amd/host/partition.cpp -o $@
 
 synth: $(LIBDIR)/libsynth.so $(BINDIR)/synth_reads
 $(LIBDIR)/libsynth.so: mecat_amd/tools/synth_reads.c

@@ -251,7 +251,7 @@ __global__ __launch_bounds__(XB_BLOCK) void xd_extend(const uint32_t* __restrict
 
 // ------------------------------------------------------------------------------------------------------------------
 // xd_extend_w — one WAVE per (candidate, direction).  A row of the dynamic program is per-cell independent work plus two
-// prefix-max scans over the window (oracle/xdrop_rowpar.c states and checks the equivalence with the sequential row):
+// prefix-max scans over the window (the tests check the equivalence with the sequential row state by state):
 //   diag_b = H'[b-1] + s(A_a, B_{b-1}) (MIN for the row's first cell),  M_b = max(diag_b, F'[b]),
 //   E_b = max_{j<b}(M_j + j) - b,  H_b = max(M_b, E_b),  best_b = max(best, max_{j<b} H_j),  dropped <=> best_b - H_b > X;
 // a value carried across a dropped cell is below every later kept cell's score, so it only shows in the op bits of dropped

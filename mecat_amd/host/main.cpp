@@ -24,6 +24,7 @@
 
 #include "mecat_hip.h"
 #include "options.h"
+#include "partition.h"
 #include "volume.h"
 
 #define DIE(...)                                                  \
@@ -127,7 +128,7 @@ static void run_threads(int nt, F f) {
     for (auto& x : th) x.join();
 }
 
-static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, const std::vector<std::string>& vn, FILE* out) {
+static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, const std::vector<std::string>& vn, FILE* out, PartitionWriter* pw) {
     mhip_params P;
     mhip_params_default(&P, opt.tech);
     P.maxc = opt.num_candidates;
@@ -185,6 +186,7 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
             auto range_of = [&](int t, int* lo, int* hi) { *lo = (int)((long long)nr * t / nt); *hi = (int)((long long)nr * (t + 1) / nt); };
             if (opt.task == TASK_SEED) {
                 // candidate_detect, pw_impl.cpp:767-801 ; line format alignment.cpp:18-32
+                std::vector<std::vector<CanRec>> prec(pw ? (size_t)nt : 0);
                 run_threads(nt, [&](int t) {
                     int lo, hi;
                     range_of(t, &lo, &hi);
@@ -201,11 +203,14 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
                             const int w = snprintf(line, sizeof(line), "%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\n", qid, c.readno, c.chain, 0, qext,
                                                    sext, c.score, qsize, ssize);
                             o.append(line, (size_t)w);
+                            if (pw) prec[(size_t)t].push_back(CanRec{qid, c.readno, c.chain, 0, qext, sext, c.score, qsize, ssize});
                         }
                     }
                 });
                 for (const std::string& o : text)
                     if (!o.empty() && fwrite(o.data(), 1, o.size(), out) != o.size()) DIE("write error!");
+                if (pw)      // the same lines, in the same order, as records (no text round trip)
+                    for (const std::vector<CanRec>& v : prec) pw->add(v.data(), v.size());
                 continue;
             }
             // pairwise_mapping, pw_impl.cpp:674-700
@@ -365,16 +370,29 @@ int main(int argc, char* argv[]) {
         if (mhip_ctx_create(device, NULL, &ctx) != 0) DIE("cannot use the GPU: %s", mhip_last_error());
     }
 
+    // MECAT_HIP_PARTITION=<batch_size>[,<min_read_size>] (additive, -j 0 only): also write mecat2cns' candidate partition
+    // files <output>.part<k> + <output>.partition_files (partition.h).  Records are taken straight from the candidate arrays
+    // when this process computes every row itself; after a resume or in multi-process mode the merged text is partitioned.
+    long part_batch = 0;
+    int part_min = opt.tech == TECH_NANOPORE ? 2000 : 5000;      // mecat2cns defaults, options.cpp:16,27
+    if (const char* pe = getenv("MECAT_HIP_PARTITION")) {
+        if (opt.task != TASK_SEED) DIE("MECAT_HIP_PARTITION needs -j 0 (candidate output)");
+        part_batch = atol(pe);
+        if (const char* comma = strchr(pe, ',')) part_min = atoi(comma + 1);
+        if (part_batch <= 0) DIE("MECAT_HIP_PARTITION: batch size must be positive");
+    }
+    PartitionWriter* pw = (part_batch > 0 && world == 1) ? new PartitionWriter(opt.output, part_batch, part_min) : NULL;
     for (int i = rank; i < num_vols; i += world) {
         const std::string fin = results_name(opt.wrk_dir, i, false);
         if (access(fin.c_str(), F_OK) == 0) {
             fprintf(stderr, "[%s, %u] volume %d has been finished\n\n", __func__, __LINE__, i);
+            if (pw) { pw->abandon(); delete pw; pw = NULL; }      // that row's records are only on disk
             continue;
         }
         const std::string wrk = results_name(opt.wrk_dir, i, true);
         FILE* out = fopen(wrk.c_str(), "w");
         if (!out) DIE("failed to open file '%s' with mode 'ios::out'", wrk.c_str());
-        process_one_volume(opt, ctx, i, vn, out);
+        process_one_volume(opt, ctx, i, vn, out, pw);
         if (fclose(out) != 0) DIE("write error!");
         if (rename(wrk.c_str(), fin.c_str()) != 0) DIE("cannot rename %s", wrk.c_str());
     }
@@ -388,6 +406,14 @@ int main(int argc, char* argv[]) {
         while (world > 1 && access(fin.c_str(), F_OK) != 0) usleep(50 * 1000);
         const std::string cmd = std::string("cat ") + fin + (i == 0 ? " >" : " >> ") + opt.output;
         if (system(cmd.c_str()) != 0) DIE("'%s' failed", cmd.c_str());
+    }
+    if (pw) {
+        TraceTimer tt("partition_files");
+        pw->finish();
+        delete pw;
+    } else if (part_batch > 0) {
+        TraceTimer tt("partition_files(text)");
+        partition_candidates_text(opt.output, part_batch, part_min, opt.num_threads);
     }
     return 0;
 }

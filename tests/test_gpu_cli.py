@@ -169,3 +169,53 @@ def test_cli_multi_volume_grid_m4(tmp_path):
     got = sorted(open(out).read().splitlines())
     assert got == sorted(want)
     assert len(got) > 300
+
+
+def test_cli_candidate_partition_files(tmp_path):
+    """MECAT_HIP_PARTITION: mecat2cns' partition files straight from the candidate arrays == the threaded
+    text partitioner on the produced .can == the restatement (oracle/partition_oracle.py, pinned to the reference by
+    tests/test_partition_cpu.py); a resumed run (every row already on disk) takes the text path and writes the same bytes."""
+    import sys
+
+    import numpy as np
+    sys.path.insert(0, os.path.join(H.ROOT, "oracle"))
+    import partition_oracle as PO
+    fa = _fasta(tmp_path, "tiny")
+    out = str(tmp_path / "p.can")
+    wrk = str(tmp_path / "w_p")
+    env = dict(os.environ, MECAT_HIP_PARTITION="7,1000", MECAT_HIP_SLAB="41")
+    cmd = [BIN, "-j", "0", "-d", fa, "-o", out, "-w", wrk, "-t", "3"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = open(out).read()
+    assert sorted(text.splitlines()) == open(os.path.join(H.GOLDEN, "tiny.can.sorted")).read().splitlines()
+
+    def parts(can):
+        d, base = os.path.dirname(can), os.path.basename(can)
+        return {f[len(base):]: open(os.path.join(d, f), "rb").read() for f in sorted(os.listdir(d)) if f.startswith(base + ".part")}
+    direct = parts(out)
+    assert len(direct) > 3
+    ofiles, oidx = PO.partition(PO.parse_can(text), 7, 1000)
+    assert sum(len(v) for v in ofiles.values()) > 100
+    for k, recs in ofiles.items():
+        assert np.array_equal(np.frombuffer(direct[".part%d" % k], dtype=np.int32).reshape(-1, 13), np.array(recs, dtype=np.int32).reshape(-1, 13))
+    assert direct[".partition_files"].decode().splitlines() == ["%s.part%d\t%d\t%d" % (out, k, lo, hi) for k, lo, hi in oidx]
+    # the standalone tool on a copy of the text
+    os.mkdir(tmp_path / "t")
+    can2 = str(tmp_path / "t" / "p.can")
+    open(can2, "w").write(text)
+    tool = os.path.join(H.ROOT, "mecat_amd", "bin", "mecat2cns_partition")
+    assert subprocess.run([tool, can2, "7", "1000", "2"], capture_output=True).returncode == 0
+    t = parts(can2)
+    assert sorted(t) == sorted(direct)
+    assert all(t[k] == direct[k] for k in t if k != ".partition_files")
+    # resume: rows are skipped, the merged text is partitioned instead
+    for f in list(os.listdir(tmp_path)):
+        if f.startswith("p.can.part"):
+            os.remove(tmp_path / f)
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "has been finished" in r.stderr, r.stderr[-2000:]
+    assert parts(out) == direct
+    # -j 1 has no candidate output to partition
+    r = subprocess.run([BIN, "-j", "1", "-d", fa, "-o", str(tmp_path / "q.m4"), "-w", str(tmp_path / "w_q")], capture_output=True, text=True, env=env)
+    assert r.returncode != 0 and "MECAT_HIP_PARTITION" in r.stderr

@@ -128,7 +128,8 @@ static void run_threads(int nt, F f) {
     for (auto& x : th) x.join();
 }
 
-static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, const std::vector<std::string>& vn, FILE* out, PartitionWriter* pw) {
+static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, const std::vector<std::string>& vn, FILE* out, PartitionWriter* pw,
+                               double part_ratio) {
     mhip_params P;
     mhip_params_default(&P, opt.tech);
     P.maxc = opt.num_candidates;
@@ -235,6 +236,7 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
             // aligner by technology (pw_impl.cpp:638-644): DiffAligner (dw) for PacBio, XdropAligner for nanopore
             if (opt.tech == TECH_NANOPORE) MCHK(mhip_xalign_candidates(ctx, dref, dreads, jobs.data(), (int)jobs.size(), P.min_align_size, res.data()));
             else MCHK(mhip_align_candidates(ctx, dref, dreads, jobs.data(), (int)jobs.size(), P.min_align_size, res.data()));
+            std::vector<std::vector<M4Rec>> mrec(pw ? (size_t)nt : 0);
             run_threads(nt, [&](int t) {
                 int lo, hi;
                 range_of(t, &lo, &hi);
@@ -286,11 +288,17 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
                         if (opt.output_gapped_start_point) w += snprintf(line + w, 64, "\t%lld\t%lld", (long long)m.qext, (long long)m.sext);
                         line[w++] = '\n';
                         o.append(line, (size_t)w);
+                        if (pw)
+                            mrec[(size_t)t].push_back(M4Rec{(int32_t)m.qid, (int32_t)m.sid, m.vscore, m.qdir, (int32_t)m.qoff, (int32_t)m.qend,
+                                                            (int32_t)m.qsize, m.sdir, (int32_t)m.soff, (int32_t)m.send, (int32_t)m.ssize,
+                                                            (int32_t)m.qext, (int32_t)m.sext});
                     }
                 }
             });
             for (const std::string& o : text)
                 if (!o.empty() && fwrite(o.data(), 1, o.size(), out) != o.size()) DIE("write error!");
+            if (pw)
+                for (const std::vector<M4Rec>& v : mrec) pw->add_m4(v.data(), v.size(), part_ratio);
         }
         if (dreads != dref) mhip_volume_free(dreads);
     }
@@ -370,17 +378,24 @@ int main(int argc, char* argv[]) {
         if (mhip_ctx_create(device, NULL, &ctx) != 0) DIE("cannot use the GPU: %s", mhip_last_error());
     }
 
-    // MECAT_HIP_PARTITION=<batch_size>[,<min_read_size>] (additive, -j 0 only): also write mecat2cns' candidate partition
-    // files <output>.part<k> + <output>.partition_files (partition.h).  Records are taken straight from the candidate arrays
-    // when this process computes every row itself; after a resume or in multi-process mode the merged text is partitioned.
+    // MECAT_HIP_PARTITION=<batch_size>[,<min_read_size>[,<mapping_ratio>]] (additive): also write mecat2cns' partition files
+    // <output>.part<k> + <output>.partition_files (partition.h) — partition_candidates for -j 0, partition_m4records for
+    // -j 1 -g 1.  Records are taken straight from the result arrays when this process computes every row itself; after a
+    // resume or in multi-process mode the merged text is partitioned.
     long part_batch = 0;
-    int part_min = opt.tech == TECH_NANOPORE ? 2000 : 5000;      // mecat2cns defaults, options.cpp:16,27
+    int part_min = opt.tech == TECH_NANOPORE ? 2000 : 5000;      // mecat2cns defaults -l and -r, options.cpp:13-27
+    double part_ratio = opt.tech == TECH_NANOPORE ? 0.4 : 0.9;
     if (const char* pe = getenv("MECAT_HIP_PARTITION")) {
-        if (opt.task != TASK_SEED) DIE("MECAT_HIP_PARTITION needs -j 0 (candidate output)");
+        if (opt.task == TASK_ALN && !opt.output_gapped_start_point)
+            DIE("MECAT_HIP_PARTITION with -j 1 needs -g 1 (mecat2cns reads the gapped start points)");
         part_batch = atol(pe);
-        if (const char* comma = strchr(pe, ',')) part_min = atoi(comma + 1);
+        if (const char* comma = strchr(pe, ',')) {
+            part_min = atoi(comma + 1);
+            if (const char* c2 = strchr(comma + 1, ',')) part_ratio = atof(c2 + 1);
+        }
         if (part_batch <= 0) DIE("MECAT_HIP_PARTITION: batch size must be positive");
     }
+    part_ratio = part_ratio - 0.02;                               // reads_correction_m4.cpp:79
     PartitionWriter* pw = (part_batch > 0 && world == 1) ? new PartitionWriter(opt.output, part_batch, part_min) : NULL;
     for (int i = rank; i < num_vols; i += world) {
         const std::string fin = results_name(opt.wrk_dir, i, false);
@@ -392,7 +407,7 @@ int main(int argc, char* argv[]) {
         const std::string wrk = results_name(opt.wrk_dir, i, true);
         FILE* out = fopen(wrk.c_str(), "w");
         if (!out) DIE("failed to open file '%s' with mode 'ios::out'", wrk.c_str());
-        process_one_volume(opt, ctx, i, vn, out, pw);
+        process_one_volume(opt, ctx, i, vn, out, pw, part_ratio);
         if (fclose(out) != 0) DIE("write error!");
         if (rename(wrk.c_str(), fin.c_str()) != 0) DIE("cannot rename %s", wrk.c_str());
     }
@@ -413,7 +428,8 @@ int main(int argc, char* argv[]) {
         delete pw;
     } else if (part_batch > 0) {
         TraceTimer tt("partition_files(text)");
-        partition_candidates_text(opt.output, part_batch, part_min, opt.num_threads);
+        if (opt.task == TASK_SEED) partition_candidates_text(opt.output, part_batch, part_min, opt.num_threads);
+        else partition_m4_text(opt.output, part_ratio, part_batch, part_min, opt.num_threads);
     }
     return 0;
 }

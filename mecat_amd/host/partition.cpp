@@ -82,6 +82,34 @@ void PartitionWriter::add(const CanRec* recs, size_t n) {
     }
 }
 
+static inline void normalise_m4(const M4Rec& m, bool subject_is_target, PartRecord* d) {   // normalize_m4record + m4_to_candidate
+    if (subject_is_target) {
+        d->qdir = m.qdir; d->qid = m.qid; d->qext = m.qext; d->qsize = m.qsize; d->qoff = m.qoff; d->qend = m.qend;
+        d->sdir = m.sdir; d->sid = m.sid; d->sext = m.sext; d->ssize = m.ssize; d->soff = m.soff; d->send = m.send;
+    } else {                                              // reverse_m4record, common/alignment.h:72-88
+        d->qdir = m.sdir; d->qid = m.sid; d->qext = m.sext; d->qsize = m.ssize; d->qoff = m.soff; d->qend = m.send;
+        d->sdir = m.qdir; d->sid = m.qid; d->sext = m.qext; d->ssize = m.qsize; d->soff = m.qoff; d->send = m.qend;
+    }
+    d->score = m.vscore;
+    if (d->sdir == 1) { d->sdir = 0; d->qdir = 1 - d->qdir; }
+}
+
+void PartitionWriter::add_m4(const M4Rec* recs, size_t n, double min_cov_ratio) {
+    PartRecord r;
+    for (size_t i = 0; i < n; ++i) {
+        const M4Rec& m = recs[i];
+        max_id_seen_ = std::max(max_id_seen_, std::max(m.qid, m.sid));      // get_qualified_m4record_counts, :44-68 (all lines)
+        if (m.qsize < min_read_size_ || m.ssize < min_read_size_) continue;
+        const long qm = (long)m.qend - m.qoff, qs = (long)(m.qsize * min_cov_ratio);
+        const long sm = (long)m.send - m.soff, ss = (long)(m.ssize * min_cov_ratio);
+        if (!(qm >= qs || sm >= ss)) continue;
+        normalise_m4(m, false, &r);
+        put(m.qid / batch_size_, m.qid, r);
+        normalise_m4(m, true, &r);
+        put(m.sid / batch_size_, m.sid, r);
+    }
+}
+
 void PartitionWriter::finish() {
     if (finished_) return;
     finished_ = true;
@@ -107,38 +135,45 @@ void PartitionWriter::finish() {
     if (fclose(f) != 0) PDIE("write error on %s", idx.c_str());
 }
 
-// nine whitespace separated integers per line (operator>>, common/alignment.cpp:8-16)
-static const char* parse_line(const char* p, const char* end, CanRec* r, bool* ok) {
-    int32_t v[9];
-    for (int k = 0; k < 9; ++k) {
+// whitespace separated numbers; column `skip` (the m4 identity, a real) is stepped over.  Returns the number of integers read.
+static const char* parse_ints(const char* p, const char* end, int32_t* v, int want, int skip, int* got) {
+    int k = 0;
+    for (int col = 0; k < want; ++col) {
         while (p < end && (*p == ' ' || *p == '\t')) ++p;
+        if (p >= end || *p == '\n') break;
+        if (col == skip) {
+            while (p < end && *p != ' ' && *p != '\t' && *p != '\n') ++p;
+            continue;
+        }
         bool neg = false;
-        if (p < end && (*p == '-' || *p == '+')) { neg = *p == '-'; ++p; }
-        if (p >= end || *p < '0' || *p > '9') { *ok = false; return p; }
+        if (*p == '-' || *p == '+') { neg = *p == '-'; ++p; }
+        if (p >= end || *p < '0' || *p > '9') break;
         long x = 0;
         while (p < end && *p >= '0' && *p <= '9') { x = x * 10 + (*p - '0'); ++p; }
-        v[k] = (int32_t)(neg ? -x : x);
+        v[k++] = (int32_t)(neg ? -x : x);
     }
     while (p < end && *p != '\n') ++p;
     if (p < end) ++p;
-    r->qid = v[0]; r->sid = v[1]; r->qdir = v[2]; r->sdir = v[3]; r->qext = v[4]; r->sext = v[5]; r->score = v[6]; r->qsize = v[7]; r->ssize = v[8];
-    *ok = true;
+    *got = k;
     return p;
 }
 
-long partition_candidates_text(const char* can_path, long batch_size, int min_read_size, int num_threads) {
-    const int fd = open(can_path, O_RDONLY);
-    if (fd < 0) PDIE("cannot open %s: %s", can_path, strerror(errno));
+// REC = CanRec (9 ints per line) or M4Rec (13 ints + the identity column); FEED(writer, recs, n)
+template <class REC, class FEED>
+static long partition_text(const char* path, long batch_size, int min_read_size, int num_threads, int ints, int skip, const char* what,
+                           FEED feed) {
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) PDIE("cannot open %s: %s", path, strerror(errno));
     struct stat sb;
-    if (fstat(fd, &sb) != 0) PDIE("cannot stat %s", can_path);
+    if (fstat(fd, &sb) != 0) PDIE("cannot stat %s", path);
     const size_t size = (size_t)sb.st_size;
-    PartitionWriter w(can_path, batch_size, min_read_size);
+    PartitionWriter w(path, batch_size, min_read_size);
     if (size == 0) { close(fd); w.finish(); return 0; }
     const char* base = (const char*)mmap(NULL, size, PROT_READ, MAP_PRIVATE, fd, 0);
-    if (base == MAP_FAILED) PDIE("cannot map %s: %s", can_path, strerror(errno));
+    if (base == MAP_FAILED) PDIE("cannot map %s: %s", path, strerror(errno));
     const int nt = std::max(1, std::min(num_threads, 64));
     const size_t slab = (size_t)64 << 20;                     // text bytes per thread and round
-    std::vector<std::vector<CanRec>> recs((size_t)nt);
+    std::vector<std::vector<REC>> recs((size_t)nt);
     std::vector<int> bad((size_t)nt, 0);
     size_t pos = 0;
     while (pos < size) {
@@ -151,16 +186,15 @@ long partition_candidates_text(const char* can_path, long batch_size, int min_re
             cut[(size_t)t] = std::max(c, cut[(size_t)t - 1]);
         }
         auto work = [&](int t) {
-            std::vector<CanRec>& o = recs[(size_t)t];
+            std::vector<REC>& o = recs[(size_t)t];
             o.clear();
             const char* p = base + cut[(size_t)t];
             const char* e = base + cut[(size_t)t + 1];
-            CanRec r;
+            REC r;
             while (p < e) {
-                if (*p == '\n') { ++p; bad[(size_t)t] = 1; continue; }      // an empty line repeats the previous record in the reference: not supported
-                bool ok;
-                p = parse_line(p, e, &r, &ok);
-                if (!ok) { bad[(size_t)t] = 1; break; }
+                int got;
+                p = parse_ints(p, e, (int32_t*)&r, ints, skip, &got);      // (an empty line repeats the previous record in the reference: not supported)
+                if (got != ints) { bad[(size_t)t] = got + 1; break; }
                 o.push_back(r);
             }
         };
@@ -169,8 +203,12 @@ long partition_candidates_text(const char* can_path, long batch_size, int min_re
         work(0);
         for (auto& x : th) x.join();
         for (int t = 0; t < nt; ++t) {
-            if (bad[(size_t)t]) PDIE("%s: malformed candidate line (nine integers per line expected)", can_path);
-            w.add(recs[(size_t)t].data(), recs[(size_t)t].size());
+            if (bad[(size_t)t] == 12 && ints == 13) {         // get_qualified_m4record_counts, overlaps_partition.cpp:56-59
+                w.abandon();
+                PDIE("no gapped start position is provided, please make sure that you have run 'mecat2pw' with option '-g 1'");
+            }
+            if (bad[(size_t)t]) { w.abandon(); PDIE("%s: malformed line (%s expected)", path, what); }
+            feed(w, recs[(size_t)t].data(), recs[(size_t)t].size());
         }
         pos = cut[(size_t)nt];
     }
@@ -178,4 +216,14 @@ long partition_candidates_text(const char* can_path, long batch_size, int min_re
     close(fd);
     w.finish();
     return w.records_written();
+}
+
+long partition_candidates_text(const char* can_path, long batch_size, int min_read_size, int num_threads) {
+    return partition_text<CanRec>(can_path, batch_size, min_read_size, num_threads, 9, -1, "nine integers per line",
+                                  [](PartitionWriter& w, const CanRec* r, size_t n) { w.add(r, n); });
+}
+
+long partition_m4_text(const char* m4_path, double min_cov_ratio, long batch_size, int min_read_size, int num_threads) {
+    return partition_text<M4Rec>(m4_path, batch_size, min_read_size, num_threads, 13, 2, "14 columns per line",
+                                 [min_cov_ratio](PartitionWriter& w, const M4Rec* r, size_t n) { w.add_m4(r, n, min_cov_ratio); });
 }

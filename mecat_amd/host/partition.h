@@ -13,6 +13,10 @@ struct CanRec {            // one `.can` line in column order (common/alignment.
     int32_t qid, sid, qdir, sdir, qext, sext, score, qsize, ssize;
 };
 
+struct M4Rec {             // one `.m4` line written with -g 1 (common/alignment.cpp:34-56; ident is not used here)
+    int32_t qid, sid, vscore, qdir, qoff, qend, qsize, sdir, soff, send, ssize, qext, sext;
+};
+
 struct PartRecord {        // ExtensionCandidate, 13 ints = 52 bytes (common/alignment.h:8-13)
     int32_t qdir, qid, qext, qsize, qoff, qend;
     int32_t sdir, sid, sext, ssize, soff, send;
@@ -31,6 +35,11 @@ public:
     PartitionWriter(const std::string& can_path, long batch_size, int min_read_size);
     ~PartitionWriter();
     void add(const CanRec* recs, size_t n);
+    // the `-j 1 -g 1` flavour (partition_m4records, overlaps_partition.cpp:344-412): lines whose reads are long enough and of
+    // which min_cov_ratio of the query or of the subject is covered (check_m4record_mapping_range, :17-25); all 13 ints of a
+    // record are defined here (m4_to_candidate, common/alignment.h:170-186).  mecat2cns passes its -r value minus 0.02
+    // (reads_correction_m4.cpp:79-80).
+    void add_m4(const M4Rec* recs, size_t n, double min_cov_ratio);
     void finish();
     void abandon() { finished_ = true; }      // stop without an index file (the caller will partition the text instead)
     long records_written() const { return total_; }
@@ -57,3 +66,5 @@ private:
 // The same from the text file itself (what mecat2cns would parse), scanned by `num_threads` threads over the mapped file.
 // Returns the number of records written.
 long partition_candidates_text(const char* can_path, long batch_size, int min_read_size, int num_threads);
+// `.m4` text written with -g 1 (14 columns; 12 columns is the reference's "run with -g 1" error)
+long partition_m4_text(const char* m4_path, double min_cov_ratio, long batch_size, int min_read_size, int num_threads);

@@ -41,3 +41,45 @@ def partition(cands, batch_size, min_read_size):
             lo[k] = min(lo.get(k, rid), rid)
             hi[k] = max(hi.get(k, rid), rid)
     return files, [(k, lo[k], hi[k]) for k in sorted(lo)]                        # :210-215: batches without records are skipped
+
+
+def parse_m4(text):
+    """operator>>(istream&, M4Record&), common/alignment.cpp:34-56 with -g 1: qid sid ident vscore qdir qoff qend qsize sdir soff send
+    ssize qext sext -> (qid, sid, vscore, qdir, qoff, qend, qsize, sdir, soff, send, ssize, qext, sext)"""
+    out = []
+    for ln in text.splitlines():
+        f = ln.split()
+        out.append(tuple(int(x) for x in f[:2] + f[3:14]))
+    return out
+
+
+def normalise_m4(m, subject_is_target):
+    """normalize_m4record (common/alignment.h:90-102) + m4_to_candidate (:170-186)"""
+    qid, sid, vscore, qdir, qoff, qend, qsize, sdir, soff, send, ssize, qext, sext = m
+    if subject_is_target:
+        d = [qdir, qid, qext, qsize, qoff, qend, sdir, sid, sext, ssize, soff, send, vscore]
+    else:
+        d = [sdir, sid, sext, ssize, soff, send, qdir, qid, qext, qsize, qoff, qend, vscore]
+    if d[6] == 1:
+        d[6] = 0
+        d[0] = 1 - d[0]
+    return tuple(d)
+
+
+def partition_m4(recs, min_cov_ratio, batch_size, min_read_size):
+    """partition_m4records, overlaps_partition.cpp:344-412 (the repeat-read set is empty there)"""
+    num_reads = max([max(m[0], m[1]) for m in recs], default=-1) + 1
+    num_batches = (num_reads + batch_size - 1) // batch_size
+    files = {k: [] for k in range(num_batches)}
+    lo, hi = {}, {}
+    for m in recs:
+        if m[6] < min_read_size or m[10] < min_read_size:
+            continue
+        if not (m[5] - m[4] >= int(m[6] * min_cov_ratio) or m[9] - m[8] >= int(m[10] * min_cov_ratio)):      # :17-25
+            continue
+        for rid, subject_is_target in ((m[0], False), (m[1], True)):
+            k = rid // batch_size
+            files[k].append(normalise_m4(m, subject_is_target))
+            lo[k] = min(lo.get(k, rid), rid)
+            hi[k] = max(hi.get(k, rid), rid)
+    return files, [(k, lo[k], hi[k]) for k in sorted(lo)]

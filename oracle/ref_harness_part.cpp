@@ -10,4 +10,9 @@ void refp_partition_candidates(const char* input, long batch_size, int min_read_
     partition_candidates(input, (idx_t)batch_size, min_read_size, num_files);
 }
 
+// partition_m4records (overlaps_partition.cpp:344-412), the `-j 1 -g 1` flavour
+void refp_partition_m4records(const char* input, double min_cov_ratio, long batch_size, int min_read_size, int num_files) {
+    partition_m4records(input, min_cov_ratio, (index_t)batch_size, min_read_size, num_files);
+}
+
 }

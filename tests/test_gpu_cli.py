@@ -216,6 +216,25 @@ def test_cli_candidate_partition_files(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, env=env)
     assert r.returncode == 0 and "has been finished" in r.stderr, r.stderr[-2000:]
     assert parts(out) == direct
-    # -j 1 has no candidate output to partition
+    # -j 1 without -g 1 has no start points for mecat2cns
     r = subprocess.run([BIN, "-j", "1", "-d", fa, "-o", str(tmp_path / "q.m4"), "-w", str(tmp_path / "w_q")], capture_output=True, text=True, env=env)
     assert r.returncode != 0 and "MECAT_HIP_PARTITION" in r.stderr
+    # -j 1 -g 1: partition_m4records (coverage filter with mecat2cns' -r 0.9 minus 0.02; tiny reads overlap end to end often enough)
+    env4 = dict(os.environ, MECAT_HIP_PARTITION="9,1000,0.5", MECAT_HIP_SLAB="41")
+    out4 = str(tmp_path / "p.m4")
+    cmd4 = [BIN, "-j", "1", "-g", "1", "-d", fa, "-o", out4, "-w", str(tmp_path / "w_p4"), "-t", "3"]
+    r = subprocess.run(cmd4, capture_output=True, text=True, env=env4)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text4 = open(out4).read()
+    d4 = parts(out4)
+    ofiles, oidx = PO.partition_m4(PO.parse_m4(text4), 0.5 - 0.02, 9, 1000)
+    assert sum(len(v) for v in ofiles.values()) > 50
+    for k, recs in ofiles.items():
+        assert np.array_equal(np.frombuffer(d4[".part%d" % k], dtype=np.int32).reshape(-1, 13), np.array(recs, dtype=np.int32).reshape(-1, 13))
+    assert d4[".partition_files"].decode().splitlines() == ["%s.part%d\t%d\t%d" % (out4, k, lo, hi) for k, lo, hi in oidx]
+    for f in list(os.listdir(tmp_path)):
+        if f.startswith("p.m4.part"):
+            os.remove(tmp_path / f)
+    r = subprocess.run(cmd4, capture_output=True, text=True, env=env4)          # resumed: the text path
+    assert r.returncode == 0 and "has been finished" in r.stderr, r.stderr[-2000:]
+    assert parts(out4) == d4

@@ -117,3 +117,72 @@ def test_tool_and_oracle_equal_reference(tmp_path, num_files):
     for k in rf:
         assert rf[k].shape == of[k].shape
         assert np.array_equal(rf[k][:, PO.DEFINED], of[k][:, PO.DEFINED]), k
+
+
+# ---- the m4 flavour (partition_m4records)
+def _random_m4(rng, n, nreads, min_size):
+    lines = []
+    for _ in range(n):
+        qid, sid = int(rng.integers(0, nreads)), int(rng.integers(0, nreads))
+        qs = int(rng.integers(min_size - 300, min_size + 5000))
+        ss = int(rng.integers(min_size - 300, min_size + 5000))
+        qo = int(rng.integers(0, qs // 2)); qe = int(rng.integers(qo + 1, qs + 1))
+        so = int(rng.integers(0, ss // 2)); se = int(rng.integers(so + 1, ss + 1))
+        if rng.random() < 0.3:
+            qo, qe = 0, qs - int(rng.integers(0, qs // 8))
+        lines.append("%d\t%d\t%g\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d" % (
+            qid, sid, 70 + 30 * rng.random(), int(rng.integers(1, 90)), 0, qo, qe, qs, int(rng.integers(0, 2)), so, se, ss,
+            int(rng.integers(qo, qe)), int(rng.integers(so, se))))
+    return "\n".join(lines) + ("\n" if lines else "")
+
+
+def _check_m4_against_oracle(path, text, ratio, batch, min_size):
+    files, idx = _read_parts(path)
+    ofiles, oidx = PO.partition_m4(PO.parse_m4(text), ratio, batch, min_size)
+    assert sorted(files) == sorted(ofiles)
+    for k in ofiles:
+        assert np.array_equal(files[k], np.array(ofiles[k], dtype=np.int32).reshape(-1, 13)), k
+    assert idx == [(os.path.basename(path) + ".part%d" % k, lo, hi) for k, lo, hi in oidx]
+    return files
+
+
+@pytest.mark.parametrize("n,threads", [(0, 1), (4000, 3)])
+def test_m4_tool_equals_oracle(tmp_path, n, threads):
+    rng = np.random.default_rng(5 + n)
+    text = _random_m4(rng, n, 900, 2000)
+    path = str(tmp_path / "o.m4")
+    open(path, "w").write(text)
+    r = subprocess.run([_tool(), "-m", "0.88", path, "128", "2000", str(threads)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    files = _check_m4_against_oracle(path, text, 0.88, 128, 2000)
+    if n:
+        assert 200 < sum(len(v) for v in files.values()) < 2 * n          # the coverage filter drops some, keeps some
+
+
+def test_m4_without_gapped_start_points_is_the_reference_error(tmp_path):
+    path = str(tmp_path / "g0.m4")
+    open(path, "w").write("1\t2\t88.5\t30\t0\t0\t9000\t9000\t0\t0\t9000\t9000\n")
+    r = subprocess.run([_tool(), "-m", "0.88", path, "100", "2000"], capture_output=True, text=True)
+    assert r.returncode != 0 and "-g 1" in r.stderr
+
+
+@pytest.mark.skipif(not os.path.exists(REFLIB), reason="oracle/_ref/libref_part.so not built (needs /root/reference)")
+def test_m4_tool_and_oracle_equal_reference(tmp_path):
+    rng = np.random.default_rng(12)
+    text = _random_m4(rng, 20000, 1500, 2000)
+    for sub in ("ref", "ours"):
+        os.mkdir(tmp_path / sub)
+        open(tmp_path / sub / "o.m4", "w").write(text)
+    ratio = 0.9 - 0.02                                            # what mecat2cns passes for PacBio (reads_correction_m4.cpp:79)
+    code = ("import ctypes as C; L = C.CDLL(%r); L.refp_partition_m4records.argtypes = [C.c_char_p, C.c_double, C.c_long, C.c_int, C.c_int]; "
+            "L.refp_partition_m4records(%r, %r, 200, 2000, 4)" % (REFLIB, str(tmp_path / "ref" / "o.m4").encode(), ratio))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([_tool(), "-m", repr(ratio), str(tmp_path / "ours" / "o.m4"), "200", "2000", "3"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rf, ri = _read_parts(str(tmp_path / "ref" / "o.m4"))
+    of = _check_m4_against_oracle(str(tmp_path / "ours" / "o.m4"), text, ratio, 200, 2000)
+    _, oi = _read_parts(str(tmp_path / "ours" / "o.m4"))
+    assert ri == oi and sorted(rf) == sorted(of)
+    for k in rf:
+        assert np.array_equal(rf[k], of[k]), k                    # all 13 ints are defined in this flavour

@@ -282,17 +282,17 @@ template <int HFN> struct XwLds {
     uint32_t win[XW_WIN / 4];
 };
 
+template <int CTRL, int RMASK> __device__ __forceinline__ int xw_dpp_max(int v) {
+    // old = the identity of max: lets the DPP combiner fuse mov_dpp + max into one v_max_i32_dpp and schedule around the hazard
+    return max(v, __builtin_amdgcn_update_dpp((int)0x80000000, v, CTRL, RMASK, 0xf, false));
+}
 __device__ __forceinline__ int xw_scan_max(int v) {          // inclusive prefix max over the 64 lanes, all lanes active
-    // fused v_max_i32_dpp steps (a lane without a source keeps its value); a DPP source written by the previous VALU
-    // instruction needs two wait states (dw_helpers.h)
-    asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-                 "s_nop 1"
-                 : "+v"(v));
+    v = xw_dpp_max<0x111, 0xf>(v);                            // row_shr:1,2,4,8
+    v = xw_dpp_max<0x112, 0xf>(v);
+    v = xw_dpp_max<0x114, 0xf>(v);
+    v = xw_dpp_max<0x118, 0xf>(v);
+    v = xw_dpp_max<0x142, 0xa>(v);                            // row_bcast:15 into rows 1 and 3
+    v = xw_dpp_max<0x143, 0xc>(v);                            // row_bcast:31 into rows 2 and 3
     return v;
 }
 __device__ __forceinline__ int xw_shr1(int v, int fill) {    // lane l gets lane l-1, lane 0 gets fill
@@ -330,7 +330,7 @@ __device__ void xdrop_block_w(XwLds<HFN>& S, const XView& q, int qidx, int M, co
         const int f0 = first_b, n0 = b_size;
         uint8_t* srow = st + (size_t)a * STRIDE;
         if (lane == 0) S.rstart[a] = (int16_t)f0;
-        int runP = XW_NEG, bb = best, rowmax = X_MIN_SCORE, rowarg = -1, firstkept = -1, lastkept = -1, lastkeptH = 0;
+        int runP = XW_NEG, bb = best, rowarg = -1, firstkept = -1, lastkept = -1, lastkeptH = 0;
         int prevHp = 0;
         for (int c0 = f0; c0 < n0; c0 += 64) {
             const int b = c0 + lane;
@@ -345,10 +345,15 @@ __device__ void xdrop_block_w(XwLds<HFN>& S, const XView& q, int qidx, int M, co
             const int pex = max(xw_shr1(incl, XW_NEG), runP);         // max over all earlier cells of the row of M_j + j
             const int Ec = (b == f0) ? X_MIN_SCORE : pex - b;
             const int Hc = max(Mv, Ec);
-            const int inclH = xw_scan_max(in ? Hc : XW_NEG);
-            const int bbefore = max(bb, xw_shr1(inclH, XW_NEG));
+            // best so far before cell b = max(bb, max_{j<b} H_j).  No scan needed: a row's scores exceed the best of the rows before
+            // by at most the match reward (every H derives from the previous row, at most +1), so all cells above bb hold the same
+            // value and only the position of the first one matters.
+            const unsigned long long ex = __builtin_amdgcn_ballot_w64(in && Hc > bb);
+            int j1 = 64, nb = bb;
+            if (ex) { j1 = __ffsll((long long)ex) - 1; nb = __builtin_amdgcn_readlane(Hc, j1); }
+            const int bbefore = lane > j1 ? nb : bb;
             const bool kept = in && !(bbefore - Hc > X);
-            const unsigned long long km = __ballot(kept);
+            const unsigned long long km = __builtin_amdgcn_ballot_w64(kept);
             // op bits: SUB unless the column gap, then the row gap, is strictly better (:99-107)
             int sc = diag, script = XS_SUB;
             if (sc < Fp) { script = XS_GAP_IN_B; sc = Fp; }
@@ -364,13 +369,9 @@ __device__ void xdrop_block_w(XwLds<HFN>& S, const XView& q, int qidx, int M, co
             else if (in && (lower || firstkept >= 0)) stH(b, X_MIN_SCORE);   // interior; a leading one only moves first_b
             if (in) srow[b - f0] = (uint8_t)(script | (mt ? XS_MATCH : 0));
             // carries
-            const int cmaxH = __builtin_amdgcn_readlane(inclH, 63);
             runP = max(runP, __builtin_amdgcn_readlane(incl, 63));
-            if (cmaxH > rowmax) {
-                rowmax = cmaxH;
-                rowarg = c0 + __ffsll((long long)__ballot(in && Hc == cmaxH)) - 1;
-            }
-            bb = max(bb, cmaxH);
+            if (ex && rowarg < 0) rowarg = c0 + j1;
+            bb = nb;
             if (km) {
                 if (firstkept < 0) firstkept = c0 + __ffsll((long long)km) - 1;
                 const int lk = 63 - __clzll((long long)km);
@@ -379,7 +380,7 @@ __device__ void xdrop_block_w(XwLds<HFN>& S, const XView& q, int qidx, int M, co
             }
             prevHp = __builtin_amdgcn_readlane(Hp, 63);
         }
-        if (rowmax > best) { best = rowmax; ae = a; be = rowarg; }
+        if (bb > best) { best = bb; ae = a; be = rowarg; }
         if (firstkept < 0) { first_b = n0; break; }
         first_b = firstkept;
         if (lastkept < n0 - 1) b_size = lastkept + 1;

@@ -177,3 +177,29 @@ def test_xdrop_wide_windows_low_complexity(hip, ctx, capfd):
     assert out.tobytes() == lane.tobytes()
     assert sum(w[0] for w in want) > 10
     gv.free()
+
+
+def test_xdrop_wave_kernel_equals_lane_kernel_at_scale(hip, ctx):
+    """133 855 candidates of 5 000 ONT-style 10 kb reads (2.1 M blocks, a few hundred of them through the wide-window path):
+    the wave-per-alignment kernel and the lane-per-alignment replay are independent implementations and must agree on every
+    field of every result."""
+    from mecat_amd import workload as W
+    codes, lens = W.synth_reads(5000, 10000, 0.12, 1_700_000, 7, 1)
+    pac, offs, nb = W.pack_volume(codes, lens)
+    vol = hip.Volume(ctx, pac, offs, nb, 0)
+    idx = hip.Index(ctx, vol)
+    p = hip.default_params(1)
+    cands, cnt = hip.seed_reads(ctx, idx, vol, vol, 0, len(lens), p)
+    jobs = W.jobs_from_candidates(cands, cnt, 0)
+    assert len(jobs) > 100000
+    wave = hip.align_candidates(ctx, vol, vol, jobs, p.min_align_size, tech=1).copy()
+    os.environ["MECAT_XD_KERNEL"] = "1"
+    try:
+        lane = hip.align_candidates(ctx, vol, vol, jobs, p.min_align_size, tech=1).copy()
+    finally:
+        os.environ.pop("MECAT_XD_KERNEL")
+    diff = np.nonzero(wave.view(np.int32).reshape(len(jobs), -1) != lane.view(np.int32).reshape(len(jobs), -1))[0]
+    assert diff.size == 0, (diff[:5], wave[diff[:3]], lane[diff[:3]])
+    assert int((wave["ok"] != 0).sum()) > 0.9 * len(jobs)
+    idx.free()
+    vol.free()

@@ -13,7 +13,7 @@
 //
 // One wave per (candidate, direction); lanes are the diagonals of a d-row.  Every row's furthest-x values go to a per-wave
 // global scratch because the traceback walks all of them; the walk pulls them back into LDS a window of rows at a time
-// (coalesced copies), which keeps the LDS footprint at 9 KB per wave = 16 waves per CU.
+// (coalesced copies), which keeps the LDS footprint at 6.3 KB per wave = 24 waves per CU.
 #include <algorithm>
 
 #include "dw_helpers.h"
@@ -26,7 +26,7 @@
 #define CN_VLEN (2 * CN_MAX_D + 8)
 #define CN_ROW_W 192               // diagonals per row: band of 2 * int(0.3 * 600) = 360 -> 181 + 2
 #define CN_SEQ_WORDS 44            // 600 bases + 32 of window slack = 40 words, one leading pad word, slack
-#define CN_RING 1536               // cells of the traceback's row window in LDS (~60 rows at 15 %)
+#define CN_RING 512                // cells of the traceback's row window in LDS (~20 rows at 15 %); >= CN_MAX_D (reused per row below)
 #define CN_GROW ((size_t)CN_MAX_D * CN_ROW_W)
 
 struct CnsLds {
@@ -34,17 +34,19 @@ struct CnsLds {
     uint32_t Tp[CN_SEQ_WORDS];
     int16_t V[CN_VLEN];
     int16_t rmin[CN_MAX_D], rmax[CN_MAX_D];
-    uint16_t woff[CN_MAX_D];       // traceback: offset of the row in the window; afterwards: columns before the row's snake
-    uint16_t ring[CN_RING];        // the row window
+    uint16_t woff[64];             // traceback: offset of row r in the window, at r mod 64 (a window holds <= 64 consecutive rows)
+    uint16_t ring[CN_RING];        // the row window; after the walk: columns before row r's snake, at r
     uint16_t tlen[CN_MAX_D];       // the path: snake length of the row, bit 15 = the row's indel is a query-only column
 };
+
+static_assert(CN_RING >= CN_MAX_D, "the ring doubles as the per-row column prefix");
 
 struct CnsDir {                    // one direction of one candidate
     int32_t cols, qbases, tbases, ins, del, pad;
 };
 
 __device__ __forceinline__ int cns_cell(const CnsLds& S, int r, int k) {
-    return (int)S.ring[(int)S.woff[r] + ((k - (int)S.rmin[r]) >> 1)];
+    return (int)S.ring[(int)S.woff[r & 63] + ((k - (int)S.rmin[r]) >> 1)];
 }
 
 // rows in the window ending at row r (going down): as many of r, r - 1, ... (at most 64) as fit CN_RING cells.  Copies them
@@ -59,7 +61,7 @@ __device__ __forceinline__ int cns_load_window(CnsLds& S, const volatile uint16_
     }
     const unsigned long long fits = __ballot(rr >= 0 && incl <= CN_RING);
     const int count = __popcll(fits);                      // a prefix of the lanes: incl is non-decreasing; >= 1 (a row has <= 181 cells)
-    if (lane < count) S.woff[rr] = (uint16_t)(incl - ns);
+    if (lane < count) S.woff[rr & 63] = (uint16_t)(incl - ns);
     for (int i = 0; i < count; ++i) {
         const int n_i = __shfl(ns, i), off_i = __shfl(incl - ns, i), row = r - i;
         for (int c = lane; c < n_i; c += 64) S.ring[off_i + c] = grow[(size_t)row * CN_ROW_W + c];
@@ -67,7 +69,7 @@ __device__ __forceinline__ int cns_load_window(CnsLds& S, const volatile uint16_
     return r - count + 1;
 }
 
-__global__ __launch_bounds__(CN_BLOCK) void cns_extend(const uint32_t* __restrict__ rpac, const mhip_offset_t* __restrict__ roffs,
+__global__ __launch_bounds__(CN_BLOCK, 6) void cns_extend(const uint32_t* __restrict__ rpac, const mhip_offset_t* __restrict__ roffs,
                                                        const uint32_t* __restrict__ qpac, const mhip_offset_t* __restrict__ qoffs,
                                                        const mhip_aln_job* __restrict__ jobs, int n, double error_rate, int dir_cols_cap,
                                                        uint32_t* __restrict__ ops, CnsDir* __restrict__ dres, uint16_t* __restrict__ gscratch,
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(CN_BLOCK) void cns_extend(const uint32_t* __restric
                     const int v = __shfl_up(incl, o);
                     if (lane >= o) incl += v;
                 }
-                if (in) S.woff[r] = (uint16_t)(carry + incl - len);     // columns before the snake of row r (its indel included)
+                if (in) S.ring[r] = (uint16_t)(carry + incl - len);     // columns before the snake of row r (its indel included)
                 carry += __shfl(incl, 63);
             }
             __builtin_amdgcn_wave_barrier();
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(CN_BLOCK) void cns_extend(const uint32_t* __restric
             if (more) {
                 if (rstar < 0) break;
                 const int lens = (int)(S.tlen[rstar] & 0x7FFF);
-                kept_cols = (int)S.woff[rstar] + lens - 4;
+                kept_cols = (int)S.ring[rstar] + lens - 4;
                 kept_q = x2s - 4;
                 kept_t = x2s - ks - 4;
                 if (kept_q == 0) break;                  // "i == ALN_SIZE" (:350)
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(CN_BLOCK) void cns_extend(const uint32_t* __restric
             for (int r0 = 1; r0 <= end_d; r0 += 64) {
                 const int r = r0 + lane;
                 const bool in = r <= end_d;
-                const int c = in ? (int)S.woff[r] - 1 : 0x7fffffff;          // column of the row's indel
+                const int c = in ? (int)S.ring[r] - 1 : 0x7fffffff;          // column of the row's indel
                 const bool put = in && c < kept_cols;
                 const int op = put ? ((S.tlen[r] & 0x8000) ? 2 : 1) : 0;
                 if (put) {
@@ -330,7 +332,7 @@ int mhip_cns_align_candidates_dev(mhip_ctx* c, const mhip_volume* ref, const mhi
     if (n <= 0) return 0;
     if (dir_cols_cap < 16 || (dir_cols_cap & 15)) { mhip_set_error("dir_cols_cap must be a positive multiple of 16"); return -1; }
     if (!(error_rate > 0.0) || error_rate > 0.20) { mhip_set_error("error_rate %.3f outside (0, 0.20]", error_rate); return -1; }
-    const int waves_per_cu = 16;                      // 9 KB of LDS per wave
+    const int waves_per_cu = getenv("MECAT_CNS_WAVES") ? atoi(getenv("MECAT_CNS_WAVES")) : 24;      // 6.3 KB of LDS per wave, <= 80 VGPRs
     const int max_waves = c->num_cus * waves_per_cu;
     const int grid = std::min(max_waves / CN_WAVES, (2 * n + CN_WAVES - 1) / CN_WAVES);
     CnsDir* d_dres;

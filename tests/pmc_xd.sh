@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_INSTS_VMEM_WR SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_SMEM"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $set --output-format csv -d /tmp/pmc$i -- python /root/repo/tests/bench_xdrop.py > /tmp/pmc$i.log 2>&1
+  timeout 300 rocprofv3 --pmc $set --output-format csv -d /tmp/pmc$i -- python /root/repo/tests/${PMC_SCRIPT:-bench_xdrop.py} > /tmp/pmc$i.log 2>&1
 done
 python3 - <<'PY'
 import csv, glob, collections
@@ -12,7 +12,8 @@ tot = collections.defaultdict(lambda: collections.defaultdict(float))
 for f in glob.glob("/tmp/pmc*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0]
-        if "xd_" in k:
+        import os
+        if os.environ.get("PMC_FILTER", "xd_") in k:
             tot[k][r["Counter_Name"]] += float(r["Counter_Value"])
 for k, d in tot.items():
     print(k)

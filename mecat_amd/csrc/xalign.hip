@@ -278,7 +278,7 @@ __global__ __launch_bounds__(XB_BLOCK) void xd_extend(const uint32_t* __restrict
 template <int HFN> struct XwLds {
     int2 HF[HFN];                                        // (H, F) of cell b at b mod XW_RING; WIDE blocks: at b
     uint8_t Qb[X_MAXN + 8], Tb[X_MAXN + 72];             // Tb[b + 1] = target base b (one pad in front, 64 behind for idle lanes)
-    int16_t rstart[X_MAXN + 2];
+    int16_t rstart[HFN == XW_RING ? 2 : X_MAXN + 2];     // WIDE blocks only; 128-byte rows carry their first column in bytes 126-127
     uint32_t win[XW_WIN / 4];
 };
 
@@ -321,7 +321,7 @@ __device__ void xdrop_block_w(XwLds<HFN>& S, const XView& q, int qidx, int M, co
     for (int i = lane; i < N; i += 64) S.Tb[i + 1] = (uint8_t)xv_at(t, tidx + i);
     // row 0 (xdrop_gapalign.cpp:45-57): cells 1.. hold -1, -2, ... while >= -X
     const int n_init = min(N, X);
-    if (lane == 0) S.rstart[0] = 0;
+    if (lane == 0) { if (WIDE) S.rstart[0] = 0; else *(uint16_t*)(st + XW_STRIDE - 2) = 0; }
     if (lane <= n_init) { stHF(lane, -lane, -lane - 1); if (lane) st[lane] = XS_GAP_IN_A; }
     int b_size = n_init + 1, best = 0, first_b = 0, ae = 0, be = 0;      // b_size == N + 1 when N <= X, as in the reference
     __builtin_amdgcn_wave_barrier();
@@ -329,7 +329,7 @@ __device__ void xdrop_block_w(XwLds<HFN>& S, const XView& q, int qidx, int M, co
         const int AC = S.Qb[a - 1];
         const int f0 = first_b, n0 = b_size;
         uint8_t* srow = st + (size_t)a * STRIDE;
-        if (lane == 0) S.rstart[a] = (int16_t)f0;
+        if (lane == 0) { if (WIDE) S.rstart[a] = (int16_t)f0; else *(uint16_t*)(srow + XW_STRIDE - 2) = (uint16_t)f0; }
         int runP = XW_NEG, bb = best, rowarg = -1, firstkept = -1, lastkept = -1, lastkeptH = 0;
         int prevHp = 0;
         for (int c0 = f0; c0 < n0; c0 += 64) {
@@ -392,7 +392,7 @@ __device__ void xdrop_block_w(XwLds<HFN>& S, const XView& q, int qidx, int M, co
             if (lane < cnt) {
                 const int bnew = b_size + lane;
                 stHF(bnew, e_end - lane, e_end - lane - 1);
-                if (bnew - f0 < STRIDE) srow[bnew - f0] = XS_GAP_IN_A;
+                if (bnew - f0 < STRIDE - 2) srow[bnew - f0] = XS_GAP_IN_A;
             }
             b_size += cnt;
         }
@@ -400,7 +400,7 @@ __device__ void xdrop_block_w(XwLds<HFN>& S, const XView& q, int qidx, int M, co
             if (lane == 0) stHF(b_size, X_MIN_SCORE, X_MIN_SCORE);
             ++b_size;
         }
-        if (!WIDE && (b_size - first_b > XW_RING - 2 || b_size - f0 > XW_STRIDE)) { o.overflow = 2; return; }
+        if (!WIDE && (b_size - first_b > XW_RING - 2 || b_size - f0 > XW_STRIDE - 2)) { o.overflow = 2; return; }
         __builtin_amdgcn_wave_barrier();
     }
     o.ae = ae; o.be = be;
@@ -411,8 +411,7 @@ __device__ void xdrop_block_w(XwLds<HFN>& S, const XView& q, int qidx, int M, co
     int wbase = 1 << 30;                                 // first scratch byte in the LDS window; nothing loaded yet
     // row registers: lane l holds the bytes of cells rstart + l and rstart + 64 + l
     auto fetch_row = [&](int a, int& r, int& rs) {
-        rs = __builtin_amdgcn_readfirstlane((int)S.rstart[a]);
-        if (WIDE) return;                                // bytes are read one by one below
+        if (WIDE) { rs = __builtin_amdgcn_readfirstlane((int)S.rstart[a]); return; }      // bytes are read one by one below
         const int off = a * XW_STRIDE;
         if (off < wbase) {
             __builtin_amdgcn_wave_barrier();
@@ -422,6 +421,7 @@ __device__ void xdrop_block_w(XwLds<HFN>& S, const XView& q, int qidx, int M, co
         }
         const uint8_t* wb = (const uint8_t*)S.win + (off - wbase);
         r = (int)wb[lane] | ((int)wb[64 + lane] << 8);
+        rs = (__builtin_amdgcn_readlane(r, 62) >> 8) | (__builtin_amdgcn_readlane(r, 63) & 0xff00);
     };
     auto wide_byte = [&](int a, int b, int rs) -> int {
         const int idx = a * XW_WSTRIDE + (b - rs);

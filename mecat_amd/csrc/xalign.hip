@@ -268,7 +268,7 @@ __global__ __launch_bounds__(XB_BLOCK) void xd_extend(const uint32_t* __restrict
 #define XW_BLOCK (XW_WAVES * 64)
 #define XW_RING 128
 #define XW_STRIDE 128                    // script bytes per row in the scratch
-#define XW_WIN 2048                      // = 16 rows
+#define XW_WIN 4096                      // = 32 rows of XW_STRIDE bytes
 #define XW_STATE_BYTES ((size_t)(X_MAXN + 2) * XW_STRIDE)
 #define XW_WSTRIDE 768                   // WIDE: any window fits a row (N + 1 <= 737 cells)
 #define XW_WIDE_BYTES ((size_t)(X_MAXN + 2) * XW_WSTRIDE)
@@ -434,35 +434,108 @@ __device__ void xdrop_block_w(XwLds<HFN>& S, const XView& q, int qidx, int M, co
         return __builtin_amdgcn_readfirstlane((int)((const uint8_t*)S.win)[idx - wbase]);
     };
     int a_index = ae, b_index = be;
-    int cr = 0, crs, nr = 0, nrs = 0;
-    fetch_row(a_index, cr, crs);
-    if (a_index > 0) fetch_row(a_index - 1, nr, nrs);
     // One step = one byte: the op is the previous one while its extension bit is set in this byte, else the byte's own
     // (bit 4 continues GAP_IN_A, bit 6 GAP_IN_B; bit 5 is never set and stands in for "after a substitution").
     int st_op = XS_SUB;
     int n = 0, nmatch = 0, m = 0, found = 0, want_l1 = 0, first = 0, l1 = 0;
     int sn_n = 0, sn_a = 0, sn_b = 0, sn_m = 0;          // the walk's state right after the first run of 4 matches
-    while (a_index > 0 || b_index > 0) {
-        const int li = b_index - crs;
-        const int byte = WIDE ? wide_byte(a_index, b_index, crs) : (__builtin_amdgcn_readlane(cr, li & 63) >> ((li >> 6) << 3)) & 0xff;
-        const int sh = 4 + (st_op & 1) + ((st_op >> 2) << 1);
-        const int op = ((byte >> sh) & 1) ? st_op : (byte & XS_OP_MASK);
-        st_op = op;
-        const int cq = op != XS_GAP_IN_A, ct = op != XS_GAP_IN_B;
-        const int cm = cq & ct & (byte >> 7);
-        a_index -= cq;
-        b_index -= ct;
-        const int pk = cq | (ct << 1) | (cm << 2);
-        first = n == 0 ? pk : first;
-        l1 = want_l1 ? pk : l1;
-        want_l1 = 0;
-        ++n;
-        nmatch += cm;
-        m = cm ? m + 1 : 0;
-        if (m == 4 && !found) { found = 1; want_l1 = 1; sn_n = n; sn_a = a_index; sn_b = b_index; sn_m = nmatch; }
-        if (cq) {
-            cr = nr; crs = nrs;
-            if (a_index > 0) fetch_row(a_index - 1, nr, nrs);
+    if constexpr (WIDE) {
+        int cr = 0, crs, nr = 0, nrs = 0;
+        fetch_row(a_index, cr, crs);
+        if (a_index > 0) fetch_row(a_index - 1, nr, nrs);
+        while (a_index > 0 || b_index > 0) {
+            const int byte = wide_byte(a_index, b_index, crs);
+            const int sh = 4 + (st_op & 1) + ((st_op >> 2) << 1);
+            const int op = ((byte >> sh) & 1) ? st_op : (byte & XS_OP_MASK);
+            st_op = op;
+            const int cq = op != XS_GAP_IN_A, ct = op != XS_GAP_IN_B;
+            const int cm = cq & ct & (byte >> 7);
+            a_index -= cq;
+            b_index -= ct;
+            const int pk = cq | (ct << 1) | (cm << 2);
+            first = n == 0 ? pk : first;
+            l1 = want_l1 ? pk : l1;
+            want_l1 = 0;
+            ++n;
+            nmatch += cm;
+            m = cm ? m + 1 : 0;
+            if (m == 4 && !found) { found = 1; want_l1 = 1; sn_n = n; sn_a = a_index; sn_b = b_index; sn_m = nmatch; }
+            if (cq) {
+                cr = nr; crs = nrs;
+                if (a_index > 0) fetch_row(a_index - 1, nr, nrs);
+            }
+        }
+    } else {
+        // Diagonal runs at once: lane i looks at cell (a - i, b - i) in the LDS window; once a step is a substitution the walk
+        // stays on the diagonal for as long as the cells' own op bits say SUB, so the length of the run is one ballot + one
+        // bit scan, and the counters (columns, matches, the first run of four matches) follow from the run's match bits.
+        // A step that is not a substitution (1 in 8 on ONT-style reads) is taken alone.
+        constexpr int WROWS = XW_WIN / XW_STRIDE;
+        int wlo = 1 << 29;                               // first row in the window
+        while (a_index > 0 || b_index > 0) {
+            if (a_index < wlo || a_index >= wlo + WROWS || (wlo > 0 && a_index - wlo < 12)) {
+                __builtin_amdgcn_wave_barrier();
+                wlo = max(a_index - (WROWS - 1), 0);
+                for (int w = lane; w < XW_WIN / 4; w += 64) S.win[w] = stw[wlo * (XW_STRIDE / 4) + w];
+                __builtin_amdgcn_wave_barrier();
+            }
+            const int ri = a_index - lane, bi = b_index - lane;
+            const bool vl = lane < 32 && ri >= max(wlo, 1) && bi >= 1;
+            const uint8_t* wrow = (const uint8_t*)S.win + (vl ? ri - wlo : a_index - wlo) * XW_STRIDE;
+            const int rs = *(const uint16_t*)(wrow + XW_STRIDE - 2);
+            const int ci = (vl ? bi : b_index) - rs;
+            const int byte = wrow[min(max(ci, 0), XW_STRIDE - 3)];
+            const unsigned long long sm = __builtin_amdgcn_ballot_w64(vl && ci >= 0 && ci < XW_STRIDE - 2 && (byte & XS_OP_MASK) == XS_SUB);
+            const uint32_t mm = (uint32_t)__builtin_amdgcn_ballot_w64((byte & XS_MATCH) != 0);
+            const int byte0 = __builtin_amdgcn_readfirstlane(byte);
+            const int sh = 4 + (st_op & 1) + ((st_op >> 2) << 1);
+            const int op = ((byte0 >> sh) & 1) ? st_op : (byte0 & XS_OP_MASK);
+            st_op = op;
+            if (op != XS_SUB || !(sm & 1)) {             // a gap step (or a cell the window does not vouch for): alone
+                const int cq = op != XS_GAP_IN_A, ct = op != XS_GAP_IN_B;
+                const int cm = cq & ct & (byte0 >> 7);
+                a_index -= cq;
+                b_index -= ct;
+                const int pk = cq | (ct << 1) | (cm << 2);
+                first = n == 0 ? pk : first;
+                l1 = want_l1 ? pk : l1;
+                want_l1 = 0;
+                ++n;
+                nmatch += cm;
+                m = cm ? m + 1 : 0;
+                if (m == 4 && !found) { found = 1; want_l1 = 1; sn_n = n; sn_a = a_index; sn_b = b_index; sn_m = nmatch; }
+                continue;
+            }
+            const uint32_t s32 = (uint32_t)sm;
+            const int r = s32 == 0xffffffffu ? 32 : __builtin_ctz(~s32);      // >= 1
+            const uint32_t mask = r >= 32 ? 0xffffffffu : ((1u << r) - 1u);
+            const uint32_t M = mm & mask;                                      // bit i: step i is a match
+            const int pk0 = 3 | ((M & 1u) << 2);
+            first = n == 0 ? pk0 : first;
+            l1 = want_l1 ? pk0 : l1;
+            want_l1 = 0;
+            const uint32_t inv = ~M & mask;                                    // the mismatches of the run
+            if (!found) {
+                const int z = inv ? __builtin_ctz(inv) : r;                    // leading matches
+                int hit = -1;                                                  // the step at which the streak first reaches 4
+                if (m + z >= 4) hit = 3 - m;
+                else {
+                    const uint32_t Q = M & (M >> 1) & (M >> 2) & (M >> 3);
+                    if (Q) hit = __builtin_ctz(Q) + 3;
+                }
+                if (hit >= 0) {
+                    found = 1;
+                    sn_n = n + hit + 1; sn_a = a_index - (hit + 1); sn_b = b_index - (hit + 1);
+                    sn_m = nmatch + __builtin_popcount(M & ((2u << hit) - 1u));
+                    if (hit + 1 < r) l1 = 3 | (int)(((M >> (hit + 1)) & 1u) << 2);
+                    else want_l1 = 1;
+                }
+            }
+            m = inv ? r - 1 - (31 - __builtin_clz(inv)) : m + r;               // matches after the last mismatch
+            n += r;
+            nmatch += __builtin_popcount(M);
+            a_index -= r;
+            b_index -= r;
         }
     }
     o.n = n; o.nmatch = nmatch;

@@ -306,10 +306,10 @@ __device__ void xdrop_block_w(XwLds<HFN>& S, const XView& q, int qidx, int M, co
     static_assert(!WIDE || HFN >= XW_WIDE_HF, "WIDE blocks index the score array by b");
     auto slot = [&](int b) -> int { return WIDE ? min(b, HFN - 1) : b & (XW_RING - 1); };      // (idle lanes read a valid slot)
     auto ldHF = [&](int b, bool in) -> int2 {
-        const int2 v = S.HF[slot(b)];
+        int2 v = S.HF[slot(b)];
+        asm volatile("" : "+v"(v.x), "+v"(v.y));          // every lane loads (the slot is always valid): no exec round trip
         return in ? v : make_int2(X_MIN_SCORE, X_MIN_SCORE);
     };
-    auto stH = [&](int b, int v) { S.HF[slot(b)].x = v; };
     auto stHF = [&](int b, int h, int f) { S.HF[slot(b)] = make_int2(h, f); };
     o.ae = o.be = 0; o.n = o.nmatch = 0; o.qcnt = o.tcnt = o.acnt = o.mtail = 0; o.trim_ok = 0; o.overflow = 0;
     o.l0q = o.l0t = o.l0m = o.l1q = o.l1t = o.l1m = 0;
@@ -329,7 +329,6 @@ __device__ void xdrop_block_w(XwLds<HFN>& S, const XView& q, int qidx, int M, co
         const int AC = S.Qb[a - 1];
         const int f0 = first_b, n0 = b_size;
         uint8_t* srow = st + (size_t)a * STRIDE;
-        if (lane == 0) { if (WIDE) S.rstart[a] = (int16_t)f0; else *(uint16_t*)(srow + XW_STRIDE - 2) = (uint16_t)f0; }
         int runP = XW_NEG, bb = best, rowarg = -1, firstkept = -1, lastkept = -1, lastkeptH = 0;
         int prevHp = 0;
         for (int c0 = f0; c0 < n0; c0 += 64) {
@@ -365,9 +364,10 @@ __device__ void xdrop_block_w(XwLds<HFN>& S, const XView& q, int qidx, int M, co
             if (sc < (kept ? Ec : et)) script = XS_GAP_IN_A;
             if (kept && Fp >= Hc) script += XS_EXT_A;
             if (kept && Ec >= Hc) script += XS_EXT_B;
-            if (kept) stHF(b, Hc, max(Fp - 1, Hc - 1));
-            else if (in && (lower || firstkept >= 0)) stH(b, X_MIN_SCORE);   // interior; a leading one only moves first_b
-            if (in) srow[b - f0] = (uint8_t)(script | (mt ? XS_MATCH : 0));
+            // kept: (H, F') with F' = max(F - 1, H - 1) = H - 1 (H >= F); dropped between kept cells: H = MIN, F stays; a leading
+            // dropped cell only moves first_b.  One predicated store.
+            if (kept || (in && (lower || firstkept >= 0))) stHF(b, kept ? Hc : X_MIN_SCORE, kept ? Hc - 1 : Fp);
+            srow[b - f0] = (uint8_t)(script | (mt ? XS_MATCH : 0));          // lanes past the window write bytes nobody reads
             // carries
             runP = max(runP, __builtin_amdgcn_readlane(incl, 63));
             if (ex && rowarg < 0) rowarg = c0 + j1;
@@ -383,6 +383,8 @@ __device__ void xdrop_block_w(XwLds<HFN>& S, const XView& q, int qidx, int M, co
         if (bb > best) { best = bb; ae = a; be = rowarg; }
         if (firstkept < 0) { first_b = n0; break; }
         first_b = firstkept;
+        // the row's first column (after the passes: their idle lanes may have written over these two bytes)
+        if (lane == 0) { if (WIDE) S.rstart[a] = (int16_t)f0; else *(uint16_t*)(srow + XW_STRIDE - 2) = (uint16_t)f0; }
         if (lastkept < n0 - 1) b_size = lastkept + 1;
         else {
             // the row gap keeps the window open while it stays within X of the best (:139-147); H >= E at a kept cell

@@ -86,6 +86,10 @@ void mhip_host_free(void* p);
 int  mhip_ctx_create(int device, void* stream, mhip_ctx** out);
 void mhip_ctx_destroy(mhip_ctx* ctx);
 int  mhip_ctx_sync(mhip_ctx* ctx);
+/* Optional, additive: allocates the scratch the first mhip_index_build of a volume of up to `bases` bases would allocate
+ * (two arrays of 8 bytes per base; tens of GB take hundreds of milliseconds to map).  May run on another thread while the
+ * caller still parses its input; every other call on the context that needs scratch waits for it. */
+int  mhip_ctx_reserve_index(mhip_ctx* ctx, int64_t bases);
 void mhip_params_default(mhip_params* p, int tech);           /* pw_options.cpp:30-50 + pw_impl.cpp:843-851 */
 
 /* per-kernel timing with HIP events on the context's stream (for bench.py's roofline block).

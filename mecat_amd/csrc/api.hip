@@ -3,6 +3,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <thread>
+
 #include "common.h"
 #include <mutex>
 
@@ -88,6 +90,36 @@ int mhip_host_alloc(size_t bytes, void** out) {
 
 void mhip_host_free(void* p) {
     if (p) (void)hipHostFree(p);
+}
+
+int mhip_ctx_reserve_index(mhip_ctx* c, int64_t bases) {
+    if (bases <= 0) return 0;
+    const size_t bytes = sizeof(uint64_t) * ((size_t)bases + 64);      // ix_ent1 / ix_ent2 of the binned index build
+    std::lock_guard<std::mutex> lk(c->bufs_mu);
+    const char* names[2] = {"ix_ent1", "ix_ent2"};
+    void* p[2] = {nullptr, nullptr};
+    hipError_t err[2] = {hipSuccess, hipSuccess};
+    bool need[2];
+    for (int i = 0; i < 2; ++i) need[i] = c->bufs[names[i]].cap < bytes;
+    const int device = c->device;
+    auto grab = [&](int i) {                                           // the two mappings proceed side by side
+        if (hipSetDevice(device) != hipSuccess) { err[i] = hipErrorInvalidDevice; return; }
+        err[i] = hipMalloc(&p[i], bytes + 4096);
+    };
+    std::thread t1;
+    if (need[1]) t1 = std::thread(grab, 1);
+    if (need[0]) grab(0);
+    if (t1.joinable()) t1.join();
+    int rc = 0;
+    for (int i = 0; i < 2; ++i) {
+        if (!need[i]) continue;
+        if (err[i] != hipSuccess) { mhip_set_error("hipMalloc of %zu bytes for the index scratch failed: %s", bytes, hipGetErrorString(err[i])); rc = -1; continue; }
+        DevBuf& b = c->bufs[names[i]];
+        if (b.p) (void)hipFree(b.p);
+        b.p = p[i];
+        b.cap = bytes + 4096;
+    }
+    return rc;
 }
 
 int mhip_ctx_sync(mhip_ctx* c) {
@@ -245,6 +277,7 @@ void dev_recycler_release(int device) {
 }
 
 int mhip_ctx::scratch(const char* name, size_t bytes, void** out) {
+    std::lock_guard<std::mutex> lk(bufs_mu);
     DevBuf& b = bufs[name];
     if (b.cap < bytes) {
         if (b.p) {

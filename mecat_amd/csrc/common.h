@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -53,6 +54,7 @@ struct mhip_ctx {
     std::vector<PendingEv> pending;
     std::vector<hipEvent_t> ev_pool;
     std::map<std::string, DevBuf> bufs;   // named scratch buffers, grown on demand, freed with the context
+    std::mutex bufs_mu;                   // scratch() vs mhip_ctx_reserve_index on another thread
     int64_t* d_counters = nullptr;        // 8 work counters (see mecat_hip.h)
     int num_cus = 256;
 

@@ -91,6 +91,7 @@ def lib():
     L.mhip_align_candidates_dev.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     L.mhip_xalign_candidates.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     L.mhip_xalign_candidates_dev.argtypes = [vp, vp, vp, vp, i32, i32, vp]
+    L.mhip_ctx_reserve_index.argtypes = [vp, C.c_int64]
     L.mhip_cns_align_candidates.argtypes = [vp, vp, vp, vp, i32, C.c_double, i32, i32, vp, vp]
     L.mhip_cns_align_candidates_dev.argtypes = [vp, vp, vp, vp, i32, C.c_double, i32, i32, vp, vp]
     L.mhip_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]

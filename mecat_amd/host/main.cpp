@@ -14,11 +14,13 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <sys/time.h>
 #include <unistd.h>
 
 #include <algorithm>
 #include <string>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -342,6 +344,37 @@ int main(int argc, char* argv[]) {
     std::string marker(opt.wrk_dir);
     if (marker.empty() || marker[marker.size() - 1] != '/') marker += '/';
     marker += "split_done";
+    // The GPU context and the index-build scratch (two arrays of 8 bytes per base of a volume: hundreds of milliseconds to map
+    // at volume size) are set up on a second thread while this one parses the input.
+    mhip_ctx* ctx = NULL;
+    std::atomic<int> ctx_state{0};                       // 0 pending, 1 ready, -1 failed
+    std::string ctx_error;
+    const int device = env_int("MECAT_HIP_DEVICE", world > 1 ? "LOCAL_RANK" : NULL, 0);
+    long long est_bases = 0;
+    {
+        struct stat sb;
+        FILE* f = fopen(opt.reads, "rb");
+        if (f && fstat(fileno(f), &sb) == 0) {
+            const int c0 = fgetc(f);
+            est_bases = (long long)sb.st_size / (c0 == '@' ? 2 : 1);      // FASTQ carries a quality byte per base
+        }
+        if (f) fclose(f);
+        est_bases = std::min(est_bases, (long long)kMaxVolumeBases + 64);
+        if (getenv("MECAT_HIP_NO_RESERVE")) est_bases = 0;
+    }
+    std::thread gpu_setup([&]() {
+        TraceTimer tt("ctx_create+reserve (background)");
+        mhip_ctx* made = NULL;
+        if (mhip_ctx_create(device, NULL, &made) != 0) {
+            ctx_error = mhip_last_error();
+            ctx_state.store(-1);
+            return;
+        }
+        ctx = made;
+        ctx_state.store(1);
+        if (est_bases > 0) (void)mhip_ctx_reserve_index(made, est_bases);      // best effort
+    });
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } gpu_setup_joiner{gpu_setup};
     int num_vols = 0;
     if (rank == 0) {
         if (world > 1) unlink(marker.c_str());
@@ -371,11 +404,11 @@ int main(int argc, char* argv[]) {
     const std::vector<std::string> vn = load_volume_names(idx_name);
     if ((int)vn.size() != num_vols) DIE("assertion 'num_vols == vn->num_vols' failed");
 
-    mhip_ctx* ctx = NULL;
-    const int device = env_int("MECAT_HIP_DEVICE", world > 1 ? "LOCAL_RANK" : NULL, 0);
     {
-        TraceTimer tt("ctx_create");
-        if (mhip_ctx_create(device, NULL, &ctx) != 0) DIE("cannot use the GPU: %s", mhip_last_error());
+        TraceTimer tt("wait for ctx_create");
+        // only the context is needed from here on; a reservation still in flight is waited for inside the library
+        while (ctx_state.load() == 0) usleep(500);
+        if (ctx_state.load() < 0) { gpu_setup.join(); DIE("cannot use the GPU: %s", ctx_error.c_str()); }
     }
 
     // MECAT_HIP_PARTITION=<batch_size>[,<min_read_size>[,<mapping_ratio>]] (additive): also write mecat2cns' partition files
@@ -411,6 +444,7 @@ int main(int argc, char* argv[]) {
         if (fclose(out) != 0) DIE("write error!");
         if (rename(wrk.c_str(), fin.c_str()) != 0) DIE("cannot rename %s", wrk.c_str());
     }
+    gpu_setup.join();
     mhip_ctx_destroy(ctx);
     if (rank != 0) return 0;
 

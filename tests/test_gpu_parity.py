@@ -250,3 +250,32 @@ def test_tandem_repeats_match_oracle(hip, ctx):
         assert np.array_equal(cnt, cnt2) and not _cmp_cands(got2, cnt2, want)
     gi.free()
     gv.free()
+
+
+def test_reserved_index_scratch_changes_nothing():
+    """mhip_ctx_reserve_index (the driver calls it on a second thread while it parses the input): an index built on the
+    reserved scratch — reserved too small, just right, or while the build is waiting for it — is the same index."""
+    import threading
+
+    import mecat_amd.hip as M
+    from mecat_amd import workload as W
+    codes, lens = W.synth_reads(300, 3000, 0.15, 60000, 5, 0)
+    pac, offs, nb = W.pack_volume(codes, lens)
+    base = None
+    for reserve in (0, 1000, int(nb), 4 * int(nb)):
+        ctx = M.Context(0)
+        vol = M.Volume(ctx, pac, offs, nb, 0)
+        t = None
+        if reserve:
+            t = threading.Thread(target=lambda: M._chk(M.lib().mhip_ctx_reserve_index(ctx.h, reserve)))
+            t.start()
+        idx = M.Index(ctx, vol)
+        if t:
+            t.join()
+        got = idx.download()
+        if base is None:
+            base = got
+        assert np.array_equal(got[0], base[0]) and np.array_equal(got[1], base[1]), reserve
+        idx.free()
+        vol.free()
+        ctx.close()

@@ -178,11 +178,18 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
                 fflush(stdout);
                 abort();
             }
+        double st[5] = {0, 0, 0, 0, 0};      // MECAT_TRACE: seconds in seeding, job assembly, extension, formatting, writing
+        struct StageClock {
+            double* acc; double t0;
+            static double now() { struct timeval t; gettimeofday(&t, NULL); return t.tv_sec + 1e-6 * t.tv_usec; }
+            explicit StageClock(double* a) : acc(a), t0(now()) {}
+            ~StageClock() { *acc += now() - t0; }
+        };
         for (int rb = 0; rb < rd->num_reads; rb += slab) {
             const int re = std::min(rd->num_reads, rb + slab), nr = re - rb;
             cands.resize((size_t)nr * P.maxc);
             counts.resize((size_t)nr);
-            MCHK(mhip_seed_reads(ctx, idx, dref, dreads, rb, re, &P, cands.data(), counts.data()));
+            { StageClock sc(&st[0]); MCHK(mhip_seed_reads(ctx, idx, dref, dreads, rb, re, &P, cands.data(), counts.data())); }
             // text assembly is per read and order preserving: thread t formats a contiguous range of the slab's reads
             const int nt = std::max(1, std::min(opt.num_threads, 64));
             std::vector<std::string> text((size_t)nt);
@@ -217,27 +224,37 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
                 continue;
             }
             // pairwise_mapping, pw_impl.cpp:674-700
+            StageClock* sc_jobs = new StageClock(&st[1]);
             jfirst.assign((size_t)nr + 1, 0);
             for (int r = 0; r < nr; ++r) jfirst[(size_t)r + 1] = jfirst[(size_t)r] + (size_t)counts[(size_t)r];
             jobs.resize(jfirst[(size_t)nr]);
-            for (int r = 0; r < nr; ++r) {
-                size_t jn = jfirst[(size_t)r];
-                for (int k = 0; k < counts[(size_t)r]; ++k) {
-                    const mhip_candidate& c = cands[(size_t)r * P.maxc + k];
-                    mhip_aln_job j;
-                    j.qid_local = rb + r;
-                    j.sid_local = c.readno - ref.start_read_id;
-                    j.chain = c.chain;
-                    j.qstart = c.loc2;
-                    j.sstart = c.loc1;
-                    if (j.qstart && j.sstart) { j.qstart += MHIP_KMER_SIZE / 2; j.sstart += MHIP_KMER_SIZE / 2; }
-                    jobs[jn++] = j;
+            run_threads(nt, [&](int t) {
+                int lo, hi;
+                range_of(t, &lo, &hi);
+                for (int r = lo; r < hi; ++r) {
+                    size_t jn = jfirst[(size_t)r];
+                    for (int k = 0; k < counts[(size_t)r]; ++k) {
+                        const mhip_candidate& c = cands[(size_t)r * P.maxc + k];
+                        mhip_aln_job j;
+                        j.qid_local = rb + r;
+                        j.sid_local = c.readno - ref.start_read_id;
+                        j.chain = c.chain;
+                        j.qstart = c.loc2;
+                        j.sstart = c.loc1;
+                        if (j.qstart && j.sstart) { j.qstart += MHIP_KMER_SIZE / 2; j.sstart += MHIP_KMER_SIZE / 2; }
+                        jobs[jn++] = j;
+                    }
                 }
-            }
+            });
             res.resize(jobs.size());
-            // aligner by technology (pw_impl.cpp:638-644): DiffAligner (dw) for PacBio, XdropAligner for nanopore
-            if (opt.tech == TECH_NANOPORE) MCHK(mhip_xalign_candidates(ctx, dref, dreads, jobs.data(), (int)jobs.size(), P.min_align_size, res.data()));
-            else MCHK(mhip_align_candidates(ctx, dref, dreads, jobs.data(), (int)jobs.size(), P.min_align_size, res.data()));
+            delete sc_jobs;
+            {
+                StageClock sc(&st[2]);
+                // aligner by technology (pw_impl.cpp:638-644): DiffAligner (dw) for PacBio, XdropAligner for nanopore
+                if (opt.tech == TECH_NANOPORE) MCHK(mhip_xalign_candidates(ctx, dref, dreads, jobs.data(), (int)jobs.size(), P.min_align_size, res.data()));
+                else MCHK(mhip_align_candidates(ctx, dref, dreads, jobs.data(), (int)jobs.size(), P.min_align_size, res.data()));
+            }
+            StageClock* sc_fmt = new StageClock(&st[3]);
             std::vector<std::vector<M4Rec>> mrec(pw ? (size_t)nt : 0);
             run_threads(nt, [&](int t) {
                 int lo, hi;
@@ -297,11 +314,18 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
                     }
                 }
             });
-            for (const std::string& o : text)
-                if (!o.empty() && fwrite(o.data(), 1, o.size(), out) != o.size()) DIE("write error!");
-            if (pw)
-                for (const std::vector<M4Rec>& v : mrec) pw->add_m4(v.data(), v.size(), part_ratio);
+            delete sc_fmt;
+            {
+                StageClock sc(&st[4]);
+                for (const std::string& o : text)
+                    if (!o.empty() && fwrite(o.data(), 1, o.size(), out) != o.size()) DIE("write error!");
+                if (pw)
+                    for (const std::vector<M4Rec>& v : mrec) pw->add_m4(v.data(), v.size(), part_ratio);
+            }
         }
+        if (getenv("MECAT_TRACE"))
+            fprintf(stderr, "[trace] volume %d stages: seed %.3f s, jobs %.3f s, extend %.3f s, format %.3f s, write %.3f s\n", vid, st[0], st[1],
+                    st[2], st[3], st[4]);
         if (dreads != dref) mhip_volume_free(dreads);
     }
     mhip_index_free(idx);

@@ -331,7 +331,7 @@ __device__ void xdrop_block_w(XwLds<HFN>& S, const XView& q, int qidx, int M, co
         uint8_t* srow = st + (size_t)a * STRIDE;
         int runP = XW_NEG, bb = best, rowarg = -1, firstkept = -1, lastkept = -1, lastkeptH = 0;
         int prevHp = 0;
-        for (int c0 = f0; c0 < n0; c0 += 64) {
+        auto pass = [&](const int c0) __attribute__((always_inline)) {
             const int b = c0 + lane;
             const bool in = b < n0;
             const int2 hf = ldHF(b, in);
@@ -379,7 +379,11 @@ __device__ void xdrop_block_w(XwLds<HFN>& S, const XView& q, int qidx, int M, co
                 lastkeptH = __builtin_amdgcn_readlane(Hc, lk);
             }
             prevHp = __builtin_amdgcn_readlane(Hp, 63);
-        }
+        };
+        // two in three rows fit one pass: with the carries still at their initial constants the compiler drops their bookkeeping
+        if (n0 - f0 <= 64) pass(f0);
+        else if (!WIDE) { pass(f0); pass(f0 + 64); }      // the ring bounds a row to 126 cells
+        else for (int c0 = f0; c0 < n0; c0 += 64) pass(c0);
         if (bb > best) { best = bb; ae = a; be = rowarg; }
         if (firstkept < 0) { first_b = n0; break; }
         first_b = firstkept;

@@ -389,22 +389,20 @@ __device__ void xdrop_block_w(XwLds<HFN>& S, const XView& q, int qidx, int M, co
         first_b = firstkept;
         // the row's first column (after the passes: their idle lanes may have written over these two bytes)
         if (lane == 0) { if (WIDE) S.rstart[a] = (int16_t)f0; else *(uint16_t*)(srow + XW_STRIDE - 2) = (uint16_t)f0; }
-        if (lastkept < n0 - 1) b_size = lastkept + 1;
-        else {
-            // the row gap keeps the window open while it stays within X of the best (:139-147); H >= E at a kept cell
+        // The window ends after the last kept cell; if that is the row's last cell, the row gap keeps it open while it stays
+        // within X of the best (:139-147; H >= E at a kept cell), and a closing (MIN, MIN) cell follows unless the block ends.
+        // (b_size is N + 1 in a block with N <= X, where row 0 ran off the end: nothing is appended then.)
+        {
+            const bool ext = lastkept >= n0 - 1;
             const int e_end = lastkeptH - 1;
-            int cnt = e_end >= best - X ? e_end - (best - X) + 1 : 0;
-            cnt = max(min(cnt, N - b_size), 0);          // b_size is N + 1 in a block with N <= X (row 0 ran off the end)
-            if (lane < cnt) {
-                const int bnew = b_size + lane;
-                stHF(bnew, e_end - lane, e_end - lane - 1);
-                if (bnew - f0 < STRIDE - 2) srow[bnew - f0] = XS_GAP_IN_A;
-            }
-            b_size += cnt;
-        }
-        if (b_size < N) {
-            if (lane == 0) stHF(b_size, X_MIN_SCORE, X_MIN_SCORE);
-            ++b_size;
+            const int bsz0 = ext ? n0 : lastkept + 1;
+            const int cnt = max(min(ext ? e_end - (best - X) + 1 : 0, N - bsz0), 0);
+            const int sent = bsz0 + cnt < N ? 1 : 0;
+            const int bnew = bsz0 + lane;
+            const bool tail = lane < cnt;
+            if (lane < cnt + sent) stHF(bnew, tail ? e_end - lane : X_MIN_SCORE, tail ? e_end - lane - 1 : X_MIN_SCORE);
+            if (tail && bnew - f0 < STRIDE - 2) srow[bnew - f0] = XS_GAP_IN_A;
+            b_size = bsz0 + cnt + sent;
         }
         if (!WIDE && (b_size - first_b > XW_RING - 2 || b_size - f0 > XW_STRIDE - 2)) { o.overflow = 2; return; }
         __builtin_amdgcn_wave_barrier();

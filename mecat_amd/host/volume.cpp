@@ -160,6 +160,11 @@ long read_one_seq(LineReader& r, std::string& seq, bool* have_header) {
     return (long)seq.size();
 }
 
+// the volume written last stays in memory for its first load_volume (one volume is the common case: no re-read of the file
+// that was just written)
+std::string g_kept_path;
+HostVolume g_kept;
+
 void dump_volume(const std::string& path, const HostVolume& v) {
     FILE* out = fopen(path.c_str(), "wb");
     if (!out) DIE("cannot open '%s' for writing", path.c_str());
@@ -309,6 +314,7 @@ bool split_plain_fasta(const char* reads, const char* wrk_dir, long max_volume_b
         const std::string name = volume_file_name(wrk_dir, (int)k);
         fprintf(idx_file, "%s\n", name.c_str());
         dump_volume(name, v);
+        if (k + 1 == vols.size()) { g_kept_path = name; g_kept = std::move(v); }
     }
     fclose(idx_file);
     munmap((void*)txt, size);
@@ -420,6 +426,11 @@ std::vector<std::string> load_volume_names(const std::string& idx_file) {
 }
 
 void load_volume(const std::string& path, HostVolume* v) {
+    if (!g_kept_path.empty() && path == g_kept_path) {      // still in memory from split_raw_dataset
+        *v = std::move(g_kept);
+        g_kept_path.clear();
+        return;
+    }
     FILE* in = fopen(path.c_str(), "rb");
     if (!in) { fprintf(stderr, "[%s, %u] failed to open file '%s'.\n", __func__, __LINE__, path.c_str()); exit(1); }
     bool ok = fread(&v->num_reads, sizeof(int), 1, in) == 1 && fread(&v->num_bases, sizeof(int), 1, in) == 1 &&

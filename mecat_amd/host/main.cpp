@@ -21,6 +21,8 @@
 #include <algorithm>
 #include <string>
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -151,11 +153,16 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
 
     const char* slab_env = getenv("MECAT_HIP_SLAB");
     const int slab = slab_env ? std::max(1, atoi(slab_env)) : 20000;
-    PinnedBuf<mhip_candidate> cands;      // buffers that cross the PCIe link: page-locked
-    PinnedBuf<int32_t> counts;
-    PinnedBuf<mhip_aln_job> jobs;
-    std::vector<size_t> jfirst;
-    PinnedBuf<mhip_aln_result> res;
+
+    struct SlabBuf {
+        PinnedBuf<mhip_candidate> cands;      // buffers that cross the PCIe link: page-locked
+        PinnedBuf<int32_t> counts;
+        PinnedBuf<mhip_aln_job> jobs;
+        PinnedBuf<mhip_aln_result> res;
+        std::vector<size_t> jfirst;
+        int rb = 0, nr = 0;
+    };
+    SlabBuf slabs[2];                         // slab s is written out while slab s + 1 is on the GPU
 
     for (int vid = svid; vid < (int)vn.size(); ++vid) {
         char info[64];
@@ -185,16 +192,20 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
             explicit StageClock(double* a) : acc(a), t0(now()) {}
             ~StageClock() { *acc += now() - t0; }
         };
-        for (int rb = 0; rb < rd->num_reads; rb += slab) {
-            const int re = std::min(rd->num_reads, rb + slab), nr = re - rb;
-            cands.resize((size_t)nr * P.maxc);
-            counts.resize((size_t)nr);
-            { StageClock sc(&st[0]); MCHK(mhip_seed_reads(ctx, idx, dref, dreads, rb, re, &P, cands.data(), counts.data())); }
-            // text assembly is per read and order preserving: thread t formats a contiguous range of the slab's reads
-            const int nt = std::max(1, std::min(opt.num_threads, 64));
+        // Two-stage pipeline over the slabs: this thread drives the GPU (seeding, job assembly, extension) for slab s + 1 while a
+        // second thread formats and writes slab s (text assembly is per read and order preserving; one writer keeps the order).
+        const int nt = std::max(1, std::min(opt.num_threads, 64));
+        auto emit = [&](SlabBuf& B) {
+            PinnedBuf<mhip_candidate>& cands = B.cands;
+            PinnedBuf<int32_t>& counts = B.counts;
+            PinnedBuf<mhip_aln_job>& jobs = B.jobs;
+            PinnedBuf<mhip_aln_result>& res = B.res;
+            std::vector<size_t>& jfirst = B.jfirst;
+            const int rb = B.rb, nr = B.nr;
             std::vector<std::string> text((size_t)nt);
             auto range_of = [&](int t, int* lo, int* hi) { *lo = (int)((long long)nr * t / nt); *hi = (int)((long long)nr * (t + 1) / nt); };
             if (opt.task == TASK_SEED) {
+                StageClock sc(&st[3]);
                 // candidate_detect, pw_impl.cpp:767-801 ; line format alignment.cpp:18-32
                 std::vector<std::vector<CanRec>> prec(pw ? (size_t)nt : 0);
                 run_threads(nt, [&](int t) {
@@ -221,38 +232,7 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
                     if (!o.empty() && fwrite(o.data(), 1, o.size(), out) != o.size()) DIE("write error!");
                 if (pw)      // the same lines, in the same order, as records (no text round trip)
                     for (const std::vector<CanRec>& v : prec) pw->add(v.data(), v.size());
-                continue;
-            }
-            // pairwise_mapping, pw_impl.cpp:674-700
-            StageClock* sc_jobs = new StageClock(&st[1]);
-            jfirst.assign((size_t)nr + 1, 0);
-            for (int r = 0; r < nr; ++r) jfirst[(size_t)r + 1] = jfirst[(size_t)r] + (size_t)counts[(size_t)r];
-            jobs.resize(jfirst[(size_t)nr]);
-            run_threads(nt, [&](int t) {
-                int lo, hi;
-                range_of(t, &lo, &hi);
-                for (int r = lo; r < hi; ++r) {
-                    size_t jn = jfirst[(size_t)r];
-                    for (int k = 0; k < counts[(size_t)r]; ++k) {
-                        const mhip_candidate& c = cands[(size_t)r * P.maxc + k];
-                        mhip_aln_job j;
-                        j.qid_local = rb + r;
-                        j.sid_local = c.readno - ref.start_read_id;
-                        j.chain = c.chain;
-                        j.qstart = c.loc2;
-                        j.sstart = c.loc1;
-                        if (j.qstart && j.sstart) { j.qstart += MHIP_KMER_SIZE / 2; j.sstart += MHIP_KMER_SIZE / 2; }
-                        jobs[jn++] = j;
-                    }
-                }
-            });
-            res.resize(jobs.size());
-            delete sc_jobs;
-            {
-                StageClock sc(&st[2]);
-                // aligner by technology (pw_impl.cpp:638-644): DiffAligner (dw) for PacBio, XdropAligner for nanopore
-                if (opt.tech == TECH_NANOPORE) MCHK(mhip_xalign_candidates(ctx, dref, dreads, jobs.data(), (int)jobs.size(), P.min_align_size, res.data()));
-                else MCHK(mhip_align_candidates(ctx, dref, dreads, jobs.data(), (int)jobs.size(), P.min_align_size, res.data()));
+                return;
             }
             StageClock* sc_fmt = new StageClock(&st[3]);
             std::vector<std::vector<M4Rec>> mrec(pw ? (size_t)nt : 0);
@@ -322,7 +302,92 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
                 if (pw)
                     for (const std::vector<M4Rec>& v : mrec) pw->add_m4(v.data(), v.size(), part_ratio);
             }
+        };
+        std::mutex pm;
+        std::condition_variable pcv;
+        int produced = 0, consumed = 0;
+        bool closing = false;
+        std::thread writer([&]() {
+            for (;;) {
+                int s;
+                {
+                    std::unique_lock<std::mutex> lk(pm);
+                    pcv.wait(lk, [&]() { return consumed < produced || closing; });
+                    if (consumed >= produced) return;
+                    s = consumed;
+                }
+                emit(slabs[s & 1]);
+                {
+                    std::lock_guard<std::mutex> lk(pm);
+                    ++consumed;
+                }
+                pcv.notify_all();
+            }
+        });
+        int sno = 0;
+        for (int rb = 0; rb < rd->num_reads; rb += slab, ++sno) {
+            const int re = std::min(rd->num_reads, rb + slab), nr = re - rb;
+            {
+                std::unique_lock<std::mutex> lk(pm);                  // the buffers of slab sno - 2 must have been written out
+                pcv.wait(lk, [&]() { return consumed >= sno - 1; });
+            }
+            SlabBuf& B = slabs[sno & 1];
+            PinnedBuf<mhip_candidate>& cands = B.cands;
+            PinnedBuf<int32_t>& counts = B.counts;
+            PinnedBuf<mhip_aln_job>& jobs = B.jobs;
+            PinnedBuf<mhip_aln_result>& res = B.res;
+            std::vector<size_t>& jfirst = B.jfirst;
+            B.rb = rb;
+            B.nr = nr;
+            cands.resize((size_t)nr * P.maxc);
+            counts.resize((size_t)nr);
+            { StageClock sc(&st[0]); MCHK(mhip_seed_reads(ctx, idx, dref, dreads, rb, re, &P, cands.data(), counts.data())); }
+            if (opt.task != TASK_SEED) {
+                auto range_of = [&](int t, int* lo, int* hi) { *lo = (int)((long long)nr * t / nt); *hi = (int)((long long)nr * (t + 1) / nt); };
+                // pairwise_mapping, pw_impl.cpp:674-700
+                StageClock* sc_jobs = new StageClock(&st[1]);
+                jfirst.assign((size_t)nr + 1, 0);
+                for (int r = 0; r < nr; ++r) jfirst[(size_t)r + 1] = jfirst[(size_t)r] + (size_t)counts[(size_t)r];
+                jobs.resize(jfirst[(size_t)nr]);
+                run_threads(nt, [&](int t) {
+                    int lo, hi;
+                    range_of(t, &lo, &hi);
+                    for (int r = lo; r < hi; ++r) {
+                        size_t jn = jfirst[(size_t)r];
+                        for (int k = 0; k < counts[(size_t)r]; ++k) {
+                            const mhip_candidate& c = cands[(size_t)r * P.maxc + k];
+                            mhip_aln_job j;
+                            j.qid_local = rb + r;
+                            j.sid_local = c.readno - ref.start_read_id;
+                            j.chain = c.chain;
+                            j.qstart = c.loc2;
+                            j.sstart = c.loc1;
+                            if (j.qstart && j.sstart) { j.qstart += MHIP_KMER_SIZE / 2; j.sstart += MHIP_KMER_SIZE / 2; }
+                            jobs[jn++] = j;
+                        }
+                    }
+                });
+                res.resize(jobs.size());
+                delete sc_jobs;
+                {
+                    StageClock sc(&st[2]);
+                    // aligner by technology (pw_impl.cpp:638-644): DiffAligner (dw) for PacBio, XdropAligner for nanopore
+                    if (opt.tech == TECH_NANOPORE) MCHK(mhip_xalign_candidates(ctx, dref, dreads, jobs.data(), (int)jobs.size(), P.min_align_size, res.data()));
+                    else MCHK(mhip_align_candidates(ctx, dref, dreads, jobs.data(), (int)jobs.size(), P.min_align_size, res.data()));
+                }
+            }
+            {
+                std::lock_guard<std::mutex> lk(pm);
+                ++produced;
+            }
+            pcv.notify_all();
         }
+        {
+            std::lock_guard<std::mutex> lk(pm);
+            closing = true;
+        }
+        pcv.notify_all();
+        writer.join();
         if (getenv("MECAT_TRACE"))
             fprintf(stderr, "[trace] volume %d stages: seed %.3f s, jobs %.3f s, extend %.3f s, format %.3f s, write %.3f s\n", vid, st[0], st[1],
                     st[2], st[3], st[4]);

@@ -260,8 +260,9 @@ __global__ __launch_bounds__(XB_BLOCK) void xd_extend(const uint32_t* __restrict
 // scratch with a fixed row stride (coalesced 64-byte stores), plus bit 7 = "the diagonal step into this cell is a match" so
 // that the traceback needs nothing but these bytes.  The traceback is a scalar walk: a row's bytes sit in two registers
 // (one cell per lane), fetched one row ahead from a 4 KB LDS window over the scratch, and are read with v_readlane.
-// A window wider than XW_RING - 2 cells hands the unit over (overflow list) to a second launch with a bigger per-wave
-// scratch, which redoes the unit and runs the WIDE instantiation of the same code for the blocks that overflow: scores in
+// A window wider than XW_RING - 2 cells hands the unit over (overflow list: unit, position and partial result) to a second
+// launch with a bigger per-wave scratch, which resumes it there and runs the WIDE instantiation of the same code for the
+// blocks that overflow: scores in
 // per-wave global arrays instead of the ring, rows of XW_WSTRIDE bytes, traceback reading byte by byte through the LDS
 // window — slower per row, but only a fraction of a percent of the units (low-complexity sequence) have such blocks.
 #define XW_WAVES 4
@@ -567,7 +568,13 @@ __global__ __launch_bounds__(XW_BLOCK) void xd_extend_w(const uint32_t* __restri
         if (lane == 0) unit = atomicAdd(cursor, 1u);
         unit = __builtin_amdgcn_readfirstlane(unit);
         if (unit >= nunits) break;
-        if (ulist) unit = ulist[unit];
+        int qidx = 0, tidx = 0;
+        XDir R = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (ulist) {                                     // a handed-over unit resumes at the block that overflowed
+            const unsigned int* e = ulist + 3 * (size_t)unit;
+            unit = e[0]; qidx = (int)e[1]; tidx = (int)e[2];
+            R = dres[unit];
+        }
         const mhip_aln_job jb = jobs[unit >> 1];
         const int right = unit & 1;
         const int qsize = qoffs[jb.qid_local].size, tsize = roffs[jb.sid_local].size;
@@ -579,8 +586,6 @@ __global__ __launch_bounds__(XW_BLOCK) void xd_extend_w(const uint32_t* __restri
         t.A = right ? jb.sstart : jb.sstart - 1; t.B = step;
         const int query_size = right ? qsize - jb.qstart : jb.qstart;
         const int target_size = right ? tsize - jb.sstart : jb.sstart;
-        int qidx = 0, tidx = 0;
-        XDir R = {0, 0, 0, 0, 0, 0, 0, 0};
         bool handed_over = false;
         while (true) {      // align_ex (xdrop_gapalign.cpp:263-357)
             const int qleft = query_size - qidx, tleft = target_size - tidx;
@@ -595,7 +600,7 @@ __global__ __launch_bounds__(XW_BLOCK) void xd_extend_w(const uint32_t* __restri
             ++nblocks;
             R.blocks += 1;
             if (o.overflow) {
-                if (!WIDE) { handed_over = true; break; }
+                if (!WIDE) { handed_over = true; R.blocks -= 1; break; }      // the block is counted again when it is redone
                 if constexpr (WIDE) xdrop_block_w<true, HFN>(S, q, qidx, qblk, t, tidx, tblk, st, o);      // only the blocks that need it
             }
             const int full_map = (qblk - o.ae <= 20 || tblk - o.be <= 20);
@@ -616,8 +621,11 @@ __global__ __launch_bounds__(XW_BLOCK) void xd_extend_w(const uint32_t* __restri
             tidx += o.be - o.tcnt;
         }
         if (lane == 0) {
-            if (handed_over) ovf_list[1 + atomicAdd(ovf_list, 1u)] = unit;     // the WIDE launch redoes the whole unit
-            else dres[unit] = R;
+            dres[unit] = R;                              // final, or the state in front of the block that overflowed
+            if (handed_over) {
+                unsigned int* e = ovf_list + 1 + 3 * (size_t)atomicAdd(ovf_list, 1u);
+                e[0] = unit; e[1] = (unsigned int)qidx; e[2] = (unsigned int)tidx;
+            }
         }
     }
     if (lane == 0) atomicAdd(&counters[3], nblocks);
@@ -659,7 +667,7 @@ int mhip_xalign_candidates_dev(mhip_ctx* c, const mhip_volume* ref, const mhip_v
     if (c->scratch("xa_dres", sizeof(XDir) * 2 * (size_t)n, (void**)&d_dres)) return -1;
     unsigned int* d_ovf;
     if (c->scratch("xa_cursor", 64, (void**)&d_cur)) return -1;
-    if (c->scratch("xa_ovf", sizeof(unsigned int) * (2 * (size_t)n + 4), (void**)&d_ovf)) return -1;
+    if (c->scratch("xa_ovf", sizeof(unsigned int) * (6 * (size_t)n + 8), (void**)&d_ovf)) return -1;      // count + {unit, qidx, tidx} each
     HIPCHK(hipMemsetAsync(d_cur, 0, 16, c->stream));
     const char* kv = getenv("MECAT_XD_KERNEL");      // 1 = the one-lane-per-unit kernel (independent implementation, tests)
     if (!(kv && atoi(kv) == 1)) {
@@ -680,7 +688,7 @@ int mhip_xalign_candidates_dev(mhip_ctx* c, const mhip_volume* ref, const mhip_v
             if (c->scratch("xw_wide", XW_WIDE_BYTES * (size_t)wgrid, (void**)&d_w)) return -1;
             LAUNCH(c, "xd_extend_wide", xd_extend_w<true>, wgrid, 64, 0, (const uint32_t*)ref->d_pac, (const mhip_offset_t*)ref->d_offs,
                    (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs, (const mhip_aln_job*)d_jobs, n, d_dres, d_w, d_cur + 2,
-                   d_ovf + 2 * (size_t)n + 1, (unsigned long long*)c->d_counters, (const unsigned int*)(d_ovf + 1), nwide);
+                   d_ovf + 6 * (size_t)n + 4, (unsigned long long*)c->d_counters, (const unsigned int*)(d_ovf + 1), nwide);
         }
     } else {
         int nthreads = c->num_cus * 4 * XB_BLOCK;

@@ -720,14 +720,14 @@ __global__ __launch_bounds__(WAVE) void seed_cand(SeedArrays A, const mhip_offse
             const int k0 = min(k, 64);
             auto vote_loops = [&](auto ddf) {
                 for (int j = 1; j < k0; ++j) {
-                    const int lj = T->t_loc[j], dj = T->t_seed[j];
+                    const int lj = __builtin_amdgcn_readlane(l0, j), dj = __builtin_amdgcn_readlane(d0, j);     // entry j lives in lane j
                     bool v0 = i0 < j && temp0 != dj && dj - d0 > 0 && lj - l0 > 0 && lj - l0 < read_size && ddf(lj - l0, dj - d0);
                     if (v0) { ++sc0; temp0 = dj; }
                     const int votes = __popcll(__ballot(v0));
                     if (lane == j) sc0 += votes;
                 }
                 for (int j = 64; j < k; ++j) {
-                    const int lj = T->t_loc[j], dj = T->t_seed[j];
+                    const int lj = __builtin_amdgcn_readlane(l1, j - 64), dj = __builtin_amdgcn_readlane(d1, j - 64);
                     bool v0 = temp0 != dj && dj - d0 > 0 && lj - l0 > 0 && lj - l0 < read_size && ddf(lj - l0, dj - d0);
                     bool v1 = i1 < j && temp1 != dj && dj - d1 > 0 && lj - l1 > 0 && lj - l1 < read_size && ddf(lj - l1, dj - d1);
                     if (v0) { ++sc0; temp0 = dj; }

@@ -94,17 +94,19 @@ void mhip_host_free(void* p) {
 
 int mhip_ctx_reserve_index(mhip_ctx* c, int64_t bases) {
     if (bases <= 0) return 0;
-    const size_t bytes = sizeof(uint64_t) * ((size_t)bases + 64);      // ix_ent1 / ix_ent2 of the binned index build
+    // ix_ent1 (every k-mer start of the volume) and ix_ent2 (the ping buffer of one group of coarse bins: a quarter of the
+    // k-mer space; 40 % leaves room for uneven groups — a build that needs more simply reallocates it)
+    const size_t nbytes[2] = {sizeof(uint64_t) * ((size_t)bases + 64), sizeof(uint64_t) * ((size_t)(bases * 2 / 5) + 64)};
     std::lock_guard<std::mutex> lk(c->bufs_mu);
     const char* names[2] = {"ix_ent1", "ix_ent2"};
     void* p[2] = {nullptr, nullptr};
     hipError_t err[2] = {hipSuccess, hipSuccess};
     bool need[2];
-    for (int i = 0; i < 2; ++i) need[i] = c->bufs[names[i]].cap < bytes;
+    for (int i = 0; i < 2; ++i) need[i] = c->bufs[names[i]].cap < nbytes[i];
     const int device = c->device;
     auto grab = [&](int i) {                                           // the two mappings proceed side by side
         if (hipSetDevice(device) != hipSuccess) { err[i] = hipErrorInvalidDevice; return; }
-        err[i] = hipMalloc(&p[i], bytes + 4096);
+        err[i] = hipMalloc(&p[i], nbytes[i] + 4096);
     };
     std::thread t1;
     if (need[1]) t1 = std::thread(grab, 1);
@@ -113,11 +115,11 @@ int mhip_ctx_reserve_index(mhip_ctx* c, int64_t bases) {
     int rc = 0;
     for (int i = 0; i < 2; ++i) {
         if (!need[i]) continue;
-        if (err[i] != hipSuccess) { mhip_set_error("hipMalloc of %zu bytes for the index scratch failed: %s", bytes, hipGetErrorString(err[i])); rc = -1; continue; }
+        if (err[i] != hipSuccess) { mhip_set_error("hipMalloc of %zu bytes for the index scratch failed: %s", nbytes[i], hipGetErrorString(err[i])); rc = -1; continue; }
         DevBuf& b = c->bufs[names[i]];
         if (b.p) (void)hipFree(b.p);
         b.p = p[i];
-        b.cap = bytes + 4096;
+        b.cap = nbytes[i] + 4096;
     }
     return rc;
 }

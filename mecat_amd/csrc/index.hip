@@ -464,11 +464,11 @@ __global__ __launch_bounds__(IDX_BLOCK) void idx_scatter1(const uint32_t* __rest
 
 // level 2: inside coarse bin c (its own 64 fine cursors), by the next 6 k-mer bits.  blockIdx.y = coarse bin.
 __global__ __launch_bounds__(IDX_BLOCK) void idx_scatter2(const uint64_t* __restrict__ ent1, const uint32_t* __restrict__ fine_base,
-                                                          uint32_t* __restrict__ cur2, uint64_t* __restrict__ ent2) {
+                                                          uint32_t* __restrict__ cur2, uint64_t* __restrict__ ent2, int coarse0) {
     __shared__ uint32_t hist[NCOARSE], lbase[NCOARSE + 1], gbase[NCOARSE];
     __shared__ uint64_t stage[TILE_POS];
     __shared__ uint8_t sbin[TILE_POS];
-    const int c = blockIdx.y;
+    const int c = coarse0 + blockIdx.y;      // (ent2 is addressed by volume-wide entry positions: the caller passes the group's base pointer shifted)
     const uint32_t cb = fine_base[c * 64], ce = fine_base[(c + 1) * 64];
     const uint64_t first = (uint64_t)cb + (uint64_t)blockIdx.x * TILE_POS;
     if (first >= ce) return;
@@ -496,11 +496,11 @@ __global__ __launch_bounds__(IDX_BLOCK) void idx_scatter2(const uint64_t* __rest
 // total, and the entry ranges of its 64 sub-bins (all occurrences, dropped buckets included) for the level-3 scatter
 __global__ __launch_bounds__(BIN_THREADS) void idx_bin_count(const uint64_t* __restrict__ ent2, const uint32_t* __restrict__ fine_base,
                                                              uint32_t* __restrict__ starts, uint32_t* __restrict__ bintot,
-                                                             uint32_t* __restrict__ sub_base, uint32_t* __restrict__ cur3) {
+                                                             uint32_t* __restrict__ sub_base, uint32_t* __restrict__ cur3, int fine0) {
     __shared__ uint32_t cnt[IDS_PER_FINE];     // 64 KB
     __shared__ uint32_t wtot[BIN_THREADS / WAVE];
     __shared__ uint32_t subtot[NSUB];
-    const int b = blockIdx.x;
+    const int b = fine0 + blockIdx.x;
     for (int i = threadIdx.x; i < IDS_PER_FINE; i += BIN_THREADS) cnt[i] = 0;
     __syncthreads();
     const uint32_t eb = fine_base[b], ee = fine_base[b + 1];
@@ -545,11 +545,11 @@ __global__ __launch_bounds__(BIN_THREADS) void idx_bin_count(const uint64_t* __r
 
 // level 3: inside fine bin b (its own 64 sub-bin cursors), by k-mer bits 13..8.  blockIdx.y = fine bin.
 __global__ __launch_bounds__(IDX_BLOCK) void idx_scatter3(const uint64_t* __restrict__ ent2, const uint32_t* __restrict__ fine_base,
-                                                          uint32_t* __restrict__ cur3, uint64_t* __restrict__ ent3) {
+                                                          uint32_t* __restrict__ cur3, uint64_t* __restrict__ ent3, int fine0) {
     __shared__ uint32_t hist[NCOARSE], lbase[NCOARSE + 1], gbase[NCOARSE];
     __shared__ uint64_t stage[TILE_POS];
     __shared__ uint8_t sbin[TILE_POS];
-    const int b = blockIdx.y;
+    const int b = fine0 + blockIdx.y;
     const uint32_t cb = fine_base[b], ce = fine_base[b + 1];
     const uint64_t first = (uint64_t)cb + (uint64_t)blockIdx.x * TILE_POS;
     if (first >= ce) return;
@@ -671,38 +671,42 @@ static int index_build_binned(mhip_ctx* c, const mhip_volume* v, mhip_index* idx
            v->num_reads, v->num_bases, d_hist);
     LAUNCH(c, "idx_scan4096", idx_scan4096, 1, 1024, 0, (const uint32_t*)d_hist, d_fbase);
     TRACE("hist+scan");
-    uint32_t nent = 0;
-    HIPCHK(hipMemcpyAsync(&nent, d_fbase + NFINE, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    // Entries: level 1 scatters the whole volume into ent1 (64 coarse bins).  Levels 2 and 3 run per group of IDX_GROUP coarse
+    // bins: level 2 moves the group's entries into the small ping buffer ent2, level 3 moves them back into the same range of
+    // ent1 (fine bins keep their ranges through both levels) — so the ping buffer is a group's size, not the volume's.
+    std::vector<uint32_t> fb(NFINE + 1);
+    HIPCHK(hipMemcpyAsync(fb.data(), d_fbase, sizeof(uint32_t) * (NFINE + 1), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    const uint32_t nent = fb[NFINE];
+    constexpr int IDX_GROUP = 16, NGROUP = NCOARSE / IDX_GROUP;
+    uint32_t gmax = 0;
+    for (int g = 0; g < NGROUP; ++g) gmax = std::max(gmax, fb[(size_t)(g + 1) * IDX_GROUP * 64] - fb[(size_t)g * IDX_GROUP * 64]);
     uint64_t *d_e1, *d_e2;
     if (c->scratch("ix_ent1", sizeof(uint64_t) * ((size_t)nent + 64), (void**)&d_e1)) return -1;
-    if (c->scratch("ix_ent2", sizeof(uint64_t) * ((size_t)nent + 64), (void**)&d_e2)) return -1;
+    if (c->scratch("ix_ent2", sizeof(uint64_t) * ((size_t)gmax + 64), (void**)&d_e2)) return -1;
     TRACE("scratch");
-    unsigned gx3 = 0;
-    LAUNCH(c, "idx_init_cursors", idx_init_cursors, NFINE / 256, 256, 0, (const uint32_t*)d_fbase, d_cur1, d_cur2);
-    LAUNCH(c, "idx_scatter1", idx_scatter1, tiles, IDX_BLOCK, 0, (const uint32_t*)v->d_pac, (const mhip_offset_t*)v->d_offs, v->num_reads,
-           v->num_bases, d_cur1, d_e1);
-    {
-        // grid.x covers the largest coarse bin; blocks past a bin's end exit immediately
-        std::vector<uint32_t> fb(NFINE + 1);
-        HIPCHK(hipMemcpyAsync(fb.data(), d_fbase, sizeof(uint32_t) * (NFINE + 1), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        uint32_t mx = 0;
-        for (int cc = 0; cc < NCOARSE; ++cc) mx = std::max(mx, fb[(size_t)(cc + 1) * 64] - fb[(size_t)cc * 64]);
-        const unsigned gx = (mx + TILE_POS - 1) / TILE_POS;
-        uint32_t mx3 = 0;
-        for (int f = 0; f < NFINE; ++f) mx3 = std::max(mx3, fb[(size_t)f + 1] - fb[(size_t)f]);
-        gx3 = (mx3 + TILE_POS - 1) / TILE_POS;
-        if (gx) LAUNCH(c, "idx_scatter2", idx_scatter2, dim3(gx, NCOARSE), IDX_BLOCK, 0, (const uint64_t*)d_e1, (const uint32_t*)d_fbase, d_cur2, d_e2);
-    }
-    TRACE("scatter");
     uint32_t *d_subbase, *d_cur3;
     if (c->scratch("ix_subbase", sizeof(uint32_t) * ((size_t)NFINE * NSUB + 1), (void**)&d_subbase)) return -1;
     if (c->scratch("ix_cur3", sizeof(uint32_t) * (size_t)NFINE * NSUB, (void**)&d_cur3)) return -1;
-    LAUNCH(c, "idx_bin_count", idx_bin_count, NFINE, BIN_THREADS, 0, (const uint64_t*)d_e2, (const uint32_t*)d_fbase, idx->d_starts, d_bintot,
-           d_subbase, d_cur3);
+    LAUNCH(c, "idx_init_cursors", idx_init_cursors, NFINE / 256, 256, 0, (const uint32_t*)d_fbase, d_cur1, d_cur2);
+    LAUNCH(c, "idx_scatter1", idx_scatter1, tiles, IDX_BLOCK, 0, (const uint32_t*)v->d_pac, (const mhip_offset_t*)v->d_offs, v->num_reads,
+           v->num_bases, d_cur1, d_e1);
+    for (int g = 0; g < NGROUP; ++g) {
+        const int c0 = g * IDX_GROUP, f0 = c0 * 64, nf = IDX_GROUP * 64;
+        const uint32_t gbase = fb[(size_t)f0];
+        // grid.x covers the largest bin of the group; blocks past a bin's end exit immediately
+        uint32_t mx = 0, mx3 = 0;
+        for (int cc = c0; cc < c0 + IDX_GROUP; ++cc) mx = std::max(mx, fb[(size_t)(cc + 1) * 64] - fb[(size_t)cc * 64]);
+        for (int f = f0; f < f0 + nf; ++f) mx3 = std::max(mx3, fb[(size_t)f + 1] - fb[(size_t)f]);
+        const unsigned gx = (mx + TILE_POS - 1) / TILE_POS, gx3 = (mx3 + TILE_POS - 1) / TILE_POS;
+        uint64_t* e2v = d_e2 - gbase;                    // the kernels index ent2 by volume-wide entry positions
+        if (gx) LAUNCH(c, "idx_scatter2", idx_scatter2, dim3(gx, IDX_GROUP), IDX_BLOCK, 0, (const uint64_t*)d_e1, (const uint32_t*)d_fbase, d_cur2, e2v, c0);
+        LAUNCH(c, "idx_bin_count", idx_bin_count, nf, BIN_THREADS, 0, (const uint64_t*)e2v, (const uint32_t*)d_fbase, idx->d_starts, d_bintot,
+               d_subbase, d_cur3, f0);
+        if (gx3) LAUNCH(c, "idx_scatter3", idx_scatter3, dim3(gx3, nf), IDX_BLOCK, 0, (const uint64_t*)e2v, (const uint32_t*)d_fbase, d_cur3, d_e1, f0);
+    }
+    TRACE("scatter");
     LAUNCH(c, "idx_scan4096", idx_scan4096, 1, 1024, 0, (const uint32_t*)d_bintot, d_binout);
-    if (gx3) LAUNCH(c, "idx_scatter3", idx_scatter3, dim3(gx3, NFINE), IDX_BLOCK, 0, (const uint64_t*)d_e2, (const uint32_t*)d_fbase, d_cur3, d_e1);
     LAUNCH(c, "idx_bin_starts", idx_bin_starts, NFINE, BIN_THREADS, 0, (const uint32_t*)d_binout, idx->d_starts);
     uint32_t total = 0;
     HIPCHK(hipMemcpyAsync(&total, d_binout + NFINE, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));

@@ -549,6 +549,9 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
 #ifdef MECAT_DW_STATS
             nwide += NJ > 1 ? 1u : 0u;
 #endif
+            // one or two passes of 32 diagonals per half cover 99 % of the rows: with the pass count a constant the pass loop, the
+            // previous-pass bookkeeping and the choice of band update fold away
+            auto row_body = [&](const int NJ) __attribute__((always_inline)) {
             int mmax = -1, m0 = -0x40000000, mp = -0x40000000;      // x + y of the lane's diagonal in the last / previous pass
             unsigned long long ended = 0;    // lanes whose diagonal reached an end of the block in some pass (rare: once per block)
             int j = 0;
@@ -631,6 +634,10 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
                 max_k = nmax + 1;
                 min_k = nmin - 1;
             }
+            };
+            if (NJ == 1) row_body(1);
+            else if (NJ == 2) row_body(2);
+            else row_body(NJ);
             d += 1;
             __builtin_amdgcn_wave_barrier();
         }

@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--workload", default="config2")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-align", action="store_true", help="-j 0 only (index + candidates)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed cns_realign / xdrop_extend measurements")
     ap.add_argument("--stats", default="", help="write per-kernel stats JSON here (rank 0)")
     args = ap.parse_args()
 
@@ -286,7 +287,7 @@ def main():
         }
         # not part of the metric: the mecat2cns re-aligner (full aligned strings as 2-bit columns) on the first
         # 200 000 candidates of this run, device resident
-        if world == 1 and not args.no_align and keep["njobs"] > 0:
+        if world == 1 and not args.no_align and not args.no_extras and keep["njobs"] > 0:
             try:
                 nj, cap = min(200000, keep["njobs"]), 32768
                 c_res = torch.empty((nj, 16), dtype=torch.int32, device=dev)
@@ -308,7 +309,7 @@ def main():
             except Exception as e:          # never let the extra measurement break the contract line
                 log("[bench] cns_realign skipped: %r" % (e,))
         # not part of the metric either: the X-drop aligner (nanopore mode) on the first 100 000 candidates
-        if world == 1 and not args.no_align and keep["njobs"] > 0:
+        if world == 1 and not args.no_align and not args.no_extras and keep["njobs"] > 0:
             try:
                 nj = min(100000, keep["njobs"])
                 x_res = torch.empty((nj, 8), dtype=torch.int32, device=dev)

@@ -44,7 +44,7 @@ def main():
     traffic = {}
     with open(os.path.join(here, "%s_hbm_counters.md" % tag), "w") as f:
         f.write("# %s - HBM traffic counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)\n\n" % tag)
-        f.write("Command: `python bench.py --steps 1 --warmup 1 --no-cpu` (config 2), i.e. %d passes of the hot path per run.\n" % passes)
+        f.write("Command: `python bench.py --steps 1 --warmup 1 --no-cpu --no-extras` (config 2), i.e. %d passes of the hot path per run.\n" % passes)
         f.write("Counter unit is KiB; bytes = value x 1024.  MI355X_MICROARCH.md (HBM): FETCH_SIZE reports half the bytes of a\n"
                 "16 B/lane coalesced streaming read and is uncalibrated for other widths; none of these kernels issues 16 B/lane\n"
                 "streams (4-8 B/lane gathers and scatters), so the values are reported uncorrected.  Infinity-Cache hits count.\n\n")

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Instruction mix per kernel from rocprofv3 --pmc SQ_* passes of `python bench.py --steps 1 --warmup 1 --no-cpu`.
+"""Instruction mix per kernel from rocprofv3 --pmc SQ_* passes of `python bench.py --steps 1 --warmup 1 --no-cpu --no-extras`.
 
     python profiles/summarize_sq.py r01 2 gpurun_out/pmc_dw1 gpurun_out/pmc_dw2 gpurun_out/pmc_dw3
 

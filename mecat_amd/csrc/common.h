@@ -79,13 +79,14 @@ struct mhip_index {
     int device = 0;
     uint32_t* d_starts = nullptr;   // [NKMER + 1] bucket boundaries into d_offsets (dropped buckets are empty)
     int32_t* d_offsets = nullptr;   // [num_kmers] k-mer start positions, ascending inside a bucket
+    uint16_t* d_slots = nullptr;    // [num_kmers] (position / 2000) mod 2^15: all the relevance filter's bucket walk needs, at half the bytes
     int64_t num_kmers = 0;
     int num_bases = 0;
-    size_t cap_starts = 0, cap_offsets = 0;   // allocation sizes, for the recycler below
+    size_t cap_starts = 0, cap_offsets = 0, cap_slots = 0;   // allocation sizes, for the recycler below
 };
 
 // Recycler for the index's two large device arrays: a per-read-volume rebuild (one per `-j` grid row) otherwise pays a
-// multi-GB hipMalloc + hipFree (~0.2 s) every time.  Freed blocks are parked per device (at most two) and handed back
+// multi-GB hipMalloc + hipFree (~0.2 s) every time.  Freed blocks are parked per device (at most three) and handed back
 // to the next request they fit without more than 2x slack; mhip_ctx_destroy releases what is parked.
 int dev_alloc_recycled(int device, size_t bytes, void** p, size_t* cap);
 void dev_free_recycled(int device, void* p, size_t cap);

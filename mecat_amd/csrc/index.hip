@@ -724,6 +724,31 @@ static int index_build_binned(mhip_ctx* c, const mhip_volume* v, mhip_index* idx
     return 0;
 }
 
+// slot of a k-mer position in the seeding stage's relevance table: (position / ZV) mod 2^15, ZV = 2000 (seed.hip)
+__global__ __launch_bounds__(256) void idx_slots(const int32_t* __restrict__ offsets, int64_t n, uint16_t* __restrict__ slots) {
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 + 3 < n) {
+        const int4 p = *(const int4*)(offsets + i0);
+        ushort4 o;
+        o.x = (uint16_t)(((uint32_t)p.x / 2000u) & 0x7FFFu); o.y = (uint16_t)(((uint32_t)p.y / 2000u) & 0x7FFFu);
+        o.z = (uint16_t)(((uint32_t)p.z / 2000u) & 0x7FFFu); o.w = (uint16_t)(((uint32_t)p.w / 2000u) & 0x7FFFu);
+        *(ushort4*)(slots + i0) = o;
+    } else {
+        for (int64_t i = i0; i < n; ++i) slots[i] = (uint16_t)(((uint32_t)offsets[i] / 2000u) & 0x7FFFu);
+    }
+}
+
+// The relevance filter of the seeding stage only needs each position's 2 kb-segment slot (15 bits): a second array at half the
+// bytes halves the sectors its bucket walk touches.
+static int index_add_slots(mhip_ctx* c, mhip_index* idx) {
+    if (idx->num_kmers <= 0) return 0;
+    if (dev_alloc_recycled(c->device, sizeof(uint16_t) * ((size_t)idx->num_kmers + 64), (void**)&idx->d_slots, &idx->cap_slots)) return -1;
+    LAUNCH(c, "idx_slots", idx_slots, (unsigned)((idx->num_kmers + 1023) / 1024), 256, 0, (const int32_t*)idx->d_offsets, idx->num_kmers,
+           idx->d_slots);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 extern "C" {
 
 int mhip_index_build(mhip_ctx* c, const mhip_volume* v, mhip_index** out) {
@@ -746,6 +771,7 @@ int mhip_index_build(mhip_ctx* c, const mhip_volume* v, mhip_index** out) {
         if (!(e && atoi(e) == 1)) {
             if (getenv("MECAT_TRACE")) fprintf(stderr, "[idx trace] pre-alloc      %.2f ms\n", now_ms() - tb0);
             if (index_build_binned(c, v, idx)) { mhip_index_free(idx); return -1; }
+            if (index_add_slots(c, idx)) { mhip_index_free(idx); return -1; }
             *out = idx;
             return 0;
         }
@@ -774,6 +800,7 @@ int mhip_index_build(mhip_ctx* c, const mhip_volume* v, mhip_index** out) {
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (index_add_slots(c, idx)) { mhip_index_free(idx); return -1; }
     *out = idx;
     return 0;
 }
@@ -783,6 +810,7 @@ void mhip_index_free(mhip_index* idx) {
     (void)hipSetDevice(idx->device);
     dev_free_recycled(idx->device, idx->d_starts, idx->cap_starts);
     dev_free_recycled(idx->device, idx->d_offsets, idx->cap_offsets);
+    dev_free_recycled(idx->device, idx->d_slots, idx->cap_slots);
     delete idx;
 }
 

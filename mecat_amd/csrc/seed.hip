@@ -171,8 +171,8 @@ __global__ __launch_bounds__(1024) void seed_scan(const uint32_t* __restrict__ h
 // Four buckets per group are in flight at once (their (start, size) and first two 64-byte pieces are loaded before any is
 // consumed): the walk is a gather of ~88-byte runs, so throughput comes from outstanding loads, not from arithmetic.
 // `begin(slot, km)`, `f(slot, km, r, pos, valid)`, `end(slot, km)`; slot 0..3 is a compile-time index for per-bucket state.
-template <typename B, typename F, typename E>
-__device__ __forceinline__ void for_each_hit16(const SeedArrays& A, const int32_t* __restrict__ offsets, const uint32_t kb, const int K,
+template <typename T, typename B, typename F, typename E>
+__device__ __forceinline__ void for_each_hit16(const SeedArrays& A, const T* __restrict__ offsets, const uint32_t kb, const int K,
                                                B begin, F f, E end) {
     const int g = threadIdx.x >> 4, sub = threadIdx.x & 15;
     constexpr int G = SEED_BLOCK / 16;
@@ -228,7 +228,8 @@ __device__ __forceinline__ bool rel_test(const uint32_t* rel, uint32_t seg) {
 // the key arrays) come from passes over the 32 K-entry table.  A counter that would wrap (>= 256 hits in one slot: repeats)
 // turns the filter off for the strand.
 __global__ __launch_bounds__(SEED_BLOCK) void seed_filter(const mhip_offset_t* __restrict__ roffs, int rid_begin, int rid_stride,
-                                                          const int32_t* __restrict__ offsets, SeedArrays A, int gate, int enable) {
+                                                          const uint16_t* __restrict__ slots, SeedArrays A, int gate, int enable) {
+    static_assert(ZV == 2000 && FLT_M == (1 << 15), "idx_slots (index.hip) computes (position / 2000) mod 2^15");
     __shared__ uint32_t cnt[FLT_M / 4];          // 32 KB
     __shared__ uint32_t rel[REL_WORDS];          // 4 KB
     __shared__ uint32_t wtot[SEED_WAVES];
@@ -247,9 +248,8 @@ __global__ __launch_bounds__(SEED_BLOCK) void seed_filter(const mhip_offset_t* _
         if (threadIdx.x == 0) s_wrap = 0;
         __syncthreads();
         auto nop = [](int, int) {};
-        for_each_hit16(A, offsets, kb, K, nop, [&](int, int, uint32_t, uint32_t pos, bool valid) {
+        for_each_hit16(A, slots, kb, K, nop, [&](int, int, uint32_t, uint32_t e, bool valid) {      // e = the hit's table slot
             if (valid) {
-                const uint32_t e = (pos / ZV) & (FLT_M - 1);
                 const uint32_t sh = (e & 3u) * 8u;
                 const uint32_t old = atomicAdd(&cnt[e >> 2], 1u << sh);
                 if (((old >> sh) & 255u) == 255u) s_wrap = 1;
@@ -952,7 +952,7 @@ static int seed_batch(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref
         const int gate = 2 * P->min_kmer_match;
         const int enable = filter_enabled(P) ? 1 : 0;
         LAUNCH(c, "seed_filter", seed_filter, ns, SEED_BLOCK, 0, (const mhip_offset_t*)reads->d_offs, rb, stride,
-               (const int32_t*)idx->d_offsets, A, gate, enable);
+               (const uint16_t*)idx->d_slots, A, gate, enable);
     }
     LAUNCH(c, "seed_scan", seed_scan, 1, 1024, 0, (const uint32_t*)A.strand_hits, ns, A.hit_base);
     uint64_t Htot = 0;

@@ -380,9 +380,12 @@ __global__ __launch_bounds__(SEED_BLOCK) void seed_emit(const mhip_offset_t* __r
 }
 
 // ------------------------------------------------------------------------------------------------ sort (one LSD pass)
-// digit = (key >> shift) & (2^bits - 1), bits <= 8.  Wave w of the block owns the w-th quarter of the strand's keys.
+// digit = (key >> shift) & (2^bits - 1), bits <= SORT_MAXBITS (two passes cover the 20-21 segment bits of a volume).  Wave w
+// of the block owns the w-th quarter of the strand's keys.
+#define SORT_MAXBITS 11
+#define SORT_BINS (1 << SORT_MAXBITS)
 __global__ __launch_bounds__(SEED_BLOCK) void seed_sort_pass(SeedArrays A, int from_b, int shift, int bits) {
-    __shared__ uint32_t hist[SEED_WAVES][256];
+    __shared__ uint32_t hist[SEED_WAVES][SORT_BINS];      // 32 KB
     __shared__ uint32_t wtot[SEED_WAVES];
     const int s = blockIdx.x;
     const uint32_t H = A.strand_hits[s];
@@ -394,19 +397,30 @@ __global__ __launch_bounds__(SEED_BLOCK) void seed_sort_pass(SeedArrays A, int f
     const uint32_t mask = (1u << bits) - 1u;
     const uint32_t chunk = (((H + SEED_WAVES - 1) / SEED_WAVES) + 63u) & ~63u;
     const uint32_t lo = min(H, w * chunk), hi = min(H, lo + chunk);
-    for (int i = threadIdx.x; i < SEED_WAVES * 256; i += SEED_BLOCK) (&hist[0][0])[i] = 0;
+    const uint32_t nbins = 1u << bits;
+    for (uint32_t i = threadIdx.x; i < nbins; i += SEED_BLOCK)
+#pragma unroll
+        for (int q = 0; q < SEED_WAVES; ++q) hist[q][i] = 0;
     __syncthreads();
     for (uint32_t i = lo + lane; i < hi; i += 64) atomicAdd(&hist[w][(uint32_t)(src[i] >> shift) & mask], 1u);
     __syncthreads();
     {
-        // thread t = bin t: bases in (bin major, wave minor) order
-        uint32_t c[SEED_WAVES], tot = 0;
+        // bases in (bin major, wave minor) order, SEED_BLOCK bins per round
+        uint32_t carry = 0;
+        for (uint32_t b0 = 0; b0 < nbins; b0 += SEED_BLOCK) {
+            const uint32_t bin = b0 + threadIdx.x;
+            const bool in = bin < nbins;
+            uint32_t c[SEED_WAVES], tot = 0;
 #pragma unroll
-        for (int q = 0; q < SEED_WAVES; ++q) { c[q] = hist[q][threadIdx.x]; tot += c[q]; }
-        uint32_t all;
-        uint32_t ex = block_excl_scan(tot, wtot, &all);
+            for (int q = 0; q < SEED_WAVES; ++q) { c[q] = in ? hist[q][bin] : 0u; tot += c[q]; }
+            uint32_t all;
+            uint32_t ex = carry + block_excl_scan(tot, wtot, &all);
+            if (in) {
 #pragma unroll
-        for (int q = 0; q < SEED_WAVES; ++q) { hist[q][threadIdx.x] = ex; ex += c[q]; }
+                for (int q = 0; q < SEED_WAVES; ++q) { hist[q][bin] = ex; ex += c[q]; }
+            }
+            carry += all;
+        }
     }
     __syncthreads();
     volatile uint32_t* cur = hist[w];
@@ -974,7 +988,7 @@ static int seed_batch(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref
     if (Htot > 0) {
         LAUNCH(c, "seed_emit", seed_emit, ns, SEED_BLOCK, 0, (const mhip_offset_t*)reads->d_offs, rb, stride, (const int32_t*)idx->d_offsets, A);
         const int nbits = bits_for((uint32_t)(ref->num_bases / ZV));
-        const int npass = (nbits + 7) / 8;
+        const int npass = (nbits + SORT_MAXBITS - 1) / SORT_MAXBITS;
         const int per = (nbits + npass - 1) / npass;
         int done = 0;
         for (int p = 0; p < npass; ++p) {

@@ -454,7 +454,12 @@ int main(int argc, char* argv[]) {
     std::thread gpu_setup([&]() {
         TraceTimer tt("ctx_create+reserve (background)");
         mhip_ctx* made = NULL;
-        if (mhip_ctx_create(device, NULL, &made) != 0) {
+        int rc = -1;
+        for (int attempt = 0; attempt < 3 && rc != 0; ++attempt) {      // several processes opening a cold device at once can see a transient failure
+            if (attempt) usleep(300 * 1000);
+            rc = mhip_ctx_create(device, NULL, &made);
+        }
+        if (rc != 0) {
             ctx_error = mhip_last_error();
             ctx_state.store(-1);
             return;

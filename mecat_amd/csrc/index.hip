@@ -606,7 +606,8 @@ __global__ __launch_bounds__(BIN_THREADS) void idx_bin_starts(const uint32_t* __
 // the reference's fill order is ascending position and is load-bearing), and the slice is written out in one coalesced
 // sweep.  A sub-bin with more kept positions than SUB_CAP (possible up to 256 x 128) does the same directly in global memory.
 __global__ __launch_bounds__(SUB_THREADS) void idx_sub_fill(const uint64_t* __restrict__ ent3, const uint32_t* __restrict__ sub_base,
-                                                            const uint32_t* __restrict__ starts, int32_t* __restrict__ offsets) {
+                                                            const uint32_t* __restrict__ starts, int32_t* __restrict__ offsets,
+                                                            uint16_t* __restrict__ slots) {
     __shared__ uint32_t lstart[IDS_PER_SUB + 1];
     __shared__ uint32_t cursor[IDS_PER_SUB];
     __shared__ int32_t buf[SUB_CAP];
@@ -639,9 +640,17 @@ __global__ __launch_bounds__(SUB_THREADS) void idx_sub_fill(const uint64_t* __re
         if (in_lds) sort_wave_buckets(lstart[id], lstart[id + 1], buf);
         else sort_wave_buckets(lstart[id], lstart[id + 1], gdst);
     }
+    // positions out, and with them each position's slot in the seeding stage's relevance table: (position / ZV) mod 2^15, ZV = 2000
+    __syncthreads();
     if (in_lds) {
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < total; i += SUB_THREADS) gdst[i] = buf[i];
+        for (uint32_t i = threadIdx.x; i < total; i += SUB_THREADS) {
+            const int32_t pos = buf[i];
+            gdst[i] = pos;
+            slots[first + i] = (uint16_t)(((uint32_t)pos / 2000u) & 0x7FFFu);
+        }
+    } else {
+        __threadfence_block();
+        for (uint32_t i = threadIdx.x; i < total; i += SUB_THREADS) slots[first + i] = (uint16_t)(((uint32_t)gdst[i] / 2000u) & 0x7FFFu);
     }
 }
 
@@ -716,8 +725,9 @@ static int index_build_binned(mhip_ctx* c, const mhip_volume* v, mhip_index* idx
     if (dev_alloc_recycled(c->device, sizeof(int32_t) * ((size_t)total + 64), (void**)&idx->d_offsets, &idx->cap_offsets)) return -1;
     TRACE("malloc offsets");
     HIPCHK(hipMemcpyAsync(idx->d_starts + NKMER, d_binout + NFINE, sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    if (dev_alloc_recycled(c->device, sizeof(uint16_t) * ((size_t)total + 64), (void**)&idx->d_slots, &idx->cap_slots)) return -1;
     LAUNCH(c, "idx_sub_fill", idx_sub_fill, NFINE * NSUB, SUB_THREADS, 0, (const uint64_t*)d_e1, (const uint32_t*)d_subbase,
-           (const uint32_t*)idx->d_starts, idx->d_offsets);
+           (const uint32_t*)idx->d_starts, idx->d_offsets, idx->d_slots);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     TRACE("bin_fill");
@@ -741,7 +751,7 @@ __global__ __launch_bounds__(256) void idx_slots(const int32_t* __restrict__ off
 // The relevance filter of the seeding stage only needs each position's 2 kb-segment slot (15 bits): a second array at half the
 // bytes halves the sectors its bucket walk touches.
 static int index_add_slots(mhip_ctx* c, mhip_index* idx) {
-    if (idx->num_kmers <= 0) return 0;
+    if (idx->num_kmers <= 0 || idx->d_slots) return 0;      // the binned build writes the slots with the positions
     if (dev_alloc_recycled(c->device, sizeof(uint16_t) * ((size_t)idx->num_kmers + 64), (void**)&idx->d_slots, &idx->cap_slots)) return -1;
     LAUNCH(c, "idx_slots", idx_slots, (unsigned)((idx->num_kmers + 1023) / 1024), 256, 0, (const int32_t*)idx->d_offsets, idx->num_kmers,
            idx->d_slots);

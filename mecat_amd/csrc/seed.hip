@@ -1017,7 +1017,7 @@ static bool filter_enabled(const mhip_params* P) {
 // so larger batches are what fills the chip.
 static int next_batch_end(const mhip_index* idx, const mhip_volume* reads, int rid0, int stride, int rb, int re, const mhip_params* P) {
     const double hits_per_lookup = (double)idx->num_kmers / (double)NKMER + 2.0;
-    double budget = filter_enabled(P) ? 1.6e9 : 200e6;   // ~12 GB of batch arrays either way
+    double budget = filter_enabled(P) ? 3.2e9 : 400e6;   // ~25 GB of batch arrays either way (1.6e9: 5 ms more per config-2 pass, tail of the one-wave-per-read kernel)
     if (const char* e = getenv("MECAT_SEED_BATCH_HITS")) budget = std::max(1e6, atof(e));   // tuning knob
     double acc = 0;
     int r = rb;

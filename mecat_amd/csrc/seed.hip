@@ -548,9 +548,12 @@ __global__ __launch_bounds__(SEED_BLOCK) void seed_build(SeedArrays A, int sorte
         uint64_t key = in ? S[i] : 0, prev = (in && i > 0) ? S[i - 1] : 0;
         bool head = in && (i == 0 || key_seg(key) != key_seg(prev));
         bool rec = in && (head || key_km(key) != key_km(prev));
-        uint32_t rtot, stot;
-        uint32_t rpos = rec_run + block_excl_scan(rec ? 1u : 0u, wtot, &rtot);
-        uint32_t spos = seg_run + block_excl_scan(head ? 1u : 0u, wtot, &stot);
+        // one scan for both counts: recorded events in the low half, segment heads in the high half (<= 256 each per round)
+        uint32_t both;
+        const uint32_t ex = block_excl_scan((rec ? 1u : 0u) | (head ? 0x10000u : 0u), wtot, &both);
+        const uint32_t rtot = both & 0xFFFFu, stot = both >> 16;
+        uint32_t rpos = rec_run + (ex & 0xFFFFu);
+        uint32_t spos = seg_run + (ex >> 16);
         if (rec) ent[rpos] = (key_off(key) << 16) | ((key_km(key) + 1u) & 0xFFFFu);
         if (head) {
             seg_id[spos] = key_seg(key);

@@ -475,8 +475,10 @@ __device__ void replay_overflow(const uint32_t* __restrict__ ev, int c, uint32_t
     if (lane < SM) { uint32_t e = ev[lane]; loc = ent_loc(e); seed = ent_seed(e); }
     for (int e = lane; e < SM; e += 64) esc[e] = (uint16_t)(e + 1);
     int score = SM;
+    uint32_t evreg = 0;                      // events e0 .. e0 + 63, one per lane: no load latency inside the serial replay
     for (int e = SM; e < c; ++e) {
-        uint32_t ne = ev[e];
+        if (((e - SM) & 63) == 0) evreg = e + lane < c ? ev[e + lane] : 0u;
+        const uint32_t ne = (uint32_t)__builtin_amdgcn_readlane((int)evreg, (e - SM) & 63);
         const int nloc = ent_loc(ne), nseed = ent_seed(ne);
         ++score;   // loc = ++spr->score (pw_impl.cpp:267)
         // element 40 of the 41-entry working list is the new seed
@@ -490,7 +492,7 @@ __device__ void replay_overflow(const uint32_t* __restrict__ ev, int c, uint32_t
         } else {
             int sc = 0;
             for (int i = 0; i < SM; ++i) {
-                int li = __shfl(myloc, i), si = __shfl(myseed, i);
+                const int li = __builtin_amdgcn_readlane(myloc, i), si = __builtin_amdgcn_readlane(myseed, i);      // entry i lives in lane i
                 bool pass = lane > i && lane <= SM && myseed - si > 0 && myloc - li > 0 && ddf_insert(myloc - li, myseed - si, cutoff);
                 uint64_t b = __ballot(pass);
                 sc += pass ? 1 : 0;

@@ -471,13 +471,39 @@ __device__ __forceinline__ bool ddf_find_quarter(int dloc, int dseed) { return 2
 __device__ void replay_overflow(const uint32_t* __restrict__ ev, int c, uint32_t* __restrict__ fin, uint16_t* __restrict__ esc,
                                 double cutoff, int* score_out) {
     const int lane = lane_id();
+    // The events up to the first one that leaves the exact diagonal of its predecessor (strictly increasing seed numbers, loc
+    // advancing by BC per seed) need no replay: while the working list is one exact chain every pair passes, the minimum
+    // is SM, and the new event just replaces the last entry (the fast path below).  A read against its own copy in the
+    // volume is the common overflow and is such a chain from end to end.  brk = length of that prefix.
+    int brk = c;
+    for (int i0 = 1; i0 < c && brk == c; i0 += 64) {
+        const int i = i0 + lane;
+        bool bad = false;
+        if (i < c) {
+            const uint32_t a = ev[i - 1], b = ev[i];
+            const int ds = ent_seed(b) - ent_seed(a), dl = ent_loc(b) - ent_loc(a);
+            bad = !(ds > 0 && dl == ds * BC);
+        }
+        const unsigned long long bm = __ballot(bad);
+        if (bm) brk = i0 + __builtin_ctzll(bm);
+    }
     int loc = 0, seed = 0;
-    if (lane < SM) { uint32_t e = ev[lane]; loc = ent_loc(e); seed = ent_seed(e); }
-    for (int e = lane; e < SM; e += 64) esc[e] = (uint16_t)(e + 1);
-    int score = SM;
-    uint32_t evreg = 0;                      // events e0 .. e0 + 63, one per lane: no load latency inside the serial replay
-    for (int e = SM; e < c; ++e) {
-        if (((e - SM) & 63) == 0) evreg = e + lane < c ? ev[e + lane] : 0u;
+    int score = SM, start = SM;
+    if (brk > SM) {                          // state after the events SM .. brk - 1: entries 0 .. 38 and the last event of the prefix
+        start = brk;
+        score = brk;
+        if (lane < SM) { const uint32_t e = ev[lane < SM - 1 ? lane : brk - 1]; loc = ent_loc(e); seed = ent_seed(e); }
+        for (int e = lane; e < brk; e += 64) esc[e] = (uint16_t)(e + 1);
+    } else {
+        if (lane < SM) { const uint32_t e = ev[lane]; loc = ent_loc(e); seed = ent_seed(e); }
+        for (int e = lane; e < SM; e += 64) esc[e] = (uint16_t)(e + 1);
+    }
+    uint32_t evreg = 0;                      // events of the current 64-chunk, one per lane: no load latency inside the serial replay
+    for (int e = start; e < c; ++e) {
+        if (((e - SM) & 63) == 0 || e == start) {
+            const int base = SM + ((e - SM) & ~63);
+            evreg = base + lane < c ? ev[base + lane] : 0u;
+        }
         const uint32_t ne = (uint32_t)__builtin_amdgcn_readlane((int)evreg, (e - SM) & 63);
         const int nloc = ent_loc(ne), nseed = ent_seed(ne);
         ++score;   // loc = ++spr->score (pw_impl.cpp:267)

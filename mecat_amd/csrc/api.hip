@@ -198,6 +198,26 @@ int mhip_volume_upload(mhip_ctx* c, const uint8_t* pac, const mhip_offset_t* off
     if (nb) HIPCHK(hipMemcpyAsync(v->d_pac, pac, nb, hipMemcpyHostToDevice, c->stream));
     v->h_offs.assign(offs, offs + num_reads);
     if (num_reads) HIPCHK(hipMemcpyAsync(v->d_offs, offs, sizeof(mhip_offset_t) * (size_t)num_reads, hipMemcpyHostToDevice, c->stream));
+    // position -> read without a binary search over the offsets (get_read_id_from_offset_list, common/split_database.cpp:15-35,
+    // is 17 dependent loads at volume size): table entry b = the read that holds base 1024 b
+    std::vector<uint32_t> blk((size_t)(num_bases >> 10) + 2, 0u);
+    {
+        uint32_t last = 0;
+        size_t filled = 0;
+        for (int r = 0; r < num_reads; ++r) {
+            const size_t b0 = ((size_t)offs[r].offset + 1023) >> 10, b1 = ((size_t)offs[r].offset + (size_t)std::max(offs[r].size, 1) - 1) >> 10;
+            for (; filled < b0 && filled < blk.size(); ++filled) blk[filled] = last;      // bases between reads: the read before
+            for (size_t b = b0; b <= b1 && b < blk.size(); ++b) { blk[b] = (uint32_t)r; filled = b + 1; }
+            last = (uint32_t)r;
+        }
+        for (; filled < blk.size(); ++filled) blk[filled] = last;
+    }
+    if (hipMalloc((void**)&v->d_blk2read, sizeof(uint32_t) * blk.size()) != hipSuccess) {
+        mhip_set_error("hipMalloc failed for the read lookup table");
+        mhip_volume_free(v);
+        return -1;
+    }
+    HIPCHK(hipMemcpyAsync(v->d_blk2read, blk.data(), sizeof(uint32_t) * blk.size(), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     *out = v;
     return 0;
@@ -208,6 +228,7 @@ void mhip_volume_free(mhip_volume* v) {
     (void)hipSetDevice(v->device);
     if (v->d_pac) (void)hipFree(v->d_pac);
     if (v->d_offs) (void)hipFree(v->d_offs);
+    if (v->d_blk2read) (void)hipFree(v->d_blk2read);
     delete v;
 }
 

@@ -71,6 +71,7 @@ struct mhip_volume {
     int start_read_id = 0;
     uint32_t* d_pac = nullptr;  // 2-bit store as big-endian-in-byte bytes, padded with >= 64 zero bytes
     mhip_offset_t* d_offs = nullptr;
+    uint32_t* d_blk2read = nullptr;   // [num_bases / 1024 + 2] read holding base 1024 b (or the one before it when that base is a pad)
     std::vector<mhip_offset_t> h_offs;
     size_t pac_bytes = 0;
 };

@@ -704,8 +704,21 @@ __device__ __forceinline__ int read_id_from_offset(const mhip_offset_t* __restri
     return mid;
 }
 
+// The same answer from the volume's block table for every position inside a read (the only positions a k-mer hit can have):
+// entry b is the read holding base 1024 b, so the read of `offset` is that one or one of the next few.  Anything else (a pad
+// base, the "unset" location 0 of find_location landing between reads) takes the literal search.
+__device__ __forceinline__ int read_id_lookup(const mhip_offset_t* __restrict__ a, int n, const uint32_t* __restrict__ blk, int offset) {
+    if (offset >= 0) {
+        int r = (int)blk[offset >> 10];
+        while (r + 1 < n && a[r].offset + a[r].size <= offset) ++r;
+        const int o = a[r].offset, z = a[r].size;
+        if (o <= offset && o + z > offset) return r;
+    }
+    return read_id_from_offset(a, n, offset);
+}
+
 // one wave per read: F strand then R strand into one top-MAXC list kept in LDS (12 ints per entry)
-__global__ __launch_bounds__(WAVE) void seed_cand(SeedArrays A, const mhip_offset_t* __restrict__ ref_offs, int ref_nreads,
+__global__ __launch_bounds__(WAVE) void seed_cand(SeedArrays A, const mhip_offset_t* __restrict__ ref_offs, const uint32_t* __restrict__ ref_blk, int ref_nreads,
                                                   int ref_start_id, const mhip_offset_t* __restrict__ roffs, int rid_begin, int rid_stride,
                                                   int reads_start_id, mhip_params P, mhip_candidate* __restrict__ out,
                                                   int32_t* __restrict__ out_counts, unsigned long long* __restrict__ counters) {
@@ -820,7 +833,7 @@ __global__ __launch_bounds__(WAVE) void seed_cand(SeedArrays A, const mhip_offse
             if (vote < 2 * P.min_kmer_match + 2) continue;
             const int loc_seed = T->t_seed[rep_loc];
             const int loc_list = start_loc + T->t_loc[rep_loc];
-            int sid = read_id_from_offset(ref_offs, ref_nreads, loc_list);
+            int sid = read_id_lookup(ref_offs, ref_nreads, ref_blk, loc_list);
             const int sstart = ref_offs[sid].offset, ssize = ref_offs[sid].size;
             const int send = sstart + ssize + 1;
             sid += ref_start_id;
@@ -1031,7 +1044,8 @@ static int seed_batch(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref
     }
     LAUNCH(c, "seed_build", seed_build, ns, SEED_BLOCK, 0, A, in_b, (int)P->min_kmer_match, P->ddfs_cutoff);
     const size_t lds = sizeof(int) * 12 * (size_t)P->maxc + sizeof(CandLds);
-    LAUNCH(c, "seed_cand", seed_cand, nr, WAVE, lds, A, (const mhip_offset_t*)ref->d_offs, ref->num_reads, ref->start_read_id,
+    LAUNCH(c, "seed_cand", seed_cand, nr, WAVE, lds, A, (const mhip_offset_t*)ref->d_offs, (const uint32_t*)ref->d_blk2read, ref->num_reads,
+           ref->start_read_id,
            (const mhip_offset_t*)reads->d_offs, rb, stride, reads->start_read_id, *P, d_out, d_counts, (unsigned long long*)c->d_counters);
     HIPCHK(hipGetLastError());
     return 0;

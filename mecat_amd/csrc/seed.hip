@@ -750,21 +750,38 @@ __global__ __launch_bounds__(WAVE) void seed_cand(SeedArrays A, const mhip_offse
 #define SEG_SCORE(g) (seg_score[g] & ~OVF_FLAG)
 #define SET_SCORE(g, v) seg_score[g] = (seg_score[g] & OVF_FLAG) | (v)
 
+        // The immutable part of the next gated segment's record (its index, segment ids, list starts) is fetched one iteration
+        // ahead: the walk is a chain of dependent loads (gated -> ids/starts -> scores -> lists), and the scores alone have to
+        // be read fresh (earlier iterations zero them).
+        int g_n = 0, seg_n = 0, segm1_n = -1;
+        uint32_t st_n = 0, stm1_n = 0;
+        auto prefetch = [&](int gi) {
+            g_n = (int)gated[gi];
+            seg_n = (int)seg_id[g_n];
+            st_n = seg_start[g_n];
+            segm1_n = g_n > 0 ? (int)seg_id[g_n - 1] : -1;
+            stm1_n = g_n > 0 ? seg_start[g_n - 1] : 0u;
+        };
+        if (ng > 0) prefetch(0);
         for (int gi = 0; gi < ng; ++gi) {
-            const int g = (int)gated[gi];
-            const int seg = (int)seg_id[g];
-            int s_k = SEG_SCORE(g);
+            const int g = g_n, seg = seg_n, segm1 = segm1_n;
+            const uint32_t st_g = st_n, st_gm1 = stm1_n;
+            if (gi + 1 < ng) prefetch(gi + 1);
+            const int raw_g = seg_score[g];
+            int s_k = raw_g & ~OVF_FLAG;
             if (s_k == 0) continue;
             int start_loc = seg * ZV;
-            int loc = 0;
-            const bool has_left = seg > 0 && g > 0 && seg_id[g - 1] == (uint32_t)(seg - 1);
-            if (has_left) loc = SEG_SCORE(g - 1);
+            int loc = 0, raw_gm1 = 0;
+            const bool has_left = seg > 0 && g > 0 && segm1 == seg - 1;
+            if (has_left) { raw_gm1 = seg_score[g - 1]; loc = raw_gm1 & ~OVF_FLAG; }
             if (loc > 0) start_loc = (seg - 1) * ZV;
             const int n1 = loc > 0 ? min(loc, SM) : 0, n2 = min(s_k, SM);
             const int k = n1 + n2;
+            const uint32_t* list_g = ((raw_g & OVF_FLAG) ? fin : ent) + st_g;
+            const uint32_t* list_gm1 = ((raw_gm1 & OVF_FLAG) ? fin : ent) + st_gm1;
             __syncthreads();
             for (int i = lane; i < k; i += 64) {
-                uint32_t e = i < n1 ? SEG_LIST(g - 1)[i] : SEG_LIST(g)[i - n1];
+                uint32_t e = i < n1 ? list_gm1[i] : list_g[i - n1];
                 T->t_loc[i] = ent_loc(e) + ((i >= n1 && loc > 0) ? ZV : 0);
                 T->t_seed[i] = ent_seed(e);
             }

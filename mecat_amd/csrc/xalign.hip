@@ -412,7 +412,16 @@ __device__ void xdrop_block_w(XwLds<HFN>& S, const XView& q, int qidx, int M, co
     // ---- traceback (:165-210) fused with script_to_aligned_string + trim_mismatch_end, as in the lane kernel
     __threadfence();
     __builtin_amdgcn_wave_barrier();
-    const volatile uint32_t* stw = (const volatile uint32_t*)st;
+    // window reload: the bytes were written by this wave, so they are read past the L1 (agent scope) — all XW_WIN / 256 loads of a
+    // lane in flight at once (volatile loads would serialise one memory round trip each)
+    auto load_window = [&](int word0) {
+        constexpr int NW = XW_WIN / 4 / 64;
+        uint32_t v[NW];
+#pragma unroll
+        for (int j = 0; j < NW; ++j) v[j] = __hip_atomic_load((const uint32_t*)st + word0 + lane + 64 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int j = 0; j < NW; ++j) S.win[lane + 64 * j] = v[j];
+    };
     int wbase = 1 << 30;                                 // first scratch byte in the LDS window; nothing loaded yet
     // row registers: lane l holds the bytes of cells rstart + l and rstart + 64 + l
     auto fetch_row = [&](int a, int& r, int& rs) {
@@ -421,7 +430,7 @@ __device__ void xdrop_block_w(XwLds<HFN>& S, const XView& q, int qidx, int M, co
         if (off < wbase) {
             __builtin_amdgcn_wave_barrier();
             wbase = max(off + XW_STRIDE - XW_WIN, 0);
-            for (int w = lane; w < XW_WIN / 4; w += 64) S.win[w] = stw[wbase / 4 + w];
+            load_window(wbase / 4);
             __builtin_amdgcn_wave_barrier();
         }
         const uint8_t* wb = (const uint8_t*)S.win + (off - wbase);
@@ -433,7 +442,7 @@ __device__ void xdrop_block_w(XwLds<HFN>& S, const XView& q, int qidx, int M, co
         if (idx < wbase || idx >= wbase + XW_WIN) {
             __builtin_amdgcn_wave_barrier();
             wbase = max(((idx + 4) & ~3) - XW_WIN, 0);
-            for (int w = lane; w < XW_WIN / 4; w += 64) S.win[w] = stw[wbase / 4 + w];
+            load_window(wbase / 4);
             __builtin_amdgcn_wave_barrier();
         }
         return __builtin_amdgcn_readfirstlane((int)((const uint8_t*)S.win)[idx - wbase]);
@@ -481,7 +490,7 @@ __device__ void xdrop_block_w(XwLds<HFN>& S, const XView& q, int qidx, int M, co
             if (a_index < wlo || a_index >= wlo + WROWS || (wlo > 0 && a_index - wlo < 12)) {
                 __builtin_amdgcn_wave_barrier();
                 wlo = max(a_index - (WROWS - 1), 0);
-                for (int w = lane; w < XW_WIN / 4; w += 64) S.win[w] = stw[wlo * (XW_STRIDE / 4) + w];
+                load_window(wlo * (XW_STRIDE / 4));
                 __builtin_amdgcn_wave_barrier();
             }
             const int ri = a_index - lane, bi = b_index - lane;

@@ -5,6 +5,7 @@
 #include "options.h"
 
 #include <dirent.h>
+#include <errno.h>
 #include <getopt.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -110,7 +111,8 @@ int parse_arguments(int argc, char* argv[], Options* o) {
 
     DIR* dir = opendir(o->wrk_dir);
     if (dir == NULL) {
-        if (mkdir(o->wrk_dir, S_IRWXU) == -1) { LOGF("fail to create folder '%s'!", o->wrk_dir); exit(1); }
+        // (EEXIST: another process of a multi-process run created it between the two calls)
+        if (mkdir(o->wrk_dir, S_IRWXU) == -1 && errno != EEXIST) { LOGF("fail to create folder '%s'!", o->wrk_dir); exit(1); }
     } else closedir(dir);
     return 0;
 }

@@ -62,22 +62,23 @@ __device__ __forceinline__ int cns_load_window(CnsLds& S, const volatile uint16_
     const unsigned long long fits = __ballot(rr >= 0 && incl <= CN_RING);
     const int count = __popcll(fits);                      // a prefix of the lanes: incl is non-decreasing; >= 1 (a row has <= 181 cells)
     if (lane < count) S.woff[rr & 63] = (uint16_t)(incl - ns);
-    // the rows were written by this wave; they are read back past the L1 (agent scope), eight rows in flight at a time
+    // the rows were written by this wave; they are read back past the L1 (agent scope), CN_INFLIGHT rows in flight at a time (more spill registers)
     auto ld = [&](int row, int c) -> uint16_t {
         return __hip_atomic_load((const uint16_t*)grow + (size_t)row * CN_ROW_W + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
-    for (int i0 = 0; i0 < count; i0 += 8) {
-        uint16_t v[8];
-        int n8[8], o8[8];
+    constexpr int CN_INFLIGHT = 6;
+    for (int i0 = 0; i0 < count; i0 += CN_INFLIGHT) {
+        uint16_t v[CN_INFLIGHT];
+        int n8[CN_INFLIGHT], o8[CN_INFLIGHT];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < CN_INFLIGHT; ++j) {
             const int i = min(i0 + j, count - 1);
             n8[j] = i0 + j < count ? __shfl(ns, i) : 0;
             o8[j] = __shfl(incl - ns, i);
             v[j] = lane < n8[j] ? ld(r - i, lane) : (uint16_t)0;
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < CN_INFLIGHT; ++j) {
             if (lane < n8[j]) S.ring[o8[j] + lane] = v[j];
             for (int c = 64 + lane; c < n8[j]; c += 64) S.ring[o8[j] + c] = ld(r - (i0 + j), c);      // rows wider than 64 cells
         }

@@ -32,11 +32,14 @@
 struct CnsLds {
     uint32_t Qp[CN_SEQ_WORDS];
     uint32_t Tp[CN_SEQ_WORDS];
-    int16_t V[CN_VLEN];
+    union {
+        int16_t V[CN_VLEN];        // forward rows
+        uint16_t tlen[CN_MAX_D];   // afterwards, the path: snake length of the row, bit 15 = the row's indel is a query-only column
+    };
     int16_t rmin[CN_MAX_D], rmax[CN_MAX_D];
     uint16_t woff[64];             // traceback: offset of row r in the window, at r mod 64 (a window holds <= 64 consecutive rows)
     uint16_t ring[CN_RING];        // the row window; after the walk: columns before row r's snake, at r
-    uint16_t tlen[CN_MAX_D];       // the path: snake length of the row, bit 15 = the row's indel is a query-only column
+    uint16_t roff[CN_MAX_D];       // where row d starts in the wave's global scratch, in pairs of cells (rows are packed back to back, even length)
 };
 
 static_assert(CN_RING >= CN_MAX_D, "the ring doubles as the per-row column prefix");
@@ -49,40 +52,27 @@ __device__ __forceinline__ int cns_cell(const CnsLds& S, int r, int k) {
     return (int)S.ring[(int)S.woff[r & 63] + ((k - (int)S.rmin[r]) >> 1)];
 }
 
-// rows in the window ending at row r (going down): as many of r, r - 1, ... (at most 64) as fit CN_RING cells.  Copies them
-// from the global scratch into the ring, sets woff[]; returns the lowest row loaded.
-__device__ __forceinline__ int cns_load_window(CnsLds& S, const volatile uint16_t* grow, int r, int lane) {
+// rows in the window ending at row r (going down): as many of r, r - 1, ... (at most 64) as fit CN_RING cells.  The rows lie
+// back to back in the global scratch, so the window is one contiguous range: it is copied with full-wave 32-bit loads, all in
+// flight at once (the rows were written by this wave: agent scope, past the L1).  Sets woff[]; returns the lowest row loaded.
+__device__ __forceinline__ int cns_load_window(CnsLds& S, const uint16_t* grow, int r, int lane) {
+    const int ns_r = S.rmax[r] >= S.rmin[r] ? (((int)S.rmax[r] - (int)S.rmin[r]) >> 1) + 1 : 0;
+    const int end = 2 * (int)S.roff[r] + ns_r;
     const int rr = r - lane;
-    const int ns = rr >= 0 && S.rmax[rr] >= S.rmin[rr] ? (((int)S.rmax[rr] - (int)S.rmin[rr]) >> 1) + 1 : 0;
-    int incl = ns;
-    for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o);
-        if (lane >= o) incl += v;
-    }
-    const unsigned long long fits = __ballot(rr >= 0 && incl <= CN_RING);
-    const int count = __popcll(fits);                      // a prefix of the lanes: incl is non-decreasing; >= 1 (a row has <= 181 cells)
-    if (lane < count) S.woff[rr & 63] = (uint16_t)(incl - ns);
-    // the rows were written by this wave; they are read back past the L1 (agent scope), CN_INFLIGHT rows in flight at a time (more spill registers)
-    auto ld = [&](int row, int c) -> uint16_t {
-        return __hip_atomic_load((const uint16_t*)grow + (size_t)row * CN_ROW_W + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
-    constexpr int CN_INFLIGHT = 6;
-    for (int i0 = 0; i0 < count; i0 += CN_INFLIGHT) {
-        uint16_t v[CN_INFLIGHT];
-        int n8[CN_INFLIGHT], o8[CN_INFLIGHT];
+    const int start = rr >= 0 ? 2 * (int)S.roff[rr] : 0;
+    const unsigned long long fits = __ballot(rr >= 0 && end - start <= CN_RING);
+    const int count = __popcll(fits);                      // a prefix of the lanes (start decreases with the lane); >= 1 (a row has <= 182 cells)
+    const int base = 2 * (int)S.roff[r - count + 1];
+    if (lane < count) S.woff[rr & 63] = (uint16_t)(start - base);
+    const int words = (end - base + 1) >> 1;               // <= CN_RING / 2
+    const uint32_t* g32 = (const uint32_t*)grow + (base >> 1);
+    constexpr int NW = CN_RING / 2 / 64;
+    uint32_t v[NW];
 #pragma unroll
-        for (int j = 0; j < CN_INFLIGHT; ++j) {
-            const int i = min(i0 + j, count - 1);
-            n8[j] = i0 + j < count ? __shfl(ns, i) : 0;
-            o8[j] = __shfl(incl - ns, i);
-            v[j] = lane < n8[j] ? ld(r - i, lane) : (uint16_t)0;
-        }
+    for (int j = 0; j < NW; ++j) v[j] = lane + 64 * j < words ? __hip_atomic_load(g32 + lane + 64 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
 #pragma unroll
-        for (int j = 0; j < CN_INFLIGHT; ++j) {
-            if (lane < n8[j]) S.ring[o8[j] + lane] = v[j];
-            for (int c = 64 + lane; c < n8[j]; c += 64) S.ring[o8[j] + c] = ld(r - (i0 + j), c);      // rows wider than 64 cells
-        }
-    }
+    for (int j = 0; j < NW; ++j)
+        if (lane + 64 * j < words) ((uint32_t*)S.ring)[lane + 64 * j] = v[j];
     return r - count + 1;
 }
 
@@ -137,10 +127,11 @@ __global__ __launch_bounds__(CN_BLOCK, 6) void cns_extend(const uint32_t* __rest
             // ---- Align, forward rows (:172-210)
             int best_m = -1, min_k = 0, max_k = 0;
             int end_d = -1, end_k = 0, end_x = 0;
+            int cum = 0;                                 // cells of the rows written so far (every row padded to an even length)
             for (int d = 0; d < max_d; ++d) {
                 if (max_k - min_k > band_size) break;
                 const int nslot = max_k >= min_k ? ((max_k - min_k) >> 1) + 1 : 0;
-                if (lane == 0) { S.rmin[d] = (int16_t)min_k; S.rmax[d] = (int16_t)max_k; }
+                if (lane == 0) { S.rmin[d] = (int16_t)min_k; S.rmax[d] = (int16_t)max_k; S.roff[d] = (uint16_t)(cum >> 1); }
                 int mmax = -1, hkey = 0x7fffffff;
                 constexpr int MAXJ = (CN_ROW_W + 63) / 64;
                 int us[MAXJ];
@@ -167,7 +158,7 @@ __global__ __launch_bounds__(CN_BLOCK, 6) void cns_extend(const uint32_t* __rest
                     } while (__ballot(again));
                     us[j] = act ? x + y : -0x40000000;
                     if (act) {
-                        grow[(size_t)d * CN_ROW_W + tt] = (uint16_t)x;
+                        grow[cum + tt] = (uint16_t)x;
                         mmax = max(mmax, x + y);
                         if (x >= seg || y >= seg) hkey = min(hkey, (kk << 10) | x);           // lowest diagonal first (:198-199)
                     }
@@ -179,6 +170,7 @@ __global__ __launch_bounds__(CN_BLOCK, 6) void cns_extend(const uint32_t* __rest
                     const int tt = lane + 64 * j;
                     if (tt < nslot) { const int k = min_k + 2 * tt; S.V[k + koff] = (int16_t)((us[j] + k) >> 1); }
                 }
+                cum += (nslot + 1) & ~1;
                 best_m = max(best_m, wave_max(mmax));
                 if (__ballot(hkey != 0x7fffffff)) {      // some diagonal reached an end: the lowest one ends the block
                     hkey = wave_min(hkey);

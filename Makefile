@@ -29,7 +29,11 @@ $(LIBDIR)/libmecat_hip.so: $(HIP_OBJS)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(HIP_OBJS) -o $@
 
-host: $(BINDIR)/mecat2pw $(BINDIR)/mecat2cns_partition
+host: $(BINDIR)/mecat2pw $(BINDIR)/mecat2cns_partition $(BINDIR)/valu_peak
+# issue-rate calibration for bench.py's dw roofline (measures, computes nothing of the path)
+$(BINDIR)/valu_peak: mecat_amd/tools/valu_peak.hip
+	@mkdir -p $(BINDIR)
+	$(HIPCC) --offload-arch=$(ARCH) -O3 $< -o $@
 $(BINDIR)/mecat2pw: $(HOST_SRCS) $(wildcard mecat_amd/host/*.h) include/mecat_hip.h $(LIBDIR)/libmecat_hip.so
 	@mkdir -p $(BINDIR)
 	$(CXX) -O2 -std=c++17 -pthread -Wall -Iinclude $(HOST_SRCS) -L$(LIBDIR) -lmecat_hip -Wl,-rpath,'$$ORIGIN/../lib' -o $@

@@ -53,7 +53,9 @@ def cpu_baseline(workload, nthreads):
     fa = os.path.join(d, "s.fa")
     W.write_fasta(fa, codes, lens)
     ref = os.path.join(ROOT, "oracle", "_ref", "mecat2pw")
-    sample = "%d reads x %d bp @ %.0f%% error, genome %d (same coverage), seed %d" % (sn, L, err * 100, sG, seed)
+    sample = ("%d reads x %d bp @ %.0f%% error, genome %d (same coverage), seed %d; the sampled volume (%.2f Gbase) is %.1fx smaller than "
+              "%s's, so random 13-mer hits per lookup are that much fewer: the CPU rate is optimistic for the CPU"
+              % (sn, L, err * 100, sG, seed, sn * L * 1.05 / 1e9, n / sn, workload))
     if os.path.exists(ref):
         res = {}
         for task, name in ((0, "can"), (1, "m4")):
@@ -75,17 +77,117 @@ def cpu_baseline(workload, nthreads):
         return {"value": ncan / hot0, "unit": "candidates/s", "cores": nthreads, "kind": "reference", "sample": sample,
                 "candidates": ncan, "hot_path_s": hot0, "wall_s": wall0,
                 "j1_overlaps_per_s": nm4 / hot1, "j1_aligned_gbase_per_s": abases / 1e9 / hot1, "j1_hot_path_s": hot1}
-    # fall back to the oracle port (single thread)
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import helpers as H
-    ov = H.orc_pack(codes, lens)
+    # no reference build on this host: the oracle port (oracle/liboracle.so, single thread) on a smaller sample
+    sn2 = min(sn, 2000)
+    codes, lens = W.synth_reads(sn2, L, err, max(int(G * sn2 / n), 2 * L), seed, ont)
     t0 = time.time()
-    oidx = H.orc().orc_index_build(ov)
-    cands = H.orc_seed_all(ov, ov, oidx, H.orc_params(tech=ont))
+    ncan = oracle_port_candidates(codes, lens, ont)
     dt = time.time() - t0
-    ncan = sum(len(a) for a in cands)
-    return {"value": ncan / dt, "unit": "candidates/s", "cores": 1, "kind": "port", "sample": sample, "candidates": ncan,
-            "hot_path_s": dt}
+    return {"value": ncan / dt, "unit": "candidates/s", "cores": 1, "kind": "port", "sample": "%d reads x %d bp (oracle port)" % (sn2, L),
+            "candidates": ncan, "hot_path_s": dt}
+
+
+def oracle_port_candidates(codes, lens, ont):
+    """index + candidates of every read with oracle/liboracle.so (the checker; cpu_baseline leg only)"""
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+    lib.orc_bench_candidates.restype = C.c_int64
+    lib.orc_bench_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    lens = np.ascontiguousarray(lens, dtype=np.int32)
+    return int(lib.orc_bench_candidates(codes.ctypes.data, lens.ctypes.data, len(lens), ont))
+
+
+def cpu_baseline_config1():
+    """BASELINE.json configs[0]: the reference on 1 000 x 10 kb @ 15 %, -t 4 (and -t 2: only two 500-read chunks exist)"""
+    from mecat_amd import workload as W
+    ref = os.path.join(ROOT, "oracle", "_ref", "mecat2pw")
+    if not os.path.exists(ref):
+        return None
+    n, L, err, G, seed, ont = W.CONFIGS["config1"]
+    codes, lens = W.synth_reads(n, L, err, G, seed, ont)
+    d = tempfile.mkdtemp(prefix="mecat_c1_")
+    fa = os.path.join(d, "c1.fa")
+    W.write_fasta(fa, codes, lens)
+    out = {"workload": "config1: %d reads x %d bp @ %.0f%% error, genome %d, seed %d" % (n, L, err * 100, G, seed), "kind": "reference"}
+    for t in (4, 2):
+        for task, name in ((0, "j0"), (1, "j1")):
+            o = os.path.join(d, "o_%s_%d" % (name, t))
+            t0 = time.time()
+            p = subprocess.run([ref, "-j", str(task), "-d", fa, "-o", o, "-w", os.path.join(d, "w_%s_%d" % (name, t)), "-t", str(t), "-g", "1"],
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            wall = time.time() - t0
+            if p.returncode != 0:
+                out["error"] = p.stderr[-200:]
+                return out
+            tm = dict(re.findall(r"\[([a-z_ 0-9]+)\] takes ([0-9.]+) secs", p.stderr))
+            hot = float(tm.get("create_ref_index", 0)) + float(tm.get("process volume 0", 0))
+            nl = sum(1 for _ in open(o))
+            out["%s_t%d" % (name, t)] = {"lines": nl, "hot_path_s": hot, "wall_s": wall, "lines_per_s": nl / hot if hot > 0 else None}
+    return out
+
+
+def e2e_cli(workload, codes, lens, threads):
+    """SURVEY.md §8d's second denominator: wall clock of the drop-in binary (FASTA split, H2D/D2H, kernels, text output), -j 0 and
+    -j 1 -g 1, on the same workload.  The FASTA sits in /dev/shm (or the temp dir) so that no disk speed enters."""
+    from mecat_amd import workload as W
+    exe = os.path.join(ROOT, "mecat_amd", "bin", "mecat2pw")
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    d = tempfile.mkdtemp(prefix="mecat_e2e_", dir=base)
+    res = {"threads": threads, "dir": base or "tmp"}
+    try:
+        fa = os.path.join(d, "reads.fa")
+        W.write_fasta(fa, codes, lens)
+        res["fasta_bytes"] = os.path.getsize(fa)
+        for task, name in ((0, "j0"), (1, "j1")):
+            o = os.path.join(d, "out." + name)
+            best = None
+            for rep in range(2):                     # the first run also pays the one-off page-in of the device libraries
+                w = os.path.join(d, "w_%s_%d" % (name, rep))
+                t0 = time.time()
+                p = subprocess.run([exe, "-j", str(task), "-d", fa, "-o", o, "-w", w, "-t", str(threads), "-g", "1"],
+                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                wall = time.time() - t0
+                if p.returncode != 0:
+                    res["error"] = p.stderr[-300:]
+                    return res
+                best = wall if best is None else min(best, wall)
+                subprocess.run(["rm", "-rf", w])
+            nl, ab = 0, 0
+            with open(o) as f:
+                for ln in f:
+                    nl += 1
+                    if task == 1:
+                        x = ln.split("\t", 8)
+                        ab += int(x[6]) - int(x[5])
+            if task == 0:
+                res["j0"] = {"wall_s": best, "candidates": nl, "candidates_per_s": nl / best}
+            else:
+                res["j1"] = {"wall_s": best, "overlaps": nl, "overlaps_per_s": nl / best, "aligned_gbase_per_s": ab / 1e9 / best}
+    finally:
+        subprocess.run(["rm", "-rf", d])
+    return res
+
+
+def src_digest():
+    """sha256 over the kernel sources: the committed PMC numbers are only quoted while they describe THIS code"""
+    import hashlib
+    h = hashlib.sha256()
+    cs = os.path.join(ROOT, "mecat_amd", "csrc")
+    for f in sorted(os.listdir(cs)):
+        h.update(open(os.path.join(cs, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def issue_ceilings():
+    """live calibration (mecat_amd/bin/valu_peak, ~1 s): wave64 instruction issue rates of this device, G wave-instr/s"""
+    exe = os.path.join(ROOT, "mecat_amd", "bin", "valu_peak")
+    try:
+        p = subprocess.run([exe, "3000", "v_add_u32,v_alignbit_b32,s_add_u32,ds_read_b32"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+        r = json.loads(p.stdout)["rates"]
+        return {"valu_2cycle_class": max(r["v_add_u32"]), "valu_4cycle_class": max(r["v_alignbit_b32"]), "salu": max(r["s_add_u32"]),
+                "lds": max(r["ds_read_b32"]), "source": "mecat_amd/bin/valu_peak, live"}
+    except Exception as e:      # noqa: BLE001
+        return {"error": repr(e)[:200]}
 
 
 def main():
@@ -97,6 +199,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-align", action="store_true", help="-j 0 only (index + candidates)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed cns_realign / xdrop_extend measurements")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end CLI leg (FASTA -> .can / .m4 wall clock)")
     ap.add_argument("--stats", default="", help="write per-kernel stats JSON here (rank 0)")
     args = ap.parse_args()
 
@@ -127,7 +230,8 @@ def main():
     t0 = time.time()
     codes, lens = W.synth_reads(n, L, err, G, seed, ont)
     pac, offs, num_bases = W.pack_volume(codes, lens)
-    del codes
+    if rank != 0 or world > 1 or args.no_e2e:
+        del codes
     if rank == 0:
         log("[bench] %s: %d reads, %d bases incl. pads, generated+packed in %.1fs" % (args.workload, n, num_bases, time.time() - t0))
 
@@ -158,6 +262,7 @@ def main():
         ev[0].record(stream)
         idx = M.Index(ctx, vol)
         ev[1].record(stream)
+        keep["num_kmers"] = idx.num_kmers
         M.seed_reads_strided_dev(ctx, idx, vol, vol, rank, world, n_local, params, d_cands.data_ptr(), d_counts.data_ptr())
         # exchange step: RCCL all-gather of the per-read candidate slabs (48-byte candidate_save records); with more than one
         # rank it runs on RCCL's stream while this rank extends the candidates of its own reads
@@ -230,8 +335,7 @@ def main():
         strands = 2 * n_local
         # algorithmic bytes per step, this rank's share
         N = num_bases
-        idx_obj_kmers = None
-        b_idx = 2 * (N / 4) + 3 * 4 * (1 << 26)
+        b_idx = 2 * (N / 4) + 3 * 4 * (1 << 26) + 4 * keep["num_kmers"]      # §8d: two volume passes, the 4^13 table x3, the kept positions
         b_seed = (lens.astype(np.int64)[rank::world].sum() * 2) / 4 + 8 * lookups + 4 * hits + 48 * cands_c
         b_aln = per_step("aligned_bases") * 2 / 4 + 32 * keep["njobs"]
         phase_of = {"idx": b_idx, "seed": b_seed, "dw": b_aln}
@@ -245,28 +349,53 @@ def main():
                 "algorithmic_bytes_per_launch": alg_per_launch, "avg_launch_ms": avg_ms, "launches": dl,
                 "phase_bytes_per_step": {k: float(v) for k, v in phase_of.items()},
                 "note": "algorithmic bytes of the kernel's phase (SURVEY.md §8d) / launches; scratch/sort traffic not counted"}
-        # HBM bytes of the same kernel from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command
-        # (PMC counters cannot be read from inside the run); VALU issue rate from the committed SQ_INSTS_VALU pass.
-        prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+        # HBM bytes and SQ instruction counts of the same kernel come from committed rocprofv3 --pmc passes of this command (PMC
+        # counters cannot be read from inside the run).  They are quoted only while profiles/*_pmc_source.json records the digest
+        # of the kernel sources that are compiled now; otherwise traffic stays null and the line says why.
+        prof_dir = os.path.join(ROOT, "profiles")
+        digest = src_digest()
+        roof["kernel_source_digest"] = digest
+        pmc_ok = False
         try:
-            tfile = sorted(f for f in os.listdir(prof_dir) if f.endswith("_hbm_traffic.json"))[-1]
-            t = json.load(open(os.path.join(prof_dir, tfile))).get(dname)
-            if t and args.workload == "config2" and world == 1:
-                roof["traffic"] = t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]
-                roof["traffic_source"] = "profiles/" + tfile
+            sfile = sorted(f for f in os.listdir(prof_dir) if f.endswith("_pmc_source.json"))[-1]
+            meta = json.load(open(os.path.join(prof_dir, sfile)))
+            pmc_ok = meta.get("kernel_source_digest") == digest
+            if not pmc_ok:
+                roof["traffic_note"] = "committed PMC passes (profiles/%s) describe other kernel sources (%s): not quoted" % (sfile, meta.get("kernel_source_digest"))
+            tag = sfile[: -len("_pmc_source.json")]
         except (OSError, IndexError, ValueError):
-            pass
-        try:
-            ifile = sorted(f for f in os.listdir(prof_dir) if f.endswith("_instruction_mix.json"))[-1]
-            im = json.load(open(os.path.join(prof_dir, ifile))).get(dname)
-            if im and args.workload == "config2" and world == 1 and avg_ms > 0:
-                peak = 256 * 4 * 2.4e9 / 4 / 1e9          # 1024 SIMDs, one VALU issue slot per SIMD every 4 cycles at 2.4 GHz (measured ceiling: 0.66 T/s)
-                ach = im["valu_insts_per_launch"] / (avg_ms / 1e3) / 1e9
-                roof["valu_issue"] = {"achieved": ach, "peak": peak, "unit": "G wave-instr/s", "frac": ach / peak,
-                                      "source": "profiles/" + ifile,
-                                      "note": "integer O(ND) rows: bound by instruction issue (about one instruction per SIMD per cycle, VALU + SALU + LDS), not by HBM or MFMA; peak = nominal 1024 SIMDs x 2.4 GHz / 4"}
-        except (OSError, IndexError, ValueError):
-            pass
+            roof["traffic_note"] = "no committed PMC pass with a source digest"
+            tag = None
+        if pmc_ok and args.workload == "config2" and world == 1:
+            try:
+                t = json.load(open(os.path.join(prof_dir, tag + "_hbm_traffic.json"))).get(dname)
+                if t:
+                    roof["traffic"] = t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]
+                    roof["traffic_source"] = "profiles/%s_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command, same sources)" % tag
+            except (OSError, ValueError, KeyError):
+                pass
+        # dw is integer VALU work on LDS-resident state (HBM fraction tiny by construction): price it against the
+        # instruction-issue rates of this device, calibrated live by mecat_amd/bin/valu_peak.  CDNA4 issues a wave64 VALU
+        # instruction in 2 cycles only for the simple 32-bit class (add/sub/logic/mov/lshr, two waves of a SIMD co-issuing);
+        # min/max, shifts left, compares, selects, every VOP3 / DPP / SGPR-operand form take 4.
+        if pk == "dw" and world == 1:
+            ceil = issue_ceilings()
+            vi = {"unit": "G wave-instr/s", "ceilings": ceil}
+            if pmc_ok and args.workload == "config2" and avg_ms > 0 and "error" not in ceil:
+                try:
+                    im = json.load(open(os.path.join(prof_dir, tag + "_instruction_mix.json"))).get(dname)
+                    ach = im["valu_insts_per_launch"] / (avg_ms / 1e3) / 1e9
+                    f4 = im.get("valu_4cycle_fraction_static")          # share of 4-cycle-class instructions in the kernel's ISA
+                    vi.update({"achieved": ach, "peak": ceil["valu_2cycle_class"], "frac": min(1.0, ach / ceil["valu_2cycle_class"]),
+                               "salu_achieved": im["salu_insts_per_launch"] / (avg_ms / 1e3) / 1e9,
+                               "source": "profiles/%s_instruction_mix.json (SQ_INSTS_VALU / SQ_INSTS_SALU per launch, same sources)" % tag})
+                    if f4 is not None:
+                        mix_peak = 1.0 / (f4 / ceil["valu_4cycle_class"] + (1.0 - f4) / ceil["valu_2cycle_class"])
+                        vi.update({"mix_peak": mix_peak, "mix_frac": min(1.0, ach / mix_peak), "valu_4cycle_fraction_static": f4,
+                                   "note": "peak = the 2-cycle class (never exceeded); mix_peak = ceiling for this kernel's static share of 4-cycle-class instructions"})
+                except (OSError, ValueError, KeyError, TypeError):
+                    pass
+            roof["valu_issue"] = vi
         if pk == "dw":
             roof["dw_cells_per_s"] = per_step("dw_cells") / (phase[2] / 1e3) if phase[2] > 0 else None
             roof["dw_snake_bases_per_s"] = per_step("snake_bases") / (phase[2] / 1e3) if phase[2] > 0 else None
@@ -342,7 +471,18 @@ def main():
         except Exception as e:
             log("[bench] no debug counters: %r" % (e,))
         log("[bench] kernel ms/step: " + ", ".join("%s=%.2f" % (k, v[1] / args.steps) for k, v in sorted(kstats.items(), key=lambda kv: -kv[1][1])))
+        if world == 1 and not args.no_e2e:
+            try:
+                line["e2e"] = e2e_cli(args.workload, codes, lens, min(64, os.cpu_count() or 1))
+            except Exception as e:  # noqa: BLE001
+                line["e2e"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_cpu:
+            try:
+                c1 = cpu_baseline_config1()
+                if c1:
+                    line["cpu_baseline_config1"] = c1
+            except Exception as e:  # noqa: BLE001
+                line["cpu_baseline_config1"] = {"error": repr(e)[:300]}
             try:
                 line["cpu_baseline"] = cpu_baseline(args.workload, os.cpu_count() or 1)
             except Exception as e:  # the GPU number must survive a CPU-leg problem

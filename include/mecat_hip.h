@@ -113,7 +113,7 @@ int  mhip_volume_num_bases(const mhip_volume* v);
 
 /* index of one volume (k = 13).  Buckets with more than 128 occurrences are empty; bucket contents ascend. */
 int  mhip_index_build(mhip_ctx* ctx, const mhip_volume* v, mhip_index** out);
-void mhip_index_free(mhip_index* idx);
+void mhip_index_free(mhip_index* idx);                       /* waits for the device: work queued through *_dev calls may still read it */
 int64_t mhip_index_num_kmers(const mhip_index* idx);
 /* parity/debug: counts[4^13] (kept occurrences) and/or offsets[num_kmers]; either may be NULL */
 int  mhip_index_download(mhip_ctx* ctx, const mhip_index* idx, int32_t* counts, int32_t* offsets);

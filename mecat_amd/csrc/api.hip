@@ -182,6 +182,7 @@ int mhip_volume_upload(mhip_ctx* c, const uint8_t* pac, const mhip_offset_t* off
     if (num_reads < 0 || num_bases < 0) { mhip_set_error("bad volume sizes"); return -1; }
     HIPCHK(hipSetDevice(c->device));
     mhip_volume* v = new mhip_volume();
+    struct Guard { mhip_volume*& v; ~Guard() { if (v) mhip_volume_free(v); } } guard{v};      // every early return frees the buffers
     v->device = c->device;
     v->num_reads = num_reads;
     v->num_bases = num_bases;
@@ -191,7 +192,6 @@ int mhip_volume_upload(mhip_ctx* c, const uint8_t* pac, const mhip_offset_t* off
     if (hipMalloc((void**)&v->d_pac, v->pac_bytes) != hipSuccess ||
         hipMalloc((void**)&v->d_offs, sizeof(mhip_offset_t) * (size_t)(num_reads + 1)) != hipSuccess) {
         mhip_set_error("hipMalloc failed for a %zu-byte volume", v->pac_bytes);
-        mhip_volume_free(v);
         return -1;
     }
     HIPCHK(hipMemsetAsync(v->d_pac, 0, v->pac_bytes, c->stream));
@@ -214,12 +214,12 @@ int mhip_volume_upload(mhip_ctx* c, const uint8_t* pac, const mhip_offset_t* off
     }
     if (hipMalloc((void**)&v->d_blk2read, sizeof(uint32_t) * blk.size()) != hipSuccess) {
         mhip_set_error("hipMalloc failed for the read lookup table");
-        mhip_volume_free(v);
         return -1;
     }
     HIPCHK(hipMemcpyAsync(v->d_blk2read, blk.data(), sizeof(uint32_t) * blk.size(), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     *out = v;
+    v = nullptr;                                     // handed over: the guard lets go
     return 0;
 }
 

@@ -818,6 +818,9 @@ int mhip_index_build(mhip_ctx* c, const mhip_volume* v, mhip_index** out) {
 void mhip_index_free(mhip_index* idx) {
     if (!idx) return;
     (void)hipSetDevice(idx->device);
+    // the arrays are parked for the next build, which may run on another context / stream: nothing queued anywhere on the
+    // device may still read them (once per grid row, so a device-wide wait costs nothing measurable)
+    (void)hipDeviceSynchronize();
     dev_free_recycled(idx->device, idx->d_starts, idx->cap_starts);
     dev_free_recycled(idx->device, idx->d_offsets, idx->cap_offsets);
     dev_free_recycled(idx->device, idx->d_slots, idx->cap_slots);

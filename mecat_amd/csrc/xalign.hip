@@ -5,23 +5,20 @@
 // script_to_aligned_string (:215-261) with reward 1, penalty -1, gap_open 0, gap_extend 1, X = 30, block 500
 // (common/xdrop_gapalign.h:98-114).
 //
-// First correct version: ONE LANE per (candidate, direction) unit replays the reference's row-by-row dynamic program
-// literally — the recurrence carries the running best score, the gap-in-row score and the first/last window index along
-// each row, keeps stale best_gap values for dropped cells and lets the traceback walk through them, so a wave-parallel
-// reformulation has to reproduce all of that (next round).  All DP state lives in a per-lane slice of a
-// global scratch buffer (score pairs for the current window, one script byte per cell, per-row offsets).  As in dw, only
-// what mecat2pw consumes is produced: end coordinates, identity counts; the traceback walks the script bytes once and
-// does trim_mismatch_end and the match/column counting on the fly.
+// One WAVE per (candidate, direction) unit, lanes = cells of a row of the dynamic program (xd_extend_w below).  As in dw, only
+// what mecat2pw consumes is produced: end coordinates and identity counts; the traceback walks the script bytes once and does
+// trim_mismatch_end and the match/column counting on the fly.  Two instantiations of the same row formulation exist: the
+// 128-cell LDS ring (default) and the WIDE one (scores indexed by b, 768-byte rows, byte-by-byte traceback) that takes over the
+// blocks whose window outgrows the ring; MECAT_XD_WIDE=1 runs every block through the WIDE one (the at-scale cross-check of
+// tests/test_gpu_xalign.py; the sequential restatement both are checked against is test infrastructure, not part of this library).
 #include <stdlib.h>
 
 #include <algorithm>
 
 #include "common.h"
 
-#define XB_BLOCK 64
 #define X_SEG 500
 #define X_MAXN 736                       // last block: one side < 600, the other <= 718 (gapalign.cpp:24-30)
-#define X_STATE_CAP (192 * 1024)         // script bytes per block and lane (rows x (window + 2)); overflow -> error flag
 #define X_MIN_SCORE (-100000000)
 
 enum { XS_SUB = 3, XS_GAP_IN_A = 0, XS_GAP_IN_B = 6, XS_OP_MASK = 0x07, XS_EXT_A = 0x10, XS_EXT_B = 0x40 };   // xdrop_gapalign.h:13-34
@@ -32,13 +29,6 @@ struct XDir {
     int32_t blocks;
 };
 
-struct XLane {
-    int2* score;        // [X_MAXN + 2] (best, best_gap)
-    uint8_t* state;     // [X_STATE_CAP]
-    int32_t* row_off;   // [X_MAXN + 2] offset of edit_script[a] inside state
-    int32_t* row_start; // [X_MAXN + 2] edit_start_offset[a]
-};
-#define X_LANE_BYTES ((size_t)(X_MAXN + 2) * 8 + X_STATE_CAP + (size_t)(X_MAXN + 2) * 8)
 
 struct XView {
     const uint32_t* pac;
@@ -59,195 +49,6 @@ struct XBlockOut {
     int l1q, l1t, l1m;          // type of the column just before the trimmed tail
     int overflow;
 };
-
-// xdrop_align (xdrop_gapalign.cpp:10-213) for block [qidx, qidx + M) x [tidx, tidx + N), then one pass over the path
-__device__ void xdrop_block(const XView& q, int qidx, int M, const XView& t, int tidx, int N, XLane& L, XBlockOut& o) {
-    o.ae = o.be = 0; o.n = o.nmatch = 0; o.qcnt = o.tcnt = o.acnt = o.mtail = 0; o.trim_ok = 0; o.overflow = 0;
-    o.l0q = o.l0t = o.l0m = o.l1q = o.l1t = o.l1m = 0;
-    if (M <= 0 || N <= 0) return;
-    const int gap_open = 0, gap_extend = 1, gap_open_extend = 1;
-    int x_dropoff = 30;
-    if (x_dropoff < gap_open_extend) x_dropoff = gap_open_extend;
-    int2* score_array = L.score;
-    uint8_t* state_array = L.state;
-    int states_used = 0;
-    L.row_off[0] = 0;
-    L.row_start[0] = 0;
-    int score = -gap_open_extend;
-    score_array[0] = make_int2(0, -gap_open_extend);
-    int i;
-    for (i = 1; i <= N; ++i) {
-        if (score < -x_dropoff) break;
-        score_array[i] = make_int2(score, score - gap_open_extend);
-        score -= gap_extend;
-        state_array[i] = XS_GAP_IN_A;
-    }
-    states_used = N < i + 1 ? N : i + 1;
-    int b_size = i, best_score = 0, first_b_index = 0;
-    int ae = 0, be = 0;
-    (void)gap_open;
-    for (int a_index = 1; a_index <= M; ++a_index) {
-        const int AC = xv_at(q, qidx + a_index - 1);
-        const int roff = states_used + 1;
-        if (roff + (N - first_b_index) + 4 >= X_STATE_CAP) { o.overflow = 1; return; }
-        L.row_off[a_index] = roff;
-        L.row_start[a_index] = first_b_index;
-        uint8_t* edit_script_row = state_array + roff - first_b_index;
-        const int orig_b_index = first_b_index;
-        score = X_MIN_SCORE;
-        int score_gap_row = X_MIN_SCORE;
-        int last_b_index = first_b_index;
-        int b_index;
-        for (b_index = first_b_index; b_index < b_size; ++b_index) {
-            const int bch = xv_at(t, tidx + b_index);
-            const int2 sa = score_array[b_index];
-            int score_gap_col = sa.y;
-            const int next_score = sa.x + (AC == bch ? 1 : -1);
-            int script = XS_SUB;
-            if (score < score_gap_col) { script = XS_GAP_IN_B; score = score_gap_col; }
-            if (score < score_gap_row) { script = XS_GAP_IN_A; score = score_gap_row; }
-            if (best_score - score > x_dropoff) {
-                if (first_b_index == b_index) ++first_b_index;
-                else score_array[b_index].x = X_MIN_SCORE;
-            } else {
-                last_b_index = b_index;
-                if (score > best_score) { best_score = score; ae = a_index; be = b_index; }
-                int2 ns;
-                score_gap_col -= gap_extend;
-                if (score_gap_col < (score - gap_open_extend)) ns.y = score - gap_open_extend;
-                else { ns.y = score_gap_col; script += XS_EXT_A; }
-                score_gap_row -= gap_extend;
-                if (score_gap_row < (score - gap_open_extend)) score_gap_row = score - gap_open_extend;
-                else script += XS_EXT_B;
-                ns.x = score;
-                score_array[b_index] = ns;
-            }
-            score = next_score;
-            edit_script_row[b_index] = (uint8_t)script;
-        }
-        if (first_b_index == b_size) break;
-        if (last_b_index < b_size - 1) b_size = last_b_index + 1;
-        else {
-            while (score_gap_row >= (best_score - x_dropoff) && b_size < N) {
-                score_array[b_size] = make_int2(score_gap_row, score_gap_row - gap_open_extend);
-                score_gap_row -= gap_extend;
-                edit_script_row[b_size] = XS_GAP_IN_A;
-                ++b_size;
-            }
-        }
-        states_used += (b_index > b_size ? b_index : b_size) - orig_b_index + 1;
-        if (b_size < N) {
-            score_array[b_size] = make_int2(X_MIN_SCORE, X_MIN_SCORE);
-            ++b_size;
-        }
-    }
-    o.ae = ae; o.be = be;
-    // traceback (:165-210) fused with script_to_aligned_string + trim_mismatch_end: columns are visited tail first
-    int a_index = ae, b_index = be;
-    int script = XS_SUB;
-    int n = 0, nmatch = 0, m = 0, found = 0;
-    int qcnt = 0, tcnt = 0, acnt = 0, mtail = 0, want_l1 = 0;
-    while (a_index > 0 || b_index > 0) {
-        const int next_script = state_array[L.row_off[a_index] + b_index - L.row_start[a_index]];
-        switch (script) {
-        case XS_GAP_IN_A:
-            script = next_script & XS_OP_MASK;
-            if (next_script & XS_EXT_A) script = XS_GAP_IN_A;
-            break;
-        case XS_GAP_IN_B:
-            script = next_script & XS_OP_MASK;
-            if (next_script & XS_EXT_B) script = XS_GAP_IN_B;
-            break;
-        default:
-            script = next_script & XS_OP_MASK;
-            break;
-        }
-        int cq, ct, cm;
-        if (script == XS_GAP_IN_A) { --b_index; cq = 0; ct = 1; cm = 0; }
-        else if (script == XS_GAP_IN_B) { --a_index; cq = 1; ct = 0; cm = 0; }
-        else {
-            --a_index; --b_index;
-            cq = 1; ct = 1;
-            cm = xv_at(q, qidx + a_index) == xv_at(t, tidx + b_index);
-        }
-        if (n == 0) { o.l0q = cq; o.l0t = ct; o.l0m = cm; }
-        if (want_l1) { o.l1q = cq; o.l1t = ct; o.l1m = cm; want_l1 = 0; }
-        if (!found) {
-            ++acnt; qcnt += cq; tcnt += ct; mtail += cm;
-            if (cm) ++m; else m = 0;
-            if (m == 4) { found = 1; want_l1 = 1; }
-        }
-        ++n;
-        nmatch += cm;
-    }
-    o.n = n; o.nmatch = nmatch;
-    o.qcnt = qcnt; o.tcnt = tcnt; o.acnt = acnt; o.mtail = mtail;
-    o.trim_ok = found && (n - acnt >= 2);      // "m == mat_cnt && k > 0" (gapalign.cpp:67)
-}
-
-__global__ __launch_bounds__(XB_BLOCK) void xd_extend(const uint32_t* __restrict__ rpac, const mhip_offset_t* __restrict__ roffs,
-                                                      const uint32_t* __restrict__ qpac, const mhip_offset_t* __restrict__ qoffs,
-                                                      const mhip_aln_job* __restrict__ jobs, int n, XDir* __restrict__ dres,
-                                                      uint8_t* __restrict__ scratch, unsigned int* __restrict__ cursor,
-                                                      int* __restrict__ err_flag, unsigned long long* __restrict__ counters) {
-    const size_t tid = (size_t)blockIdx.x * XB_BLOCK + threadIdx.x;
-    uint8_t* base = scratch + tid * X_LANE_BYTES;
-    XLane L;
-    L.score = (int2*)base;
-    L.state = base + (size_t)(X_MAXN + 2) * 8;
-    L.row_off = (int32_t*)(L.state + X_STATE_CAP);
-    L.row_start = L.row_off + (X_MAXN + 2);
-    unsigned long long nblocks = 0;
-    while (true) {
-        const unsigned int unit = atomicAdd(cursor, 1u);
-        if (unit >= 2u * (unsigned)n) break;
-        const mhip_aln_job jb = jobs[unit >> 1];
-        const int right = unit & 1;
-        const int qsize = qoffs[jb.qid_local].size, tsize = roffs[jb.sid_local].size;
-        XView q, t;
-        q.pac = qpac; q.off = qoffs[jb.qid_local].offset; q.comp = jb.chain;
-        t.pac = rpac; t.off = roffs[jb.sid_local].offset; t.comp = 0;
-        const int qs0 = right ? jb.qstart : jb.qstart - 1, step = right ? 1 : -1;
-        if (jb.chain) { q.A = qsize - 1 - qs0; q.B = -step; } else { q.A = qs0; q.B = step; }
-        t.A = right ? jb.sstart : jb.sstart - 1; t.B = step;
-        const int query_size = right ? qsize - jb.qstart : jb.qstart;
-        const int target_size = right ? tsize - jb.sstart : jb.sstart;
-        int qidx = 0, tidx = 0;
-        XDir R = {0, 0, 0, 0, 0, 0, 0, 0};
-        while (true) {      // align_ex (xdrop_gapalign.cpp:263-357)
-            const int qleft = query_size - qidx, tleft = target_size - tidx;
-            int qblk, tblk, last_block;
-            if (qleft < X_SEG + 100 || tleft < X_SEG + 100) {
-                qblk = min(qleft, (int)(tleft + tleft * 0.2));
-                tblk = min(tleft, (int)(qleft + qleft * 0.2));
-                last_block = 1;
-            } else { qblk = X_SEG; tblk = X_SEG; last_block = 0; }
-            XBlockOut o;
-            xdrop_block(q, qidx, qblk, t, tidx, tblk, L, o);
-            ++nblocks;
-            R.blocks += 1;
-            if (o.overflow) { atomicExch(err_flag, 1); break; }
-            const int full_map = (qblk - o.ae <= 20 || tblk - o.be <= 20);
-            if (!full_map || last_block) {      // the whole block string is appended
-                if (o.n > 0) {
-                    R.columns += o.n; R.matches += o.nmatch; R.qbases += o.ae; R.tbases += o.be;
-                    R.last_q = o.l0q; R.last_t = o.l0t; R.last_m = o.l0m;
-                }
-                break;
-            }
-            if (!o.trim_ok) break;
-            const int kept = o.n - o.acnt;
-            if (kept > 0) {
-                R.columns += kept; R.matches += o.nmatch - o.mtail; R.qbases += o.ae - o.qcnt; R.tbases += o.be - o.tcnt;
-                R.last_q = o.l1q; R.last_t = o.l1t; R.last_m = o.l1m;
-            }
-            qidx += o.ae - o.qcnt;
-            tidx += o.be - o.tcnt;
-        }
-        dres[unit] = R;
-    }
-    atomicAdd(&counters[3], nblocks);
-}
 
 // ------------------------------------------------------------------------------------------------------------------
 // xd_extend_w — one WAVE per (candidate, direction).  A row of the dynamic program is per-cell independent work plus two
@@ -565,7 +366,7 @@ __global__ __launch_bounds__(XW_BLOCK) void xd_extend_w(const uint32_t* __restri
                                                         const mhip_aln_job* __restrict__ jobs, int n, XDir* __restrict__ dres,
                                                         uint8_t* __restrict__ scratch, unsigned int* __restrict__ cursor,
                                                         unsigned int* __restrict__ ovf_list, unsigned long long* __restrict__ counters,
-                                                        const unsigned int* __restrict__ ulist, unsigned int nunits) {
+                                                        const unsigned int* __restrict__ ulist, unsigned int nunits, int force_wide) {
     constexpr int HFN = WIDE ? XW_WIDE_HF : XW_RING;
     __shared__ XwLds<HFN> lds[WIDE ? 1 : XW_WAVES];
     XwLds<HFN>& S = lds[threadIdx.x >> 6];
@@ -605,7 +406,8 @@ __global__ __launch_bounds__(XW_BLOCK) void xd_extend_w(const uint32_t* __restri
                 last_block = 1;
             } else { qblk = X_SEG; tblk = X_SEG; last_block = 0; }
             XBlockOut o;
-            xdrop_block_w<false, HFN>(S, q, qidx, qblk, t, tidx, tblk, st, o);
+            o.overflow = 1;
+            if (!WIDE || !force_wide) xdrop_block_w<false, HFN>(S, q, qidx, qblk, t, tidx, tblk, st, o);
             ++nblocks;
             R.blocks += 1;
             if (o.overflow) {
@@ -678,42 +480,35 @@ int mhip_xalign_candidates_dev(mhip_ctx* c, const mhip_volume* ref, const mhip_v
     if (c->scratch("xa_cursor", 64, (void**)&d_cur)) return -1;
     if (c->scratch("xa_ovf", sizeof(unsigned int) * (6 * (size_t)n + 8), (void**)&d_ovf)) return -1;      // count + {unit, qidx, tidx} each
     HIPCHK(hipMemsetAsync(d_cur, 0, 16, c->stream));
-    const char* kv = getenv("MECAT_XD_KERNEL");      // 1 = the one-lane-per-unit kernel (independent implementation, tests)
-    if (!(kv && atoi(kv) == 1)) {
+    // MECAT_XD_WIDE=1: every block of every unit through the WIDE instantiation (cross-check of the ring instantiation, tests)
+    const bool all_wide = getenv("MECAT_XD_WIDE") && atoi(getenv("MECAT_XD_WIDE")) == 1;
+    unsigned int nwide = 0;
+    if (!all_wide) {
         const int waves = c->num_cus * (getenv("MECAT_XW_WAVES") ? atoi(getenv("MECAT_XW_WAVES")) : 24);
         const int grid = std::min(waves / XW_WAVES, (2 * n + XW_WAVES - 1) / XW_WAVES);
         if (c->scratch("xw_state", XW_STATE_BYTES * (size_t)waves, (void**)&d_s)) return -1;
         HIPCHK(hipMemsetAsync(d_ovf, 0, sizeof(unsigned int), c->stream));
         LAUNCH(c, "xd_extend_w", xd_extend_w<false>, grid, XW_BLOCK, 0, (const uint32_t*)ref->d_pac, (const mhip_offset_t*)ref->d_offs,
                (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs, (const mhip_aln_job*)d_jobs, n, d_dres, d_s, d_cur,
-               d_ovf, (unsigned long long*)c->d_counters, (const unsigned int*)nullptr, 2u * (unsigned)n);
-        unsigned int nwide = 0;
+               d_ovf, (unsigned long long*)c->d_counters, (const unsigned int*)nullptr, 2u * (unsigned)n, 0);
         HIPCHK(hipMemcpyAsync(&nwide, d_ovf, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         if (getenv("MECAT_TRACE")) fprintf(stderr, "[mecat_hip] X-drop: %u of %d units need the wide-window path\n", nwide, 2 * n);
-        if (nwide > 0) {
-            const int wgrid = (int)std::min(nwide, 2048u);
-            uint8_t* d_w;
-            if (c->scratch("xw_wide", XW_WIDE_BYTES * (size_t)wgrid, (void**)&d_w)) return -1;
-            LAUNCH(c, "xd_extend_wide", xd_extend_w<true>, wgrid, 64, 0, (const uint32_t*)ref->d_pac, (const mhip_offset_t*)ref->d_offs,
-                   (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs, (const mhip_aln_job*)d_jobs, n, d_dres, d_w, d_cur + 2,
-                   d_ovf + 6 * (size_t)n + 4, (unsigned long long*)c->d_counters, (const unsigned int*)(d_ovf + 1), nwide);
-        }
-    } else {
-        int nthreads = c->num_cus * 4 * XB_BLOCK;
-        nthreads = std::min(nthreads, ((2 * n + XB_BLOCK - 1) / XB_BLOCK) * XB_BLOCK);
-        if (c->scratch("xa_lanes", X_LANE_BYTES * (size_t)nthreads, (void**)&d_s)) return -1;
-        LAUNCH(c, "xd_extend", xd_extend, nthreads / XB_BLOCK, XB_BLOCK, 0, (const uint32_t*)ref->d_pac, (const mhip_offset_t*)ref->d_offs,
-               (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs, (const mhip_aln_job*)d_jobs, n, d_dres, d_s, d_cur,
-               (int*)(d_cur + 1), (unsigned long long*)c->d_counters);
+    }
+    if (nwide > 0 || all_wide) {
+        const unsigned int nu = all_wide ? 2u * (unsigned)n : nwide;
+        const int wgrid = (int)std::min(nu, 2048u);
+        uint8_t* d_w;
+        if (c->scratch("xw_wide", XW_WIDE_BYTES * (size_t)wgrid, (void**)&d_w)) return -1;
+        LAUNCH(c, "xd_extend_wide", xd_extend_w<true>, wgrid, 64, 0, (const uint32_t*)ref->d_pac, (const mhip_offset_t*)ref->d_offs,
+               (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs, (const mhip_aln_job*)d_jobs, n, d_dres, d_w, d_cur + 2,
+               d_ovf + 6 * (size_t)n + 4, (unsigned long long*)c->d_counters, all_wide ? (const unsigned int*)nullptr : (const unsigned int*)(d_ovf + 1),
+               nu, all_wide ? 1 : 0);
     }
     LAUNCH(c, "xd_stitch", xd_stitch, (n + 255) / 256, 256, 0, (const mhip_aln_job*)d_jobs, (const XDir*)d_dres, n, min_align_size,
            (mhip_aln_result*)d_out, (unsigned long long*)c->d_counters);
-    int err = 0;
-    HIPCHK(hipMemcpyAsync(&err, d_cur + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipGetLastError());
-    if (err) { mhip_set_error("X-drop aligner: traceback scratch overflow (a block needed more than %d script bytes)", X_STATE_CAP); return -1; }
     return 0;
 }
 

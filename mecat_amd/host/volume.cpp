@@ -3,7 +3,9 @@
 // What must match the reference byte for byte (so mecat2cns/mecat2canu and a resumed reference run can consume wrk/):
 //   * record grammar of FastaReader::read_one_seq (common/fasta_reader.cpp:6-54): '>' or '@' starts a record, a '+' line
 //     ends it and swallows exactly one following line, lines starting '#' or '!' are comments, ';' ends a data line,
-//     '\n', '\r' and "\r\n" all terminate lines (common/buffer_line_iterator.cpp:22-141), empty lines are skipped;
+//     '\n', '\r' and "\r\n" all terminate lines (common/buffer_line_iterator.cpp:22-141); empty lines are skipped, except
+//     inside the file's last (partial) 8 MB buffer, where the reference's line reader reports an empty line as "no more lines":
+//     there a blank line ends the record (see LineReader::next);
 //   * the plausibility check of data lines (fasta_reader.cpp:91-128) and the invalid-residue error (:57-82);
 //   * encode table (common/defs.cpp:3-36) and the UNMASKED OR of codes > 3 into the packed byte (packed_db.h:98-101);
 //   * one zero pad base after every read, volume cut when curr + rsize + 1 > MCS (split_database.cpp:240-250);
@@ -60,15 +62,16 @@ public:
     ~LineReader() { if (f_) fclose(f_); }
     long line_number() const { return line_no_; }
     void unget() { unget_ = true; }
-    // false at end of input; the line is in line()
+    // false at end of input; the line is in line().  As in the reference (buffer_line_iterator.cpp:22-73, 118-133: the last,
+    // partial 8 MB buffer sets done_, and an EMPTY line then reads as "no more lines"), a blank line inside the final buffer ends
+    // the record being read — so a blank line between two records is harmless, one inside a record makes the next call fail with
+    // "Input doesn't start with a defline", and two in a row end the input.  In earlier buffers blank lines are just skipped.
     bool next() {
         ++line_no_;
         if (unget_) { unget_ = false; return true; }
         line_.clear();
-        bool any = false;
         while (true) {
             if (cur_ == end_) { if (!fill()) break; }
-            any = true;
             size_t p = cur_;
             while (p < end_ && buf_[p] != '\n' && buf_[p] != '\r') ++p;
             line_.append(&buf_[cur_], p - cur_);
@@ -79,10 +82,10 @@ public:
                 if (cur_ == end_) fill();
                 if (cur_ < end_ && buf_[cur_] == '\n') ++cur_;
             }
-            return true;
+            if (cur_ == end_) fill();                    // the reference refills as soon as a line ends at the buffer end
+            return !(done_ && line_.empty());
         }
-        // end of input: the reference returns the trailing unterminated text as a line and stops on an empty one
-        return any && !line_.empty();
+        return !line_.empty();                           // end of input: trailing unterminated text is a line
     }
     const std::string& line() const { return line_; }
 
@@ -91,6 +94,7 @@ private:
         size_t n = fread(&buf_[0], 1, buf_.size(), f_);
         cur_ = 0;
         end_ = n;
+        if (n < buf_.size()) done_ = true;
         return n > 0;
     }
     FILE* f_ = nullptr;
@@ -98,7 +102,7 @@ private:
     size_t cur_ = 0, end_ = 0;
     std::string line_;
     long line_no_ = 0;
-    bool unget_ = false;
+    bool unget_ = false, done_ = false;
 };
 
 inline bool is_nucl(unsigned char c) { return kEnc.t[c] < 16; }
@@ -225,7 +229,7 @@ bool split_plain_fasta(const char* reads, const char* wrk_dir, long max_volume_b
             while (p < size) {                       // data lines up to the next line starting with '>'
                 const unsigned char c0 = (unsigned char)txt[p];
                 if (c0 == '>') break;
-                if (c0 == '\n') { ++p; continue; }   // empty line
+                if (c0 == '\n') { plain = 0; return; } // an empty line: the sequential reader knows the reference's rules for those
                 if (c0 == '@' || c0 == '+' || c0 == '#' || c0 == '!') { plain = 0; return; }
                 size_t q = p;
                 while (q < size && txt[q] != '\n') {

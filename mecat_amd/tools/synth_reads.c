@@ -129,6 +129,8 @@ int synth_write_fasta(const char* path, const uint8_t* bases, const int32_t* len
 }
 
 #ifdef SYNTH_MAIN
+/* CLI: streams the reads in batches (generation and FASTA text assembly in parallel, one write per batch), so that a 40 Gbase
+   set (config 5) needs a few GB of memory, not the whole read set.  Output is byte-identical to synth_reads + synth_write_fasta. */
 int main(int argc, char** argv) {
     if (argc < 7) {
         fprintf(stderr, "usage: %s out.fa nreads L err genome_len seed [ont=0]\n", argv[0]);
@@ -138,12 +140,45 @@ int main(int argc, char** argv) {
     int64_t n = atoll(argv[2]); int L = atoi(argv[3]); double e = atof(argv[4]);
     int64_t G = atoll(argv[5]); uint64_t seed = strtoull(argv[6], NULL, 10);
     int ont = argc > 7 ? atoi(argv[7]) : 0;
-    int64_t cap = n * ((int64_t)(L * 1.25) + 64);
-    uint8_t* bases = (uint8_t*)malloc((size_t)cap);
-    int32_t* lens = (int32_t*)malloc((size_t)n * 4);
-    int64_t tot = synth_reads(G, n, L, e, ont, seed, bases, cap, lens);
-    if (tot < 0) { fprintf(stderr, "synth_reads failed %lld\n", (long long)tot); return 2; }
-    if (synth_write_fasta(out, bases, lens, n)) { perror(out); return 3; }
+    double pdel, psub, pins; synth_rates(e, ont, &pdel, &psub, &pins);
+    uint8_t* g = (uint8_t*)malloc((size_t)G);
+    if (!g) { fprintf(stderr, "out of memory (genome)\n"); return 2; }
+    synth_genome(g, G, seed);
+    const int cap = (int)(L * 1.25) + 64;
+    const int64_t B = 65536;
+    uint8_t* bases = (uint8_t*)malloc((size_t)(B * cap));
+    int32_t* lens = (int32_t*)malloc((size_t)B * 4);
+    int64_t* tpos = (int64_t*)malloc((size_t)(B + 1) * 8);
+    char* text = (char*)malloc((size_t)(B * (cap + 32)));
+    if (!bases || !lens || !tpos || !text) { fprintf(stderr, "out of memory (batch)\n"); return 2; }
+    FILE* f = fopen(out, "w");
+    if (!f) { perror(out); return 3; }
+    int64_t tot = 0;
+    for (int64_t b0 = 0; b0 < n; b0 += B) {
+        const int64_t nb = n - b0 < B ? n - b0 : B;
+#pragma omp parallel for schedule(dynamic, 64)
+        for (int64_t i = 0; i < nb; ++i)
+            lens[i] = synth_one_read(g, G, b0 + i, L, pdel, psub, pins, seed, bases + i * cap, cap);
+        tpos[0] = 0;
+        for (int64_t i = 0; i < nb; ++i) {
+            char hdr[32];
+            tpos[i + 1] = tpos[i] + snprintf(hdr, sizeof(hdr), ">r%lld\n", (long long)(b0 + i)) + lens[i] + 1;
+            tot += lens[i];
+        }
+#pragma omp parallel for schedule(dynamic, 64)
+        for (int64_t i = 0; i < nb; ++i) {
+            char* o = text + tpos[i];
+            char hdr[32];
+            const int h = snprintf(hdr, sizeof(hdr), ">r%lld\n", (long long)(b0 + i));
+            memcpy(o, hdr, (size_t)h);
+            o += h;
+            const uint8_t* src = bases + i * cap;
+            for (int k = 0; k < lens[i]; ++k) o[k] = "ACGT"[src[k] & 3];
+            o[lens[i]] = '\n';
+        }
+        if (fwrite(text, 1, (size_t)tpos[nb], f) != (size_t)tpos[nb]) { perror(out); return 3; }
+    }
+    if (fclose(f)) { perror(out); return 3; }
     fprintf(stderr, "synth_reads: %lld reads, %lld bases, L=%d e=%.3f G=%lld seed=%llu ont=%d\n",
             (long long)n, (long long)tot, L, e, (long long)G, (unsigned long long)seed, ont);
     return 0;

@@ -545,6 +545,25 @@ int orc_seed_read(const orc_volume* ref, const orc_volume* reads, const orc_inde
     return n;
 }
 
+/* bench.py's cpu_baseline "port" leg (only when oracle/_ref was not built): index + candidates of every read of one
+   volume built from code arrays; returns the number of candidates */
+int64_t orc_bench_candidates(const uint8_t* codes, const int* lens, int nreads, int tech)
+{
+    orc_params p;
+    orc_params_default(&p, tech);
+    orc_volume* v = orc_volume_pack(codes, lens, nreads, 0);
+    orc_index* idx = orc_index_build(v);
+    orc_seeding_bk* bk = orc_bk_new(v->num_bases);
+    orc_candidate* out = (orc_candidate*)xmalloc(sizeof(orc_candidate) * (size_t)p.maxc);
+    int64_t total = 0;
+    for (int r = 0; r < nreads; ++r) total += orc_seed_read(v, v, idx, bk, r, 0, &p, out);
+    free(out);
+    orc_bk_free(bk);
+    orc_index_free(idx);
+    orc_volume_free(v);
+    return total;
+}
+
 int orc_seeding_state(const char* read, int read_size, const orc_index* ridx, orc_seeding_bk* bk, int cap,
                       int* seg_ids, int16_t* idx_score, int16_t* scores, int16_t* loczhi, int16_t* seedno)
 {

@@ -119,6 +119,8 @@ int orc_get_candidates(const orc_volume* ref, orc_seeding_bk* bk, int num_segs, 
 int orc_seed_read(const orc_volume* ref, const orc_volume* reads, const orc_index* ridx, orc_seeding_bk* bk,
                   int rid, int chain_as_char, const orc_params* p, orc_candidate* out);
 
+int64_t orc_bench_candidates(const uint8_t* codes, const int* lens, int nreads, int tech);   /* bench.py cpu_baseline "port" leg */
+
 /* test/debug: run orc_seeding for one strand, copy the state get_candidates would see, then reset the touched segments.
    seg_ids/idx_score in index_list (first-touch) order; scores[i], loczhi[i*40..], seedno[i*40..] for segment seg_ids[i]. */
 int orc_seeding_state(const char* read, int read_size, const orc_index* ridx, orc_seeding_bk* bk, int cap,

@@ -123,7 +123,7 @@ def test_cli_m4_nanopore_mode(tmp_path):
 
 def test_xdrop_wide_windows_low_complexity(hip, ctx, capfd):
     """Homopolymer / short-period tandem stretches keep hundreds of cells within X of the best score: those units leave the
-    128-cell fast path for the wide-window instantiation.  Wave kernel == oracle == lane kernel (independent code)."""
+    128-cell fast path for the wide-window instantiation.  Ring instantiation (+ hand-over) == oracle == the WIDE instantiation run on every block."""
     rng = np.random.default_rng(4242)
     O = H.orc()
     xa = O.orc_xaligner_new()
@@ -167,22 +167,23 @@ def test_xdrop_wide_windows_low_complexity(hip, ctx, capfd):
     err = capfd.readouterr().err
     nwide = int(err.split("X-drop: ")[1].split(" of ")[0])
     assert nwide > 5, err                                     # the wide path really ran
-    os.environ["MECAT_XD_KERNEL"] = "1"
+    os.environ["MECAT_XD_WIDE"] = "1"
     try:
-        lane = hip.align_candidates(ctx, gv, gv, ja, 500, tech=1).copy()
+        wide = hip.align_candidates(ctx, gv, gv, ja, 500, tech=1).copy()
     finally:
-        os.environ.pop("MECAT_XD_KERNEL")
+        os.environ.pop("MECAT_XD_WIDE")
     bad = [(i, jobs[i], _t(out[i]), want[i]) for i in range(len(jobs)) if _t(out[i]) != want[i]]
     assert not bad, "%d/%d differ from the oracle: %s" % (len(bad), len(jobs), bad[:4])
-    assert out.tobytes() == lane.tobytes()
+    assert out.tobytes() == wide.tobytes()
     assert sum(w[0] for w in want) > 10
     gv.free()
 
 
-def test_xdrop_wave_kernel_equals_lane_kernel_at_scale(hip, ctx):
+def test_xdrop_ring_equals_wide_instantiation_at_scale(hip, ctx):
     """133 855 candidates of 5 000 ONT-style 10 kb reads (2.1 M blocks, a few hundred of them through the wide-window path):
-    the wave-per-alignment kernel and the lane-per-alignment replay are independent implementations and must agree on every
-    field of every result."""
+    the default launch (128-cell LDS ring, two-register row traceback, hand-over of overflowing blocks) and the WIDE
+    instantiation run on every block (scores indexed by b, 768-byte rows, byte-by-byte traceback; MECAT_XD_WIDE=1) must agree
+    on every field of every result.  Oracle parity of both is pinned at small size by the tests above."""
     from mecat_amd import workload as W
     codes, lens = W.synth_reads(5000, 10000, 0.12, 1_700_000, 7, 1)
     pac, offs, nb = W.pack_volume(codes, lens)
@@ -193,13 +194,13 @@ def test_xdrop_wave_kernel_equals_lane_kernel_at_scale(hip, ctx):
     jobs = W.jobs_from_candidates(cands, cnt, 0)
     assert len(jobs) > 100000
     wave = hip.align_candidates(ctx, vol, vol, jobs, p.min_align_size, tech=1).copy()
-    os.environ["MECAT_XD_KERNEL"] = "1"
+    os.environ["MECAT_XD_WIDE"] = "1"
     try:
-        lane = hip.align_candidates(ctx, vol, vol, jobs, p.min_align_size, tech=1).copy()
+        wide = hip.align_candidates(ctx, vol, vol, jobs, p.min_align_size, tech=1).copy()
     finally:
-        os.environ.pop("MECAT_XD_KERNEL")
-    diff = np.nonzero(wave.view(np.int32).reshape(len(jobs), -1) != lane.view(np.int32).reshape(len(jobs), -1))[0]
-    assert diff.size == 0, (diff[:5], wave[diff[:3]], lane[diff[:3]])
+        os.environ.pop("MECAT_XD_WIDE")
+    diff = np.nonzero(wave.view(np.int32).reshape(len(jobs), -1) != wide.view(np.int32).reshape(len(jobs), -1))[0]
+    assert diff.size == 0, (diff[:5], wave[diff[:3]], wide[diff[:3]])
     assert int((wave["ok"] != 0).sum()) > 0.9 * len(jobs)
     idx.free()
     vol.free()

@@ -118,8 +118,9 @@ def test_cli_rejects_malformed_input(tmp_path):
 
 def test_cli_threaded_reader_equals_sequential_reader(tmp_path):
     """plain FASTA goes through the threaded mmap reader; its volumes must equal the sequential (reference-grammar) reader's:
-    ragged multi-line records, empty lines, ambiguity codes (unmasked OR quirk), lower case, no final newline, several
-    volumes, more threads than records"""
+    ragged multi-line records, ambiguity codes (unmasked OR quirk), lower case, no final newline, several
+    volumes, more threads than records (a file with empty lines always takes the sequential reader, which owns the reference's
+    rules for them: test_cli_blank_line_rules_of_the_reference_reader)"""
     rng = np.random.default_rng(7)
     recs = []
     for i in range(137):
@@ -127,8 +128,6 @@ def test_cli_threaded_reader_equals_sequential_reader(tmp_path):
         seq = "".join(rng.choice(list("ACGTacgtNnRYKM-"), size=n, p=[.2, .2, .2, .2, .03, .03, .03, .03, .02, .01, .01, .01, .01, .01, .01]))
         w = int(rng.integers(1, 80))
         lines = [seq[j:j + w] for j in range(0, n, w)]
-        if i % 5 == 0:
-            lines.insert(len(lines) // 2, "")
         recs.append(">r%d some text > with a bracket\n" % i + "\n".join(lines))
     text = ("\n".join(recs)).encode()            # no trailing newline
     fa = tmp_path / "ragged.fa"
@@ -146,3 +145,42 @@ def test_cli_threaded_reader_equals_sequential_reader(tmp_path):
     for tag in ("t1", "t7", "t64"):
         assert outs[tag][0] == outs["seq"][0], tag            # "(N reads, M nucls) into V volumes."
         assert outs[tag][1] == outs["seq"][1], tag
+
+
+def test_cli_blank_line_rules_of_the_reference_reader(tmp_path):
+    """The reference's line reader reports an EMPTY line as end-of-input once the file's last (partial) 8 MB buffer is loaded
+    (buffer_line_iterator.cpp:22-73, 118-133).  Consequences that the splitter reproduces: a blank line between records is
+    harmless; a blank line inside a record ends the record, so the data line after it aborts with 'doesn't start with a
+    defline'; two blank lines in a row end the input (later records are dropped).  Checked against the reference binary when
+    it was built here, and against the expected volumes otherwise."""
+    O = H.orc()
+
+    def vol_of(reads):
+        codes = np.array([O.orc_encode_base(ord(ch)) for r in reads for ch in r], dtype=np.uint8)
+        lens = np.array([len(r) for r in reads], dtype=np.int32)
+        p = str(tmp_path / ("want_%d" % len(reads)))
+        O.orc_volume_dump(H.orc_pack(codes, lens), p.encode())
+        return open(p, "rb").read()
+
+    a, b, c = "ACGTACGTTTGACCA", "GGCATTACGATCAGG", "TTTTACGTACGGGTA"
+    cases = {
+        "between.fa": (b">a\n" + a.encode() + b"\n\n>b\n" + b.encode() + b"\n\n>c\n" + c.encode() + b"\n", [a, b, c], 0),
+        "trailing.fa": (b">a\n" + a.encode() + b"\n>b\n" + b.encode() + b"\n\n\n\n", [a, b], 0),
+        "double.fa": (b">a\n" + a.encode() + b"\n\n\n>b\n" + b.encode() + b"\n>c\n" + c.encode() + b"\n", [a], 0),
+        "inrecord.fa": (b">a\n" + a[:7].encode() + b"\n\n" + a[7:].encode() + b"\n>b\n" + b.encode() + b"\n", None, 1),
+        "afterhdr.fa": (b">a\n\n" + a.encode() + b"\n", None, 1),
+    }
+    for name, (text, reads, fails) in cases.items():
+        r, wrk = _run_split(tmp_path, text, name)
+        if fails:
+            assert r.returncode != 0 and ("doesn't start with a defline" in r.stderr or "sequence data is missing" in r.stderr), (name, r.stderr)
+        else:
+            assert open(os.path.join(wrk, "vol0"), "rb").read() == vol_of(reads), name
+        if H.ref_bin():
+            fa = str(tmp_path / name)
+            rw = str(tmp_path / ("rw_" + name))
+            rr = subprocess.run([H.ref_bin(), "-j", "0", "-d", fa, "-o", str(tmp_path / "ro"), "-w", rw, "-t", "1"], capture_output=True, text=True)
+            if fails:
+                assert rr.returncode != 0, name
+            else:
+                assert open(os.path.join(rw, "vol0"), "rb").read() == open(os.path.join(wrk, "vol0"), "rb").read(), name

@@ -182,10 +182,15 @@ def issue_ceilings():
     """live calibration (mecat_amd/bin/valu_peak, ~1 s): wave64 instruction issue rates of this device, G wave-instr/s"""
     exe = os.path.join(ROOT, "mecat_amd", "bin", "valu_peak")
     try:
-        p = subprocess.run([exe, "3000", "v_add_u32,v_alignbit_b32,s_add_u32,ds_read_b32"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+        p = subprocess.run([exe, "3000", "v_add_u32,v_alignbit_b32,s_add_u32,ds_read_b32,mix_dw_rowbody"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           text=True, timeout=120)
         r = json.loads(p.stdout)["rates"]
+        # mix_dw_rowbody: independent streams with the d-path row body's own instruction mix (7 four-cycle + 4 two-cycle VALU, 4 SALU,
+        # 1 LDS read per 16); its VALU share is what a kernel of this mix can issue at best, by resident waves per SIMD (1, 2, 4, 8)
         return {"valu_2cycle_class": max(r["v_add_u32"]), "valu_4cycle_class": max(r["v_alignbit_b32"]), "salu": max(r["s_add_u32"]),
-                "lds": max(r["ds_read_b32"]), "source": "mecat_amd/bin/valu_peak, live"}
+                "lds": max(r["ds_read_b32"]), "valu_dw_mix": max(r["mix_dw_rowbody"]) * 11 / 16,
+                "valu_dw_mix_by_waves_per_simd": {str(w): v * 11 / 16 for w, v in zip((1, 2, 4, 8), r["mix_dw_rowbody"])},
+                "source": "mecat_amd/bin/valu_peak, live"}
     except Exception as e:      # noqa: BLE001
         return {"error": repr(e)[:200]}
 
@@ -386,13 +391,13 @@ def main():
                     im = json.load(open(os.path.join(prof_dir, tag + "_instruction_mix.json"))).get(dname)
                     ach = im["valu_insts_per_launch"] / (avg_ms / 1e3) / 1e9
                     f4 = im.get("valu_4cycle_fraction_static")          # share of 4-cycle-class instructions in the kernel's ISA
-                    vi.update({"achieved": ach, "peak": ceil["valu_2cycle_class"], "frac": min(1.0, ach / ceil["valu_2cycle_class"]),
+                    vi.update({"achieved": ach, "peak": ceil["valu_dw_mix"], "frac": min(1.0, ach / ceil["valu_dw_mix"]),
                                "salu_achieved": im["salu_insts_per_launch"] / (avg_ms / 1e3) / 1e9,
                                "source": "profiles/%s_instruction_mix.json (SQ_INSTS_VALU / SQ_INSTS_SALU per launch, same sources)" % tag})
+                    vi["note"] = ("peak = VALU rate of valu_peak's mix_dw_rowbody (independent streams, this kernel's instruction mix, best over 1-8 "
+                                  "waves per SIMD); dw_extend2 runs 4 waves per SIMD (125 VGPRs, 40 KB LDS per 4 waves)")
                     if f4 is not None:
-                        mix_peak = 1.0 / (f4 / ceil["valu_4cycle_class"] + (1.0 - f4) / ceil["valu_2cycle_class"])
-                        vi.update({"mix_peak": mix_peak, "mix_frac": min(1.0, ach / mix_peak), "valu_4cycle_fraction_static": f4,
-                                   "note": "peak = the 2-cycle class (never exceeded); mix_peak = ceiling for this kernel's static share of 4-cycle-class instructions"})
+                        vi["valu_4cycle_fraction_static"] = f4
                 except (OSError, ValueError, KeyError, TypeError):
                     pass
             roof["valu_issue"] = vi

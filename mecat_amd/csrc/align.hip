@@ -66,7 +66,7 @@ struct AlnWaveLds {
 //   bkey = (x+y) << 10 | (1023 - (k + k_offset))   max  -> first maximum of x + y in k order (diff_gapalign.cpp:160-167)
 //   hkey = (k + k_offset) << 10 | x                min  -> lowest diagonal that reached an end (:168-169), or INT_MAX
 // and leaves x + y of the lane's diagonals in S-independent registers via xy[] for the band update.
-template <int NJ, bool SPILL>
+template <int NJ, bool SPILL, bool LE>
 __device__ __forceinline__ void row_body(AlnWaveLds& S, uint16_t* __restrict__ grow, const int lane, const int d, const int nslot,
                                          const int min_k, const int max_k, const int k_offset, const int q_len, const int t_len,
                                          const int best_m, const int band_tol, unsigned int& snake, int& bkey_out, int& hkey_out,
@@ -90,7 +90,7 @@ __device__ __forceinline__ void row_body(AlnWaveLds& S, uint16_t* __restrict__ g
         for (int j = 0; j < NJ; ++j) {
             const int x = xs[j], y = ys[j];
             const int lim = min(q_len - x, t_len - y);
-            const int n0 = match32(S.Qp, x, S.Tp, min(y, MAX_BLK));
+            const int n0 = LE ? match32_le(S.Qp, x, S.Tp, min(y, MAX_BLK)) : match32(S.Qp, x, S.Tp, min(y, MAX_BLK));
             const int n = max(0, min(n0, lim));
             xs[j] = x + n; ys[j] = y + n;
             snake += (unsigned int)n;
@@ -118,7 +118,7 @@ __device__ __forceinline__ void row_body(AlnWaveLds& S, uint16_t* __restrict__ g
 // in the lane that held k+1 (SHL = false) resp. k-1 (SHL = true) in the previous row, and the other neighbour is one
 // lane away: one wave_shr:1 / wave_shl:1 DPP move replaces the two LDS reads of V.  The lowest end-reaching diagonal
 // and the first maximum are found with ballots (lane order == diagonal order) instead of key reductions.
-template <bool SPILL, bool SHL>
+template <bool SPILL, bool SHL, bool LE>
 __device__ __forceinline__ void row_fast(AlnWaveLds& S, uint16_t* __restrict__ grow, const int lane, const int d, const int nslot,
                                          const int min_k, const int max_k, const int k_offset, const int q_len, const int t_len,
                                          unsigned int& snake, int& xreg, int& m_out, int& bkey_out, int& hkey_out) {
@@ -133,7 +133,7 @@ __device__ __forceinline__ void row_fast(AlnWaveLds& S, uint16_t* __restrict__ g
     bool more;
     do {
         const int lim = min(q_len - x, t_len - y);
-        const int n0 = match32(S.Qp, x, S.Tp, min(y, MAX_BLK));
+        const int n0 = LE ? match32_le(S.Qp, x, S.Tp, min(y, MAX_BLK)) : match32(S.Qp, x, S.Tp, min(y, MAX_BLK));
         const int n = max(0, min(n0, lim));
         x += n; y += n;
         snake += (unsigned int)n;           // inactive lanes sit at (0, 0) of both sequences; corrected below
@@ -187,7 +187,8 @@ struct BlockOut {
 };
 
 // One block: Align + tail traceback + trim_mismatch_end.  SPILL = false: d-rows in the LDS ring; true: in global rows.
-template <bool SPILL>
+// LE: the staged sequences are in dw_extend2's layout (view_word_le), otherwise in dw_extend's (view_word + pad word).
+template <bool SPILL, bool LE = false>
 __device__ void align_block(AlnWaveLds& S, const int q_len, const int t_len, uint16_t* __restrict__ grow, BlockOut& o,
                             unsigned int& cells, unsigned int& snake, DwStats& st) {
     const int lane = lane_id();
@@ -220,15 +221,15 @@ __device__ void align_block(AlnWaveLds& S, const int q_len, const int t_len, uin
         const bool fast_l = nj == 1 && reg_ok && min_k == reg_min_k + 1 && nslot <= 63;
         const bool fast = fast_r || fast_l;
         if (fast_r) {
-            row_fast<SPILL, false>(S, grow, lane, d, nslot, min_k, max_k, k_offset, q_len, t_len, snake, xreg, mreg, bkey, hkey);
+            row_fast<SPILL, false, LE>(S, grow, lane, d, nslot, min_k, max_k, k_offset, q_len, t_len, snake, xreg, mreg, bkey, hkey);
         } else if (fast_l) {
-            row_fast<SPILL, true>(S, grow, lane, d, nslot, min_k, max_k, k_offset, q_len, t_len, snake, xreg, mreg, bkey, hkey);
+            row_fast<SPILL, true, LE>(S, grow, lane, d, nslot, min_k, max_k, k_offset, q_len, t_len, snake, xreg, mreg, bkey, hkey);
         } else {
             switch (nj) {
-            case 1: row_body<1, SPILL>(S, grow, lane, d, nslot, min_k, max_k, k_offset, q_len, t_len, best_m, band_tol, snake, bkey, hkey, x0); break;
-            case 2: row_body<2, SPILL>(S, grow, lane, d, nslot, min_k, max_k, k_offset, q_len, t_len, best_m, band_tol, snake, bkey, hkey, x0); break;
-            case 3: row_body<3, SPILL>(S, grow, lane, d, nslot, min_k, max_k, k_offset, q_len, t_len, best_m, band_tol, snake, bkey, hkey, x0); break;
-            default: row_body<4, SPILL>(S, grow, lane, d, nslot, min_k, max_k, k_offset, q_len, t_len, best_m, band_tol, snake, bkey, hkey, x0); break;
+            case 1: row_body<1, SPILL, LE>(S, grow, lane, d, nslot, min_k, max_k, k_offset, q_len, t_len, best_m, band_tol, snake, bkey, hkey, x0); break;
+            case 2: row_body<2, SPILL, LE>(S, grow, lane, d, nslot, min_k, max_k, k_offset, q_len, t_len, best_m, band_tol, snake, bkey, hkey, x0); break;
+            case 3: row_body<3, SPILL, LE>(S, grow, lane, d, nslot, min_k, max_k, k_offset, q_len, t_len, best_m, band_tol, snake, bkey, hkey, x0); break;
+            default: row_body<4, SPILL, LE>(S, grow, lane, d, nslot, min_k, max_k, k_offset, q_len, t_len, best_m, band_tol, snake, bkey, hkey, x0); break;
             }
             xreg = x0;
         }
@@ -506,9 +507,9 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
                 tblk = max(tblk, 0);
                 band_tol = (int)(0.3 * (qblk > tblk ? qblk : tblk));
                 max_d = (int)(.3 * (qblk + tblk));
-                for (int w = sl; w < SEQ_WORDS; w += 32) {
-                    S.Qp[w] = (w > 0 && (w - 1) * 16 < qblk + 32) ? view_word(q, qidx + (w - 1) * 16) : 0u;
-                    S.Tp[w] = (w > 0 && (w - 1) * 16 < tblk + 32) ? view_word(t, tidx + (w - 1) * 16) : 0u;
+                for (int w = sl; w < SEQ_WORDS; w += 32) {      // word w = logical bases 16w .. 16w+15, first base in the low bits
+                    S.Qp[w] = (w * 16 < qblk + 32) ? view_word_le(q, qidx + w * 16) : 0u;
+                    S.Tp[w] = (w * 16 < tblk + 32) ? view_word_le(t, tidx + w * 16) : 0u;
                 }
                 // The reference zero-fills V per block (:232-233); row d only reads diagonals written by row d - 1, except
                 // row 0, which reads V[k_offset + 1].
@@ -531,80 +532,10 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
         // The inner loop runs while every half that has a block is still rowing.
         const unsigned long long inmask = BALLOT(inblock);
         bool row_ok;
-        while (true) {
-            const int nslot = ((max_k - min_k) >> 1) + 1;        // min_k and max_k have the same parity; exhausted halves: 0
-            row_ok = d < dlim && nslot <= band_tol + 1;          // :118 "max_k - min_k <= band_size"
-            const unsigned long long rmask = BALLOT(row_ok);
-            if (rmask != inmask) break;
-#ifdef MECAT_DW_STATS
-            nrows += 1;
-            nidle += (rmask == ~0ull) ? 0u : 1u;
-#endif
-            {                                // row record: band limits + linear ring position.  Every lane of the half stores the same
-                int4* rr = &S.rrec[d & (RROWS - 1)];      // three words to the same address (no exec juggling on the scalar unit)
-                rr->x = min_k; rr->y = max_k; rr->z = (int)lin;
-            }
-            const int ns_a = __builtin_amdgcn_readlane(nslot, 0), ns_b = __builtin_amdgcn_readlane(nslot, 32);
-            const int NJ = (max(ns_a, ns_b) + 31) >> 5;
-#ifdef MECAT_DW_STATS
-            nwide += NJ > 1 ? 1u : 0u;
-#endif
-            // one or two passes of 32 diagonals per half cover 99 % of the rows: with the pass count a constant the pass loop, the
-            // previous-pass bookkeeping and the choice of band update fold away
-            auto row_body = [&](const int NJ) __attribute__((always_inline)) {
-            int mmax = -1, m0 = -0x40000000, mp = -0x40000000;      // x + y of the lane's diagonal in the last / previous pass
-            unsigned long long ended = 0;    // lanes whose diagonal reached an end of the block in some pass (rare: once per block)
-            int j = 0;
-            do {                                 // at least one pass (a pass over an empty band only moves idle lanes)
-                const int tt = sl + 32 * j;
-                const bool act = tt < nslot;
-                const int k = min_k + 2 * tt, kk = k + k_offset;
-                const int16_t* vp = &S.V[kk - 1];                  // idle lanes read (and ignore) in-range garbage
-                const int vl = vp[0], vr = vp[2];
-                int x = (k == min_k || (k != max_k && vl < vr)) ? vr : vl + 1;       // :138-142
-                // 0 <= y <= t_len and x <= q_len on every live diagonal (a diagonal at an end stops the block); idle lanes sit
-                // at (q_len, 0), where lim == 0
-                x = act ? x : q_len;
-                int y = act ? x - k : 0;
-                bool more;
-                int lim, nn;
-                do {
-                    lim = min(q_len - x, t_len - y);
-                    const int m = min(match16(S.Qp, x, S.Tp, y), lim);      // 0..15, or lim when all 16 bases match
-                    nn = min(m, 16);
-                    x += nn; y += nn;
-                    more = m > 16;
-                } while (BALLOT(more));
-                if (act) {
-                    S.V[kk] = (int16_t)x;
-                    S.ring[(lin + (unsigned)tt) & (RCAP - 1)] = (uint16_t)x;
-                }
-                ended |= BALLOT(act && lim == nn);  // nothing left of the query or of the target on this diagonal
-                mp = m0;
-                m0 = act ? x + y : -0x40000000;     // also read by the band update below (NJ <= 2); idle lanes never qualify
-                mmax = max(mmax, m0);
-            } while (++j < NJ);
-            lin += (unsigned)nslot;
-            __builtin_amdgcn_wave_barrier();
-            // running maximum of x + y (:160-167); lowest diagonal that reached an end (:168-169)
-            const int rm = half_max(mmax);
-            best_m = max(best_m, rm);
-            if (ended) {                     // once per block: the lowest diagonal that reached an end, from the values just stored in V
-                int hkey = 0x7fffffff;
-                for (int jj = 0; jj < NJ; ++jj) {
-                    const int tt = sl + 32 * jj, k = min_k + 2 * tt, kk = k + k_offset;
-                    if (tt < nslot) {
-                        const int x = S.V[kk];
-                        if (x >= q_len || x - k >= t_len) hkey = min(hkey, (kk << 10) | x);
-                    }
-                }
-                hkey = half_min(hkey);
-                if (inblock && hkey != 0x7fffffff) {
-                    aligned = 1; end_k = (hkey >> 10) - k_offset; end_x = hkey & 1023; end_d = d;
-                    dlim = 0;
-                }
-            }
-            // band update (:172-179)
+        unsigned long long ended = 0;        // lanes whose diagonal reached an end of its block in the row that was just run
+        int NJ = 1;
+        // band update (:172-179) of one row; m0 / mp = x + y of the lane's diagonal in the last / previous pass
+        auto band_update = [&](const int NJ, const int m0, const int mp) __attribute__((always_inline)) {
             int nmin = max_k, nmax = min_k;
             if (NJ <= 2) {
                 // up to 64 diagonals per half: two ballots, the half's 2 x 32 qualification bits, first / last set bit
@@ -620,11 +551,12 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
                 }
             } else {
                 int lo = 0x7fffffff, hi = -0x7fffffff;
+                const int nslot = ((max_k - min_k) >> 1) + 1;
                 for (int j = 0; j < NJ; ++j) {
                     const int tt = sl + 32 * j;
                     const bool act = inblock && tt < nslot;
                     const int k = min_k + 2 * tt;
-                    const int u = act ? 2 * (int)S.V[k + k_offset] - k : -0x40000000;
+                    const int u = act ? 2 * (int)S.V[k + max_d] - k : -0x40000000;
                     if (act && u >= best_m - band_tol) { lo = min(lo, k); hi = max(hi, k); }
                 }
                 lo = half_min(lo); hi = half_max(hi);
@@ -634,12 +566,108 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
                 max_k = nmax + 1;
                 min_k = nmin - 1;
             }
+        };
+        int last_m0 = 0, last_mp = 0;
+        while (true) {
+            const int nslot = ((max_k - min_k) >> 1) + 1;        // min_k and max_k have the same parity; exhausted halves: 0
+            // :118 "max_k - min_k <= band_size"; the two conditions as masks (a ballot of their conjunction makes the compiler
+            // turn the mask into a 0/1 vector and compare it again)
+            const unsigned long long rmask = BALLOT(d < dlim) & BALLOT(nslot <= band_tol + 1);
+            if (rmask != inmask) break;
+#ifdef MECAT_DW_STATS
+            nrows += 1;
+            nidle += (rmask == ~0ull) ? 0u : 1u;
+#endif
+            {                                // row record: band limits + linear ring position.  Every lane of the half stores the same
+                int4* rr = &S.rrec[d & (RROWS - 1)];      // three words to the same address (no exec juggling on the scalar unit)
+                rr->x = min_k; rr->y = max_k; rr->z = (int)lin;
+            }
+            const int ns_a = __builtin_amdgcn_readlane(nslot, 0), ns_b = __builtin_amdgcn_readlane(nslot, 32);
+            NJ = (max(ns_a, ns_b) + 31) >> 5;
+#ifdef MECAT_DW_STATS
+            nwide += NJ > 1 ? 1u : 0u;
+#endif
+            // one or two passes of 32 diagonals per half cover 99 % of the rows: with the pass count a constant the pass loop and
+            // the previous-pass bookkeeping fold away
+            auto row_passes = [&](const int NJ) __attribute__((always_inline)) {
+                int mmax = -0x40000000, m0 = -0x40000000, mp = -0x40000000;
+                unsigned long long e = 0;
+                int j = 0;
+                do {                                 // at least one pass (a pass over an empty band only moves idle lanes)
+                    const int tt = sl + 32 * j;
+                    const bool act = tt < nslot;
+                    const int k = min_k + 2 * tt, kk = k + k_offset;
+                    const int16_t* vp = &S.V[kk - 1];                  // idle lanes read (and ignore) in-range garbage
+                    const int vl = vp[0], vr = vp[2];
+                    int x = (k == min_k || (k != max_k && vl < vr)) ? vr : vl + 1;       // :138-142
+                    // 0 <= y <= t_len and x <= q_len on every live diagonal (a diagonal at an end stops the block); idle lanes sit
+                    // at (q_len, 0), where lim == 0
+                    x = act ? x : q_len;
+                    int y = act ? x - k : 0;
+                    int lim, nn;
+                    do {
+                        lim = min(q_len - x, t_len - y);
+                        // 0..15 equal bases, or >= 16 (0x7fffffff) when the whole window matches.  A lane with exactly 16 bases left
+                        // that all match asks for one more step, which then moves nothing.
+                        nn = min(min(match16_le(S.Qp, x, S.Tp, y), lim), 16);
+                        x += nn; y += nn;
+                    } while (BALLOT(nn == 16));
+                    if (act) {
+                        S.V[kk] = (int16_t)x;
+                        S.ring[(lin + (unsigned)tt) & (RCAP - 1)] = (uint16_t)x;
+                    }
+                    e |= BALLOT(lim == nn) & BALLOT(act);     // nothing left of the query or of the target on this diagonal
+                    mp = m0;
+                    m0 = act ? x + y : -0x40000000;     // also read by the band update (NJ <= 2); idle lanes never qualify
+                    mmax = NJ == 1 ? m0 : max(mmax, m0);
+                } while (++j < NJ);
+                ended = e;
+                last_m0 = m0; last_mp = mp;
+                lin += (unsigned)nslot;
+                __builtin_amdgcn_wave_barrier();
+                best_m = max(best_m, half_max(mmax));      // running maximum of x + y (:160-167)
             };
-            if (NJ == 1) row_body(1);
-            else if (NJ == 2) row_body(2);
-            else row_body(NJ);
+            if (NJ == 1) {
+                row_passes(1);
+                if (ended) break;
+                band_update(1, last_m0, last_mp);
+            } else if (NJ == 2) {
+                row_passes(2);
+                if (ended) break;
+                band_update(2, last_m0, last_mp);
+            } else {
+                row_passes(NJ);
+                if (ended) break;
+                band_update(NJ, last_m0, last_mp);
+            }
             d += 1;
             __builtin_amdgcn_wave_barrier();
+        }
+        if (ended) {
+            // Once per block, outside the row loop (inside it, the state written here costs register copies on every row): the
+            // lowest diagonal that reached an end (:168-169), from the values just stored in V; then the rest of that row for the
+            // other half.
+            const int nslot = ((max_k - min_k) >> 1) + 1;
+            int hkey = 0x7fffffff;
+            for (int jj = 0; jj < NJ; ++jj) {
+                const int tt = sl + 32 * jj, k = min_k + 2 * tt, kk = k + k_offset;
+                if (tt < nslot) {
+                    const int x = S.V[kk];
+                    if (x >= q_len || x - k >= t_len) hkey = min(hkey, (kk << 10) | x);
+                }
+            }
+            hkey = half_min(hkey);
+            if (inblock && hkey != 0x7fffffff) {
+                aligned = 1; end_k = (hkey >> 10) - k_offset; end_x = hkey & 1023; end_d = d;
+                dlim = 0;
+            }
+            band_update(NJ, last_m0, last_mp);
+            d += 1;
+            __builtin_amdgcn_wave_barrier();
+        }
+        {
+            const int nslot = ((max_k - min_k) >> 1) + 1;
+            row_ok = d < dlim && nslot <= band_tol + 1;
         }
 
         const bool fin = inblock && !row_ok;
@@ -699,7 +727,7 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
                 BlockOut o;
                 unsigned int c2 = 0, s2 = 0;
                 DwStats st2 = {0, 0, 0, 0, 0};
-                align_block<true>(*(AlnWaveLds*)&lds[threadIdx.x >> 6][hx], ql, tl, grow, o, c2, s2, st2);
+                align_block<true, true>(*(AlnWaveLds*)&lds[threadIdx.x >> 6][hx], ql, tl, grow, o, c2, s2, st2);
                 ++nfallback;
                 if (hh == hx) {
                     has_aln = o.aligned_or_best; o_qe = o.qe; o_te = o.te; o_dist = o.dist;

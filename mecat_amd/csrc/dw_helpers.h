@@ -34,6 +34,19 @@ __device__ __forceinline__ uint32_t view_word(const SeqView& s, int i0) {
     }
     return s.comp ? ~w : w;
 }
+// The same 16 logical bases with base i0 in the LOWEST two bits (base i0 + j at bits 2j .. 2j+1): the layout of dw_extend2's
+// staged blocks, where a 16-base window at base x is ({P[w+1], P[w]} >> 2(x & 15)) — v_alignbit takes the shift modulo 32, so
+// the shift operand is just x + x (no multiply, no pad word) and the run of equal bases is counted from the low end.
+__device__ __forceinline__ uint32_t view_word_le(const SeqView& s, int i0) {
+    const int64_t o0 = s.off + s.A + (int64_t)s.B * i0;
+    uint32_t w;
+    if (s.B > 0) w = rev_groups(pac_win16(s.pac, o0));
+    else {
+        const int64_t lo = o0 - 15;                     // volume bases lo .. o0: the window already has logical base j at bits 2j
+        w = lo >= 0 ? pac_win16(s.pac, lo) : (pac_win16(s.pac, 0) >> ((-lo) << 1));
+    }
+    return s.comp ? ~w : w;
+}
 // ({hi, lo} << s) >> 32 for s in 0..30, branch-free (HIP's __funnelshift_l lowers to a divergent branch on s == 0)
 __device__ __forceinline__ uint32_t funnel_l(uint32_t lo, uint32_t hi, int s) {
     const uint32_t r = __builtin_amdgcn_alignbit(hi, lo, (32 - s) & 31);
@@ -73,6 +86,24 @@ __device__ __forceinline__ int match16(const uint32_t* Q, int x, const uint32_t*
     uint32_t lead;
     asm("v_ffbh_u32 %0, %1" : "=v"(lead) : "v"(dh));
     return (int)(lead >> 1);
+}
+
+// little-endian staged blocks (view_word_le; no pad word: base i lives in word i >> 4)
+__device__ __forceinline__ int match16_le(const uint32_t* Q, int x, const uint32_t* T, int y) {
+    const int wq = x >> 4, wt = y >> 4;
+    const uint32_t d = __builtin_amdgcn_alignbit(Q[wq + 1], Q[wq], (uint32_t)(x + x)) ^ __builtin_amdgcn_alignbit(T[wt + 1], T[wt], (uint32_t)(y + y));
+    uint32_t tz;                                        // v_ffbl_b32 of 0 is -1: 16 equal bases read as 0x7fffffff
+    asm("v_ffbl_b32 %0, %1" : "=v"(tz) : "v"(d));
+    return (int)(tz >> 1);
+}
+__device__ __forceinline__ int match32_le(const uint32_t* Q, int x, const uint32_t* T, int y) {
+    const int wq = x >> 4, wt = y >> 4;
+    const uint32_t sq = (uint32_t)(x + x), st = (uint32_t)(y + y);
+    const uint32_t q0 = Q[wq], q1 = Q[wq + 1], q2 = Q[wq + 2], t0 = T[wt], t1 = T[wt + 1], t2 = T[wt + 2];
+    const uint32_t dl = __builtin_amdgcn_alignbit(q1, q0, sq) ^ __builtin_amdgcn_alignbit(t1, t0, st);
+    const uint32_t dh = __builtin_amdgcn_alignbit(q2, q1, sq) ^ __builtin_amdgcn_alignbit(t2, t1, st);
+    const int nl = dl ? (__builtin_ctz(dl) >> 1) : 16, nh = dh ? 16 + (__builtin_ctz(dh) >> 1) : 32;
+    return dl ? nl : nh;
 }
 
 // ---- wave64 reductions on the DPP network (no LDS traffic): quad swaps, half-row / row mirrors, row broadcasts.

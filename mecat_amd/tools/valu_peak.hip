@@ -26,7 +26,7 @@
         uint64_t m = 0x5555aaaa3333ccccull ^ blockIdx.x;                                                                   \
         lds[threadIdx.x] = a0; lds[threadIdx.x + 256] = a1; lds[threadIdx.x + 512] = a2; lds[threadIdx.x + 768] = a3;       \
         __syncthreads();                                                                                                   \
-        uint32_t la = (threadIdx.x & 255) * 16;                                                                            \
+        uint32_t la = (threadIdx.x & 255) * 4;                                                                             \
         asm volatile("v_cmp_lt_u32 vcc, %0, %1\n v_cmp_lt_u32 s[24:25], %0, %1\n s_mov_b64 s[26:27], %2\n" PRE : : "v"(a0), "v"(b), "s"(m) : "vcc", "s24", "s25", "s26", "s27"); \
         for (int i = 0; i < iters; ++i) {                                                                                  \
             REP8(asm volatile(BODY : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+s"(s0), \
@@ -146,6 +146,12 @@
 #define I_SMOV_VCC_CNDMASK(d, n) "s_mov_b64 vcc, %13\n v_cndmask_b32 " d ", " d ", %12, vcc\n"
 #define I_MAX_I16_PAIR(d, n) "v_max_i16 " d ", " d ", %12\n v_add_u16 " d ", " d ", %12\n"
 #define I_MIX_ADD_MAXI32(d, n) "v_add_u32 " d ", " d ", %12\n v_add_u32 " d ", " d ", %12\n v_add_u32 " d ", " d ", %12\n v_max_i32 " d ", " d ", %12\n"
+// the d-path row body's own mix (tools/isa_mix.py on dw_extend2: 64 % of the VALU instructions in the 4-cycle class, 0.36 SALU
+// and 0.09 LDS instructions per VALU instruction), independent streams: 7 four-cycle + 4 two-cycle VALU, 4 SALU, 1 LDS read
+#define I_MIX_DW(d, n) "v_alignbit_b32 " d ", " d ", " n ", %12\n s_add_u32 %8, %8, 1\n v_add_u32 " d ", " d ", %12\n v_min_i32 " d ", " d ", %12\n" \
+                       "v_cmp_lt_u32 s[20:21], " n ", %12\n s_and_b64 s[24:25], s[20:21], %13\n v_cndmask_b32 " d ", " d ", %12, s[24:25]\n v_xor_b32 " d ", " d ", %12\n" \
+                       "v_lshl_add_u32 " d ", " d ", 1, %12\n s_add_u32 %9, %9, 3\n v_sub_u32 " d ", " d ", %12\n v_max_i32 " d ", " d ", %12\n" \
+                       "ds_read_b32 v30, %14\n v_ffbh_u32 " d ", " d "\n s_bcnt1_i32_b64 %10, %13\n v_add_u32 " d ", " d ", %12\n"
 #define WAIT "s_waitcnt lgkmcnt(0)\n"
 
 #define KERNELS(X)                                                                                                      \
@@ -182,7 +188,8 @@
     X(ds_read_b64, S8(I_DS_READ_B64) WAIT, 8) X(ds_read_b128, S8(I_DS_READ_B128) WAIT, 8) X(ds_read_u8, S8(I_DS_READ_U8) WAIT, 8) \
     X(mix_ds_read_3vadd, S8(I_MIX_DS_VALU) WAIT, 32) X(seq_v_cmp_vcc_3cndmask, S8(I_CMP_3CNDMASK), 32)                            \
     X(seq_v_cmp_sgpr_3cndmask, S8(I_CMP_3CNDMASK_SGPR), 32) X(seq_s_mov_vcc_cndmask, S8(I_SMOV_VCC_CNDMASK), 16)                 \
-    X(mix_max_i16_add_u16, S8(I_MAX_I16_PAIR), 16) X(mix_3vadd_1vmax, S8(I_MIX_ADD_MAXI32), 32)
+    X(mix_max_i16_add_u16, S8(I_MAX_I16_PAIR), 16) X(mix_3vadd_1vmax, S8(I_MIX_ADD_MAXI32), 32)                                   \
+    X(mix_dw_rowbody, S8(I_MIX_DW) WAIT, 128)
 
 #define X_DEF(NAME, BODY, N) DEF_KERNEL(NAME, BODY)
 KERNELS(X_DEF)

@@ -156,6 +156,57 @@ int  mhip_xalign_candidates(mhip_ctx* ctx, const mhip_volume* ref, const mhip_vo
 int  mhip_xalign_candidates_dev(mhip_ctx* ctx, const mhip_volume* ref, const mhip_volume* reads, const void* d_jobs,
                                 int n, int min_align_size, void* d_out);
 
+/* ---- multi-GPU: one process per GPU, the all-vs-all grid sharded statically, candidate lists exchanged over
+ * RCCL.  The reference parallelises a grid cell (reference volume i x query volume j) over pthreads pulling chunks of 500 query
+ * reads from a shared cursor (mecat2pw/pw_impl.cpp:612-621, 866-876); here chunk c of query volume j belongs to rank
+ * (c + cell_shift) mod nranks (the driver passes cell_shift = j).  Every rank builds the index of volume i itself
+ * (mhip_index_build: recompute beats moving it), seeds the reads of its own chunks, and ONE count-then-payload all-gather per
+ * slab of reads leaves the complete candidate table on every rank: one int32 per read first, then only the occupied 48-byte
+ * records, sent directly to every peer (xGMI is point to point).  Nothing here has a counterpart in the reference.
+ *
+ * mhip_comm_unique_id / mhip_comm_init wrap ncclGetUniqueId / ncclCommInitRank (RCCL is opened lazily, single-GPU runs never
+ * load it): rank 0 creates the id and hands it to the other ranks by any means (the driver uses a file in wrk_dir, bench.py a
+ * torch.distributed broadcast).  Collectives run on the context's stream.  mhip_comm_init_hostfile is a TEST HOOK for boxes
+ * with fewer GPUs than ranks (RCCL refuses two ranks on one device): same calls, transport through files in `dir`. */
+typedef struct mhip_comm mhip_comm;
+#define MHIP_COMM_ID_BYTES 128
+#define MHIP_SHARD_CHUNK 500       /* CHUNK_SIZE, mecat2pw/pw_impl.h:15 */
+int  mhip_comm_unique_id(uint8_t id[MHIP_COMM_ID_BYTES]);
+int  mhip_comm_init(mhip_ctx* ctx, int nranks, int rank, const uint8_t id[MHIP_COMM_ID_BYTES], mhip_comm** out);
+int  mhip_comm_init_hostfile(mhip_ctx* ctx, int nranks, int rank, const char* dir, const char* run_id, mhip_comm** out);
+void mhip_comm_destroy(mhip_comm* comm);
+int  mhip_comm_rank(const mhip_comm* comm);
+int  mhip_comm_nranks(const mhip_comm* comm);
+int  mhip_comm_barrier(mhip_comm* comm);
+int64_t mhip_comm_bytes_received(const mhip_comm* comm);      /* payload + counts received from peers so far */
+
+/* shard arithmetic for the reads [rid_begin, rid_end) of a query volume (rid_begin must be a multiple of chunk): how many of
+ * them `rank` owns and the first one; local index i is read first + (i / chunk) * chunk * nranks + i % chunk */
+int  mhip_shard_local_count(int rid_begin, int rid_end, int chunk, int cell_shift, int rank, int nranks);
+int  mhip_shard_first_read(int rid_begin, int rid_end, int chunk, int cell_shift, int rank, int nranks);
+/* mhip_seed_reads_dev for the local reads of such a shard (first = mhip_shard_first_read, n = mhip_shard_local_count) */
+int  mhip_seed_reads_chunked_dev(mhip_ctx* ctx, const mhip_index* idx, const mhip_volume* ref, const mhip_volume* reads, int first,
+                                 int chunk, int nranks, int n, const mhip_params* p, void* d_out, void* d_out_counts);
+
+/* The exchange step: d_cands[n_local][maxc] / d_counts[n_local] are this rank's lists (DEVICE pointers); on return
+ * d_all_cands[rid_end - rid_begin][maxc] / d_all_counts[rid_end - rid_begin] hold the complete table of the slab, read-major,
+ * on every rank — the layout mhip_seed_reads produces. */
+int  mhip_allgather_candidates(mhip_comm* comm, const void* d_cands, const void* d_counts, int rid_begin, int rid_end, int chunk,
+                               int cell_shift, int maxc, void* d_all_cands, void* d_all_counts);
+
+/* mhip_seed_reads over all ranks: seeds this rank's chunks of [rid_begin, rid_end) and exchanges.  out / out_counts are HOST
+ * pointers in mhip_seed_reads' layout and may be NULL (the table stays on the device, see mhip_sharded_tables). */
+int  mhip_seed_reads_sharded(mhip_comm* comm, const mhip_index* idx, const mhip_volume* ref, const mhip_volume* reads, int rid_begin,
+                             int rid_end, int chunk, int cell_shift, const mhip_params* p, mhip_candidate* out, int32_t* out_counts);
+/* mhip_align_candidates / mhip_xalign_candidates (tech 0 / 1) over all ranks, for the slab of the preceding
+ * mhip_seed_reads_sharded call: every rank extends the candidates of its own reads, the 32-byte results are exchanged like the
+ * candidates.  out (HOST, may be NULL) receives one result per candidate, read-major: read rid_begin's candidates in list order,
+ * then read rid_begin + 1's ... — the order of the job list the driver builds from the table.  *num_jobs = their number. */
+int  mhip_align_sharded(mhip_comm* comm, const mhip_volume* ref, const mhip_volume* reads, int tech, int min_align_size,
+                        mhip_aln_result* out, int64_t* num_jobs);
+/* device views of the tables the last two calls left on this rank (complete on every rank) */
+int  mhip_sharded_tables(mhip_comm* comm, void** d_cands, void** d_counts, void** d_results, int64_t* num_jobs);
+
 /* ---- mecat2cns re-aligner: ns_banded_sw::GetAlignment of src/mecat2cns/dw.cpp:482-553, which
  * mecat2cns calls for up to 200 candidates per template read (mecat_correction.cpp:286, 347, 431, 494) -------------------
  * Jobs are mhip_aln_job records: qid_local = the candidate read in `reads`, taken reverse-complemented when chain != 0;

@@ -1,0 +1,538 @@
+// comm.hip — multi-GPU entry points of the C ABI (include/mecat_hip.h).
+//
+// The reference parallelises one grid cell (reference volume i x query volume j) over pthreads that pull chunks of 500
+// query reads from a shared cursor (mecat2pw/pw_impl.cpp:612-621, 866-876).  Here the same chunks are dealt out statically
+// to the P GPUs of a node — chunk c of query volume j belongs to rank (c + j) mod P — every rank seeds (and extends) the reads of
+// its own chunks against its own copy of the index (rebuilt locally: recompute beats shipping up to 8.5 GB of positions over
+// a 153 GB/s xGMI link), and the per-read candidate lists are exchanged in ONE all-gather per slab of reads:
+//     counts first   ncclAllGather of one int32 per read
+//     then payload   only the occupied 48-byte candidate_save records (about 22 of MAXC = 100 per read at config 2), as a
+//                    grouped ncclSend / ncclRecv with every peer — xGMI is point to point, every pair of GPUs has its own link,
+//                    so the all-gather-v is P - 1 direct transfers per rank in parallel, not a ring
+// after which every rank holds the complete table in mhip_seed_reads' layout (rank 0 writes r_<i>, the file protocol is
+// unchanged).  The extension results (32 bytes per candidate) travel the same way.
+//
+// RCCL is opened lazily (dlopen) by mhip_comm_init, so single-GPU runs never map the library.  mhip_comm_init_hostfile is a
+// TEST HOOK: RCCL refuses two ranks on one device ("Duplicate GPU detected"), so the two-process tests on a one-GPU box
+// exchange through files in a directory instead; same call sequence, same kernels, host-staged transport.
+#include <dlfcn.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <string>
+#include <vector>
+
+#include <rccl/rccl.h>
+
+#include "common.h"
+
+int mhip_seed_reads_chunked_dev(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref, const mhip_volume* reads, int rid0, int chunk,
+                                int nranks, int n, const mhip_params* P, void* d_out, void* d_out_counts);
+
+namespace {
+
+struct RcclApi {
+    void* handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+RcclApi* rccl() {
+    static RcclApi api;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (api.handle) return &api;
+    // a copy already mapped by the process (e.g. the one torch ships) is found by its SONAME; otherwise ROCm's
+    const char* names[] = {getenv("MECAT_HIP_RCCL"), "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+    void* h = nullptr;
+    for (const char* n : names) {
+        if (!n || !*n) continue;
+        h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (h) break;
+    }
+    if (!h) { mhip_set_error("cannot load RCCL (librccl.so.1): %s", dlerror()); return nullptr; }
+#define SYM(f)                                                                         \
+    api.f = (decltype(api.f))dlsym(h, "nccl" #f);                                       \
+    if (!api.f) { mhip_set_error("RCCL symbol nccl" #f " missing"); dlclose(h); return nullptr; }
+    SYM(GetUniqueId) SYM(CommInitRank) SYM(CommDestroy) SYM(AllGather) SYM(Send) SYM(Recv) SYM(GroupStart) SYM(GroupEnd) SYM(GetErrorString)
+#undef SYM
+    api.handle = h;
+    return &api;
+}
+
+#define NCHK(expr)                                                                                            \
+    do {                                                                                                      \
+        ncclResult_t r_ = (expr);                                                                             \
+        if (r_ != ncclSuccess) { mhip_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, rccl()->GetErrorString(r_)); return -1; } \
+    } while (0)
+
+// ---- shard arithmetic: reads [rb, re) of a volume in chunks of `chunk`; chunk c belongs to rank (c + shift) mod P
+struct Shard {
+    int rb, re, chunk, shift, P;
+    int cb() const { return rb / chunk; }
+    int first_chunk(int rank) const {
+        const int b = cb();
+        return b + (((rank - (b + shift)) % P) + P) % P;
+    }
+    int rid0(int rank) const { return first_chunk(rank) * chunk; }
+    int local_count(int rank) const {
+        long n = 0;
+        for (long c = first_chunk(rank); c * chunk < re; c += P) n += std::min<long>(re, (c + 1) * chunk) - c * chunk;
+        return (int)n;
+    }
+};
+__host__ __device__ inline int shard_rid(int rid0, int chunk, int P, int i) { return rid0 + (i / chunk) * chunk * P + i % chunk; }
+
+}  // namespace
+
+struct mhip_comm {
+    mhip_ctx* ctx = nullptr;
+    int nranks = 1, rank = 0;
+    ncclComm_t nc = nullptr;
+    // host-file transport (test hook)
+    bool hostfile = false;
+    std::string dir, run_id;
+    unsigned long seq = 0;
+    // state of the last mhip_seed_reads_sharded call (consumed by mhip_align_sharded)
+    Shard sh{0, 0, 1, 0, 1};
+    int maxc = 0, n_pad = 0;
+    std::vector<int64_t> totals;            // candidates per rank
+    mhip_candidate* d_local = nullptr;      // [n_local][maxc]
+    int32_t* d_local_cnt = nullptr;         // [n_local]
+    int32_t* d_cnt_all = nullptr;           // [P][n_pad]
+    uint32_t* d_pref = nullptr;             // [P][n_pad] exclusive prefix of d_cnt_all inside each rank
+    mhip_candidate* d_all = nullptr;        // [re - rb][maxc]
+    int32_t* d_all_cnt = nullptr;           // [re - rb]
+    mhip_aln_result* d_all_res = nullptr;   // dense, read-major
+    int64_t n_jobs_total = 0;
+    int64_t bytes_received = 0;
+};
+
+namespace {
+
+// one block per rank: exclusive prefix of its counts, total to totals[rank]
+__global__ __launch_bounds__(1024) void xg_prefix(const int32_t* __restrict__ cnt_all, int n_pad, uint32_t* __restrict__ pref, long long* __restrict__ totals) {
+    __shared__ unsigned int wtot[16];
+    __shared__ unsigned int carry;
+    const int r = blockIdx.x;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int t0 = 0; t0 < n_pad; t0 += 1024) {
+        const int i = t0 + threadIdx.x;
+        const unsigned int c = i < n_pad ? (unsigned int)cnt_all[(size_t)r * n_pad + i] : 0u;
+        unsigned int incl = c;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned int v = __shfl_up(incl, o);
+            if ((threadIdx.x & 63) >= (unsigned)o) incl += v;
+        }
+        if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        unsigned int base = carry;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += wtot[w];
+        if (i < n_pad) pref[(size_t)r * n_pad + i] = base + incl - c;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = base + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) totals[r] = (long long)carry;
+}
+
+// this rank's occupied records, dense, local read-major
+__global__ void xg_pack(const mhip_candidate* __restrict__ cands, const int32_t* __restrict__ cnt, const uint32_t* __restrict__ pref, int n_local,
+                        int maxc, mhip_candidate* __restrict__ pack) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = (int)(t / (unsigned)maxc), k = (int)(t % (unsigned)maxc);
+    if (i >= n_local || k >= cnt[i]) return;
+    pack[(size_t)pref[i] + k] = cands[(size_t)i * maxc + k];
+}
+
+// dense rank-major records -> the read-major table of mhip_seed_reads
+__global__ void xg_scatter(const mhip_candidate* __restrict__ dense, const int32_t* __restrict__ cnt_all, const uint32_t* __restrict__ pref,
+                           const long long* __restrict__ displ, int n_pad, int maxc, int rb, int re, int chunk, int P, const int* __restrict__ rid0s,
+                           mhip_candidate* __restrict__ all, int32_t* __restrict__ all_cnt) {
+    const int r = blockIdx.y;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = (int)(t / (unsigned)maxc), k = (int)(t % (unsigned)maxc);
+    if (i >= n_pad) return;
+    const int rid = shard_rid(rid0s[r], chunk, P, i);
+    if (rid >= re) return;
+    const int c = cnt_all[(size_t)r * n_pad + i];
+    if (k == 0) all_cnt[rid - rb] = c;
+    if (k < c) all[(size_t)(rid - rb) * maxc + k] = dense[(size_t)displ[r] + pref[(size_t)r * n_pad + i] + k];
+}
+
+// jobs of this rank's reads, dense at pref[i] + k (the loop head of pairwise_mapping, pw_impl.cpp:674-686)
+__global__ void xg_make_jobs(const mhip_candidate* __restrict__ cands, const int32_t* __restrict__ cnt, const uint32_t* __restrict__ pref, int n_local,
+                             int maxc, int rid0, int chunk, int P, int ref_start_id, mhip_aln_job* __restrict__ jobs) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = (int)(t / (unsigned)maxc), k = (int)(t % (unsigned)maxc);
+    if (i >= n_local || k >= cnt[i]) return;
+    const mhip_candidate cd = cands[(size_t)i * maxc + k];
+    mhip_aln_job jb;
+    jb.qid_local = shard_rid(rid0, chunk, P, i);
+    jb.sid_local = cd.readno - ref_start_id;
+    jb.chain = cd.chain;
+    int qstart = cd.loc2, sstart = cd.loc1;
+    if (qstart && sstart) { qstart += MHIP_KMER_SIZE / 2; sstart += MHIP_KMER_SIZE / 2; }
+    jb.qstart = qstart;
+    jb.sstart = sstart;
+    jobs[(size_t)pref[i] + k] = jb;
+}
+
+// exclusive scan of the read-major counts (one block)
+__global__ __launch_bounds__(1024) void xg_read_first(const int32_t* __restrict__ counts, int n, uint32_t* __restrict__ first) {
+    __shared__ unsigned int wtot[16];
+    __shared__ unsigned int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int t0 = 0; t0 < n; t0 += 1024) {
+        const int i = t0 + threadIdx.x;
+        const unsigned int c = i < n ? (unsigned int)counts[i] : 0u;
+        unsigned int incl = c;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned int v = __shfl_up(incl, o);
+            if ((threadIdx.x & 63) >= (unsigned)o) incl += v;
+        }
+        if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        unsigned int base = carry;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += wtot[w];
+        if (i < n) first[i] = base + incl - c;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = base + incl;
+        __syncthreads();
+    }
+}
+
+// dense rank-major results -> dense read-major results
+__global__ void xg_scatter_res(const mhip_aln_result* __restrict__ dense, const int32_t* __restrict__ cnt_all, const uint32_t* __restrict__ pref,
+                               const long long* __restrict__ displ, int n_pad, int maxc, int rb, int re, int chunk, int P, const int* __restrict__ rid0s,
+                               const uint32_t* __restrict__ first, mhip_aln_result* __restrict__ all) {
+    const int r = blockIdx.y;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = (int)(t / (unsigned)maxc), k = (int)(t % (unsigned)maxc);
+    if (i >= n_pad) return;
+    const int rid = shard_rid(rid0s[r], chunk, P, i);
+    if (rid >= re) return;
+    if (k < cnt_all[(size_t)r * n_pad + i]) all[(size_t)first[rid - rb] + k] = dense[(size_t)displ[r] + pref[(size_t)r * n_pad + i] + k];
+}
+
+// ---- transport: every rank contributes bytes[rank] bytes at d_send; afterwards d_recv + displ[r] holds rank r's bytes on every rank
+int allgatherv(mhip_comm* cm, const void* d_send, void* d_recv, const std::vector<size_t>& bytes, const std::vector<size_t>& displ) {
+    mhip_ctx* c = cm->ctx;
+    const int P = cm->nranks, me = cm->rank;
+    if (bytes[me]) HIPCHK(hipMemcpyAsync((char*)d_recv + displ[me], d_send, bytes[me], hipMemcpyDeviceToDevice, c->stream));
+    if (P == 1) return 0;
+    for (int r = 0; r < P; ++r)
+        if (r != me) cm->bytes_received += (int64_t)bytes[r];
+    if (!cm->hostfile) {
+        RcclApi* R = rccl();
+        if (!R) return -1;
+        bool equal = true;
+        for (int r = 0; r < P; ++r) equal = equal && bytes[r] == bytes[0] && displ[r] == (size_t)r * bytes[0];
+        if (equal) {
+            if (bytes[0]) NCHK(R->AllGather(d_send, d_recv, bytes[0], ncclInt8, cm->nc, c->stream));
+            return 0;
+        }
+        NCHK(R->GroupStart());
+        for (int r = 0; r < P; ++r) {
+            if (r == me) continue;
+            if (bytes[me]) NCHK(R->Send(d_send, bytes[me], ncclInt8, r, cm->nc, c->stream));
+            if (bytes[r]) NCHK(R->Recv((char*)d_recv + displ[r], bytes[r], ncclInt8, r, cm->nc, c->stream));
+        }
+        NCHK(R->GroupEnd());
+        return 0;
+    }
+    // host-file transport (test hook): one file per rank and exchange, written under a temporary name and renamed
+    const unsigned long seq = cm->seq++;
+    std::vector<char> h(std::max<size_t>(bytes[me], 1));
+    if (bytes[me]) HIPCHK(hipMemcpyAsync(h.data(), d_send, bytes[me], hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    auto name = [&](int r) { return cm->dir + "/xchg." + cm->run_id + "." + std::to_string(seq) + "." + std::to_string(r); };
+    {
+        const std::string tmp = name(me) + ".tmp";
+        FILE* f = fopen(tmp.c_str(), "wb");
+        if (!f || (bytes[me] && fwrite(h.data(), 1, bytes[me], f) != bytes[me]) || fclose(f) != 0) { mhip_set_error("cannot write %s", tmp.c_str()); return -1; }
+        if (rename(tmp.c_str(), name(me).c_str()) != 0) { mhip_set_error("cannot rename %s", tmp.c_str()); return -1; }
+    }
+    for (int r = 0; r < P; ++r) {
+        if (r == me) continue;
+        const std::string fn = name(r);
+        struct stat sb;
+        long waited = 0;
+        const long limit_ms = 1000L * (getenv("MECAT_HIP_COMM_TIMEOUT_S") ? atol(getenv("MECAT_HIP_COMM_TIMEOUT_S")) : 120L);
+        while (stat(fn.c_str(), &sb) != 0) {
+            usleep(2000);
+            if ((waited += 2) > limit_ms) { mhip_set_error("rank %d never wrote %s (waited %ld s)", r, fn.c_str(), limit_ms / 1000); return -1; }
+        }
+        if ((size_t)sb.st_size != bytes[r]) { mhip_set_error("%s: %ld bytes, expected %zu", fn.c_str(), (long)sb.st_size, bytes[r]); return -1; }
+        std::vector<char> g(std::max<size_t>(bytes[r], 1));
+        FILE* f = fopen(fn.c_str(), "rb");
+        if (!f || (bytes[r] && fread(g.data(), 1, bytes[r], f) != bytes[r])) { mhip_set_error("cannot read %s", fn.c_str()); if (f) fclose(f); return -1; }
+        fclose(f);
+        if (bytes[r]) HIPCHK(hipMemcpy((char*)d_recv + displ[r], g.data(), bytes[r], hipMemcpyHostToDevice));
+    }
+    // a rank may only remove its own file once every peer has read it: the file of exchange seq - 2 is certainly consumed
+    if (seq >= 2) unlink((cm->dir + "/xchg." + cm->run_id + "." + std::to_string(seq - 2) + "." + std::to_string(me)).c_str());
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mhip_comm_unique_id(uint8_t id[MHIP_COMM_ID_BYTES]) {
+    static_assert(sizeof(ncclUniqueId) == MHIP_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    RcclApi* R = rccl();
+    if (!R) return -1;
+    ncclUniqueId u;
+    NCHK(R->GetUniqueId(&u));
+    memcpy(id, &u, sizeof(u));
+    return 0;
+}
+
+int mhip_comm_init(mhip_ctx* ctx, int nranks, int rank, const uint8_t id[MHIP_COMM_ID_BYTES], mhip_comm** out) {
+    *out = nullptr;
+    if (nranks < 1 || rank < 0 || rank >= nranks) { mhip_set_error("bad rank %d of %d", rank, nranks); return -1; }
+    HIPCHK(hipSetDevice(ctx->device));
+    mhip_comm* cm = new mhip_comm();
+    cm->ctx = ctx;
+    cm->nranks = nranks;
+    cm->rank = rank;
+    if (nranks > 1) {
+        RcclApi* R = rccl();
+        if (!R) { delete cm; return -1; }
+        ncclUniqueId u;
+        memcpy(&u, id, sizeof(u));
+        ncclResult_t r = R->CommInitRank(&cm->nc, nranks, u, rank);
+        if (r != ncclSuccess) { mhip_set_error("ncclCommInitRank(rank %d of %d) failed: %s", rank, nranks, R->GetErrorString(r)); delete cm; return -1; }
+    }
+    *out = cm;
+    return 0;
+}
+
+int mhip_comm_init_hostfile(mhip_ctx* ctx, int nranks, int rank, const char* dir, const char* run_id, mhip_comm** out) {
+    *out = nullptr;
+    if (nranks < 1 || rank < 0 || rank >= nranks || !dir || !run_id) { mhip_set_error("bad host-file communicator arguments"); return -1; }
+    mhip_comm* cm = new mhip_comm();
+    cm->ctx = ctx;
+    cm->nranks = nranks;
+    cm->rank = rank;
+    cm->hostfile = true;
+    cm->dir = dir;
+    cm->run_id = run_id;
+    *out = cm;
+    return 0;
+}
+
+void mhip_comm_destroy(mhip_comm* cm) {
+    if (!cm) return;
+    if (cm->nc) {
+        (void)hipSetDevice(cm->ctx->device);
+        (void)hipStreamSynchronize(cm->ctx->stream);
+        RcclApi* R = rccl();
+        if (R) (void)R->CommDestroy(cm->nc);
+    }
+    // (host-file transport: the files of the last two exchanges stay behind — a peer may still be reading them)
+    delete cm;
+}
+
+int mhip_comm_rank(const mhip_comm* cm) { return cm->rank; }
+int mhip_comm_nranks(const mhip_comm* cm) { return cm->nranks; }
+int64_t mhip_comm_bytes_received(const mhip_comm* cm) { return cm->bytes_received; }
+
+int mhip_comm_barrier(mhip_comm* cm) {
+    mhip_ctx* c = cm->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    char* d;
+    if (c->scratch("xg_barrier", 64 * (size_t)(cm->nranks + 1), (void**)&d)) return -1;
+    std::vector<size_t> bytes((size_t)cm->nranks, 64), displ((size_t)cm->nranks);
+    for (int r = 0; r < cm->nranks; ++r) displ[(size_t)r] = 64 * (size_t)(r + 1);
+    if (allgatherv(cm, d, d, bytes, displ)) return -1;      // (self copy d -> d + 64 (rank + 1): disjoint)
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int mhip_shard_local_count(int rid_begin, int rid_end, int chunk, int cell_shift, int rank, int nranks) {
+    if (chunk < 1 || nranks < 1 || rid_begin % chunk != 0) return -1;
+    const Shard s{rid_begin, rid_end, chunk, cell_shift, nranks};
+    return s.local_count(rank);
+}
+int mhip_shard_first_read(int rid_begin, int rid_end, int chunk, int cell_shift, int rank, int nranks) {
+    if (chunk < 1 || nranks < 1 || rid_begin % chunk != 0) return -1;
+    const Shard s{rid_begin, rid_end, chunk, cell_shift, nranks};
+    return s.rid0(rank);
+}
+
+// d_cands[n_local][maxc], d_counts[n_local]: this rank's reads of the shard (local index i = read rid0 + (i / chunk) * chunk * P + i % chunk).
+// d_all_cands[(rid_end - rid_begin)][maxc], d_all_counts[rid_end - rid_begin]: the complete table, on every rank.
+int mhip_allgather_candidates(mhip_comm* cm, const void* d_cands, const void* d_counts, int rid_begin, int rid_end, int chunk, int cell_shift,
+                              int maxc, void* d_all_cands, void* d_all_counts) {
+    mhip_ctx* c = cm->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    const int P = cm->nranks, me = cm->rank;
+    if (chunk < 1 || rid_begin % chunk != 0 || rid_end < rid_begin || maxc < 1) { mhip_set_error("bad shard [%d,%d) chunk %d", rid_begin, rid_end, chunk); return -1; }
+    const Shard sh{rid_begin, rid_end, chunk, cell_shift, P};
+    std::vector<int> nloc((size_t)P), rid0s((size_t)P);
+    int n_pad = 1;
+    for (int r = 0; r < P; ++r) { nloc[(size_t)r] = sh.local_count(r); rid0s[(size_t)r] = sh.rid0(r); n_pad = std::max(n_pad, nloc[(size_t)r]); }
+    const int n_local = nloc[(size_t)me];
+    cm->sh = sh;
+    cm->maxc = maxc;
+    cm->n_pad = n_pad;
+    int32_t *d_pad, *d_cnt_all;
+    uint32_t* d_pref;
+    long long* d_tot;      // [P] totals, [P] displacements
+    int* d_rid0;
+    if (c->scratch("xg_cntpad", sizeof(int32_t) * (size_t)n_pad, (void**)&d_pad)) return -1;
+    if (c->scratch("xg_cntall", sizeof(int32_t) * (size_t)n_pad * P, (void**)&d_cnt_all)) return -1;
+    if (c->scratch("xg_pref", sizeof(uint32_t) * (size_t)n_pad * P, (void**)&d_pref)) return -1;
+    if (c->scratch("xg_tot", sizeof(long long) * 2 * (size_t)P, (void**)&d_tot)) return -1;
+    if (c->scratch("xg_rid0", sizeof(int) * (size_t)P, (void**)&d_rid0)) return -1;
+    HIPCHK(hipMemsetAsync(d_pad, 0, sizeof(int32_t) * (size_t)n_pad, c->stream));
+    if (n_local) HIPCHK(hipMemcpyAsync(d_pad, d_counts, sizeof(int32_t) * (size_t)n_local, hipMemcpyDeviceToDevice, c->stream));
+    // 1. counts
+    {
+        std::vector<size_t> bytes((size_t)P, sizeof(int32_t) * (size_t)n_pad), displ((size_t)P);
+        for (int r = 0; r < P; ++r) displ[(size_t)r] = bytes[0] * (size_t)r;
+        if (allgatherv(cm, d_pad, d_cnt_all, bytes, displ)) return -1;
+    }
+    LAUNCH(c, "xg_prefix", xg_prefix, P, 1024, 0, (const int32_t*)d_cnt_all, n_pad, d_pref, d_tot);
+    std::vector<long long> tot((size_t)P);
+    HIPCHK(hipMemcpyAsync(tot.data(), d_tot, sizeof(long long) * (size_t)P, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    cm->totals.assign(tot.begin(), tot.end());
+    std::vector<long long> displ_rec((size_t)P);
+    long long total = 0;
+    for (int r = 0; r < P; ++r) { displ_rec[(size_t)r] = total; total += tot[(size_t)r]; }
+    cm->n_jobs_total = total;
+    HIPCHK(hipMemcpyAsync(d_tot + P, displ_rec.data(), sizeof(long long) * (size_t)P, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d_rid0, rid0s.data(), sizeof(int) * (size_t)P, hipMemcpyHostToDevice, c->stream));
+    // 2. payload: only the occupied records
+    mhip_candidate *d_pack, *d_dense;
+    if (c->scratch("xg_pack", sizeof(mhip_candidate) * (size_t)std::max<long long>(tot[(size_t)me], 1), (void**)&d_pack)) return -1;
+    if (c->scratch("xg_dense", sizeof(mhip_candidate) * (size_t)std::max<long long>(total, 1), (void**)&d_dense)) return -1;
+    if (n_local) {
+        const size_t nt = (size_t)n_local * (size_t)maxc;
+        LAUNCH(c, "xg_pack", xg_pack, (unsigned)((nt + 255) / 256), 256, 0, (const mhip_candidate*)d_cands, (const int32_t*)d_counts,
+               (const uint32_t*)(d_pref + (size_t)me * n_pad), n_local, maxc, d_pack);
+    }
+    {
+        std::vector<size_t> bytes((size_t)P), displ((size_t)P);
+        for (int r = 0; r < P; ++r) { bytes[(size_t)r] = sizeof(mhip_candidate) * (size_t)tot[(size_t)r]; displ[(size_t)r] = sizeof(mhip_candidate) * (size_t)displ_rec[(size_t)r]; }
+        if (allgatherv(cm, d_pack, d_dense, bytes, displ)) return -1;
+    }
+    // 3. back into the read-major table
+    const int n = rid_end - rid_begin;
+    if (n > 0) {
+        HIPCHK(hipMemsetAsync(d_all_counts, 0, sizeof(int32_t) * (size_t)n, c->stream));
+        const size_t nt = (size_t)n_pad * (size_t)maxc;
+        LAUNCH(c, "xg_scatter", xg_scatter, dim3((unsigned)((nt + 255) / 256), (unsigned)P), 256, 0, (const mhip_candidate*)d_dense,
+               (const int32_t*)d_cnt_all, (const uint32_t*)d_pref, (const long long*)(d_tot + P), n_pad, maxc, rid_begin, rid_end, chunk, P,
+               (const int*)d_rid0, (mhip_candidate*)d_all_cands, (int32_t*)d_all_counts);
+    }
+    HIPCHK(hipGetLastError());
+    cm->d_cnt_all = d_cnt_all;
+    cm->d_pref = d_pref;
+    return 0;
+}
+
+int mhip_seed_reads_sharded(mhip_comm* cm, const mhip_index* idx, const mhip_volume* ref, const mhip_volume* reads, int rid_begin, int rid_end,
+                            int chunk, int cell_shift, const mhip_params* P, mhip_candidate* out, int32_t* out_counts) {
+    mhip_ctx* c = cm->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    if (rid_begin < 0 || rid_end > reads->num_reads || rid_begin > rid_end || chunk < 1 || rid_begin % chunk != 0) {
+        mhip_set_error("bad sharded read range [%d,%d) chunk %d", rid_begin, rid_end, chunk);
+        return -1;
+    }
+    const int n = rid_end - rid_begin;
+    if (n == 0) return 0;
+    const Shard sh{rid_begin, rid_end, chunk, cell_shift, cm->nranks};
+    const int n_local = sh.local_count(cm->rank);
+    if (c->scratch("xg_local", sizeof(mhip_candidate) * (size_t)std::max(n_local, 1) * (size_t)P->maxc, (void**)&cm->d_local)) return -1;
+    if (c->scratch("xg_localcnt", sizeof(int32_t) * (size_t)std::max(n_local, 1), (void**)&cm->d_local_cnt)) return -1;
+    if (c->scratch("xg_all", sizeof(mhip_candidate) * (size_t)n * (size_t)P->maxc, (void**)&cm->d_all)) return -1;
+    if (c->scratch("xg_allcnt", sizeof(int32_t) * (size_t)n, (void**)&cm->d_all_cnt)) return -1;
+    if (n_local && mhip_seed_reads_chunked_dev(c, idx, ref, reads, sh.rid0(cm->rank), chunk, cm->nranks, n_local, P, cm->d_local, cm->d_local_cnt))
+        return -1;
+    if (mhip_allgather_candidates(cm, cm->d_local, cm->d_local_cnt, rid_begin, rid_end, chunk, cell_shift, P->maxc, cm->d_all, cm->d_all_cnt)) return -1;
+    if (out_counts) HIPCHK(hipMemcpyAsync(out_counts, cm->d_all_cnt, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    if (out) HIPCHK(hipMemcpyAsync(out, cm->d_all, sizeof(mhip_candidate) * (size_t)n * (size_t)P->maxc, hipMemcpyDeviceToHost, c->stream));
+    if (out || out_counts) HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int mhip_align_sharded(mhip_comm* cm, const mhip_volume* ref, const mhip_volume* reads, int tech, int min_align_size, mhip_aln_result* out,
+                       int64_t* num_jobs) {
+    mhip_ctx* c = cm->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    const int P = cm->nranks, me = cm->rank;
+    const Shard& sh = cm->sh;
+    const int n = sh.re - sh.rb;
+    if (num_jobs) *num_jobs = cm->n_jobs_total;
+    if (n <= 0 || cm->totals.empty()) return 0;
+    const int n_local = sh.local_count(me), maxc = cm->maxc, n_pad = cm->n_pad;
+    const long long mine = cm->totals[(size_t)me], total = cm->n_jobs_total;
+    mhip_aln_job* d_jobs;
+    mhip_aln_result *d_res, *d_dense;
+    if (c->scratch("xg_jobs", sizeof(mhip_aln_job) * (size_t)std::max<long long>(mine, 1), (void**)&d_jobs)) return -1;
+    if (c->scratch("xg_res", sizeof(mhip_aln_result) * (size_t)std::max<long long>(mine, 1), (void**)&d_res)) return -1;
+    if (c->scratch("xg_resdense", sizeof(mhip_aln_result) * (size_t)std::max<long long>(total, 1), (void**)&d_dense)) return -1;
+    if (c->scratch("xg_resall", sizeof(mhip_aln_result) * (size_t)std::max<long long>(total, 1), (void**)&cm->d_all_res)) return -1;
+    if (mine > 0x7fffffffLL) { mhip_set_error("too many alignment jobs in one slab"); return -1; }
+    if (mine) {
+        const size_t nt = (size_t)n_local * (size_t)maxc;
+        LAUNCH(c, "xg_make_jobs", xg_make_jobs, (unsigned)((nt + 255) / 256), 256, 0, (const mhip_candidate*)cm->d_local, (const int32_t*)cm->d_local_cnt,
+               (const uint32_t*)(cm->d_pref + (size_t)me * n_pad), n_local, maxc, sh.rid0(me), sh.chunk, P, ref->start_read_id, d_jobs);
+        const int rc = tech == 1 ? mhip_xalign_candidates_dev(c, ref, reads, d_jobs, (int)mine, min_align_size, d_res)
+                                 : mhip_align_candidates_dev(c, ref, reads, d_jobs, (int)mine, min_align_size, d_res);
+        if (rc) return -1;
+    }
+    std::vector<size_t> bytes((size_t)P), displ((size_t)P);
+    std::vector<long long> displ_rec((size_t)P);
+    long long acc = 0;
+    for (int r = 0; r < P; ++r) {
+        displ_rec[(size_t)r] = acc;
+        bytes[(size_t)r] = sizeof(mhip_aln_result) * (size_t)cm->totals[(size_t)r];
+        displ[(size_t)r] = sizeof(mhip_aln_result) * (size_t)acc;
+        acc += cm->totals[(size_t)r];
+    }
+    if (allgatherv(cm, d_res, d_dense, bytes, displ)) return -1;
+    long long* d_tot;
+    int* d_rid0;
+    uint32_t* d_first;
+    if (c->scratch("xg_tot", sizeof(long long) * 2 * (size_t)P, (void**)&d_tot)) return -1;       // [P + r] = displacements, still valid
+    if (c->scratch("xg_rid0", sizeof(int) * (size_t)P, (void**)&d_rid0)) return -1;
+    if (c->scratch("xg_first", sizeof(uint32_t) * (size_t)n, (void**)&d_first)) return -1;
+    LAUNCH(c, "xg_read_first", xg_read_first, 1, 1024, 0, (const int32_t*)cm->d_all_cnt, n, d_first);
+    const size_t nt = (size_t)n_pad * (size_t)maxc;
+    LAUNCH(c, "xg_scatter_res", xg_scatter_res, dim3((unsigned)((nt + 255) / 256), (unsigned)P), 256, 0, (const mhip_aln_result*)d_dense,
+           (const int32_t*)cm->d_cnt_all, (const uint32_t*)cm->d_pref, (const long long*)(d_tot + P), n_pad, maxc, sh.rb, sh.re, sh.chunk, P,
+           (const int*)d_rid0, (const uint32_t*)d_first, cm->d_all_res);
+    HIPCHK(hipGetLastError());
+    if (out && total) {
+        HIPCHK(hipMemcpyAsync(out, cm->d_all_res, sizeof(mhip_aln_result) * (size_t)total, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+int mhip_sharded_tables(mhip_comm* cm, void** d_cands, void** d_counts, void** d_results, int64_t* num_jobs) {
+    if (d_cands) *d_cands = cm->d_all;
+    if (d_counts) *d_counts = cm->d_all_cnt;
+    if (d_results) *d_results = cm->d_all_res;
+    if (num_jobs) *num_jobs = cm->n_jobs_total;
+    return 0;
+}
+
+}  // extern "C"

@@ -101,13 +101,21 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wtot /
     return base + incl - v;
 }
 
+// Which reads a call works on: local index i -> read rid0 + (i / chunk) * cstride + i % chunk.  chunk == 1 is a plain stride
+// (a contiguous range has cstride == 1); chunk > 1 is the multi-GPU shard of a grid cell by chunks of reads (SURVEY.md §8e:
+// the reference hands out chunks of 500 reads, mecat2pw/pw_impl.cpp:612-621; rank r of P owns every P-th chunk).
+struct ReadSel { int rid0, chunk, cstride; };
+__host__ __device__ __forceinline__ int sel_rid(const ReadSel& s, int i) {
+    return s.chunk == 1 ? s.rid0 + i * s.cstride : s.rid0 + (i / s.chunk) * s.cstride + i % s.chunk;
+}
+
 // ------------------------------------------------------------------------------------------------ probe
 __global__ __launch_bounds__(SEED_BLOCK) void seed_probe(const uint32_t* __restrict__ pac, const mhip_offset_t* __restrict__ roffs,
-                                                         int rid_begin, int rid_stride, const uint32_t* __restrict__ starts, SeedArrays A,
+                                                         ReadSel sel, int ib, const uint32_t* __restrict__ starts, SeedArrays A,
                                                          unsigned long long* __restrict__ counters) {
     __shared__ uint32_t wtot[SEED_WAVES];
     const int s = blockIdx.x;
-    const int rid = rid_begin + (s >> 1) * rid_stride;
+    const int rid = sel_rid(sel, ib + (s >> 1));
     const bool rev = s & 1;
     const int off = roffs[rid].offset, L = roffs[rid].size;
     const int K = kmers_of(L);
@@ -227,7 +235,7 @@ __device__ __forceinline__ bool rel_test(const uint32_t* rel, uint32_t seg) {
 // hot slots, the relevance bitmap and the exact number of kept hits (sum of h over relevant slots: the strand's room in
 // the key arrays) come from passes over the 32 K-entry table.  A counter that would wrap (>= 256 hits in one slot: repeats)
 // turns the filter off for the strand.
-__global__ __launch_bounds__(SEED_BLOCK) void seed_filter(const mhip_offset_t* __restrict__ roffs, int rid_begin, int rid_stride,
+__global__ __launch_bounds__(SEED_BLOCK) void seed_filter(const mhip_offset_t* __restrict__ roffs, ReadSel sel, int ib,
                                                           const uint16_t* __restrict__ slots, SeedArrays A, int gate, int enable) {
     static_assert(ZV == 2000 && FLT_M == (1 << 15), "idx_slots (index.hip) computes (position / 2000) mod 2^15");
     __shared__ uint32_t cnt[FLT_M / 4];          // 32 KB
@@ -235,7 +243,7 @@ __global__ __launch_bounds__(SEED_BLOCK) void seed_filter(const mhip_offset_t* _
     __shared__ uint32_t wtot[SEED_WAVES];
     __shared__ uint32_t s_wrap;
     const int s = blockIdx.x;
-    const int rid = rid_begin + (s >> 1) * rid_stride;
+    const int rid = sel_rid(sel, ib + (s >> 1));
     const int L = roffs[rid].size;
     const int K = kmers_of(L);
     const uint32_t kb = A.km_base[s];
@@ -294,14 +302,14 @@ __global__ __launch_bounds__(SEED_BLOCK) void seed_filter(const mhip_offset_t* _
 // The strand's k-mers are taken 64 at a time (16 lanes per bucket, four buckets per group as in for_each_hit16): count the
 // kept hits per bucket, scan the 64 counts, write.  The first 32 entries of a bucket stay in registers between the two
 // steps; longer buckets are read again (from cache).
-__global__ __launch_bounds__(SEED_BLOCK) void seed_emit(const mhip_offset_t* __restrict__ roffs, int rid_begin, int rid_stride,
+__global__ __launch_bounds__(SEED_BLOCK) void seed_emit(const mhip_offset_t* __restrict__ roffs, ReadSel sel, int ib,
                                                         const int32_t* __restrict__ offsets, SeedArrays A) {
     __shared__ uint32_t rel[REL_WORDS];
     __shared__ uint32_t ccnt[64];
     __shared__ uint32_t coff[64];
     __shared__ uint32_t s_tot;
     const int s = blockIdx.x;
-    const int rid = rid_begin + (s >> 1) * rid_stride;
+    const int rid = sel_rid(sel, ib + (s >> 1));
     const int L = roffs[rid].size;
     const int K = kmers_of(L);
     const uint32_t kb = A.km_base[s];
@@ -719,7 +727,7 @@ __device__ __forceinline__ int read_id_lookup(const mhip_offset_t* __restrict__ 
 
 // one wave per read: F strand then R strand into one top-MAXC list kept in LDS (12 ints per entry)
 __global__ __launch_bounds__(WAVE) void seed_cand(SeedArrays A, const mhip_offset_t* __restrict__ ref_offs, const uint32_t* __restrict__ ref_blk, int ref_nreads,
-                                                  int ref_start_id, const mhip_offset_t* __restrict__ roffs, int rid_begin, int rid_stride,
+                                                  int ref_start_id, const mhip_offset_t* __restrict__ roffs, ReadSel sel, int ib,
                                                   int reads_start_id, mhip_params P, mhip_candidate* __restrict__ out,
                                                   int32_t* __restrict__ out_counts, unsigned long long* __restrict__ counters) {
     extern __shared__ __attribute__((aligned(16))) int smem[];
@@ -727,7 +735,7 @@ __global__ __launch_bounds__(WAVE) void seed_cand(SeedArrays A, const mhip_offse
     CandLds* T = (CandLds*)(smem + P.maxc * 12);
     const int lane = lane_id();
     const int r = blockIdx.x;
-    const int rid = rid_begin + r * rid_stride;
+    const int rid = sel_rid(sel, ib + r);
     const int read_id = rid + reads_start_id;
     const int read_size = roffs[rid].size;
     const int MAXC = P.maxc;
@@ -991,15 +999,14 @@ static int bits_for(uint32_t maxv) {
 
 static bool filter_enabled(const mhip_params* P);
 
-// reads rid0 + i * stride for i in [ib, ie)
-static int seed_batch(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref, const mhip_volume* reads, int rid0, int stride,
+// the reads with local index in [ib, ie) of the selection
+static int seed_batch(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref, const mhip_volume* reads, const ReadSel sel,
                       int ib, int ie, const mhip_params* P, mhip_candidate* d_out, int32_t* d_counts) {
     const int nr = ie - ib, ns = 2 * nr;
-    const int rb = rid0 + ib * stride;
     std::vector<uint32_t> kmb((size_t)ns);
     uint64_t sumK = 0;
     for (int r = 0; r < nr; ++r) {
-        int L = reads->h_offs[(size_t)(rb + r * stride)].size;
+        int L = reads->h_offs[(size_t)sel_rid(sel, ib + r)].size;
         int K = L < MHIP_KMER_SIZE ? 0 : (L - MHIP_KMER_SIZE) / BC + 1;
         kmb[(size_t)2 * r] = (uint32_t)sumK; sumK += (uint64_t)K;
         kmb[(size_t)2 * r + 1] = (uint32_t)sumK; sumK += (uint64_t)K;
@@ -1021,12 +1028,12 @@ static int seed_batch(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref
     if (c->scratch("sd_ngated", sizeof(uint32_t) * (size_t)ns, (void**)&A.ngated)) return -1;
     A.km_base = d_kmb;
     HIPCHK(hipMemcpyAsync(d_kmb, kmb.data(), sizeof(uint32_t) * (size_t)ns, hipMemcpyHostToDevice, c->stream));
-    LAUNCH(c, "seed_probe", seed_probe, ns, SEED_BLOCK, 0, (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs, rb, stride,
+    LAUNCH(c, "seed_probe", seed_probe, ns, SEED_BLOCK, 0, (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs, sel, ib,
            (const uint32_t*)idx->d_starts, A, (unsigned long long*)c->d_counters);
     {
         const int gate = 2 * P->min_kmer_match;
         const int enable = filter_enabled(P) ? 1 : 0;
-        LAUNCH(c, "seed_filter", seed_filter, ns, SEED_BLOCK, 0, (const mhip_offset_t*)reads->d_offs, rb, stride,
+        LAUNCH(c, "seed_filter", seed_filter, ns, SEED_BLOCK, 0, (const mhip_offset_t*)reads->d_offs, sel, ib,
                (const uint16_t*)idx->d_slots, A, gate, enable);
     }
     LAUNCH(c, "seed_scan", seed_scan, 1, 1024, 0, (const uint32_t*)A.strand_hits, ns, A.hit_base);
@@ -1047,7 +1054,7 @@ static int seed_batch(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref
     if (c->scratch("sd_gated", sizeof(uint32_t) * Hc, (void**)&A.gated)) return -1;
     int in_b = 0;
     if (Htot > 0) {
-        LAUNCH(c, "seed_emit", seed_emit, ns, SEED_BLOCK, 0, (const mhip_offset_t*)reads->d_offs, rb, stride, (const int32_t*)idx->d_offsets, A);
+        LAUNCH(c, "seed_emit", seed_emit, ns, SEED_BLOCK, 0, (const mhip_offset_t*)reads->d_offs, sel, ib, (const int32_t*)idx->d_offsets, A);
         const int nbits = bits_for((uint32_t)(ref->num_bases / ZV));
         const int npass = (nbits + SORT_MAXBITS - 1) / SORT_MAXBITS;
         const int per = (nbits + npass - 1) / npass;
@@ -1063,7 +1070,7 @@ static int seed_batch(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref
     const size_t lds = sizeof(int) * 12 * (size_t)P->maxc + sizeof(CandLds);
     LAUNCH(c, "seed_cand", seed_cand, nr, WAVE, lds, A, (const mhip_offset_t*)ref->d_offs, (const uint32_t*)ref->d_blk2read, ref->num_reads,
            ref->start_read_id,
-           (const mhip_offset_t*)reads->d_offs, rb, stride, reads->start_read_id, *P, d_out, d_counts, (unsigned long long*)c->d_counters);
+           (const mhip_offset_t*)reads->d_offs, sel, ib, reads->start_read_id, *P, d_out, d_counts, (unsigned long long*)c->d_counters);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1077,14 +1084,14 @@ static bool filter_enabled(const mhip_params* P) {
 // reads per launch: bounded by an estimate of the bucket hits they produce.  The batch arrays cost ~54 bytes per KEPT
 // hit (about one hit in seven survives the relevance filter); seed_cand runs one wave per read and is latency bound,
 // so larger batches are what fills the chip.
-static int next_batch_end(const mhip_index* idx, const mhip_volume* reads, int rid0, int stride, int rb, int re, const mhip_params* P) {
+static int next_batch_end(const mhip_index* idx, const mhip_volume* reads, const ReadSel sel, int rb, int re, const mhip_params* P) {
     const double hits_per_lookup = (double)idx->num_kmers / (double)NKMER + 2.0;
     double budget = filter_enabled(P) ? 3.2e9 : 400e6;   // ~25 GB of batch arrays either way (1.6e9: 5 ms more per config-2 pass, tail of the one-wave-per-read kernel)
     if (const char* e = getenv("MECAT_SEED_BATCH_HITS")) budget = std::max(1e6, atof(e));   // tuning knob
     double acc = 0;
     int r = rb;
     while (r < re) {
-        int L = reads->h_offs[(size_t)(rid0 + r * stride)].size;
+        int L = reads->h_offs[(size_t)sel_rid(sel, r)].size;
         double k = L < MHIP_KMER_SIZE ? 0 : (double)((L - MHIP_KMER_SIZE) / BC + 1);
         acc += 2.0 * k * hits_per_lookup;
         ++r;
@@ -1095,24 +1102,39 @@ static int next_batch_end(const mhip_index* idx, const mhip_volume* reads, int r
 
 extern "C" {
 
-int mhip_seed_reads_strided_dev(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref, const mhip_volume* reads, int rid_begin,
-                                int rid_stride, int n, const mhip_params* P, void* d_out, void* d_out_counts) {
+static int seed_selection(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref, const mhip_volume* reads, const ReadSel sel, int n,
+                          const mhip_params* P, void* d_out, void* d_out_counts) {
     HIPCHK(hipSetDevice(c->device));
-    if (n < 0 || rid_stride < 1 || rid_begin < 0 || (n > 0 && (int64_t)rid_begin + (int64_t)(n - 1) * rid_stride >= reads->num_reads)) {
-        mhip_set_error("bad read selection begin %d stride %d n %d", rid_begin, rid_stride, n);
+    if (n < 0 || sel.chunk < 1 || sel.cstride < 1 || sel.rid0 < 0 || (n > 0 && sel_rid(sel, n - 1) >= reads->num_reads)) {
+        mhip_set_error("bad read selection begin %d chunk %d stride %d n %d", sel.rid0, sel.chunk, sel.cstride, n);
         return -1;
     }
     if (P->maxc < 1 || P->maxc > MAXC_LIMIT) { mhip_set_error("maxc %d outside 1..%d", P->maxc, MAXC_LIMIT); return -1; }
     if (ref->num_reads == 0) { mhip_set_error("empty reference volume"); return -1; }
     int ib = 0;
     while (ib < n) {
-        int ie = next_batch_end(idx, reads, rid_begin, rid_stride, ib, n, P);
-        if (seed_batch(c, idx, ref, reads, rid_begin, rid_stride, ib, ie, P, (mhip_candidate*)d_out + (size_t)ib * P->maxc,
-                       (int32_t*)d_out_counts + ib))
+        int ie = next_batch_end(idx, reads, sel, ib, n, P);
+        if (seed_batch(c, idx, ref, reads, sel, ib, ie, P, (mhip_candidate*)d_out + (size_t)ib * P->maxc, (int32_t*)d_out_counts + ib))
             return -1;
         ib = ie;
     }
     return 0;
+}
+
+int mhip_seed_reads_strided_dev(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref, const mhip_volume* reads, int rid_begin,
+                                int rid_stride, int n, const mhip_params* P, void* d_out, void* d_out_counts) {
+    if (n > 0 && (int64_t)rid_begin + (int64_t)(n - 1) * rid_stride >= reads->num_reads) {
+        mhip_set_error("bad read selection begin %d stride %d n %d", rid_begin, rid_stride, n);
+        return -1;
+    }
+    return seed_selection(c, idx, ref, reads, ReadSel{rid_begin, 1, rid_stride}, n, P, d_out, d_out_counts);
+}
+
+// local reads of a chunked shard (mecat_hip.h: mhip_shard_*): local index i -> read rid0 + (i / chunk) * chunk * nranks + i % chunk
+int mhip_seed_reads_chunked_dev(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref, const mhip_volume* reads, int rid0, int chunk,
+                                int nranks, int n, const mhip_params* P, void* d_out, void* d_out_counts) {
+    if (chunk < 1 || nranks < 1 || (int64_t)chunk * nranks > 0x7fffffff) { mhip_set_error("bad shard: chunk %d ranks %d", chunk, nranks); return -1; }
+    return seed_selection(c, idx, ref, reads, ReadSel{rid0, chunk, chunk * nranks}, n, P, d_out, d_out_counts);
 }
 
 int mhip_seed_reads_dev(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref, const mhip_volume* reads, int rid_begin,

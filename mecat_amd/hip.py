@@ -94,6 +94,21 @@ def lib():
     L.mhip_ctx_reserve_index.argtypes = [vp, C.c_int64]
     L.mhip_cns_align_candidates.argtypes = [vp, vp, vp, vp, i32, C.c_double, i32, i32, vp, vp]
     L.mhip_cns_align_candidates_dev.argtypes = [vp, vp, vp, vp, i32, C.c_double, i32, i32, vp, vp]
+    # multi-GPU
+    L.mhip_comm_unique_id.argtypes = [vp]
+    L.mhip_comm_init.argtypes = [vp, i32, i32, vp, C.POINTER(vp)]
+    L.mhip_comm_init_hostfile.argtypes = [vp, i32, i32, C.c_char_p, C.c_char_p, C.POINTER(vp)]
+    L.mhip_comm_destroy.argtypes = [vp]
+    L.mhip_comm_barrier.argtypes = [vp]
+    L.mhip_comm_bytes_received.restype = i64
+    L.mhip_comm_bytes_received.argtypes = [vp]
+    L.mhip_shard_local_count.argtypes = [i32, i32, i32, i32, i32, i32]
+    L.mhip_shard_first_read.argtypes = [i32, i32, i32, i32, i32, i32]
+    L.mhip_seed_reads_chunked_dev.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, C.POINTER(Params), vp, vp]
+    L.mhip_allgather_candidates.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
+    L.mhip_seed_reads_sharded.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, C.POINTER(Params), vp, vp]
+    L.mhip_align_sharded.argtypes = [vp, vp, vp, i32, i32, vp, C.POINTER(i64)]
+    L.mhip_sharded_tables.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64)]
     L.mhip_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
     L.mhip_host_free.argtypes = [vp]
     assert L.mhip_abi_version() == 1
@@ -276,3 +291,67 @@ def cns_expand(res, ops_row, qcodes, tcodes):
     ts = np.where(ops == 2, ord("-"), dec[np.asarray(tcodes)[np.minimum(ti, len(tcodes) - 1)]]).astype(np.uint8)
     a, b = int(res["first_col"]), int(res["last_col"])
     return qs[a:b].tobytes(), ts[a:b].tobytes()
+
+
+COMM_ID_BYTES = 128
+SHARD_CHUNK = 500
+
+
+def comm_unique_id():
+    """rank 0: the RCCL unique id (bytes) to hand to every rank"""
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    _chk(lib().mhip_comm_unique_id(buf))
+    return bytes(buf)
+
+
+class Comm:
+    """mhip_comm: RCCL communicator over one context per rank (hostfile_dir: the test-hook transport)"""
+
+    def __init__(self, ctx, nranks, rank, unique_id=None, hostfile_dir=None, run_id="0"):
+        self.h = C.c_void_p()
+        self.ctx, self.nranks, self.rank = ctx, nranks, rank
+        if hostfile_dir is not None:
+            _chk(lib().mhip_comm_init_hostfile(ctx.h, nranks, rank, hostfile_dir.encode(), run_id.encode(), C.byref(self.h)))
+        else:
+            buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id if unique_id is not None else bytes(COMM_ID_BYTES))
+            _chk(lib().mhip_comm_init(ctx.h, nranks, rank, buf, C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().mhip_comm_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def barrier(self):
+        _chk(lib().mhip_comm_barrier(self.h))
+
+    def bytes_received(self):
+        return int(lib().mhip_comm_bytes_received(self.h))
+
+    def seed_reads_sharded(self, idx, ref, reads, rid_begin, rid_end, params, chunk=SHARD_CHUNK, cell_shift=0, host=True):
+        """-> (cands [n, maxc] structured, counts [n]) on the host when host=True, else None (tables stay on the device)"""
+        n = rid_end - rid_begin
+        if host:
+            out = np.zeros((n, params.maxc), dtype=CAND_DTYPE)
+            cnt = np.zeros(n, dtype=np.int32)
+            _chk(lib().mhip_seed_reads_sharded(self.h, idx.h, ref.h, reads.h, rid_begin, rid_end, chunk, cell_shift, C.byref(params),
+                                               out.ctypes.data, cnt.ctypes.data))
+            return out, cnt
+        _chk(lib().mhip_seed_reads_sharded(self.h, idx.h, ref.h, reads.h, rid_begin, rid_end, chunk, cell_shift, C.byref(params), None, None))
+        return None
+
+    def align_sharded(self, ref, reads, min_align_size, tech=0, host=True):
+        """-> results of every candidate of the slab, read-major (host=True), and their number"""
+        nj = C.c_int64()
+        if not host:
+            _chk(lib().mhip_align_sharded(self.h, ref.h, reads.h, tech, min_align_size, None, C.byref(nj)))
+            return None, nj.value
+        _, _, _, total = self.tables()
+        out = np.zeros(max(total, 1), dtype=ALN_DTYPE)
+        _chk(lib().mhip_align_sharded(self.h, ref.h, reads.h, tech, min_align_size, out.ctypes.data, C.byref(nj)))
+        return out[: nj.value], nj.value
+
+    def tables(self):
+        """device pointers (cands, counts, results) of the last sharded calls and the number of jobs"""
+        a, b, c2, nj = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int64()
+        _chk(lib().mhip_sharded_tables(self.h, C.byref(a), C.byref(b), C.byref(c2), C.byref(nj)))
+        return a.value, b.value, c2.value, nj.value

@@ -1,0 +1,93 @@
+"""Multi-GPU entry points of the C ABI (mhip_comm_*, mhip_seed_reads_sharded, mhip_align_sharded) on ONE GPU:
+two or three ranks as threads of this process, each with its own context (stream + scratch) and a communicator on the
+host-file transport — the test hook for boxes with fewer GPUs than ranks (RCCL refuses two ranks on one device).  Same call
+sequence, same kernels and the same count-then-payload exchange as with RCCL; only the bytes travel through files.
+
+Checks: every rank ends up with exactly the table / results of the single-GPU calls, for the reference's chunk of 500 reads and
+for ragged shards (chunk 64, a read count that is not a multiple of anything, a slab that starts inside the volume)."""
+import os
+import tempfile
+import threading
+import uuid
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+os.environ.setdefault("MECAT_HIP_COMM_TIMEOUT_S", "30")      # a failed rank must not leave its peer waiting for minutes
+
+
+@pytest.fixture(scope="module")
+def data():
+    import mecat_amd.hip as M
+    from mecat_amd import workload as W
+    codes, lens = W.synth_reads(2731, 3000, 0.15, 300_000, 21)
+    pac, offs, nb = W.pack_volume(codes, lens)
+    ctx = M.Context(0)
+    vol = M.Volume(ctx, pac, offs, nb, 0)
+    idx = M.Index(ctx, vol)
+    p = M.default_params(0)
+    cands, cnt = M.seed_reads(ctx, idx, vol, vol, 0, len(lens), p)
+    jobs = W.jobs_from_candidates(cands, cnt, 0)
+    res = M.align_candidates(ctx, vol, vol, jobs, p.min_align_size)
+    d = dict(M=M, ctx=ctx, vol=vol, idx=idx, p=p, n=len(lens), cands=cands, cnt=cnt, res=res)
+    yield d
+    idx.free()
+    vol.free()
+    ctx.close()
+
+
+def _run_ranks(nranks, fn):
+    out, err = [None] * nranks, [None] * nranks
+
+    def body(r):
+        try:
+            out[r] = fn(r)
+        except Exception as e:      # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            err[r] = e
+
+    th = [threading.Thread(target=body, args=(r,)) for r in range(nranks)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for e in err:
+        if e is not None:
+            raise e
+    return out
+
+
+@pytest.mark.parametrize("nranks,chunk,rb,re,shift", [(2, 500, 0, None, 0), (3, 64, 0, None, 1), (2, 64, 640, 2500, 5), (3, 500, 500, None, 2)])
+def test_sharded_seeding_and_extension_equal_single_gpu(data, nranks, chunk, rb, re, shift):
+    M, vol, idx, p = data["M"], data["vol"], data["idx"], data["p"]
+    re = data["n"] if re is None else re
+    d = tempfile.mkdtemp(prefix="mecat_comm_")
+    run = uuid.uuid4().hex[:8]
+
+    def rank_body(r):
+        ctx = M.Context(0)
+        cm = M.Comm(ctx, nranks, r, hostfile_dir=d, run_id=run)
+        cm.barrier()
+        cands, cnt = cm.seed_reads_sharded(idx, vol, vol, rb, re, p, chunk=chunk, cell_shift=shift)
+        res, nj = cm.align_sharded(vol, vol, p.min_align_size)
+        got = (cands.copy(), cnt.copy(), res.copy(), nj, cm.bytes_received())
+        cm.barrier()
+        cm.close()
+        ctx.close()
+        return got
+
+    outs = _run_ranks(nranks, rank_body)
+    want_c, want_n = data["cands"][rb:re], data["cnt"][rb:re]
+    first = np.concatenate([[0], np.cumsum(data["cnt"].astype(np.int64))])
+    want_r = data["res"][first[rb]: first[re]]
+    mask = np.arange(p.maxc)[None, :] < want_n[:, None]
+    for r, (cands, cnt, res, nj, nbytes) in enumerate(outs):
+        assert np.array_equal(cnt, want_n), r
+        assert np.array_equal(cands[mask], want_c[mask]), r
+        assert nj == int(want_n.sum()) == len(res)
+        assert res.tobytes() == want_r.tobytes(), r
+        # count-then-payload: what a rank receives is the other ranks' records and counts, not max-padded slabs
+        total = int(want_n.sum())
+        assert nbytes < (48 + 32) * total + 4 * (re - rb + nranks * chunk) * 2 + 4096, (nbytes, total)

@@ -9,7 +9,10 @@
 // the host (`-t` threads; the same option sizes the FASTA reader's thread pool).  There is no CPU fallback for the kernels: any failure aborts with the library's message.
 //
 // Additive, environment-only knobs:  MECAT_HIP_DEVICE=<n> (default 0),  MECAT_HIP_SLAB=<reads per seed call>,
-// WORLD_SIZE / RANK / LOCAL_RANK (or MECAT_HIP_WORLD / MECAT_HIP_RANK): one process per GPU, grid rows dealt out cyclically.
+// WORLD_SIZE / RANK / LOCAL_RANK (or MECAT_HIP_WORLD / MECAT_HIP_RANK): one process per GPU (see "Multi-GPU mode" below),
+// MECAT_HIP_SHARD=rows|cells, MECAT_HIP_SHARD_CHUNK=<reads>, MECAT_HIP_RUN_ID=<token>, MECAT_HIP_COMM=file (test hook).
+#include <fcntl.h>
+#include <signal.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -31,11 +34,19 @@
 #include "partition.h"
 #include "volume.h"
 
+// multi-process runs: a rank that dies leaves this marker so that the ranks waiting for its files stop too
+static char g_fail_marker[1024] = "";
+static void leave_fail_marker() {
+    if (!g_fail_marker[0]) return;
+    const int fd = open(g_fail_marker, O_CREAT | O_WRONLY, 0644);
+    if (fd >= 0) close(fd);
+}
 #define DIE(...)                                                  \
     do {                                                          \
         fprintf(stderr, "[%s, %u] ", __func__, __LINE__);         \
         fprintf(stderr, __VA_ARGS__);                             \
         fprintf(stderr, "\n");                                    \
+        leave_fail_marker();                                      \
         abort();                                                  \
     } while (0)
 #define MCHK(call)                                                 \
@@ -132,8 +143,11 @@ static void run_threads(int nt, F f) {
     for (auto& x : th) x.join();
 }
 
+// comm == NULL: this process computes the whole grid row.  Otherwise every rank of the communicator runs this function for the
+// same row: the reads of a slab are dealt out in chunks (chunk c of query volume j -> rank (c + j) mod P), each rank seeds and
+// extends its own, the lists are all-gathered (mhip_seed_reads_sharded / mhip_align_sharded), and rank 0 (out != NULL) writes.
 static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, const std::vector<std::string>& vn, FILE* out, PartitionWriter* pw,
-                               double part_ratio) {
+                               double part_ratio, mhip_comm* comm, int shard_chunk) {
     mhip_params P;
     mhip_params_default(&P, opt.tech);
     P.maxc = opt.num_candidates;
@@ -152,7 +166,9 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
     printf("number of kmers: %lld\n", (long long)mhip_index_num_kmers(idx));
 
     const char* slab_env = getenv("MECAT_HIP_SLAB");
-    const int slab = slab_env ? std::max(1, atoi(slab_env)) : 20000;
+    int slab = slab_env ? std::max(1, atoi(slab_env)) : 20000;
+    if (comm) slab = std::max(shard_chunk, slab - slab % shard_chunk);      // slabs start on chunk boundaries
+    const bool writes = out != NULL;
 
     struct SlabBuf {
         PinnedBuf<mhip_candidate> cands;      // buffers that cross the PCIe link: page-locked
@@ -308,6 +324,7 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
         int produced = 0, consumed = 0;
         bool closing = false;
         std::thread writer([&]() {
+            if (!writes) return;
             for (;;) {
                 int s;
                 {
@@ -339,10 +356,20 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
             std::vector<size_t>& jfirst = B.jfirst;
             B.rb = rb;
             B.nr = nr;
-            cands.resize((size_t)nr * P.maxc);
-            counts.resize((size_t)nr);
-            { StageClock sc(&st[0]); MCHK(mhip_seed_reads(ctx, idx, dref, dreads, rb, re, &P, cands.data(), counts.data())); }
-            if (opt.task != TASK_SEED) {
+            if (writes) {
+                cands.resize((size_t)nr * P.maxc);
+                counts.resize((size_t)nr);
+            }
+            if (comm) {
+                StageClock sc(&st[0]);
+                MCHK(mhip_seed_reads_sharded(comm, idx, dref, dreads, rb, re, shard_chunk, vid, &P, writes ? cands.data() : NULL,
+                                             writes ? counts.data() : NULL));
+            } else { StageClock sc(&st[0]); MCHK(mhip_seed_reads(ctx, idx, dref, dreads, rb, re, &P, cands.data(), counts.data())); }
+            if (opt.task != TASK_SEED && comm && !writes) {
+                StageClock sc(&st[2]);
+                int64_t nj = 0;
+                MCHK(mhip_align_sharded(comm, dref, dreads, opt.tech == TECH_NANOPORE ? 1 : 0, P.min_align_size, NULL, &nj));
+            } else if (opt.task != TASK_SEED) {
                 auto range_of = [&](int t, int* lo, int* hi) { *lo = (int)((long long)nr * t / nt); *hi = (int)((long long)nr * (t + 1) / nt); };
                 // pairwise_mapping, pw_impl.cpp:674-700
                 StageClock* sc_jobs = new StageClock(&st[1]);
@@ -372,13 +399,21 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
                 {
                     StageClock sc(&st[2]);
                     // aligner by technology (pw_impl.cpp:638-644): DiffAligner (dw) for PacBio, XdropAligner for nanopore
-                    if (opt.tech == TECH_NANOPORE) MCHK(mhip_xalign_candidates(ctx, dref, dreads, jobs.data(), (int)jobs.size(), P.min_align_size, res.data()));
+                    if (comm) {
+                        int64_t nj = 0;
+                        MCHK(mhip_align_sharded(comm, dref, dreads, opt.tech == TECH_NANOPORE ? 1 : 0, P.min_align_size, res.data(), &nj));
+                        if ((size_t)nj != jobs.size()) DIE("sharded extension returned %lld results for %zu candidates", (long long)nj, jobs.size());
+                    } else if (opt.tech == TECH_NANOPORE) MCHK(mhip_xalign_candidates(ctx, dref, dreads, jobs.data(), (int)jobs.size(), P.min_align_size, res.data()));
                     else MCHK(mhip_align_candidates(ctx, dref, dreads, jobs.data(), (int)jobs.size(), P.min_align_size, res.data()));
                 }
             }
-            {
+            if (writes) {
                 std::lock_guard<std::mutex> lk(pm);
                 ++produced;
+            } else {
+                std::lock_guard<std::mutex> lk(pm);      // nothing to write on this rank: the buffers are free again at once
+                ++produced;
+                ++consumed;
             }
             pcv.notify_all();
         }
@@ -418,9 +453,52 @@ static double now_s() {
 }
 
 // Multi-GPU mode (additive): P processes, one per GPU, started with WORLD_SIZE / RANK / LOCAL_RANK in the environment (e.g.
-// `python -m torch.distributed.run --no-python --nproc-per-node 8 mecat2pw ...`) or MECAT_HIP_WORLD / MECAT_HIP_RANK.  The
-// rows of the volume x volume grid (one r_<i> file each) are dealt out cyclically; no data moves between the processes.  Rank
-// 0 splits the input and merges the r_<i> files; the hand-offs are files in wrk_dir, like the resume protocol itself.
+// `python -m torch.distributed.run --no-python --nproc-per-node 8 mecat2pw ...`) or MECAT_HIP_WORLD / MECAT_HIP_RANK.  Rank 0
+// splits the input, merges the r_<i> files and writes the output; hand-offs between the processes are files in wrk_dir, like
+// the resume protocol itself.  Two ways to share the volume x volume grid (MECAT_HIP_SHARD=rows|cells overrides the choice):
+//   rows   (#volumes >= P)  grid row i -> rank i mod P, each row computed by one GPU exactly as in a single-GPU run (one index
+//          build per row, no data moves between the processes);
+//   cells  (#volumes <  P)  every rank works on every cell: the query reads of a cell are dealt out in chunks of 500
+//          (MECAT_HIP_SHARD_CHUNK; chunk c of query volume j -> rank (c + j) mod P), each rank builds the index of
+//          the row's reference volume itself, and the candidate lists / extension results are all-gathered over RCCL
+//          (mhip_seed_reads_sharded, mhip_align_sharded); rank 0 writes r_<i>.  A one-volume input (config 2) uses every GPU.
+// A run is identified by a token (MECAT_HIP_RUN_ID, else the launcher's TORCHELASTIC_RUN_ID + the parent pid, which every rank
+// of one launch shares): rank 0 puts it into the split marker, the other ranks accept no other marker.  Ranks above 0 keep a
+// heartbeat file fresh and leave a failure marker when they abort; rank 0 stops waiting for a row whose owner has died.
+struct RunFiles {
+    std::string dir, token;
+    std::string marker() const { return dir + "split_done"; }
+    std::string alive(int r) const { return dir + "rank_" + std::to_string(r) + ".alive." + token; }
+    std::string failed(int r) const { return dir + "rank_" + std::to_string(r) + ".failed." + token; }
+};
+
+static std::string run_token() {
+    if (const char* e = getenv("MECAT_HIP_RUN_ID")) return std::string("x") + e;
+    std::string t = "p" + std::to_string((long)getppid());
+    if (const char* e = getenv("TORCHELASTIC_RUN_ID")) t += std::string("_") + e;
+    if (const char* e = getenv("MASTER_PORT")) t += std::string("_") + e;
+    for (char& ch : t)
+        if (!isalnum((unsigned char)ch) && ch != '_' && ch != '-') ch = '_';
+    return t;
+}
+
+static std::string to_hex(const uint8_t* p, size_t n) {
+    static const char* d = "0123456789abcdef";
+    std::string s;
+    for (size_t i = 0; i < n; ++i) { s += d[p[i] >> 4]; s += d[p[i] & 15]; }
+    return s;
+}
+static bool from_hex(const std::string& s, uint8_t* p, size_t n) {
+    if (s.size() != 2 * n) return false;
+    auto v = [](char c) { return c >= '0' && c <= '9' ? c - '0' : c >= 'a' && c <= 'f' ? c - 'a' + 10 : -1; };
+    for (size_t i = 0; i < n; ++i) {
+        const int a = v(s[2 * i]), b = v(s[2 * i + 1]);
+        if (a < 0 || b < 0) return false;
+        p[i] = (uint8_t)(a * 16 + b);
+    }
+    return true;
+}
+
 int main(int argc, char* argv[]) {
     Options opt;
     if (parse_arguments(argc, argv, &opt)) {
@@ -430,9 +508,12 @@ int main(int argc, char* argv[]) {
     const int world = std::max(1, env_int("MECAT_HIP_WORLD", "WORLD_SIZE", 1));
     const int rank = std::min(world - 1, std::max(0, env_int("MECAT_HIP_RANK", "RANK", 0)));
     const double t_start = now_s();
-    std::string marker(opt.wrk_dir);
-    if (marker.empty() || marker[marker.size() - 1] != '/') marker += '/';
-    marker += "split_done";
+    RunFiles rf;
+    rf.dir = opt.wrk_dir;
+    if (rf.dir.empty() || rf.dir[rf.dir.size() - 1] != '/') rf.dir += '/';
+    rf.token = run_token();
+    const bool explicit_token = getenv("MECAT_HIP_RUN_ID") != NULL;
+    const std::string marker = rf.marker();
     // The GPU context and the index-build scratch (two arrays of 8 bytes per base of a volume: hundreds of milliseconds to map
     // at volume size) are set up on a second thread while this one parses the input.
     mhip_ctx* ctx = NULL;
@@ -469,28 +550,72 @@ int main(int argc, char* argv[]) {
         if (est_bases > 0) (void)mhip_ctx_reserve_index(made, est_bases);      // best effort
     });
     struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } gpu_setup_joiner{gpu_setup};
+
+    // heartbeat + failure marker of the ranks above 0
+    std::atomic<bool> beat_stop{false};
+    std::thread beat;
+    if (world > 1 && rank > 0) {
+        snprintf(g_fail_marker, sizeof(g_fail_marker), "%s", rf.failed(rank).c_str());
+        unlink(g_fail_marker);
+        signal(SIGSEGV, [](int) { leave_fail_marker(); _exit(139); });
+        signal(SIGTERM, [](int) { leave_fail_marker(); _exit(143); });
+        const std::string alive = rf.alive(rank);
+        beat = std::thread([&beat_stop, alive]() {
+            while (!beat_stop.load()) {
+                const int fd = open(alive.c_str(), O_CREAT | O_WRONLY | O_TRUNC, 0644);
+                if (fd >= 0) { (void)!write(fd, "1\n", 2); close(fd); }
+                for (int i = 0; i < 20 && !beat_stop.load(); ++i) usleep(100 * 1000);
+            }
+            unlink(alive.c_str());
+        });
+    }
+    struct BeatJoiner { std::atomic<bool>& stop; std::thread& t; ~BeatJoiner() { stop.store(true); if (t.joinable()) t.join(); } } beat_joiner{beat_stop, beat};
+
+    const int shard_chunk = std::max(1, env_int("MECAT_HIP_SHARD_CHUNK", NULL, MHIP_SHARD_CHUNK));
+    const bool file_comm = getenv("MECAT_HIP_COMM") && !strcmp(getenv("MECAT_HIP_COMM"), "file");
     int num_vols = 0;
+    bool cells = false;
+    std::vector<int> todo;                                // grid rows this run still has to compute
+    uint8_t comm_id[MHIP_COMM_ID_BYTES];
+    memset(comm_id, 0, sizeof(comm_id));
     if (rank == 0) {
         if (world > 1) unlink(marker.c_str());
         num_vols = split_raw_dataset(opt.reads, opt.wrk_dir, opt.num_threads);
+        for (int i = 0; i < num_vols; ++i)
+            if (access(results_name(opt.wrk_dir, i, false).c_str(), F_OK) != 0) todo.push_back(i);
         if (world > 1) {
+            const char* se = getenv("MECAT_HIP_SHARD");
+            cells = se ? !strcmp(se, "cells") : num_vols < world;
+            if (cells && !file_comm) MCHK(mhip_comm_unique_id(comm_id));
             FILE* m = fopen((marker + ".tmp").c_str(), "w");
             if (!m) DIE("cannot write '%s'", marker.c_str());
-            fprintf(m, "%.3f %d\n", t_start, num_vols);
+            fprintf(m, "%s %.3f %d %d %s\n", rf.token.c_str(), t_start, num_vols, cells ? 1 : 0, to_hex(comm_id, sizeof(comm_id)).c_str());
+            for (int i : todo) fprintf(m, "%d ", i);
+            fprintf(m, "\n");
             fclose(m);
             if (rename((marker + ".tmp").c_str(), marker.c_str()) != 0) DIE("cannot rename %s", marker.c_str());
         }
     } else {
-        // wait for THIS run's split: the marker carries rank 0's start time (a stale one is much older than our own start)
-        usleep(300 * 1000);
+        // wait for THIS run's split: the marker carries the run token (and, for a token that was not given explicitly, must be
+        // younger than this process: a restart by the same parent would reuse the token)
+        const double wait_limit = env_int("MECAT_HIP_WAIT_S", NULL, 6 * 3600);
         for (;;) {
             FILE* m = fopen(marker.c_str(), "r");
+            char tok[256] = "", hex[2 * MHIP_COMM_ID_BYTES + 8] = "";
             double t0 = 0;
-            int nv = 0;
-            const bool ok = m && fscanf(m, "%lf %d", &t0, &nv) == 2;
+            int nv = 0, cl = 0;
+            const bool ok = m && fscanf(m, "%255s %lf %d %d %300s", tok, &t0, &nv, &cl, hex) == 5;
+            if (ok && rf.token == tok && (explicit_token || t0 > t_start - 120.0) && from_hex(hex, comm_id, sizeof(comm_id))) {
+                int v;
+                while (fscanf(m, "%d", &v) == 1) todo.push_back(v);
+                fclose(m);
+                num_vols = nv;
+                cells = cl != 0;
+                break;
+            }
             if (m) fclose(m);
-            if (ok && t0 > t_start - 120.0) { num_vols = nv; break; }
-            usleep(50 * 1000);
+            if (now_s() - t_start > wait_limit) DIE("rank %d: no split marker of run '%s' in %s after %.0f s", rank, rf.token.c_str(), opt.wrk_dir, wait_limit);
+            usleep(20 * 1000);
         }
     }
     const std::string idx_name = index_file_name(opt.wrk_dir);
@@ -503,6 +628,13 @@ int main(int argc, char* argv[]) {
         // only the context is needed from here on; a reservation still in flight is waited for inside the library
         while (ctx_state.load() == 0) usleep(500);
         if (ctx_state.load() < 0) { gpu_setup.join(); DIE("cannot use the GPU: %s", ctx_error.c_str()); }
+    }
+    mhip_comm* comm = NULL;
+    if (cells) {
+        TraceTimer tt("comm_init");
+        if (file_comm) MCHK(mhip_comm_init_hostfile(ctx, world, rank, opt.wrk_dir, rf.token.c_str(), &comm));
+        else MCHK(mhip_comm_init(ctx, world, rank, comm_id, &comm));
+        MCHK(mhip_comm_barrier(comm));
     }
 
     // MECAT_HIP_PARTITION=<batch_size>[,<min_read_size>[,<mapping_ratio>]] (additive): also write mecat2cns' partition files
@@ -524,29 +656,53 @@ int main(int argc, char* argv[]) {
     }
     part_ratio = part_ratio - 0.02;                               // reads_correction_m4.cpp:79
     PartitionWriter* pw = (part_batch > 0 && world == 1) ? new PartitionWriter(opt.output, part_batch, part_min) : NULL;
-    for (int i = rank; i < num_vols; i += world) {
-        const std::string fin = results_name(opt.wrk_dir, i, false);
-        if (access(fin.c_str(), F_OK) == 0) {
-            fprintf(stderr, "[%s, %u] volume %d has been finished\n\n", __func__, __LINE__, i);
-            if (pw) { pw->abandon(); delete pw; pw = NULL; }      // that row's records are only on disk
+    if (pw && (int)todo.size() != num_vols) { pw->abandon(); delete pw; pw = NULL; }      // finished rows' records are only on disk
+    for (int i = 0; i < num_vols; ++i) {
+        if (std::find(todo.begin(), todo.end(), i) == todo.end()) {
+            if (rank == 0) fprintf(stderr, "[%s, %u] volume %d has been finished\n\n", __func__, __LINE__, i);
             continue;
         }
-        const std::string wrk = results_name(opt.wrk_dir, i, true);
-        FILE* out = fopen(wrk.c_str(), "w");
-        if (!out) DIE("failed to open file '%s' with mode 'ios::out'", wrk.c_str());
-        process_one_volume(opt, ctx, i, vn, out, pw, part_ratio);
-        if (fclose(out) != 0) DIE("write error!");
-        if (rename(wrk.c_str(), fin.c_str()) != 0) DIE("cannot rename %s", wrk.c_str());
+        if (!cells && i % world != rank) continue;               // rows: dealt out cyclically
+        const bool writes = !cells || rank == 0;
+        const std::string fin = results_name(opt.wrk_dir, i, false), wrk = results_name(opt.wrk_dir, i, true);
+        FILE* out = NULL;
+        if (writes) {
+            out = fopen(wrk.c_str(), "w");
+            if (!out) DIE("failed to open file '%s' with mode 'ios::out'", wrk.c_str());
+        }
+        process_one_volume(opt, ctx, i, vn, out, pw, part_ratio, comm, shard_chunk);
+        if (writes) {
+            if (fclose(out) != 0) DIE("write error!");
+            if (rename(wrk.c_str(), fin.c_str()) != 0) DIE("cannot rename %s", wrk.c_str());
+        }
+    }
+    if (comm) {
+        MCHK(mhip_comm_barrier(comm));
+        mhip_comm_destroy(comm);
     }
     gpu_setup.join();
     mhip_ctx_destroy(ctx);
     if (rank != 0) return 0;
 
-    // merge_results, pw.cpp:34-46 (rank 0; waits for the rows of the other ranks)
+    // merge_results, pw.cpp:34-46 (rank 0; in rows mode it waits for the rows of the other ranks, but not for a dead one)
     TraceTimer tt_merge("merge_results");
+    const double merge_wait = env_int("MECAT_HIP_WAIT_S", NULL, 6 * 3600);
     for (int i = 0; i < num_vols; ++i) {
         const std::string fin = results_name(opt.wrk_dir, i, false);
-        while (world > 1 && access(fin.c_str(), F_OK) != 0) usleep(50 * 1000);
+        const int owner = i % world;
+        const double w0 = now_s();
+        while (world > 1 && !cells && access(fin.c_str(), F_OK) != 0) {
+            if (access(rf.failed(owner).c_str(), F_OK) == 0) DIE("rank %d failed before it finished volume %d", owner, i);
+            struct stat sb;
+            const double now = now_s();
+            if (stat(rf.alive(owner).c_str(), &sb) == 0) {
+                if (now - (double)sb.st_mtime > 60.0) DIE("rank %d stopped responding (volume %d unfinished)", owner, i);
+            } else if (now - w0 > 120.0 && access(fin.c_str(), F_OK) != 0) {
+                DIE("rank %d is not running (no heartbeat; volume %d unfinished)", owner, i);
+            }
+            if (now - w0 > merge_wait) DIE("gave up waiting for volume %d of rank %d after %.0f s", i, owner, merge_wait);
+            usleep(50 * 1000);
+        }
         const std::string cmd = std::string("cat ") + fin + (i == 0 ? " >" : " >> ") + opt.output;
         if (system(cmd.c_str()) != 0) DIE("'%s' failed", cmd.c_str());
     }

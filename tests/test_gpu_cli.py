@@ -131,6 +131,51 @@ def test_cli_two_processes_share_the_grid_rows(tmp_path, task):
     assert sorted(f for f in os.listdir(wrk) if f.startswith("r_")) == ["r_0", "r_1", "r_2"]
 
 
+@pytest.mark.parametrize("task,nproc,vols", [("0", 2, 1), ("1", 2, 1), ("1", 3, 3), ("0", 2, 3)])
+def test_cli_processes_share_the_grid_cells(tmp_path, task, nproc, vols):
+    """multi-GPU mode of the driver, cell sharding: every rank works on every (reference volume, query volume)
+    cell — the query reads dealt out in chunks, chunk c of query volume j to rank (c + j) mod P — the candidate lists and
+    extension results are all-gathered (mhip_seed_reads_sharded / mhip_align_sharded) and rank 0 writes r_<i>.  Here the ranks
+    share GPU 0 and exchange through the host-file transport (RCCL refuses two ranks on one device); a one-volume input, which
+    the row sharding cannot split, is spread over all ranks.  The output must be byte-identical to the single-process run."""
+    import uuid
+    fa = _fasta(tmp_path, "config1" if vols == 1 else "tiny")
+    env = dict(os.environ)
+    if vols > 1:
+        env["MECAT_HIP_MCS"] = "250000"
+    args = ["-j", task, "-g", "1"]
+    one = str(tmp_path / "one.out")
+    r = subprocess.run([BIN, "-d", fa, "-o", one, "-w", str(tmp_path / "w_one"), "-t", "4"] + args, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    many = str(tmp_path / "many.out")
+    wrk = str(tmp_path / "w_many")
+    run = uuid.uuid4().hex[:10]
+    procs = []
+    for rank in reversed(range(nproc)):          # rank 0 last: the others have to wait for its split
+        e = dict(env, MECAT_HIP_WORLD=str(nproc), MECAT_HIP_RANK=str(rank), MECAT_HIP_DEVICE="0", MECAT_HIP_SHARD="cells",
+                 MECAT_HIP_COMM="file", MECAT_HIP_RUN_ID=run, MECAT_HIP_SHARD_CHUNK="100" if vols > 1 else "500",
+                 MECAT_HIP_COMM_TIMEOUT_S="60", MECAT_HIP_WAIT_S="120")
+        procs.append(subprocess.Popen([BIN, "-d", fa, "-o", many, "-w", wrk, "-t", "4"] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                      text=True, env=e))
+    for p in procs:
+        out, err = p.communicate(timeout=300)
+        assert p.returncode == 0, err[-2000:]
+    assert open(many).read() == open(one).read()
+    assert len(open(many).read().splitlines()) > (5000 if vols == 1 else 300)
+    assert sorted(f for f in os.listdir(wrk) if f.startswith("r_")) == ["r_%d" % i for i in range(vols)]
+
+
+def test_cli_dead_rank_does_not_hang_rank_0(tmp_path):
+    """rows mode: rank 1 owns grid row 1 and never shows up; rank 0 must give up (no heartbeat) instead of polling forever"""
+    import uuid
+    fa = _fasta(tmp_path, "tiny")
+    env = dict(os.environ, MECAT_HIP_MCS="250000", MECAT_HIP_WORLD="2", MECAT_HIP_RANK="0", MECAT_HIP_DEVICE="0", MECAT_HIP_SHARD="rows",
+               MECAT_HIP_RUN_ID=uuid.uuid4().hex[:10], MECAT_HIP_WAIT_S="8")
+    r = subprocess.run([BIN, "-j", "0", "-d", fa, "-o", str(tmp_path / "o"), "-w", str(tmp_path / "w"), "-t", "2"], capture_output=True, text=True,
+                       env=env, timeout=120)
+    assert r.returncode != 0 and "volume 1" in r.stderr, r.stderr[-1000:]
+
+
 def test_cli_multi_volume_grid_m4(tmp_path):
     """-j 1 over a 3-volume grid: off-diagonal cells align reads of volume j against volume i (local ids, start_read_id
     offsets in every record).  Expected output: the oracle's whole `-j 1` body (orc_map_read) run cell by cell."""

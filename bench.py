@@ -9,10 +9,11 @@ Workload (BASELINE.json configs[1]): 100 000 synthetic PacBio-st
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...      (one rank per GPU, RCCL)
 
-N > 1 (strong scaling, total work fixed): every rank rebuilds the index itself (recompute beats moving up to 6 GB of
-positions over a 153 GB/s xGMI link), seeds reads r, r+N, r+2N, ... and the per-read candidate lists are exchanged with
-one RCCL all-gather of padded slabs; the extension stage takes every N-th candidate and its results are all-gathered so
-rank 0 holds the complete overlap set.
+N > 1 (strong scaling, total work fixed): the library's own multi-GPU calls, as in the mecat2pw driver — every rank rebuilds
+the index itself (recompute beats moving up to 6 GB of positions over a 153 GB/s xGMI link), the reads are dealt out in
+chunks of 500 (chunk c -> rank c mod N), each rank seeds and extends its own, and the candidate lists and extension results
+are all-gathered count-then-payload over RCCL (mhip_seed_reads_sharded / mhip_align_sharded), so every rank holds the
+complete candidate table and overlap set.
 
 Prints ONE JSON line on rank 0 (see the task contract): value = candidate overlaps/sec of the whole job, plus
 aligned Gbase/sec, a `roofline` block for the dominant kernel and a `cpu_baseline` block (the unmodified reference
@@ -250,14 +251,30 @@ def main():
     params = M.default_params(ont)
     maxc = params.maxc
 
-    # static shard of the (only) grid cell: read r -> rank r % world
-    from mecat_amd import shard as S
-    n_local = S.local_count(n, rank, world)
-    n_pad = S.padded_count(n, world)
-    d_cands = torch.zeros((n_pad, maxc, 12), dtype=torch.int32, device=dev)
-    d_counts = torch.zeros((n_pad,), dtype=torch.int32, device=dev)
-    d_jobs = torch.empty((n_pad * world * maxc // world + maxc, 5), dtype=torch.int32, device=dev)
-    d_res = torch.empty((d_jobs.shape[0], 8), dtype=torch.int32, device=dev)
+    # N > 1: the (only) grid cell is sharded over the ranks by the library itself — chunks of 500 reads, chunk c -> rank c mod P
+    # (mecat_hip.h: mhip_seed_reads_sharded / mhip_align_sharded, the calls the mecat2pw driver makes in its multi-GPU mode):
+    # every rank rebuilds the index, seeds and extends the reads of its own chunks, candidate lists and results are exchanged
+    # count-then-payload over the library's own RCCL communicator.  torch.distributed only carries the unique id, the barriers
+    # and the max-over-ranks clock of the bench contract.
+    comm = None
+    CH = M.SHARD_CHUNK
+    if world > 1:
+        if backend == "nccl":
+            box = [M.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            comm = M.Comm(ctx, world, rank, unique_id=box[0])
+        else:                       # test hook (ranks folded onto one GPU): the library's host-file transport
+            box = [tempfile.mkdtemp(prefix="mecat_bench_comm_") if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            comm = M.Comm(ctx, world, rank, hostfile_dir=box[0], run_id="bench")
+        comm.barrier()
+        n_local = M.lib().mhip_shard_local_count(0, n, CH, 0, rank, world)
+    else:
+        n_local = n
+        d_cands = torch.zeros((n, maxc, 12), dtype=torch.int32, device=dev)
+        d_counts = torch.zeros((n,), dtype=torch.int32, device=dev)
+        d_jobs = torch.empty((n * maxc + maxc, 5), dtype=torch.int32, device=dev)
+        d_res = torch.empty((d_jobs.shape[0], 8), dtype=torch.int32, device=dev)
 
     keep = {}
 
@@ -268,29 +285,24 @@ def main():
         idx = M.Index(ctx, vol)
         ev[1].record(stream)
         keep["num_kmers"] = idx.num_kmers
-        M.seed_reads_strided_dev(ctx, idx, vol, vol, rank, world, n_local, params, d_cands.data_ptr(), d_counts.data_ptr())
-        # exchange step: RCCL all-gather of the per-read candidate slabs (48-byte candidate_save records); with more than one
-        # rank it runs on RCCL's stream while this rank extends the candidates of its own reads
-        pending = S.start_all_gather_candidates(d_cands, d_counts, world) if world > 1 else None
-        ev[2].record(stream)
         njobs = 0
-        if not args.no_align:
-            njobs = M.jobs_from_candidates_dev(ctx, d_cands.data_ptr(), d_counts.data_ptr(), n_local, maxc, rank, world, 0, 0, 1,
-                                               d_jobs.data_ptr())
-            M.align_candidates_dev(ctx, vol, vol, d_jobs.data_ptr(), njobs, params.min_align_size, d_res.data_ptr())
-        if world > 1:
-            full_cands, full_counts, per_rank = S.finish_all_gather_candidates(pending, n)
+        if comm is None:
+            M.seed_reads_strided_dev(ctx, idx, vol, vol, 0, 1, n, params, d_cands.data_ptr(), d_counts.data_ptr())
+            ev[2].record(stream)
             if not args.no_align:
-                all_res = S.all_gather_results_by_rank(d_res, per_rank)          # every rank holds the complete overlap set
-                assert all_res.shape[0] == int(per_rank.sum().item()) and int(per_rank[rank].item()) == njobs
+                njobs = M.jobs_from_candidates_dev(ctx, d_cands.data_ptr(), d_counts.data_ptr(), n, maxc, 0, 1, 0, 0, 1, d_jobs.data_ptr())
+                M.align_candidates_dev(ctx, vol, vol, d_jobs.data_ptr(), njobs, params.min_align_size, d_res.data_ptr())
         else:
-            full_cands, full_counts = d_cands[:n], d_counts[:n]
+            comm.seed_reads_sharded(idx, vol, vol, 0, n, params, chunk=CH, cell_shift=0, host=False)      # seeding + candidate all-gather
+            ev[2].record(stream)
+            if not args.no_align:
+                _, njobs = comm.align_sharded(vol, vol, params.min_align_size, tech=ont, host=False)      # extension + result all-gather
         ev[3].record(stream)
         idx_handle = idx
         stream.synchronize()
         h1 = time.perf_counter()
         out = {"njobs": njobs, "ms": [ev[i].elapsed_time(ev[i + 1]) for i in range(3)]}
-        keep["full_counts"], keep["njobs"] = full_counts, njobs
+        keep["njobs"] = njobs
         idx_handle.free()
         out["host_ms"] = [(h1 - h0) * 1e3, (time.perf_counter() - h1) * 1e3]
         return out
@@ -316,17 +328,32 @@ def main():
     counters = ctx.counters()
     ctx.set_profiling(False)
 
-    # result statistics of the last timed step, read from its output buffers after the timed region
-    ncand = int(keep["full_counts"].sum().item())
-    aln = torch.zeros(2, dtype=torch.int64, device=dev)
-    if not args.no_align:
-        r = d_res[:keep["njobs"]]
-        ok = r[:, 0] != 0
-        aln[0] = ok.sum()
-        aln[1] = ((r[:, 2] - r[:, 1]).to(torch.int64) * ok).sum()
-    if world > 1:
-        dist.all_reduce(aln, op=dist.ReduceOp.SUM)
-    aln_ok, aligned_bases = int(aln[0].item()), int(aln[1].item())
+    # result statistics, after the timed region.  N = 1: read from the last step's output buffers.  N > 1: one more (untimed) pass
+    # of the same deterministic calls with the tables brought to the host — every rank holds the complete tables.
+    exch = None
+    if comm is None:
+        ncand = int(d_counts.sum().item())
+        aln_ok = aligned_bases = 0
+        if not args.no_align:
+            r = d_res[:keep["njobs"]]
+            ok = r[:, 0] != 0
+            aln_ok = int(ok.sum().item())
+            aligned_bases = int(((r[:, 2] - r[:, 1]).to(torch.int64) * ok).sum().item())
+    else:
+        exch = {"bytes_received_per_step": comm.bytes_received() / max(1, args.steps + args.warmup)}
+        idx = M.Index(ctx, vol)
+        _, h_cnt = comm.seed_reads_sharded(idx, vol, vol, 0, n, params, chunk=CH, cell_shift=0, host=True)
+        ncand = int(h_cnt.sum())
+        aln_ok = aligned_bases = 0
+        if not args.no_align:
+            h_res, nj = comm.align_sharded(vol, vol, params.min_align_size, tech=ont, host=True)
+            assert nj == ncand
+            okm = h_res["ok"] != 0
+            aln_ok = int(okm.sum())
+            aligned_bases = int((h_res["query_end"].astype(np.int64) - h_res["query_start"])[okm].sum())
+        idx.free()
+        exch["records_per_step"] = ncand
+        exch["note"] = "count-then-payload: 4 B per read + 48 B per candidate (+ 32 B per extension result) from the P - 1 peers"
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
@@ -341,8 +368,13 @@ def main():
         # algorithmic bytes per step, this rank's share
         N = num_bases
         b_idx = 2 * (N / 4) + 3 * 4 * (1 << 26) + 4 * keep["num_kmers"]      # §8d: two volume passes, the 4^13 table x3, the kept positions
-        b_seed = (lens.astype(np.int64)[rank::world].sum() * 2) / 4 + 8 * lookups + 4 * hits + 48 * cands_c
-        b_aln = per_step("aligned_bases") * 2 / 4 + 32 * keep["njobs"]
+        if comm is None:
+            local_bases = int(lens.astype(np.int64).sum())
+        else:
+            from mecat_amd import shard as S
+            local_bases = int(lens.astype(np.int64)[S.local_reads(0, n, CH, 0, rank, world)].sum())
+        b_seed = (local_bases * 2) / 4 + 8 * lookups + 4 * hits + 48 * cands_c
+        b_aln = per_step("aligned_bases") * 2 / 4 + 32 * cands_c          # this rank's candidates
         phase_of = {"idx": b_idx, "seed": b_seed, "dw": b_aln}
         pk = "idx" if dname.startswith("idx") else ("dw" if dname.startswith("dw") else "seed")
         launches_per_step = max(1, dl // args.steps)
@@ -410,7 +442,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": "%s: %d reads x %d bp @ %.0f%% error, genome %d, seed %d, k=13, all-vs-all, -j 1 (index+seed+dw)"
                                    % (args.workload, n, L, err * 100, G, seed), "reads": n, "bases": int(num_bases),
-                       "parallelism": "reads%%%d" % world},
+                       "parallelism": "1 GPU" if world == 1 else "grid cell sharded: chunks of %d reads, chunk c -> rank c mod %d; RCCL count-then-payload all-gather" % (CH, world)},
             "candidates": ncand, "overlaps_ok": aln_ok, "aligned_gbase_per_s": aligned_bases / 1e9 / (ms_step / 1e3),
             "overlaps_per_s": aln_ok / (ms_step / 1e3),
             "phase_ms": {"index": float(phase[0]), "seed": float(phase[1]), "align": float(phase[2])},
@@ -419,6 +451,8 @@ def main():
             "counters_per_step": {k: v / args.steps for k, v in counters.items()},
             "roofline": roof,
         }
+        if exch:
+            line["exchange"] = exch
         # not part of the metric: the mecat2cns re-aligner (full aligned strings as 2-bit columns) on the first
         # 200 000 candidates of this run, device resident
         if world == 1 and not args.no_align and not args.no_extras and keep["njobs"] > 0:
@@ -495,6 +529,9 @@ def main():
                                         "sample": "failed: %r" % (e,)}
         print(json.dumps(line), flush=True)
     vol.free()
+    if comm is not None:
+        comm.barrier()
+        comm.close()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

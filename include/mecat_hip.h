@@ -178,6 +178,7 @@ void mhip_comm_destroy(mhip_comm* comm);
 int  mhip_comm_rank(const mhip_comm* comm);
 int  mhip_comm_nranks(const mhip_comm* comm);
 int  mhip_comm_barrier(mhip_comm* comm);
+int  mhip_comm_selftest(mhip_ctx* ctx);                       /* RCCL loads and moves bytes on this device (one-rank communicator) */
 int64_t mhip_comm_bytes_received(const mhip_comm* comm);      /* payload + counts received from peers so far */
 
 /* shard arithmetic for the reads [rid_begin, rid_end) of a query volume (rid_begin must be a multiple of chunk): how many of

@@ -347,6 +347,35 @@ void mhip_comm_destroy(mhip_comm* cm) {
     delete cm;
 }
 
+// RCCL smoke test on one device: loads the library, creates a one-rank communicator on the context's device and runs the two
+// transport forms of allgatherv (ncclAllGather; grouped ncclSend / ncclRecv, here to the rank itself) on the context's stream.
+int mhip_comm_selftest(mhip_ctx* c) {
+    HIPCHK(hipSetDevice(c->device));
+    RcclApi* R = rccl();
+    if (!R) return -1;
+    ncclUniqueId u;
+    NCHK(R->GetUniqueId(&u));
+    ncclComm_t nc = nullptr;
+    NCHK(R->CommInitRank(&nc, 1, u, 0));
+    uint32_t* d;
+    if (c->scratch("xg_selftest", 4 * 1024 * 3, (void**)&d)) return -1;
+    std::vector<uint32_t> h(1024);
+    for (int i = 0; i < 1024; ++i) h[(size_t)i] = 0x9e3779b9u * (uint32_t)(i + 1);
+    HIPCHK(hipMemcpyAsync(d, h.data(), 4096, hipMemcpyHostToDevice, c->stream));
+    NCHK(R->AllGather(d, d + 1024, 4096, ncclInt8, nc, c->stream));
+    NCHK(R->GroupStart());
+    NCHK(R->Send(d, 4096, ncclInt8, 0, nc, c->stream));
+    NCHK(R->Recv(d + 2048, 4096, ncclInt8, 0, nc, c->stream));
+    NCHK(R->GroupEnd());
+    std::vector<uint32_t> g(2048);
+    HIPCHK(hipMemcpyAsync(g.data(), d + 1024, 8192, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    (void)R->CommDestroy(nc);
+    for (int i = 0; i < 1024; ++i)
+        if (g[(size_t)i] != h[(size_t)i] || g[(size_t)i + 1024] != h[(size_t)i]) { mhip_set_error("RCCL self test: wrong data at word %d", i); return -1; }
+    return 0;
+}
+
 int mhip_comm_rank(const mhip_comm* cm) { return cm->rank; }
 int mhip_comm_nranks(const mhip_comm* cm) { return cm->nranks; }
 int64_t mhip_comm_bytes_received(const mhip_comm* cm) { return cm->bytes_received; }

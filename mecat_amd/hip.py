@@ -100,6 +100,7 @@ def lib():
     L.mhip_comm_init_hostfile.argtypes = [vp, i32, i32, C.c_char_p, C.c_char_p, C.POINTER(vp)]
     L.mhip_comm_destroy.argtypes = [vp]
     L.mhip_comm_barrier.argtypes = [vp]
+    L.mhip_comm_selftest.argtypes = [vp]
     L.mhip_comm_bytes_received.restype = i64
     L.mhip_comm_bytes_received.argtypes = [vp]
     L.mhip_shard_local_count.argtypes = [i32, i32, i32, i32, i32, i32]

@@ -1,95 +1,92 @@
-"""Static multi-GPU sharding of one (reference volume, query volume) grid cell and the candidate exchange
-(SURVEY.md §8e).  Pure tensor plumbing on top of torch.distributed (backend "nccl" = RCCL on the GPUs, "gloo" in the
-CPU tests); no compute.
+"""Python mirror of the multi-GPU exchange protocol of libmecat_hip.so (mecat_amd/csrc/comm.hip), on
+torch.distributed tensors: the chunked static shard of a grid cell and the count-then-payload all-gather of the per-read
+candidate lists and of the extension results.  The measured path (bench.py, the mecat2pw driver) runs the C ABI
+(mhip_seed_reads_sharded / mhip_align_sharded over RCCL); this module exists so that the protocol — shard arithmetic taken
+from the library's own exported mhip_shard_* functions, packing, displacements, the scatter back into read-major order —
+is also exercised by a world-size-2 gloo test on machines without a GPU (tests/test_dist_cpu.py).  No compute here.
 
-Shard: rank r of P owns query reads r, r+P, r+2P, ... (cyclic: candidates with sid > qid are dropped,
-pw_impl.cpp:370 of the reference, so work per read grows with the read id inside a diagonal cell).
-Exchange: one all-gather of the fixed-size per-read candidate slabs [ceil(n/P)][MAXC] x 48-byte candidate_save records
-plus the per-read counts; afterwards every rank holds the complete read-major table.  The gather is started
-asynchronously (start_all_gather_candidates) and runs on RCCL's stream while the rank extends the candidates of its own
-reads (the cyclic read shard balances that work to ~1 %), then the per-rank result slabs are gathered
-(all_gather_results_by_rank).  The blocking variants re-shard the extension stage by candidate instead.
+Shard: the reads [rid_begin, rid_end) of a query volume in chunks of `chunk` reads (the reference's CHUNK_SIZE = 500,
+mecat2pw/pw_impl.h:15); chunk c belongs to rank (c + cell_shift) mod P.  Local index i of a rank is read
+first + (i // chunk) * chunk * P + i % chunk.
 """
 import torch
 import torch.distributed as dist
 
-
-def local_count(n_reads, rank, world):
-    """number of reads owned by `rank`: r, r + world, ... < n_reads"""
-    return (n_reads - rank + world - 1) // world if rank < n_reads else 0
+from . import hip as M
 
 
-def padded_count(n_reads, world):
-    return (n_reads + world - 1) // world
+def local_count(rid_begin, rid_end, chunk, cell_shift, rank, world):
+    return M.lib().mhip_shard_local_count(rid_begin, rid_end, chunk, cell_shift, rank, world)
 
 
-def all_gather_candidates(local_cands, local_counts, n_reads, world):
-    """local_cands [n_pad, maxc, 12] int32, local_counts [n_pad] int32 (row i = read rank + i * world; rows past the
-    rank's share must have count 0).  Returns read-major (cands [n_reads, maxc, 12], counts [n_reads])."""
-    if world == 1:
-        return local_cands[:n_reads], local_counts[:n_reads]
-    n_pad, maxc, w = local_cands.shape
-    g_counts = torch.empty((world, n_pad), dtype=local_counts.dtype, device=local_counts.device)
-    g_cands = torch.empty((world, n_pad, maxc, w), dtype=local_cands.dtype, device=local_cands.device)
-    # flat views: the gloo backend (CPU tests) only accepts a concatenated 1-D output; RCCL takes either
-    dist.all_gather_into_tensor(g_counts.view(-1), local_counts.contiguous().view(-1))
-    dist.all_gather_into_tensor(g_cands.view(-1), local_cands.contiguous().view(-1))
-    # table row i of rank r is read r + i * world  ->  read id = i * world + r
-    counts = g_counts.transpose(0, 1).reshape(-1)[:n_reads].contiguous()
-    cands = g_cands.transpose(0, 1).reshape(n_pad * world, maxc, w)[:n_reads].contiguous()
-    return cands, counts
+def first_read(rid_begin, rid_end, chunk, cell_shift, rank, world):
+    return M.lib().mhip_shard_first_read(rid_begin, rid_end, chunk, cell_shift, rank, world)
 
 
-def my_job_count(total_jobs, rank, world):
-    """jobs g with g % world == rank, stored at slot g // world (mhip_jobs_from_candidates_dev part_index/part_count)"""
-    return total_jobs // world + (1 if rank < total_jobs % world else 0)
+def local_reads(rid_begin, rid_end, chunk, cell_shift, rank, world):
+    """read ids owned by `rank`, ascending (local index order)"""
+    n, f = local_count(rid_begin, rid_end, chunk, cell_shift, rank, world), first_read(rid_begin, rid_end, chunk, cell_shift, rank, world)
+    return [f + (i // chunk) * chunk * world + i % chunk for i in range(n)]
 
 
-def all_gather_results(local_res, n_local, total_jobs, world):
-    """local_res [cap, 8] int32 with the first n_local rows valid (job g = slot * world + rank).
-    Returns [total_jobs, 8] in global job order on every rank."""
-    if world == 1:
-        return local_res[:total_jobs]
-    m = (total_jobs + world - 1) // world
-    slab = torch.zeros((m, local_res.shape[1]), dtype=local_res.dtype, device=local_res.device)
-    slab[:n_local] = local_res[:n_local]
-    g = torch.empty((world, m, local_res.shape[1]), dtype=local_res.dtype, device=local_res.device)
-    dist.all_gather_into_tensor(g.view(-1), slab.view(-1))
-    return g.transpose(0, 1).reshape(m * world, local_res.shape[1])[:total_jobs].contiguous()
+def _allgatherv(parts_of_me, sizes, rank):
+    """every rank contributes a [sizes[rank], w] tensor; returns the list of all ranks' tensors (exact sizes: one broadcast
+    per rank — the gloo stand-in for the grouped send/recv of the RCCL transport)"""
+    out = []
+    for r, n in enumerate(sizes):
+        t = parts_of_me if r == rank else torch.empty((n,) + tuple(parts_of_me.shape[1:]), dtype=parts_of_me.dtype)
+        if n:
+            dist.broadcast(t, src=r)
+        out.append(t)
+    return out
 
 
-def start_all_gather_candidates(local_cands, local_counts, world):
-    """Asynchronous form of all_gather_candidates: returns a pending object for finish_all_gather_candidates.  The
-    collective waits for the work already queued on the current stream and then proceeds on the backend's own stream."""
-    n_pad, maxc, w = local_cands.shape
-    g_counts = torch.empty((world, n_pad), dtype=local_counts.dtype, device=local_counts.device)
-    g_cands = torch.empty((world, n_pad, maxc, w), dtype=local_cands.dtype, device=local_cands.device)
-    h1 = dist.all_gather_into_tensor(g_counts.view(-1), local_counts.contiguous().view(-1), async_op=True)
-    h2 = dist.all_gather_into_tensor(g_cands.view(-1), local_cands.contiguous().view(-1), async_op=True)
-    return (h1, h2, g_counts, g_cands)
+def all_gather_candidates(local_cands, local_counts, rid_begin, rid_end, chunk, cell_shift):
+    """local_cands [n_local, maxc, 12] int32, local_counts [n_local] int32 -> (cands [n, maxc, 12], counts [n], per_rank
+    totals, bytes_received) with n = rid_end - rid_begin, read-major, identical on every rank"""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    maxc, w = local_cands.shape[1], local_cands.shape[2]
+    nloc = [local_count(rid_begin, rid_end, chunk, cell_shift, r, world) for r in range(world)]
+    n_pad = max(max(nloc), 1)
+    # 1. counts: one int32 per read, padded to the longest shard
+    pad = torch.zeros(n_pad, dtype=torch.int32)
+    pad[: nloc[rank]] = local_counts[: nloc[rank]]
+    g = [torch.empty(n_pad, dtype=torch.int32) for _ in range(world)]
+    dist.all_gather(g, pad)
+    totals = [int(x.sum()) for x in g]
+    # 2. payload: only the occupied records, dense, local read-major
+    mask = torch.arange(maxc)[None, :] < local_counts[: nloc[rank], None]
+    pack = local_cands[: nloc[rank]][mask]                       # [totals[rank], 12]
+    dense = _allgatherv(pack, totals, rank)
+    received = sum(4 * n_pad + 48 * totals[r] for r in range(world) if r != rank)
+    # 3. scatter back into the read-major table
+    n = rid_end - rid_begin
+    cands = torch.zeros((n, maxc, w), dtype=local_cands.dtype)
+    counts = torch.zeros(n, dtype=torch.int32)
+    for r in range(world):
+        rids = local_reads(rid_begin, rid_end, chunk, cell_shift, r, world)
+        pos = 0
+        for i, rid in enumerate(rids):
+            c = int(g[r][i])
+            counts[rid - rid_begin] = c
+            cands[rid - rid_begin, :c] = dense[r][pos: pos + c]
+            pos += c
+    return cands, counts, totals, received
 
 
-def finish_all_gather_candidates(pending, n_reads):
-    """-> (cands [n_reads, maxc, 12], counts [n_reads]) read-major, and the per-rank candidate totals [world]"""
-    h1, h2, g_counts, g_cands = pending
-    h1.wait()
-    h2.wait()
-    world, n_pad = g_counts.shape
-    maxc, w = g_cands.shape[2], g_cands.shape[3]
-    counts = g_counts.transpose(0, 1).reshape(-1)[:n_reads].contiguous()
-    cands = g_cands.transpose(0, 1).reshape(n_pad * world, maxc, w)[:n_reads].contiguous()
-    return cands, counts, g_counts.sum(dim=1)
-
-
-def all_gather_results_by_rank(local_res, per_rank_jobs):
-    """local_res [cap, 8] with the first per_rank_jobs[rank] rows valid (the rank's own reads, read-major).  Returns the
-    rows of all ranks, rank-major, [sum(per_rank_jobs), 8] on every rank.  per_rank_jobs: 1-D tensor or list, length world."""
-    per = [int(x) for x in per_rank_jobs]
-    world = len(per)
-    rank = dist.get_rank()
-    m = max(max(per), 1)
-    slab = torch.zeros((m, local_res.shape[1]), dtype=local_res.dtype, device=local_res.device)
-    slab[: per[rank]] = local_res[: per[rank]]
-    g = torch.empty((world, m, local_res.shape[1]), dtype=local_res.dtype, device=local_res.device)
-    dist.all_gather_into_tensor(g.view(-1), slab.view(-1))
-    return torch.cat([g[r, : per[r]] for r in range(world)], dim=0)
+def all_gather_results(local_res, all_counts, rid_begin, rid_end, chunk, cell_shift):
+    """local_res [totals[rank], 8]: results of this rank's candidates, local read-major.  -> [sum(counts), 8] dense, read-major"""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    shards = [local_reads(rid_begin, rid_end, chunk, cell_shift, r, world) for r in range(world)]
+    totals = [int(sum(int(all_counts[rid - rid_begin]) for rid in s)) for s in shards]
+    dense = _allgatherv(local_res[: totals[rank]], totals, rank)
+    first = torch.zeros(rid_end - rid_begin + 1, dtype=torch.int64)
+    first[1:] = torch.cumsum(all_counts.to(torch.int64), 0)
+    out = torch.zeros((int(first[-1]), local_res.shape[1]), dtype=local_res.dtype)
+    for r in range(world):
+        pos = 0
+        for rid in shards[r]:
+            c = int(all_counts[rid - rid_begin])
+            out[int(first[rid - rid_begin]): int(first[rid - rid_begin]) + c] = dense[r][pos: pos + c]
+            pos += c
+    return out

@@ -1,19 +1,20 @@
-"""N > 1 path on CPU: world_size 2 over gloo.  Each rank computes the candidate lists of its cyclic shard (with the
-oracle as the stand-in compute, this is a test of the sharding / exchange / re-sharding plumbing in mecat_amd/shard.py
-that bench.py runs over RCCL), all-gathers the slabs and must end up with exactly the single-process result."""
+"""N > 1 path on CPU: world_size 2 over gloo.  Each rank takes its chunked shard of a grid cell (shard arithmetic from the
+library's own mhip_shard_* exports — they need no GPU), computes the candidate lists of its reads with the oracle as the
+stand-in compute, and runs the count-then-payload exchange of mecat_amd/shard.py — the torch mirror of the protocol
+libmecat_hip.so runs over RCCL (comm.hip; the GPU-side twin of this test is tests/test_gpu_comm.py).  Every rank must end
+up with exactly the single-process table, and a rank must receive the other ranks' records, not max-padded slabs."""
 import os
 import socket
 import sys
 
 import numpy as np
-import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import helpers as H
 
-N_READS, MAXC = 61, 100     # 61: not divisible by 2 -> exercises the padded slab row
+N_READS, MAXC, CHUNK, SHIFT = 61, 100, 8, 1     # 61 reads in chunks of 8: ragged last chunk, uneven shards
 
 
 def _free_port():
@@ -39,39 +40,24 @@ def _worker(rank, world, port, out_dir):
     from mecat_amd import shard as S
     ov, oidx = _dataset()
     p = H.orc_params(tech=0, maxc=MAXC)
-    n_local, n_pad = S.local_count(N_READS, rank, world), S.padded_count(N_READS, world)
-    mine = H.orc_seed_all(ov, ov, oidx, p, rids=range(rank, N_READS, world))
-    assert len(mine) == n_local
-    cands = torch.zeros((n_pad, MAXC, 12), dtype=torch.int32)
-    counts = torch.zeros((n_pad,), dtype=torch.int32)
+    rids = S.local_reads(0, N_READS, CHUNK, SHIFT, rank, world)
+    mine = H.orc_seed_all(ov, ov, oidx, p, rids=rids)
+    cands = torch.zeros((max(len(rids), 1), MAXC, 12), dtype=torch.int32)
+    counts = torch.zeros((max(len(rids), 1),), dtype=torch.int32)
     for i, a in enumerate(mine):
         counts[i] = len(a)
         if len(a):
             cands[i, : len(a)] = torch.from_numpy(np.stack([a[f] for f in H.CAND_DTYPE.names], axis=1).astype(np.int32))
-    full_cands, full_counts = S.all_gather_candidates(cands, counts, N_READS, world)
-    # extension stage re-shard: every world-th candidate; fake "results" = (global job index, read id) to check the merge
-    total = int(full_counts.sum())
-    mask = torch.arange(MAXC)[None, :] < full_counts[:, None]
-    read_of_job = torch.arange(N_READS)[:, None].expand(N_READS, MAXC)[mask]
-    my_jobs = torch.arange(total)[rank::world]
-    assert len(my_jobs) == S.my_job_count(total, rank, world)
-    res = torch.zeros((len(my_jobs) + 3, 8), dtype=torch.int32)
-    res[: len(my_jobs), 0] = my_jobs.int()
-    res[: len(my_jobs), 1] = read_of_job[my_jobs].int()
-    allres = S.all_gather_results(res, len(my_jobs), total, world)
-    # overlapped form used by bench.py: asynchronous gather, the rank extends its own reads, results gathered rank-major
-    pending = S.start_all_gather_candidates(cands, counts, world)
-    n_mine = int(counts.sum())
-    res2 = torch.zeros((n_mine + 5, 8), dtype=torch.int32)
+    full_cands, full_counts, totals, received = S.all_gather_candidates(cands, counts, 0, N_READS, CHUNK, SHIFT)
+    # extension stage: fake "results" = (rank, read id, slot) for this rank's candidates, local read-major
+    res = torch.zeros((totals[rank] + 3, 8), dtype=torch.int32)
     k = 0
-    for i in range(n_local):
+    for i, rid in enumerate(rids):
         for j in range(int(counts[i])):
-            res2[k, 0], res2[k, 1], res2[k, 2] = rank, rank + i * world, j      # (rank, read id, slot)
+            res[k, 0], res[k, 1], res[k, 2] = rank, rid, j
             k += 1
-    fc2, fn2, per_rank = S.finish_all_gather_candidates(pending, N_READS)
-    assert torch.equal(fc2, full_cands) and torch.equal(fn2, full_counts) and int(per_rank[rank]) == n_mine
-    allres2 = S.all_gather_results_by_rank(res2, per_rank)
-    torch.save({"cands": full_cands, "counts": full_counts, "res": allres, "res2": allres2, "per_rank": per_rank},
+    allres = S.all_gather_results(res, full_counts, 0, N_READS, CHUNK, SHIFT)
+    torch.save({"cands": full_cands, "counts": full_counts, "res": allres, "totals": totals, "received": received, "rids": rids},
                os.path.join(out_dir, "r%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
@@ -83,20 +69,24 @@ def test_two_rank_shard_exchange_equals_single_process(tmp_path):
     ov, oidx = _dataset()
     want = H.orc_seed_all(ov, ov, oidx, H.orc_params(tech=0, maxc=MAXC))
     outs = [torch.load(os.path.join(str(tmp_path), "r%d.pt" % r)) for r in range(world)]
-    for o in outs:
+    # the shards partition the reads: chunk c -> rank (c + SHIFT) % world
+    assert sorted(outs[0]["rids"] + outs[1]["rids"]) == list(range(N_READS))
+    for r, o in enumerate(outs):
+        assert all(((rid // CHUNK) + SHIFT) % world == r for rid in o["rids"])
+    total = sum(len(a) for a in want)
+    for r, o in enumerate(outs):
         assert [int(x) for x in o["counts"]] == [len(a) for a in want]
         for rid, a in enumerate(want):
             got = o["cands"][rid, : len(a)].numpy()
             exp = np.stack([a[f] for f in H.CAND_DTYPE.names], axis=1) if len(a) else np.zeros((0, 12), np.int32)
             assert np.array_equal(got, exp), rid
-        total = sum(len(a) for a in want)
-        assert o["res"].shape[0] == total
-        assert [int(x) for x in o["res"][:, 0]] == list(range(total))          # global job order restored
-        rid_of = [rid for rid, a in enumerate(want) for _ in range(len(a))]
-        assert [int(x) for x in o["res"][:, 1]] == rid_of
-        # rank-major result table: rank r's reads r, r + world, ... with their slots in order
-        exp2 = [(r, rid, j) for r in range(world) for rid in range(r, N_READS, world) for j in range(len(want[rid]))]
-        assert [tuple(int(v) for v in row[:3]) for row in o["res2"]] == exp2
-        assert [int(x) for x in o["per_rank"]] == [sum(len(want[rid]) for rid in range(r, N_READS, world)) for r in range(world)]
-    assert torch.equal(outs[0]["cands"], outs[1]["cands"])
-    assert sum(len(a) for a in want) > 50
+        # results come back dense and read-major: read 0's slots, read 1's slots, ...
+        exp = [(((rid // CHUNK) + SHIFT) % world, rid, j) for rid, a in enumerate(want) for j in range(len(a))]
+        assert [tuple(int(v) for v in row[:3]) for row in o["res"]] == exp
+        assert o["totals"] == [sum(len(want[rid]) for rid in outs[q]["rids"]) for q in range(world)]
+        # count-then-payload: bytes received = the peer's counts + its occupied records (far below a max-padded slab)
+        peer = 1 - r
+        assert o["received"] == 4 * max(len(outs[0]["rids"]), len(outs[1]["rids"])) + 48 * o["totals"][peer]
+        assert o["received"] < 48 * MAXC * len(outs[peer]["rids"]) / 3
+    assert torch.equal(outs[0]["cands"], outs[1]["cands"]) and torch.equal(outs[0]["res"], outs[1]["res"])
+    assert total > 50

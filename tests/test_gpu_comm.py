@@ -91,3 +91,19 @@ def test_sharded_seeding_and_extension_equal_single_gpu(data, nranks, chunk, rb,
         # count-then-payload: what a rank receives is the other ranks' records and counts, not max-padded slabs
         total = int(want_n.sum())
         assert nbytes < (48 + 32) * total + 4 * (re - rb + nranks * chunk) * 2 + 4096, (nbytes, total)
+
+
+def test_rccl_loads_and_moves_bytes_on_this_device(data):
+    """the RCCL transport itself cannot run two ranks on one GPU; this checks what can be checked here: librccl is found,
+    every symbol the library uses resolves, a communicator comes up on the context's device and both transport forms
+    (ncclAllGather, grouped ncclSend / ncclRecv) move the right bytes on the context's stream"""
+    M, ctx = data["M"], data["ctx"]
+    M._chk(M.lib().mhip_comm_selftest(ctx.h))
+    uid = M.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    cm = M.Comm(ctx, 1, 0, unique_id=uid)          # one rank: same calls, nothing to exchange
+    cands, cnt = cm.seed_reads_sharded(data["idx"], data["vol"], data["vol"], 0, data["n"], data["p"])
+    assert np.array_equal(cnt, data["cnt"])
+    res, nj = cm.align_sharded(data["vol"], data["vol"], data["p"].min_align_size)
+    assert res.tobytes() == data["res"].tobytes()
+    cm.close()

@@ -232,6 +232,31 @@ int mhip_cns_align_candidates(mhip_ctx* ctx, const mhip_volume* ref, const mhip_
 int mhip_cns_align_candidates_dev(mhip_ctx* ctx, const mhip_volume* ref, const mhip_volume* reads, const void* d_jobs, int n,
                                   double error_rate, int min_align_size, int dir_cols_cap, void* d_results, void* d_ops);
 
+/* ---- mecat2cns' candidate accept loop (BASELINE config 4): the front half of
+ * consensus_one_read_can_pacbio / _nanopore (mecat2cns/mecat_correction.cpp:388-450, 452-515) for a batch of template reads.
+ * cands: ExtensionCandidate records (common/alignment.h:8-19, the 13 ints of a .can line as mecat2cns normalises them: sdir == 0,
+ * sid = the template), grouped by template: template t owns cands[tmpl_begin[t] .. tmpl_begin[t + 1]); they are sorted IN PLACE by
+ * (score desc, qid, qext) as the reference does.  All reads live in `vol` (host_pac = the packed bytes given to mhip_volume_upload).
+ * tech 0: error rate 0.15, at most 60 accepted; tech 1: 0.20 / 100.  min_mapping_ratio is the option value (0.9 / 0.4), the
+ * function subtracts the reference's 0.02.  Output (malloc'ed, release with mhip_cns_free): one record per accepted alignment
+ * in the order the reference would add them, template by template, and the gap-normalised aligned strings
+ * (normalize_gaps(.., push = true), reads_correction_aux.cpp:3-81) that meap_add_one_aln / CnsAlns::add_aln consume:
+ * strings + str_offset = qaln (aln_size chars + NUL), then saln (aln_size chars + NUL). */
+typedef struct { int32_t qdir, qid, qext, qsize, qoff, qend, sdir, sid, sext, ssize, soff, send, score; } mhip_ext_candidate;
+typedef struct {
+    int32_t template_index;      /* index into tmpl_begin */
+    int32_t qid, sid;
+    int32_t qoff, qend, soff, send;          /* m5qoff / m5qend / m5soff / m5send */
+    int32_t aln_size;
+    int64_t cand_index;          /* position of the candidate in cands[] (after the in-place sort) */
+    int64_t str_offset;
+} mhip_cns_accepted;
+int  mhip_cns_accept_templates(mhip_ctx* ctx, const mhip_volume* vol, const uint8_t* host_pac, mhip_ext_candidate* cands,
+                               const int64_t* tmpl_begin, int num_templates, int tech, int min_align_size, double min_mapping_ratio,
+                               int num_threads, mhip_cns_accepted** out_accepted, int64_t* out_count, char** out_strings,
+                               int64_t* out_strings_bytes, int64_t* out_jobs /* alignments computed, may be NULL */);
+void mhip_cns_free(void* p);
+
 #ifdef __cplusplus
 }
 #endif

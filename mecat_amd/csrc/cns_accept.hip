@@ -1,0 +1,274 @@
+// cns_accept.hip — mecat2cns' candidate accept loop on top of the device re-aligner.
+//
+// Replaces, for a batch of template reads, the front half of consensus_one_read_can_pacbio / consensus_one_read_can_nanopore
+// (mecat2cns/mecat_correction.cpp:388-450, 452-515): everything up to the point where an accepted alignment is handed to the
+// consensus table (meap_add_one_aln) and to CnsAlns::add_aln.  The reference walks a template's candidates one by one —
+//     sort by (score desc, qid, qext)                                             :362-370, :409
+//     for each, while fewer than 60 (PacBio) / 100 (nanopore) are accepted and fewer than 200 were looked at:
+//         skip a query read that was already accepted (std::set used_ids)         :424
+//         GetAlignment(error_rate 0.15 / 0.20, min_align_size)                    :431 (dw.cpp:482-553)
+//         check_ovlp_mapping_range with min_mapping_ratio - 0.02                  :191-200, :432
+//         check_cov_stats: the aligned template range must have >= 200 positions below coverage 20, then ++coverage   :372-386
+//         normalize_gaps(qaln, saln, push = true) -> meap_add_one_aln, add_aln    reads_correction_aux.cpp:3-81
+// — and every alignment depends on nothing but the two reads, so the <= 200 candidates of every template of the batch are
+// re-aligned speculatively in ONE device launch (mhip_cns_align_candidates_dev), the sequential accept decisions are replayed
+// over the results on host threads, only the 2-bit column strings of the ACCEPTED alignments are gathered on the device and
+// brought back, and the gap-normalised strings are rebuilt from them and the host copy of the reads.
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <set>
+#include <thread>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+struct CmpByScore {      // CmpExtensionCandidateByScore, mecat_correction.cpp:362-370
+    bool operator()(const mhip_ext_candidate& a, const mhip_ext_candidate& b) const {
+        if (a.score != b.score) return a.score > b.score;
+        if (a.qid != b.qid) return a.qid < b.qid;
+        return a.qext < b.qext;
+    }
+};
+
+template <typename F>
+void parallel_for(int64_t n, int nthreads, F f) {
+    nthreads = (int)std::max<int64_t>(1, std::min<int64_t>(nthreads, n));
+    std::atomic<int64_t> next{0};
+    auto body = [&]() {
+        for (;;) {
+            const int64_t i = next.fetch_add(1);
+            if (i >= n) return;
+            f(i);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nthreads; ++t) th.emplace_back(body);
+    body();
+    for (auto& x : th) x.join();
+}
+
+inline int host_base(const uint8_t* pac, int64_t idx) { return (pac[idx >> 2] >> ((~idx & 3) << 1)) & 3; }      // packed_db.h:103-107
+
+// normalize_gaps (reads_correction_aux.cpp:3-81), push = true; q / t are NUL-terminated work buffers of equal length n
+void push_gaps(char* q, char* t, int64_t n) {
+    for (int64_t i = 0; i + 1 < n; ++i) {
+        if (t[i] == '-') {
+            int64_t j = i;
+            for (;;) {
+                const char c = t[++j];
+                if (c != '-' || j > n - 1) {
+                    if (c == q[i]) { t[i] = c; t[j] = '-'; }
+                    break;
+                }
+            }
+        }
+        if (q[i] == '-') {
+            int64_t j = i;
+            for (;;) {
+                const char c = q[++j];
+                if (c != '-' || j > n - 1) {
+                    if (c == t[i]) { q[i] = c; q[j] = '-'; }
+                    break;
+                }
+            }
+        }
+    }
+}
+
+// rows of 2-bit columns of the accepted jobs -> one compact buffer
+__global__ void cns_gather_ops(const uint32_t* __restrict__ ops, const int32_t* __restrict__ sel, int nsel, int row_words, uint32_t* __restrict__ out) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t i = t / (size_t)row_words, w = t % (size_t)row_words;
+    if (i >= (size_t)nsel) return;
+    out[i * row_words + w] = ops[(size_t)sel[i] * row_words + w];
+}
+
+}  // namespace
+
+extern "C" {
+
+void mhip_cns_free(void* p) { free(p); }
+
+int mhip_cns_accept_templates(mhip_ctx* c, const mhip_volume* vol, const uint8_t* host_pac, mhip_ext_candidate* cands, const int64_t* tmpl_begin,
+                              int num_templates, int tech, int min_align_size, double min_mapping_ratio, int num_threads,
+                              mhip_cns_accepted** out_accepted, int64_t* out_count, char** out_strings, int64_t* out_strings_bytes,
+                              int64_t* out_jobs) {
+    HIPCHK(hipSetDevice(c->device));
+    *out_accepted = nullptr; *out_count = 0; *out_strings = nullptr; *out_strings_bytes = 0;
+    if (out_jobs) *out_jobs = 0;
+    if (num_templates <= 0) return 0;
+    const int max_ext = 200;                                         // mecat_correction.cpp:412
+    const int max_added = tech == 0 ? 60 : 100;                      // :407 ; MAX_CNS_OVLPS, reads_correction_aux.h:32
+    const double error_rate = tech == 0 ? 0.15 : 0.20;               // :431 / :494
+    const double ratio = min_mapping_ratio - 0.02;                   // :406
+    const int start_id = vol->start_read_id, nreads = vol->num_reads;
+    num_threads = std::max(1, num_threads);
+
+    // 1. order of the reference's walk
+    std::atomic<int> bad{0};
+    parallel_for(num_templates, num_threads, [&](int64_t t) {
+        mhip_ext_candidate* b = cands + tmpl_begin[t];
+        mhip_ext_candidate* e = cands + tmpl_begin[t + 1];
+        std::sort(b, e, CmpByScore());
+        for (mhip_ext_candidate* p = b; p < e; ++p)
+            if (p->sdir != 0 || p->qid < start_id || p->qid >= start_id + nreads || p->sid < start_id || p->sid >= start_id + nreads ||
+                p->sid != b->sid)
+                bad = 1;
+    });
+    if (bad.load()) { mhip_set_error("cns accept: a candidate is outside the volume, has sdir != 0 or sits in another template's range"); return -1; }
+
+    // 2. the first <= 200 candidates of every template, as alignment jobs
+    std::vector<int64_t> jfirst((size_t)num_templates + 1, 0);
+    for (int t = 0; t < num_templates; ++t) jfirst[(size_t)t + 1] = jfirst[(size_t)t] + std::min<int64_t>(max_ext, tmpl_begin[t + 1] - tmpl_begin[t]);
+    const int64_t nj = jfirst[(size_t)num_templates];
+    if (out_jobs) *out_jobs = nj;
+    if (nj == 0) return 0;
+    if (nj > 0x7fffffffLL) { mhip_set_error("cns accept: too many jobs in one batch"); return -1; }
+    std::vector<mhip_aln_job> jobs((size_t)nj);
+    int max_len = 16;
+    parallel_for(num_templates, num_threads, [&](int64_t t) {
+        for (int64_t k = 0; k < jfirst[(size_t)t + 1] - jfirst[(size_t)t]; ++k) {
+            const mhip_ext_candidate& ec = cands[tmpl_begin[t] + k];
+            mhip_aln_job j;
+            j.qid_local = ec.qid - start_id;
+            j.sid_local = ec.sid - start_id;
+            j.chain = ec.qdir != 0;
+            j.qstart = ec.qdir != 0 ? ec.qsize - 1 - ec.qext : ec.qext;      // :428-429
+            j.sstart = ec.sext;
+            jobs[(size_t)(jfirst[(size_t)t] + k)] = j;
+        }
+    });
+    for (int64_t i = 0; i < nj; ++i)
+        max_len = std::max(max_len, std::max(vol->h_offs[(size_t)jobs[(size_t)i].qid_local].size, vol->h_offs[(size_t)jobs[(size_t)i].sid_local].size));
+    // columns of one direction <= bases of both reads on that side; 16-column words
+    const int cap = (int)(((int64_t)max_len * 2 + 64 + 15) / 16 * 16);
+    const int row_words = 2 * (cap / 16);
+
+    // 3. one speculative device launch
+    mhip_aln_job* d_jobs;
+    mhip_cns_result* d_res;
+    uint32_t* d_ops;
+    if (c->scratch("ca_jobs", sizeof(mhip_aln_job) * (size_t)nj, (void**)&d_jobs)) return -1;
+    if (c->scratch("ca_res", sizeof(mhip_cns_result) * (size_t)nj, (void**)&d_res)) return -1;
+    if (c->scratch("ca_ops", sizeof(uint32_t) * (size_t)row_words * (size_t)nj, (void**)&d_ops)) return -1;
+    HIPCHK(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(mhip_aln_job) * (size_t)nj, hipMemcpyHostToDevice, c->stream));
+    if (mhip_cns_align_candidates_dev(c, vol, vol, d_jobs, (int)nj, error_rate, min_align_size, cap, d_res, d_ops)) return -1;
+    std::vector<mhip_cns_result> res((size_t)nj);
+    HIPCHK(hipMemcpyAsync(res.data(), d_res, sizeof(mhip_cns_result) * (size_t)nj, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+
+    // 4. the sequential accept decisions, per template
+    std::vector<std::vector<int32_t>> acc((size_t)num_templates);      // accepted job indices, in acceptance order
+    parallel_for(num_templates, num_threads, [&](int64_t t) {
+        const int64_t b = tmpl_begin[t], n = tmpl_begin[t + 1] - b;
+        if (n == 0) return;
+        const int ssize = cands[b].ssize;
+        std::vector<uint8_t> cov((size_t)std::max(ssize, 1), 0);
+        std::set<int> used;
+        int num_added = 0, num_ext = 0;
+        for (int64_t i = 0; i < n && num_added < max_added && num_ext < max_ext; ++i) {
+            ++num_ext;
+            const mhip_ext_candidate& ec = cands[b + i];
+            if (used.find(ec.qid) != used.end()) continue;
+            const int64_t ji = jfirst[(size_t)t] + i;          // i < max_ext here: the job exists
+            const mhip_cns_result& r = res[(size_t)ji];
+            if (!r.ok) continue;
+            const int oq = r.qend - r.qoff, qqs = (int)(ec.qsize * ratio), os = r.send - r.soff, qss = (int)(ec.ssize * ratio);      // :191-200
+            if (!(oq >= qqs || os >= qss)) continue;
+            int full = 0;                                        // check_cov_stats, :372-386
+            for (int p = r.soff; p < r.send; ++p) full += cov[(size_t)p] >= 20;
+            if (!(r.send - r.soff >= full + 200)) continue;
+            for (int p = r.soff; p < r.send; ++p) ++cov[(size_t)p];
+            ++num_added;
+            used.insert(ec.qid);
+            acc[(size_t)t].push_back((int32_t)ji);
+        }
+    });
+    std::vector<int64_t> afirst((size_t)num_templates + 1, 0);
+    for (int t = 0; t < num_templates; ++t) afirst[(size_t)t + 1] = afirst[(size_t)t] + (int64_t)acc[(size_t)t].size();
+    const int64_t na = afirst[(size_t)num_templates];
+    if (na == 0) return 0;
+
+    // 5. the accepted alignments' columns
+    std::vector<int32_t> sel((size_t)na);
+    for (int t = 0; t < num_templates; ++t) std::copy(acc[(size_t)t].begin(), acc[(size_t)t].end(), sel.begin() + afirst[(size_t)t]);
+    int32_t* d_sel;
+    uint32_t* d_pack;
+    if (c->scratch("ca_sel", sizeof(int32_t) * (size_t)na, (void**)&d_sel)) return -1;
+    if (c->scratch("ca_pack", sizeof(uint32_t) * (size_t)row_words * (size_t)na, (void**)&d_pack)) return -1;
+    HIPCHK(hipMemcpyAsync(d_sel, sel.data(), sizeof(int32_t) * (size_t)na, hipMemcpyHostToDevice, c->stream));
+    {
+        const size_t nt = (size_t)na * (size_t)row_words;
+        LAUNCH(c, "cns_gather_ops", cns_gather_ops, (unsigned)((nt + 255) / 256), 256, 0, (const uint32_t*)d_ops, (const int32_t*)d_sel, (int)na, row_words, d_pack);
+    }
+    std::vector<uint32_t> ops((size_t)row_words * (size_t)na);
+    HIPCHK(hipMemcpyAsync(ops.data(), d_pack, sizeof(uint32_t) * ops.size(), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+
+    // 6. strings: m5qaln / m5saln from the columns and the reads, then normalize_gaps(push = true)
+    mhip_cns_accepted* A = (mhip_cns_accepted*)malloc(sizeof(mhip_cns_accepted) * (size_t)na);
+    if (!A) { mhip_set_error("out of memory"); return -1; }
+    int64_t sbytes = 0;
+    for (int64_t a = 0; a < na; ++a) {
+        const mhip_cns_result& r = res[(size_t)sel[(size_t)a]];
+        A[a].aln_size = r.last_col - r.first_col;          // O(ND) columns are matches or indels: normalising adds no columns
+        A[a].str_offset = sbytes;
+        sbytes += 2 * ((int64_t)A[a].aln_size + 1);
+    }
+    char* S = (char*)malloc((size_t)std::max<int64_t>(sbytes, 1));
+    if (!S) { free(A); mhip_set_error("out of memory (%lld bytes of aligned strings)", (long long)sbytes); return -1; }
+    parallel_for(num_templates, num_threads, [&](int64_t t) {
+        for (int64_t a = afirst[(size_t)t]; a < afirst[(size_t)t + 1]; ++a) {
+            const int64_t ji = sel[(size_t)a];
+            const mhip_cns_result& r = res[(size_t)ji];
+            const mhip_aln_job& jb = jobs[(size_t)ji];
+            const mhip_ext_candidate& ec = cands[tmpl_begin[t] + (ji - jfirst[(size_t)t])];
+            mhip_cns_accepted& o = A[a];
+            o.template_index = (int32_t)t;
+            o.cand_index = tmpl_begin[t] + (ji - jfirst[(size_t)t]);
+            o.qid = ec.qid; o.sid = ec.sid;
+            o.qoff = r.qoff; o.qend = r.qend; o.soff = r.soff; o.send = r.send;
+            char* qa = S + o.str_offset;
+            char* sa = qa + o.aln_size + 1;
+            const uint32_t* row = ops.data() + (size_t)a * row_words;
+            const uint32_t* left = row;
+            const uint32_t* right = row + cap / 16;
+            const mhip_offset_t qo = vol->h_offs[(size_t)jb.qid_local], so = vol->h_offs[(size_t)jb.sid_local];
+            // merged column m: reverse(left) then right; query / template positions advance from the untrimmed start points
+            int qi = r.query_start, ti = r.target_start;
+            const int ncols = r.left_cols + r.right_cols;
+            for (int m = 0; m < ncols; ++m) {
+                int op;
+                if (m < r.left_cols) { const int k = r.left_cols - 1 - m; op = (left[k >> 4] >> ((k & 15) << 1)) & 3; }
+                else { const int k = m - r.left_cols; op = (right[k >> 4] >> ((k & 15) << 1)) & 3; }
+                if (m >= r.first_col && m < r.last_col) {
+                    char qc = '-', tc = '-';
+                    if (op != 1) {
+                        const int b = jb.chain ? 3 - host_base(host_pac, (int64_t)qo.offset + (qo.size - 1 - qi)) : host_base(host_pac, (int64_t)qo.offset + qi);
+                        qc = "ACGT"[b];
+                    }
+                    if (op != 2) tc = "ACGT"[host_base(host_pac, (int64_t)so.offset + ti)];
+                    qa[m - r.first_col] = qc;
+                    sa[m - r.first_col] = tc;
+                }
+                qi += op != 1;
+                ti += op != 2;
+            }
+            qa[o.aln_size] = 0;
+            sa[o.aln_size] = 0;
+            push_gaps(qa, sa, o.aln_size);
+        }
+    });
+    *out_accepted = A;
+    *out_count = na;
+    *out_strings = S;
+    *out_strings_bytes = sbytes;
+    return 0;
+}
+
+}  // extern "C"

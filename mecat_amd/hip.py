@@ -110,6 +110,9 @@ def lib():
     L.mhip_seed_reads_sharded.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, C.POINTER(Params), vp, vp]
     L.mhip_align_sharded.argtypes = [vp, vp, vp, i32, i32, vp, C.POINTER(i64)]
     L.mhip_sharded_tables.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64)]
+    L.mhip_cns_accept_templates.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, C.c_double, i32, C.POINTER(vp), C.POINTER(i64), C.POINTER(vp),
+                                            C.POINTER(i64), C.POINTER(i64)]
+    L.mhip_cns_free.argtypes = [vp]
     L.mhip_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
     L.mhip_host_free.argtypes = [vp]
     assert L.mhip_abi_version() == 1
@@ -292,6 +295,30 @@ def cns_expand(res, ops_row, qcodes, tcodes):
     ts = np.where(ops == 2, ord("-"), dec[np.asarray(tcodes)[np.minimum(ti, len(tcodes) - 1)]]).astype(np.uint8)
     a, b = int(res["first_col"]), int(res["last_col"])
     return qs[a:b].tobytes(), ts[a:b].tobytes()
+
+
+EXT_CAND_DTYPE = np.dtype([(n, np.int32) for n in ("qdir", "qid", "qext", "qsize", "qoff", "qend", "sdir", "sid", "sext", "ssize", "soff", "send",
+                                                     "score")])
+ACCEPTED_DTYPE = np.dtype([("template_index", np.int32), ("qid", np.int32), ("sid", np.int32), ("qoff", np.int32), ("qend", np.int32),
+                           ("soff", np.int32), ("send", np.int32), ("aln_size", np.int32), ("cand_index", np.int64), ("str_offset", np.int64)])
+assert EXT_CAND_DTYPE.itemsize == 52 and ACCEPTED_DTYPE.itemsize == 48
+
+
+def cns_accept_templates(ctx, vol, host_pac, cands, tmpl_begin, tech, min_align_size, min_mapping_ratio, threads=8):
+    """mecat2cns' accept loop for a batch of templates.  cands: [n] EXT_CAND_DTYPE (or [n, 13] int32) grouped by template, sorted in
+    place.  -> (accepted [k] ACCEPTED_DTYPE, strings bytes, number of alignments computed)"""
+    cands = np.ascontiguousarray(cands)
+    tb = np.ascontiguousarray(tmpl_begin, dtype=np.int64)
+    pac = np.ascontiguousarray(host_pac, dtype=np.uint8)
+    acc, st = C.c_void_p(), C.c_void_p()
+    na, sb, nj = C.c_int64(), C.c_int64(), C.c_int64()
+    _chk(lib().mhip_cns_accept_templates(ctx.h, vol.h, pac.ctypes.data, cands.ctypes.data, tb.ctypes.data, len(tb) - 1, tech, min_align_size,
+                                         float(min_mapping_ratio), threads, C.byref(acc), C.byref(na), C.byref(st), C.byref(sb), C.byref(nj)))
+    a = np.ctypeslib.as_array(C.cast(acc, C.POINTER(C.c_uint8)), shape=(na.value * 48,)).view(ACCEPTED_DTYPE).copy() if na.value else np.zeros(0, ACCEPTED_DTYPE)
+    s = bytes(np.ctypeslib.as_array(C.cast(st, C.POINTER(C.c_uint8)), shape=(sb.value,))) if sb.value else b""
+    lib().mhip_cns_free(acc)
+    lib().mhip_cns_free(st)
+    return a, s, nj.value
 
 
 COMM_ID_BYTES = 128

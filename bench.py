@@ -476,6 +476,32 @@ def main():
                 del c_res, c_ops
             except Exception as e:          # never let the extra measurement break the contract line
                 log("[bench] cns_realign skipped: %r" % (e,))
+        # not part of the metric: mecat2cns' per-template stage up to the consensus table (BASELINE config 4's front half, SURVEY.md row
+        # N1) on this run's candidates — candidates of the first templates as mecat2cns would load them, <= 200 per template re-aligned
+        # in one launch, accept decisions replayed, gap-normalised strings of the accepted alignments rebuilt (mhip_cns_accept_templates)
+        if world == 1 and not args.no_align and not args.no_extras and keep["njobs"] > 0:
+            try:
+                h_cnt = d_counts.cpu().numpy()
+                h_cands = d_cands.cpu().numpy().view(M.CAND_DTYPE).reshape(n, maxc)
+                ec = W.ext_candidates_from_table(h_cands, h_cnt, lens)
+                rec, tb, ids = W.cns_templates(ec, n)
+                T = min(len(ids), 4000)
+                rec_s = np.ascontiguousarray(rec[: tb[T]])
+                pac_h, _, _ = W.pack_volume(W.synth_reads(n, L, err, G, seed, ont)[0], lens)
+                c0 = time.perf_counter()
+                acc, strs, nja = M.cns_accept_templates(ctx, vol, pac_h, rec_s, tb[: T + 1], ont, 2000 if not ont else 500, 0.9 if not ont else 0.4,
+                                                        threads=min(64, os.cpu_count() or 1))
+                dtc = time.perf_counter() - c0
+                tbases = int(lens[ids[:T]].astype(np.int64).sum())
+                line["cns_accept"] = {"templates": T, "alignments": int(nja), "accepted": int(len(acc)), "seconds": dtc,
+                                      "templates_per_s": T / dtc, "alignments_per_s": nja / dtc, "template_gbase_per_s": tbases / 1e9 / dtc,
+                                      "aligned_string_bytes": len(strs),
+                                      "note": "sort + <= 200 re-alignments per template on the GPU + accept replay + normalised strings on %d host threads; "
+                                              "the reference does the same per template on one core at ~1.3 k alignments/s (profiles/r01_cns_bench.txt); "
+                                              "the consensus table / POA after it stay with mecat2cns" % min(64, os.cpu_count() or 1)}
+                del h_cands, ec, rec, rec_s, acc, strs, pac_h
+            except Exception as e:      # noqa: BLE001
+                log("[bench] cns_accept skipped: %r" % (e,))
         # not part of the metric either: the X-drop aligner (nanopore mode) on the first 100 000 candidates
         if world == 1 and not args.no_align and not args.no_extras and keep["njobs"] > 0:
             try:

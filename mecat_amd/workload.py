@@ -89,3 +89,48 @@ def jobs_from_candidates(cands, counts, rid_begin, ref_start_id=0):
     jobs["qstart"] = qstart
     jobs["sstart"] = sstart
     return jobs
+
+
+def ext_candidates_from_table(cands, counts, lens, reads_start_id=0):
+    """the `.can` records (ExtensionCandidate, common/alignment.h:8-19) of a candidate table, as candidate_detect writes them
+    (mecat2pw/pw_impl.cpp:767-792): [n, 13] int32 = qdir qid qext qsize qoff qend sdir sid sext ssize soff send score"""
+    n, maxc = cands.shape
+    mask = np.arange(maxc)[None, :] < counts[:, None]
+    rid = np.broadcast_to(np.arange(n, dtype=np.int32)[:, None], mask.shape)[mask]
+    c = cands[mask]
+    qext, sext = c["loc2"].copy(), c["loc1"].copy()
+    both = (qext != 0) & (sext != 0)
+    qext[both] += 6
+    sext[both] += 6
+    qsize = lens[rid].astype(np.int32)
+    rev = c["chain"] == 1
+    qext[rev] = qsize[rev] - 1 - qext[rev]
+    out = np.zeros((len(c), 13), dtype=np.int32)
+    out[:, 0], out[:, 1], out[:, 2], out[:, 3] = c["chain"], rid + reads_start_id, qext, qsize
+    out[:, 7], out[:, 8], out[:, 9], out[:, 12] = c["readno"], sext, lens[c["readno"]], c["score"]
+    return out
+
+
+def cns_templates(ec, num_reads, min_cov=4, min_size=5000):
+    """what mecat2cns does with the records before its per-template loop: every candidate once with each of its reads as the
+    template, template strand forward (normalise_candidate, mecat2cns/overlaps_partition.cpp:140-165), grouped by template; templates
+    with fewer than min_cov candidates or shorter than 0.95 * min_size are skipped (reads_correction_can.cpp:33-34).
+    -> (records [m, 13] grouped by template, tmpl_begin [T + 1], template ids [T])"""
+    a = ec.copy()
+    b = ec.copy()
+    b[:, [0, 1, 2, 3]] = ec[:, [6, 7, 8, 9]]
+    b[:, [6, 7, 8, 9]] = ec[:, [0, 1, 2, 3]]
+    rec = np.concatenate([a, b])
+    rev = rec[:, 6] == 1
+    rec[rev, 0] ^= 1
+    rec[rev, 6] ^= 1
+    rec = rec[np.argsort(rec[:, 7], kind="stable")]
+    first = np.searchsorted(rec[:, 7], np.arange(num_reads + 1))
+    n_t = np.diff(first)
+    ssize = np.zeros(num_reads, dtype=np.int64)
+    ssize[rec[:, 7]] = rec[:, 9]
+    keep = (n_t >= min_cov) & (ssize >= min_size * 0.95)
+    ids = np.nonzero(keep)[0]
+    sel = np.concatenate([np.arange(first[t], first[t + 1]) for t in ids]) if len(ids) else np.zeros(0, np.int64)
+    tb = np.concatenate([[0], np.cumsum(n_t[ids])]).astype(np.int64)
+    return np.ascontiguousarray(rec[sel]), tb, ids

@@ -50,6 +50,14 @@ struct DirResult {
     int32_t qbases, tbases, matches, columns, blocks, pad;
 };
 
+// a unit dw_extend2 could not finish (a block whose tail traceback needs a row that left the ring, or that never reached an end
+// of either sequence): where it stands, for dw_extend to take over
+struct DwHandover {
+    uint32_t unit;
+    int32_t qidx, tidx;
+    DirResult R;
+};
+
 struct AlnWaveLds {
     uint32_t Qp[SEQ_WORDS];     // staged block sequences first: their byte offsets fit the ds_read2 offset field
     uint32_t Tp[SEQ_WORDS];
@@ -310,7 +318,8 @@ __global__ __launch_bounds__(AL_BLOCK) void dw_extend(const uint32_t* __restrict
                                                       const uint32_t* __restrict__ qpac, const mhip_offset_t* __restrict__ qoffs,
                                                       const mhip_aln_job* __restrict__ jobs, int n, DirResult* __restrict__ dres,
                                                       uint16_t* __restrict__ gscratch, unsigned int* __restrict__ cursor,
-                                                      unsigned long long* __restrict__ counters) {
+                                                      unsigned long long* __restrict__ counters, const DwHandover* __restrict__ hand,
+                                                      const unsigned int* __restrict__ hand_count) {
     __shared__ AlnWaveLds lds[AL_WAVES];
     AlnWaveLds& S = lds[threadIdx.x >> 6];
     const int lane = lane_id();
@@ -323,7 +332,13 @@ __global__ __launch_bounds__(AL_BLOCK) void dw_extend(const uint32_t* __restrict
         unsigned int unit = 0;
         if (lane == 0) unit = atomicAdd(cursor, 1u);
         unit = __shfl(unit, 0);
-        if (unit >= 2u * (unsigned)n) break;
+        int qidx = 0, tidx = 0;
+        DirResult R = {0, 0, 0, 0, 0, 0};
+        if (hand) {                                   // second launch: the units dw_extend2 handed over, from where they stand
+            if (unit >= *hand_count) break;
+            const DwHandover h = hand[unit];
+            unit = h.unit; qidx = h.qidx; tidx = h.tidx; R = h.R;
+        } else if (unit >= 2u * (unsigned)n) break;
         const mhip_aln_job jb = jobs[unit >> 1];
         const int right = unit & 1;
         const int qsize = qoffs[jb.qid_local].size, tsize = roffs[jb.sid_local].size;
@@ -338,8 +353,6 @@ __global__ __launch_bounds__(AL_BLOCK) void dw_extend(const uint32_t* __restrict
         t.A = right ? jb.sstart : jb.sstart - 1; t.B = step;
         if (right) { query_size = qsize - jb.qstart; target_size = tsize - jb.sstart; }
         else { query_size = jb.qstart; target_size = jb.sstart; }
-        int qidx = 0, tidx = 0;
-        DirResult R = {0, 0, 0, 0, 0, 0};
         while (true) {
             // retrieve_next_aln_block (gapalign.cpp:9-45)
             const int qleft = query_size - qidx, tleft = target_size - tidx;
@@ -413,16 +426,16 @@ __global__ __launch_bounds__(AL_BLOCK) void dw_extend(const uint32_t* __restrict
 #ifndef RROWS
 #define RROWS 64
 #endif
+#define SEQ_WORDS2 48          // 736 bases + one 16-base window, 16 bases per word, no pad word
+// Per-half LDS, 3.4 KB (27 KB per workgroup of four waves: five workgroups per CU).  There is no V[] array: row d reads the
+// furthest x of diagonals k - 1 and k + 1 of row d - 1 straight from that row's entries in the ring (they are always inside its
+// band), at pbase + tt and pbase + tt + 1 with pbase uniform per half.
 struct HalfLds {
-    uint32_t Qp[SEQ_WORDS];
-    uint32_t Tp[SEQ_WORDS];
-    int16_t V[VU_LEN];
-    uint16_t ring[RCAP];
+    uint32_t Qp[SEQ_WORDS2];
+    uint32_t Tp[SEQ_WORDS2];
+    uint16_t ring[RCAP];        // d-rows packed back to back, wrapping (the first two entries of a block are the zeros row 0 reads)
     int4 rrec[RROWS];           // per d-row: x = min_k, y = max_k, z = linear ring position of the row (unpacked: no VALU to build it)
 };
-static_assert(offsetof(HalfLds, Qp) == offsetof(AlnWaveLds, Qp) && offsetof(HalfLds, Tp) == offsetof(AlnWaveLds, Tp) &&
-                  offsetof(HalfLds, V) == offsetof(AlnWaveLds, V),
-              "the spill fallback reuses V/Qp/Tp in place");
 
 // mask of the lanes where p holds, without the bool -> int -> compare round trip of __ballot
 #define BALLOT(p) __builtin_amdgcn_ballot_w64(p)
@@ -443,17 +456,21 @@ __device__ __forceinline__ int half_max(int v) {
 }
 __device__ __forceinline__ int half_min(int v) { return -half_max(-v); }
 
-__global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __restrict__ rpac, const mhip_offset_t* __restrict__ roffs,
+#ifndef DW2_WAVES_PER_SIMD
+#define DW2_WAVES_PER_SIMD 5
+#endif
+__global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const uint32_t* __restrict__ rpac, const mhip_offset_t* __restrict__ roffs,
                                                        const uint32_t* __restrict__ qpac, const mhip_offset_t* __restrict__ qoffs,
                                                        const mhip_aln_job* __restrict__ jobs, int n, DirResult* __restrict__ dres,
-                                                       uint16_t* __restrict__ gscratch, unsigned int* __restrict__ cursor,
-                                                       unsigned long long* __restrict__ counters) {
+                                                       DwHandover* __restrict__ hand, unsigned int* __restrict__ hand_count,
+                                                       unsigned int* __restrict__ cursor, unsigned long long* __restrict__ counters) {
     __shared__ HalfLds lds[AL_WAVES][2];
     const int lane = lane_id(), hh = lane >> 5, sl = lane & 31;
     HalfLds& S = lds[threadIdx.x >> 6][hh];
-    const int gw = blockIdx.x * AL_WAVES + (threadIdx.x >> 6);
-    uint16_t* grow = gscratch + (size_t)gw * GROW_STRIDE;
-    unsigned long long cells = 0, nblocks = 0, nfallback = 0, nrows = 0, nidle = 0, nwide = 0;
+    unsigned int cells = 0, nblocks = 0, nhand = 0;
+#ifdef MECAT_DW_STATS
+    unsigned long long nrows = 0, nidle = 0, nwide = 0;
+#endif
 
     // per-half unit state (uniform inside a half)
     bool need_unit = true, exhausted = false;
@@ -467,7 +484,9 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
     // per-half block state
     int qblk = 0, tblk = 0, last_block = 0, band_tol = 0, max_d = 0;
     int best_m = -1, min_k = 0, max_k = 0, aligned = 0, end_x = 0, end_k = 0, end_d = 0, d = 0;      // d = rows done
-    unsigned int lin = 0;
+    unsigned int lin = 0;       // ring position behind the last row
+    unsigned int pbase = 0;     // ring position of the previous row's entry for diagonal (this row's min_k) - 1
+    unsigned int rlin = 0;      // ring position of the row that ran last
     int dlim = 0;               // rows run while d < dlim: max_d of the block, 0 once an end was reached / without a block
 
     while (true) {
@@ -507,16 +526,16 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
                 tblk = max(tblk, 0);
                 band_tol = (int)(0.3 * (qblk > tblk ? qblk : tblk));
                 max_d = (int)(.3 * (qblk + tblk));
-                for (int w = sl; w < SEQ_WORDS; w += 32) {      // word w = logical bases 16w .. 16w+15, first base in the low bits
+                for (int w = sl; w < SEQ_WORDS2; w += 32) {      // word w = logical bases 16w .. 16w+15, first base in the low bits
                     S.Qp[w] = (w * 16 < qblk + 32) ? view_word_le(q, qidx + w * 16) : 0u;
                     S.Tp[w] = (w * 16 < tblk + 32) ? view_word_le(t, tidx + w * 16) : 0u;
                 }
-                // The reference zero-fills V per block (:232-233); row d only reads diagonals written by row d - 1, except
-                // row 0, which reads V[k_offset + 1].
-                if (sl == 0) S.V[max_d + 1] = 0;
+                // The reference zero-fills V per block (:232-233); row d only reads diagonals written by row d - 1, except row 0,
+                // which reads V[k_offset - 1] and V[k_offset + 1]: the two zeros in front of row 0.
+                if (sl < 2) S.ring[sl] = 0;
                 best_m = -1; min_k = 0; max_k = 0;
                 aligned = 0; end_x = 0; end_k = 0; end_d = 0; d = 0;
-                lin = 0;
+                lin = 2; pbase = 0; rlin = 0;
                 dlim = max_d; inblock = true;
                 setup = false;
             }
@@ -527,16 +546,17 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
 
         // ---- 3. one row per half (Align, diff_gapalign.cpp:107-219); the halves' row counters are independent.  Only the
         // running maximum of x + y is tracked here; a block that ends without reaching an end of either sequence (0.06 %
-        // of blocks) needs the position of that maximum and is handed to the one-unit code path below, like a block whose
-        // traceback outran the ring.
-        // The inner loop runs while every half that has a block is still rowing.
+        // of blocks) needs the position of that maximum and is handed over to dw_extend, like a block whose traceback outran
+        // the ring.  The inner loop runs while every half that has a block is still rowing.
         const unsigned long long inmask = BALLOT(inblock);
         bool row_ok;
         unsigned long long ended = 0;        // lanes whose diagonal reached an end of its block in the row that was just run
         int NJ = 1;
-        // band update (:172-179) of one row; m0 / mp = x + y of the lane's diagonal in the last / previous pass
+        // band update (:172-179) of the row at ring position rlin; m0 / mp = x + y of the lane's diagonal in the last / previous
+        // pass (NJ <= 2), otherwise recomputed from the ring
         auto band_update = [&](const int NJ, const int m0, const int mp) __attribute__((always_inline)) {
-            int nmin = max_k, nmax = min_k;
+            int first = 0, last = -1;                // qualifying lanes; none: the reference's neutral values (new_min_k = max_k, new_max_k = min_k)
+            bool any = false;
             if (NJ <= 2) {
                 // up to 64 diagonals per half: two ballots, the half's 2 x 32 qualification bits, first / last set bit
                 const int thr = best_m - band_tol;
@@ -544,10 +564,9 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
                 const unsigned int lo32 = hh ? (unsigned int)(q0 >> 32) : (unsigned int)q0;
                 const unsigned int hi32 = hh ? (unsigned int)(q1 >> 32) : (unsigned int)q1;
                 if (lo32 | hi32) {
-                    const int first = lo32 ? __ffs((int)lo32) - 1 : 31 + __ffs((int)hi32);
-                    const int last = hi32 ? 63 - __clz((int)hi32) : 31 - __clz((int)lo32);
-                    nmin = min_k + 2 * first;
-                    nmax = min_k + 2 * last;
+                    any = true;
+                    first = lo32 ? __ffs((int)lo32) - 1 : 31 + __ffs((int)hi32);
+                    last = hi32 ? 63 - __clz((int)hi32) : 31 - __clz((int)lo32);
                 }
             } else {
                 int lo = 0x7fffffff, hi = -0x7fffffff;
@@ -556,13 +575,16 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
                     const int tt = sl + 32 * j;
                     const bool act = inblock && tt < nslot;
                     const int k = min_k + 2 * tt;
-                    const int u = act ? 2 * (int)S.V[k + max_d] - k : -0x40000000;
-                    if (act && u >= best_m - band_tol) { lo = min(lo, k); hi = max(hi, k); }
+                    const int u = act ? 2 * (int)S.ring[(rlin + (unsigned)tt) & (RCAP - 1)] - k : -0x40000000;
+                    if (act && u >= best_m - band_tol) { lo = min(lo, tt); hi = max(hi, tt); }
                 }
                 lo = half_min(lo); hi = half_max(hi);
-                if (lo != 0x7fffffff) { nmin = lo; nmax = hi; }
+                if (lo != 0x7fffffff) { any = true; first = lo; last = hi; }
             }
             if (inblock) {
+                const int nmin = any ? min_k + 2 * first : max_k, nmax = any ? min_k + 2 * last : min_k;
+                // previous-row entry of diagonal (new min_k) - 1 = min_k + 2 (first - 1): ring position rlin + first - 1
+                pbase = rlin + (unsigned)(((nmin - min_k) >> 1) - 1);
                 max_k = nmax + 1;
                 min_k = nmin - 1;
             }
@@ -596,9 +618,9 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
                 do {                                 // at least one pass (a pass over an empty band only moves idle lanes)
                     const int tt = sl + 32 * j;
                     const bool act = tt < nslot;
-                    const int k = min_k + 2 * tt, kk = k + k_offset;
-                    const int16_t* vp = &S.V[kk - 1];                  // idle lanes read (and ignore) in-range garbage
-                    const int vl = vp[0], vr = vp[2];
+                    const int k = min_k + 2 * tt;
+                    const unsigned int rp = pbase + (unsigned)tt;      // idle lanes read (and ignore) whatever the ring holds there
+                    const int vl = S.ring[rp & (RCAP - 1)], vr = S.ring[(rp + 1) & (RCAP - 1)];
                     int x = (k == min_k || (k != max_k && vl < vr)) ? vr : vl + 1;       // :138-142
                     // 0 <= y <= t_len and x <= q_len on every live diagonal (a diagonal at an end stops the block); idle lanes sit
                     // at (q_len, 0), where lim == 0
@@ -612,10 +634,7 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
                         nn = min(min(match16_le(S.Qp, x, S.Tp, y), lim), 16);
                         x += nn; y += nn;
                     } while (BALLOT(nn == 16));
-                    if (act) {
-                        S.V[kk] = (int16_t)x;
-                        S.ring[(lin + (unsigned)tt) & (RCAP - 1)] = (uint16_t)x;
-                    }
+                    if (act) S.ring[(lin + (unsigned)tt) & (RCAP - 1)] = (uint16_t)x;
                     e |= BALLOT(lim == nn) & BALLOT(act);     // nothing left of the query or of the target on this diagonal
                     mp = m0;
                     m0 = act ? x + y : -0x40000000;     // also read by the band update (NJ <= 2); idle lanes never qualify
@@ -623,6 +642,7 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
                 } while (++j < NJ);
                 ended = e;
                 last_m0 = m0; last_mp = mp;
+                rlin = lin;
                 lin += (unsigned)nslot;
                 __builtin_amdgcn_wave_barrier();
                 best_m = max(best_m, half_max(mmax));      // running maximum of x + y (:160-167)
@@ -645,14 +665,14 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
         }
         if (ended) {
             // Once per block, outside the row loop (inside it, the state written here costs register copies on every row): the
-            // lowest diagonal that reached an end (:168-169), from the values just stored in V; then the rest of that row for the
+            // lowest diagonal that reached an end (:168-169), from the row just stored; then the rest of that row for the
             // other half.
             const int nslot = ((max_k - min_k) >> 1) + 1;
             int hkey = 0x7fffffff;
             for (int jj = 0; jj < NJ; ++jj) {
                 const int tt = sl + 32 * jj, k = min_k + 2 * tt, kk = k + k_offset;
                 if (tt < nslot) {
-                    const int x = S.V[kk];
+                    const int x = S.ring[(rlin + (unsigned)tt) & (RCAP - 1)];
                     if (x >= q_len || x - k >= t_len) hkey = min(hkey, (kk << 10) | x);
                 }
             }
@@ -661,7 +681,7 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
                 aligned = 1; end_k = (hkey >> 10) - k_offset; end_x = hkey & 1023; end_d = d;
                 dlim = 0;
             }
-            band_update(NJ, last_m0, last_mp);
+            band_update(max(NJ, 3), 0, 0);   // (the general form: from the ring)
             d += 1;
             __builtin_amdgcn_wave_barrier();
         }
@@ -674,7 +694,7 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
 
         // ---- 4. tail traceback == trim_mismatch_end(.., 4, ..) (gapalign.cpp:47-68), for the halves whose rows just ended
         bool has_aln = fin && aligned;
-        bool fallback = fin && d > 0 && !aligned;       // rows ran without reaching an end: needs the best point (one-unit path)
+        bool handover = fin && d > 0 && !aligned;       // rows ran without reaching an end: needs the best point (dw_extend)
         const int end_y = end_x - end_k;
         const int aln_size = (end_x + end_y + end_d) / 2;
         int cd = end_d, ck = end_k, cx2 = end_x;
@@ -687,7 +707,7 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
                     const int r = cd - 1;
                     const int4 pr = S.rrec[r & (RROWS - 1)], cr = S.rrec[cd & (RROWS - 1)];
                     const unsigned int plin = (unsigned int)pr.z;
-                    if (d - 1 - r >= RROWS || lin - plin > RCAP) { fallback = true; tracing = false; }
+                    if (d - 1 - r >= RROWS || lin - plin > RCAP) { handover = true; tracing = false; }
                     else {
                         const int pmin = pr.x, pmax = pr.y, cmin = cr.x, cmax = cr.y;
                         const int kl = ck - 1, kr = ck + 1;
@@ -714,62 +734,59 @@ __global__ __launch_bounds__(AL_BLOCK, 4) void dw_extend2(const uint32_t* __rest
                 }
             }
         }
-        int o_qe = end_x, o_te = end_y, o_dist = end_d;
-        int trim_ok = has_aln && found && (aln_size - acnt >= 2);
+        const int trim_ok = has_aln && found && (aln_size - acnt >= 2);
 
-        // ---- 5. rare: the tail needs a row that left the ring -> re-run that half's block with spilled rows (whole wave;
-        // only that half's V/Qp/Tp are touched, the other half may be in the middle of its own block)
-        const unsigned long long fb = BALLOT(fallback);
-        if (fb) {
-            for (int hx = 0; hx < 2; ++hx) {
-                if (!((fb >> (hx * 32)) & 1ull)) continue;
-                const int ql = __builtin_amdgcn_readlane(q_len, hx * 32), tl = __builtin_amdgcn_readlane(t_len, hx * 32);
-                BlockOut o;
-                unsigned int c2 = 0, s2 = 0;
-                DwStats st2 = {0, 0, 0, 0, 0};
-                align_block<true, true>(*(AlnWaveLds*)&lds[threadIdx.x >> 6][hx], ql, tl, grow, o, c2, s2, st2);
-                ++nfallback;
-                if (hh == hx) {
-                    has_aln = o.aligned_or_best; o_qe = o.qe; o_te = o.te; o_dist = o.dist;
-                    qcnt = o.qcnt; tcnt = o.tcnt; acnt = o.acnt; trim_ok = o.aligned_or_best && o.trim_ok;
-                }
-            }
-        }
-
-        // ---- 6. block accounting (dw_in_one_direction, diff_gapalign.cpp:259-290)
+        // ---- 5. block accounting (dw_in_one_direction, diff_gapalign.cpp:259-290); a block this kernel cannot finish (0.07 %: the
+        // tail needs a row that left the ring, or no end was reached) hands the unit over to dw_extend, which redoes that block
+        // and the rest of the unit with every row kept
         if (fin) {
-            nblocks += (sl == 0) ? 1u : 0u;
-            cells += (sl == 0) ? lin : 0u;              // lin = diagonals visited in this block
-            Rb += 1;
-            bool stop = !has_aln || !trim_ok;
-            if (!stop) {
-                const int full_map = (qblk - o_qe <= 20 || tblk - o_te <= 20);
-                const bool last = last_block || !full_map;
-                if (last) { qcnt -= 4; tcnt -= 4; acnt -= 4; }
-                Rc += (o_qe + o_te + o_dist) / 2 - acnt;
-                Rm += (o_qe + o_te - o_dist) / 2 - (qcnt + tcnt - acnt);
-                Rq += o_qe - qcnt;
-                Rt += o_te - tcnt;
-                if (last) stop = true;
-                else { qidx += o_qe - qcnt; tidx += o_te - tcnt; }
-            }
-            if (stop) {
-                if (sl == 0) { DirResult R = {Rq, Rt, Rm, Rc, Rb, 0}; dres[unit] = R; }
+            bool stop;
+            if (handover) {
+                if (sl == 0) {
+                    DwHandover h;
+                    h.unit = unit; h.qidx = qidx; h.tidx = tidx;
+                    h.R.qbases = Rq; h.R.tbases = Rt; h.R.matches = Rm; h.R.columns = Rc; h.R.blocks = Rb; h.R.pad = 0;
+                    hand[atomicAdd(hand_count, 1u)] = h;
+                    nhand += 1;
+                }
                 need_unit = true;
+            } else {
+                nblocks += (sl == 0) ? 1u : 0u;
+                cells += (sl == 0) ? lin - 2u : 0u;         // diagonals visited in this block
+                Rb += 1;
+                stop = !has_aln || !trim_ok;
+                if (!stop) {
+                    const int full_map = (qblk - end_x <= 20 || tblk - end_y <= 20);
+                    const bool last = last_block || !full_map;
+                    if (last) { qcnt -= 4; tcnt -= 4; acnt -= 4; }
+                    Rc += (end_x + end_y + end_d) / 2 - acnt;
+                    Rm += (end_x + end_y - end_d) / 2 - (qcnt + tcnt - acnt);
+                    Rq += end_x - qcnt;
+                    Rt += end_y - tcnt;
+                    if (last) stop = true;
+                    else { qidx += end_x - qcnt; tidx += end_y - tcnt; }
+                }
+                if (stop) {
+                    if (sl == 0) { DirResult R = {Rq, Rt, Rm, Rc, Rb, 0}; dres[unit] = R; }
+                    need_unit = true;
+                }
             }
             inblock = false;
             setup = true;
             dlim = 0;           // a half without a block must never look like it is rowing (its rows may have ended on the band limit)
         }
     }
-    for (int off = 32; off > 0; off >>= 1) { nblocks += __shfl_xor(nblocks, off); cells += __shfl_xor(cells, off); }
+    unsigned long long c64 = cells, b64 = nblocks, h64 = nhand;
+    for (int off = 32; off > 0; off >>= 1) { b64 += __shfl_xor(b64, off); c64 += __shfl_xor(c64, off); h64 += __shfl_xor(h64, off); }
     if (lane == 0) {
-        atomicAdd(&counters[3], nblocks);
-        atomicAdd(&counters[4], cells);
-        atomicAdd(&counters[8], nfallback);
+        atomicAdd(&counters[3], b64);
+        atomicAdd(&counters[4], c64);
+        atomicAdd(&counters[8], h64);          // units handed over
+#ifdef MECAT_DW_STATS
         atomicAdd(&counters[9], nrows);          // dual rows
         atomicAdd(&counters[10], nidle);         // dual rows with one idle half
         atomicAdd(&counters[11], nwide);         // dual rows with more than 32 diagonals in a half
+#endif
     }
 }
 
@@ -884,25 +901,34 @@ int mhip_align_candidates_dev(mhip_ctx* c, const mhip_volume* ref, const mhip_vo
     DirResult* d_dres;
     uint16_t* d_g;
     unsigned int* d_cur;
+    DwHandover* d_hand;
     if (c->scratch("al_dres", sizeof(DirResult) * 2 * (size_t)n, (void**)&d_dres)) return -1;
     if (c->scratch("al_rows", sizeof(uint16_t) * GROW_STRIDE * (size_t)max_waves, (void**)&d_g)) return -1;
     if (c->scratch("al_cursor", 64, (void**)&d_cur)) return -1;
-    HIPCHK(hipMemsetAsync(d_cur, 0, 4, c->stream));
+    HIPCHK(hipMemsetAsync(d_cur, 0, 16, c->stream));                 // [0] unit cursor, [1] units handed over, [2] cursor of the second launch
     const char* kv = getenv("MECAT_DW_KERNEL");      // debug knob: 1 = one unit per wave, default 2 = one unit per half-wave
     if (kv && atoi(kv) == 1) {
         LAUNCH(c, "dw_extend", dw_extend, grid, AL_BLOCK, 0, (const uint32_t*)ref->d_pac, (const mhip_offset_t*)ref->d_offs,
                (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs, (const mhip_aln_job*)d_jobs, n, d_dres, d_g, d_cur,
-               (unsigned long long*)c->d_counters);
+               (unsigned long long*)c->d_counters, (const DwHandover*)nullptr, (const unsigned int*)nullptr);
     } else {
-        grid = std::min(max_waves / AL_WAVES, (n + AL_WAVES - 1) / AL_WAVES);
+        if (c->scratch("al_hand", sizeof(DwHandover) * 2 * (size_t)n, (void**)&d_hand)) return -1;
+        int waves2 = DW2_WAVES_PER_SIMD * 4;                  // LDS 27 KB per four waves, <= 96 VGPRs
+        if (const char* e = getenv("MECAT_DW_WAVES")) waves2 = std::max(4, std::min(32, atoi(e)));
+        const int grid2 = std::min(c->num_cus * waves2 / AL_WAVES, (n + AL_WAVES - 1) / AL_WAVES);
         if (getenv("MECAT_TRACE")) {
             int nb = 0;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dw_extend2, AL_BLOCK, 0);
-            fprintf(stderr, "[dw trace] occupancy query: %d blocks of %d threads per CU; grid %d; HalfLds %zu bytes\n", nb, AL_BLOCK, grid, sizeof(HalfLds));
+            fprintf(stderr, "[dw trace] occupancy query: %d blocks of %d threads per CU; grid %d; HalfLds %zu bytes\n", nb, AL_BLOCK, grid2, sizeof(HalfLds));
         }
-        LAUNCH(c, "dw_extend2", dw_extend2, grid, AL_BLOCK, 0, (const uint32_t*)ref->d_pac, (const mhip_offset_t*)ref->d_offs,
-               (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs, (const mhip_aln_job*)d_jobs, n, d_dres, d_g, d_cur,
-               (unsigned long long*)c->d_counters);
+        LAUNCH(c, "dw_extend2", dw_extend2, grid2, AL_BLOCK, 0, (const uint32_t*)ref->d_pac, (const mhip_offset_t*)ref->d_offs,
+               (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs, (const mhip_aln_job*)d_jobs, n, d_dres, d_hand, d_cur + 1,
+               d_cur, (unsigned long long*)c->d_counters);
+        // the units it handed over (a fraction of a percent), finished by the one-unit kernel with every row kept; the launch reads
+        // their number on the device, so nothing waits for the host
+        LAUNCH(c, "dw_extend", dw_extend, grid, AL_BLOCK, 0, (const uint32_t*)ref->d_pac, (const mhip_offset_t*)ref->d_offs,
+               (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs, (const mhip_aln_job*)d_jobs, n, d_dres, d_g, d_cur + 2,
+               (unsigned long long*)c->d_counters, (const DwHandover*)d_hand, (const unsigned int*)(d_cur + 1));
     }
     LAUNCH(c, "dw_stitch", dw_stitch, (n + 255) / 256, 256, 0, (const mhip_aln_job*)d_jobs, (const DirResult*)d_dres, n,
            min_align_size, (mhip_aln_result*)d_out, (unsigned long long*)c->d_counters);

@@ -424,17 +424,17 @@ __global__ __launch_bounds__(AL_BLOCK) void dw_extend(const uint32_t* __restrict
 #define RCAP 1024
 #endif
 #ifndef RROWS
-#define RROWS 64
+#define RROWS 32              // rows the tail traceback can go back (the ring itself holds ~40 average rows)
 #endif
 #define SEQ_WORDS2 48          // 736 bases + one 16-base window, 16 bases per word, no pad word
-// Per-half LDS, 3.4 KB (27 KB per workgroup of four waves: five workgroups per CU).  There is no V[] array: row d reads the
+// Per-half LDS, 2.7 KB (21.5 KB per workgroup of four waves: seven workgroups per CU).  There is no V[] array: row d reads the
 // furthest x of diagonals k - 1 and k + 1 of row d - 1 straight from that row's entries in the ring (they are always inside its
 // band), at pbase + tt and pbase + tt + 1 with pbase uniform per half.
 struct HalfLds {
     uint32_t Qp[SEQ_WORDS2];
     uint32_t Tp[SEQ_WORDS2];
     uint16_t ring[RCAP];        // d-rows packed back to back, wrapping (the first two entries of a block are the zeros row 0 reads)
-    int4 rrec[RROWS];           // per d-row: x = min_k, y = max_k, z = linear ring position of the row (unpacked: no VALU to build it)
+    int2 rrec[RROWS];           // per d-row: x = min_k (low 16 bits) | max_k << 16, y = linear ring position of the row
 };
 
 // mask of the lanes where p holds, without the bool -> int -> compare round trip of __ballot
@@ -457,7 +457,7 @@ __device__ __forceinline__ int half_max(int v) {
 __device__ __forceinline__ int half_min(int v) { return -half_max(-v); }
 
 #ifndef DW2_WAVES_PER_SIMD
-#define DW2_WAVES_PER_SIMD 5
+#define DW2_WAVES_PER_SIMD 7
 #endif
 __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const uint32_t* __restrict__ rpac, const mhip_offset_t* __restrict__ roffs,
                                                        const uint32_t* __restrict__ qpac, const mhip_offset_t* __restrict__ qoffs,
@@ -601,8 +601,8 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
             nidle += (rmask == ~0ull) ? 0u : 1u;
 #endif
             {                                // row record: band limits + linear ring position.  Every lane of the half stores the same
-                int4* rr = &S.rrec[d & (RROWS - 1)];      // three words to the same address (no exec juggling on the scalar unit)
-                rr->x = min_k; rr->y = max_k; rr->z = (int)lin;
+                int2* rr = &S.rrec[d & (RROWS - 1)];      // two words to the same address (no exec juggling on the scalar unit)
+                rr->x = (int)__builtin_amdgcn_perm((unsigned)max_k, (unsigned)min_k, 0x05040100u); rr->y = (int)lin;
             }
             const int ns_a = __builtin_amdgcn_readlane(nslot, 0), ns_b = __builtin_amdgcn_readlane(nslot, 32);
             NJ = (max(ns_a, ns_b) + 31) >> 5;
@@ -705,11 +705,11 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                 int x1 = 0, pre_k = 0, takes_q = 0;
                 if (cd > 0) {
                     const int r = cd - 1;
-                    const int4 pr = S.rrec[r & (RROWS - 1)], cr = S.rrec[cd & (RROWS - 1)];
-                    const unsigned int plin = (unsigned int)pr.z;
+                    const int2 pr = S.rrec[r & (RROWS - 1)], cr = S.rrec[cd & (RROWS - 1)];
+                    const unsigned int plin = (unsigned int)pr.y;
                     if (d - 1 - r >= RROWS || lin - plin > RCAP) { handover = true; tracing = false; }
                     else {
-                        const int pmin = pr.x, pmax = pr.y, cmin = cr.x, cmax = cr.y;
+                        const int pmin = (int)(int16_t)pr.x, pmax = pr.x >> 16, cmin = (int)(int16_t)cr.x, cmax = cr.x >> 16;
                         const int kl = ck - 1, kr = ck + 1;
                         int vl = 0, vr = 0;
                         if (kl >= pmin && kl <= pmax) vl = S.ring[(plin + (unsigned)((kl - pmin) >> 1)) & (RCAP - 1)];
@@ -913,7 +913,7 @@ int mhip_align_candidates_dev(mhip_ctx* c, const mhip_volume* ref, const mhip_vo
                (unsigned long long*)c->d_counters, (const DwHandover*)nullptr, (const unsigned int*)nullptr);
     } else {
         if (c->scratch("al_hand", sizeof(DwHandover) * 2 * (size_t)n, (void**)&d_hand)) return -1;
-        int waves2 = DW2_WAVES_PER_SIMD * 4;                  // LDS 27 KB per four waves, <= 96 VGPRs
+        int waves2 = DW2_WAVES_PER_SIMD * 4;                  // LDS 21.5 KB per four waves, 72 VGPRs
         if (const char* e = getenv("MECAT_DW_WAVES")) waves2 = std::max(4, std::min(32, atoi(e)));
         const int grid2 = std::min(c->num_cus * waves2 / AL_WAVES, (n + AL_WAVES - 1) / AL_WAVES);
         if (getenv("MECAT_TRACE")) {

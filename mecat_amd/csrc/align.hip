@@ -456,6 +456,8 @@ __device__ __forceinline__ int half_max(int v) {
 }
 __device__ __forceinline__ int half_min(int v) { return -half_max(-v); }
 
+__device__ __forceinline__ unsigned int lowbits32(int n) { return n >= 32 ? 0xffffffffu : n <= 0 ? 0u : (1u << n) - 1u; }
+
 #ifndef DW2_WAVES_PER_SIMD
 #define DW2_WAVES_PER_SIMD 7
 #endif
@@ -555,19 +557,27 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
         // band update (:172-179) of the row at ring position rlin; m0 / mp = x + y of the lane's diagonal in the last / previous
         // pass (NJ <= 2), otherwise recomputed from the ring
         auto band_update = [&](const int NJ, const int m0, const int mp) __attribute__((always_inline)) {
-            int first = 0, last = -1;                // qualifying lanes; none: the reference's neutral values (new_min_k = max_k, new_max_k = min_k)
-            bool any = false;
-            if (NJ <= 2) {
-                // up to 64 diagonals per half: two ballots, the half's 2 x 32 qualification bits, first / last set bit
+            // qualifying lanes first .. last of the half.  The mask of a half that is in a block is never empty: the lane that holds
+            // the row maximum qualifies, and the row maximum is the running maximum (x + y grows by at least one per row along
+            // the best path, which the band never prunes).
+            int first, last;
+            if (NJ == 1) {
+                // 32 diagonals per half: one ballot; first / last set bit of the half's 32 bits with the raw instructions
+                // (v_ffbl / v_ffbh return -1 for an empty mask: a half without a block, whose values are not used)
+                const unsigned long long q0 = BALLOT(m0 >= best_m - band_tol);
+                const unsigned int m32 = hh ? (unsigned int)(q0 >> 32) : (unsigned int)q0;
+                int lz;
+                asm("v_ffbl_b32 %0, %1" : "=v"(first) : "v"(m32));
+                asm("v_ffbh_u32 %0, %1" : "=v"(lz) : "v"(m32));
+                last = 31 - lz;
+            } else if (NJ == 2) {
+                // up to 64 diagonals per half: two ballots, the half's 2 x 32 qualification bits
                 const int thr = best_m - band_tol;
-                const unsigned long long q0 = BALLOT((NJ == 2 ? mp : m0) >= thr), q1 = NJ == 2 ? BALLOT(m0 >= thr) : 0ull;
+                const unsigned long long q0 = BALLOT(mp >= thr), q1 = BALLOT(m0 >= thr);
                 const unsigned int lo32 = hh ? (unsigned int)(q0 >> 32) : (unsigned int)q0;
                 const unsigned int hi32 = hh ? (unsigned int)(q1 >> 32) : (unsigned int)q1;
-                if (lo32 | hi32) {
-                    any = true;
-                    first = lo32 ? __ffs((int)lo32) - 1 : 31 + __ffs((int)hi32);
-                    last = hi32 ? 63 - __clz((int)hi32) : 31 - __clz((int)lo32);
-                }
+                first = lo32 ? __ffs((int)lo32) - 1 : 31 + __ffs((int)hi32);
+                last = hi32 ? 63 - __clz((int)hi32) : 31 - __clz((int)lo32);
             } else {
                 int lo = 0x7fffffff, hi = -0x7fffffff;
                 const int nslot = ((max_k - min_k) >> 1) + 1;
@@ -578,15 +588,14 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                     const int u = act ? 2 * (int)S.ring[(rlin + (unsigned)tt) & (RCAP - 1)] - k : -0x40000000;
                     if (act && u >= best_m - band_tol) { lo = min(lo, tt); hi = max(hi, tt); }
                 }
-                lo = half_min(lo); hi = half_max(hi);
-                if (lo != 0x7fffffff) { any = true; first = lo; last = hi; }
+                first = half_min(lo); last = half_max(hi);
             }
             if (inblock) {
-                const int nmin = any ? min_k + 2 * first : max_k, nmax = any ? min_k + 2 * last : min_k;
-                // previous-row entry of diagonal (new min_k) - 1 = min_k + 2 (first - 1): ring position rlin + first - 1
-                pbase = rlin + (unsigned)(((nmin - min_k) >> 1) - 1);
-                max_k = nmax + 1;
-                min_k = nmin - 1;
+                // new band [min_k + 2 first - 1, min_k + 2 last + 1]; the previous-row entry of diagonal (new min_k) - 1 sits at
+                // ring position rlin + first - 1
+                pbase = rlin + (unsigned)(first - 1);
+                max_k = min_k + 2 * last + 1;
+                min_k = min_k + 2 * first - 1;
             }
         };
         int last_m0 = 0, last_mp = 0;
@@ -635,7 +644,9 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                         x += nn; y += nn;
                     } while (BALLOT(nn == 16));
                     if (act) S.ring[(lin + (unsigned)tt) & (RCAP - 1)] = (uint16_t)x;
-                    e |= BALLOT(lim == nn) & BALLOT(act);     // nothing left of the query or of the target on this diagonal
+                    // nothing left of the query or of the target on this diagonal; the mask of the active lanes of this pass comes from
+                    // the two halves' slot counts on the scalar unit
+                    e |= BALLOT(lim == nn) & (lowbits32(ns_a - 32 * j) | ((unsigned long long)lowbits32(ns_b - 32 * j) << 32));
                     mp = m0;
                     m0 = act ? x + y : -0x40000000;     // also read by the band update (NJ <= 2); idle lanes never qualify
                     mmax = NJ == 1 ? m0 : max(mmax, m0);

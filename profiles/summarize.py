@@ -23,28 +23,39 @@ def short(name):
 def main():
     tag, kdir, fdir, wdir, passes = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5])
     here = os.path.dirname(os.path.abspath(__file__))
+    # the run may hold several traced processes (bench.py calls the valu_peak calibration binary): keep the one with the hot path
+    def pick(pattern):
+        c = [f for f in glob.glob(os.path.join(kdir, "**", pattern), recursive=True)]
+        c.sort(key=lambda f: -os.path.getsize(f))
+        for f in c:
+            if pattern.endswith("agent_info.csv") or "dw_extend" in open(f).read():
+                return f
+        return c[0] if c else None
     for f in ("kernel_stats", "agent_info"):
-        src = glob.glob(os.path.join(kdir, "*_%s.csv" % f))
+        src = pick("*_%s.csv" % f)
         if src:
-            shutil.copy(src[0], os.path.join(here, "%s_%s.csv" % (tag, f)))
+            shutil.copy(src, os.path.join(here, "%s_%s.csv" % (tag, f)))
     tot = collections.defaultdict(lambda: [0, 0.0, 0.0])
     for d, col in ((fdir, 1), (wdir, 2)):
-        for r in csv.DictReader(open(glob.glob(os.path.join(d, "*counter_collection.csv"))[0])):
-            k = short(r["Kernel_Name"])
-            if col == 1:
-                tot[k][0] += 1
-            tot[k][col] += float(r["Counter_Value"])
+        for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(fn)):
+                k = short(r["Kernel_Name"])
+                if k.startswith("k_"):
+                    continue          # valu_peak's calibration kernels
+                if col == 1:
+                    tot[k][0] += 1
+                tot[k][col] += float(r["Counter_Value"])
     # average launch duration per kernel from the kernel-trace stats of the same command
     dur = {}
-    ks = glob.glob(os.path.join(kdir, "*_kernel_stats.csv"))
+    ks = pick("*_kernel_stats.csv")
     if ks:
-        for r in csv.DictReader(open(ks[0])):
+        for r in csv.DictReader(open(ks)):
             dur[short(r["Name"])] = float(r["AverageNs"])
     rows = sorted(tot.items(), key=lambda kv: -(kv[1][1] + kv[1][2]))
     traffic = {}
     with open(os.path.join(here, "%s_hbm_counters.md" % tag), "w") as f:
         f.write("# %s - HBM traffic counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)\n\n" % tag)
-        f.write("Command: `python bench.py --steps 1 --warmup 1 --no-cpu --no-extras` (config 2), i.e. %d passes of the hot path per run.\n" % passes)
+        f.write("Command: `python bench.py --steps 1 --warmup 1 --no-cpu --no-extras --no-e2e` (config 2), i.e. %d passes of the hot path per run.\n" % passes)
         f.write("Counter unit is KiB; bytes = value x 1024.  MI355X_MICROARCH.md (HBM): FETCH_SIZE reports half the bytes of a\n"
                 "16 B/lane coalesced streaming read and is uncalibrated for other widths; none of these kernels issues 16 B/lane\n"
                 "streams (4-8 B/lane gathers and scatters), so the values are reported uncorrected.  Infinity-Cache hits count.\n\n")

@@ -538,7 +538,7 @@ def main():
         log("[bench] kernel ms/step: " + ", ".join("%s=%.2f" % (k, v[1] / args.steps) for k, v in sorted(kstats.items(), key=lambda kv: -kv[1][1])))
         if world == 1 and not args.no_e2e:
             try:
-                line["e2e"] = e2e_cli(args.workload, codes, lens, min(64, os.cpu_count() or 1))
+                line["e2e"] = e2e_cli(args.workload, codes, lens, min(32, os.cpu_count() or 1))
             except Exception as e:  # noqa: BLE001
                 line["e2e"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_cpu:

@@ -427,15 +427,20 @@ __global__ __launch_bounds__(AL_BLOCK) void dw_extend(const uint32_t* __restrict
 #define RROWS 32              // rows the tail traceback can go back (the ring itself holds ~40 average rows)
 #endif
 #define SEQ_WORDS2 48          // 736 bases + one 16-base window, 16 bases per word, no pad word
-// Per-half LDS, 2.7 KB (21.5 KB per workgroup of four waves: seven workgroups per CU).  There is no V[] array: row d reads the
+// Per-half LDS, 2.7 KB incl. the ring below (21.5 KB per workgroup of four waves: seven workgroups per CU).  There is no V[] array: row d reads the
 // furthest x of diagonals k - 1 and k + 1 of row d - 1 straight from that row's entries in the ring (they are always inside its
 // band), at pbase + tt and pbase + tt + 1 with pbase uniform per half.
 struct HalfLds {
     uint32_t Qp[SEQ_WORDS2];
     uint32_t Tp[SEQ_WORDS2];
-    uint16_t ring[RCAP];        // d-rows packed back to back, wrapping (the first two entries of a block are the zeros row 0 reads)
-    int2 rrec[RROWS];           // per d-row: x = min_k (low 16 bits) | max_k << 16, y = linear ring position of the row
+    int2 rrec[RROWS];           // per d-row: x = min_k (low 16 bits) | max_k << 16, y = linear ring position of the row, in BYTES
 };
+// The ring of d-rows of a half: u16 rows packed back to back, wrapping (the first two entries of a block are the zeros row 0 reads).
+// It is its own 2 KB-aligned LDS array so that the address of ring byte position p is `base | (p & 0x7fe)`: one v_and_or_b32.
+// Positions (lin, pbase, rlin) are kept in bytes.
+typedef __attribute__((address_space(3))) uint16_t lds_u16_t;
+__device__ __forceinline__ int ring_ld(uint32_t base, uint32_t pos) { return (int)*(lds_u16_t*)(uintptr_t)(base | (pos & (2 * RCAP - 2))); }
+__device__ __forceinline__ void ring_st(uint32_t base, uint32_t pos, int x) { *(lds_u16_t*)(uintptr_t)(base | (pos & (2 * RCAP - 2))) = (uint16_t)x; }
 
 // mask of the lanes where p holds, without the bool -> int -> compare round trip of __ballot
 #define BALLOT(p) __builtin_amdgcn_ballot_w64(p)
@@ -467,8 +472,10 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                                                        DwHandover* __restrict__ hand, unsigned int* __restrict__ hand_count,
                                                        unsigned int* __restrict__ cursor, unsigned long long* __restrict__ counters) {
     __shared__ HalfLds lds[AL_WAVES][2];
+    __shared__ __attribute__((aligned(2 * RCAP))) uint16_t rings[AL_WAVES * 2][RCAP];
     const int lane = lane_id(), hh = lane >> 5, sl = lane & 31;
     HalfLds& S = lds[threadIdx.x >> 6][hh];
+    const uint32_t rbase = (uint32_t)(uintptr_t)(lds_u16_t*)&rings[(threadIdx.x >> 6) * 2 + hh][0];
     unsigned int cells = 0, nblocks = 0, nhand = 0;
 #ifdef MECAT_DW_STATS
     unsigned long long nrows = 0, nidle = 0, nwide = 0;
@@ -486,7 +493,7 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
     // per-half block state
     int qblk = 0, tblk = 0, last_block = 0, band_tol = 0, max_d = 0;
     int best_m = -1, min_k = 0, max_k = 0, aligned = 0, end_x = 0, end_k = 0, end_d = 0, d = 0;      // d = rows done
-    unsigned int lin = 0;       // ring position behind the last row
+    unsigned int lin = 0;       // ring position behind the last row (bytes, like the next two)
     unsigned int pbase = 0;     // ring position of the previous row's entry for diagonal (this row's min_k) - 1
     unsigned int rlin = 0;      // ring position of the row that ran last
     int dlim = 0;               // rows run while d < dlim: max_d of the block, 0 once an end was reached / without a block
@@ -534,10 +541,10 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                 }
                 // The reference zero-fills V per block (:232-233); row d only reads diagonals written by row d - 1, except row 0,
                 // which reads V[k_offset - 1] and V[k_offset + 1]: the two zeros in front of row 0.
-                if (sl < 2) S.ring[sl] = 0;
+                if (sl < 2) ring_st(rbase, 2u * sl, 0);
                 best_m = -1; min_k = 0; max_k = 0;
                 aligned = 0; end_x = 0; end_k = 0; end_d = 0; d = 0;
-                lin = 2; pbase = 0; rlin = 0;
+                lin = 4; pbase = 0; rlin = 0;
                 dlim = max_d; inblock = true;
                 setup = false;
             }
@@ -585,7 +592,7 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                     const int tt = sl + 32 * j;
                     const bool act = inblock && tt < nslot;
                     const int k = min_k + 2 * tt;
-                    const int u = act ? 2 * (int)S.ring[(rlin + (unsigned)tt) & (RCAP - 1)] - k : -0x40000000;
+                    const int u = act ? 2 * ring_ld(rbase, rlin + 2u * (unsigned)tt) - k : -0x40000000;
                     if (act && u >= best_m - band_tol) { lo = min(lo, tt); hi = max(hi, tt); }
                 }
                 first = half_min(lo); last = half_max(hi);
@@ -593,7 +600,7 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
             if (inblock) {
                 // new band [min_k + 2 first - 1, min_k + 2 last + 1]; the previous-row entry of diagonal (new min_k) - 1 sits at
                 // ring position rlin + first - 1
-                pbase = rlin + (unsigned)(first - 1);
+                pbase = rlin + 2u * (unsigned)(first - 1);
                 max_k = min_k + 2 * last + 1;
                 min_k = min_k + 2 * first - 1;
             }
@@ -628,8 +635,8 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                     const int tt = sl + 32 * j;
                     const bool act = tt < nslot;
                     const int k = min_k + 2 * tt;
-                    const unsigned int rp = pbase + (unsigned)tt;      // idle lanes read (and ignore) whatever the ring holds there
-                    const int vl = S.ring[rp & (RCAP - 1)], vr = S.ring[(rp + 1) & (RCAP - 1)];
+                    const unsigned int rp = pbase + 2u * (unsigned)tt;      // idle lanes read (and ignore) whatever the ring holds there
+                    const int vl = ring_ld(rbase, rp), vr = ring_ld(rbase, rp + 2u);
                     int x = (k == min_k || (k != max_k && vl < vr)) ? vr : vl + 1;       // :138-142
                     // 0 <= y <= t_len and x <= q_len on every live diagonal (a diagonal at an end stops the block); idle lanes sit
                     // at (q_len, 0), where lim == 0
@@ -640,10 +647,11 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                         lim = min(q_len - x, t_len - y);
                         // 0..15 equal bases, or >= 16 (0x7fffffff) when the whole window matches.  A lane with exactly 16 bases left
                         // that all match asks for one more step, which then moves nothing.
-                        nn = min(min(match16_le(S.Qp, x, S.Tp, y), lim), 16);
+                        const int m = match16_le(S.Qp, x, S.Tp, y);
+                        asm("v_min3_i32 %0, %1, %2, 16" : "=v"(nn) : "v"(m), "v"(lim));
                         x += nn; y += nn;
                     } while (BALLOT(nn == 16));
-                    if (act) S.ring[(lin + (unsigned)tt) & (RCAP - 1)] = (uint16_t)x;
+                    if (act) ring_st(rbase, lin + 2u * (unsigned)tt, x);
                     // nothing left of the query or of the target on this diagonal; the mask of the active lanes of this pass comes from
                     // the two halves' slot counts on the scalar unit
                     e |= BALLOT(lim == nn) & (lowbits32(ns_a - 32 * j) | ((unsigned long long)lowbits32(ns_b - 32 * j) << 32));
@@ -654,7 +662,7 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                 ended = e;
                 last_m0 = m0; last_mp = mp;
                 rlin = lin;
-                lin += (unsigned)nslot;
+                lin += 2u * (unsigned)nslot;
                 __builtin_amdgcn_wave_barrier();
                 best_m = max(best_m, half_max(mmax));      // running maximum of x + y (:160-167)
             };
@@ -683,7 +691,7 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
             for (int jj = 0; jj < NJ; ++jj) {
                 const int tt = sl + 32 * jj, k = min_k + 2 * tt, kk = k + k_offset;
                 if (tt < nslot) {
-                    const int x = S.ring[(rlin + (unsigned)tt) & (RCAP - 1)];
+                    const int x = ring_ld(rbase, rlin + 2u * (unsigned)tt);
                     if (x >= q_len || x - k >= t_len) hkey = min(hkey, (kk << 10) | x);
                 }
             }
@@ -718,13 +726,13 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                     const int r = cd - 1;
                     const int2 pr = S.rrec[r & (RROWS - 1)], cr = S.rrec[cd & (RROWS - 1)];
                     const unsigned int plin = (unsigned int)pr.y;
-                    if (d - 1 - r >= RROWS || lin - plin > RCAP) { handover = true; tracing = false; }
+                    if (d - 1 - r >= RROWS || lin - plin > 2 * RCAP) { handover = true; tracing = false; }
                     else {
                         const int pmin = (int)(int16_t)pr.x, pmax = pr.x >> 16, cmin = (int)(int16_t)cr.x, cmax = cr.x >> 16;
                         const int kl = ck - 1, kr = ck + 1;
                         int vl = 0, vr = 0;
-                        if (kl >= pmin && kl <= pmax) vl = S.ring[(plin + (unsigned)((kl - pmin) >> 1)) & (RCAP - 1)];
-                        if (kr >= pmin && kr <= pmax) vr = S.ring[(plin + (unsigned)((kr - pmin) >> 1)) & (RCAP - 1)];
+                        if (kl >= pmin && kl <= pmax) vl = ring_ld(rbase, plin + (unsigned)(kl - pmin));      // entry (kl - pmin) / 2, two bytes each
+                        if (kr >= pmin && kr <= pmax) vr = ring_ld(rbase, plin + (unsigned)(kr - pmin));
                         if (ck == cmin || (ck != cmax && vl < vr)) { x1 = vr; pre_k = kr; takes_q = 0; }
                         else { x1 = vl + 1; pre_k = kl; takes_q = 1; }
                     }
@@ -763,7 +771,7 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                 need_unit = true;
             } else {
                 nblocks += (sl == 0) ? 1u : 0u;
-                cells += (sl == 0) ? lin - 2u : 0u;         // diagonals visited in this block
+                cells += (sl == 0) ? (lin - 4u) >> 1 : 0u;      // diagonals visited in this block
                 Rb += 1;
                 stop = !has_aln || !trim_ok;
                 if (!stop) {

@@ -433,7 +433,7 @@ __global__ __launch_bounds__(AL_BLOCK) void dw_extend(const uint32_t* __restrict
 struct HalfLds {
     uint32_t Qp[SEQ_WORDS2];
     uint32_t Tp[SEQ_WORDS2];
-    int2 rrec[RROWS];           // per d-row: x = min_k (low 16 bits) | max_k << 16, y = linear ring position of the row, in BYTES
+    int2 rrec[RROWS];           // per d-row: x = min_k (low 16 bits) | nslot << 16, y = linear ring position of the row, in BYTES
 };
 // The ring of d-rows of a half: u16 rows packed back to back, wrapping (the first two entries of a block are the zeros row 0 reads).
 // It is its own 2 KB-aligned LDS array so that the address of ring byte position p is `base | (p & 0x7fe)`: one v_and_or_b32.
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
     int Rq = 0, Rt = 0, Rm = 0, Rc = 0, Rb = 0;
     // per-half block state
     int qblk = 0, tblk = 0, last_block = 0, band_tol = 0, max_d = 0;
-    int best_m = -1, min_k = 0, max_k = 0, aligned = 0, end_x = 0, end_k = 0, end_d = 0, d = 0;      // d = rows done
+    int best_m = -1, min_k = 0, nslot = 0, aligned = 0, end_x = 0, end_k = 0, end_d = 0, d = 0;      // band = nslot diagonals from min_k; d = rows done
     unsigned int lin = 0;       // ring position behind the last row (bytes, like the next two)
     unsigned int pbase = 0;     // ring position of the previous row's entry for diagonal (this row's min_k) - 1
     unsigned int rlin = 0;      // ring position of the row that ran last
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                 unsigned int u = 0;
                 if (sl == 0) u = atomicAdd(cursor, 1u);
                 u = __shfl(u, hh << 5);
-                if (u >= 2u * (unsigned)n) { exhausted = true; setup = false; min_k = 0; max_k = -2; dlim = 0; }      // nslot == 0, never rowing
+                if (u >= 2u * (unsigned)n) { exhausted = true; setup = false; min_k = 0; nslot = 0; dlim = 0; }      // never rowing
                 else {
                     unit = u;
                     const mhip_aln_job jb = jobs[u >> 1];
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                 // The reference zero-fills V per block (:232-233); row d only reads diagonals written by row d - 1, except row 0,
                 // which reads V[k_offset - 1] and V[k_offset + 1]: the two zeros in front of row 0.
                 if (sl < 2) ring_st(rbase, 2u * sl, 0);
-                best_m = -1; min_k = 0; max_k = 0;
+                best_m = -1; min_k = 0; nslot = 1;
                 aligned = 0; end_x = 0; end_k = 0; end_d = 0; d = 0;
                 lin = 4; pbase = 0; rlin = 0;
                 dlim = max_d; inblock = true;
@@ -587,7 +587,6 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                 last = hi32 ? 63 - __clz((int)hi32) : 31 - __clz((int)lo32);
             } else {
                 int lo = 0x7fffffff, hi = -0x7fffffff;
-                const int nslot = ((max_k - min_k) >> 1) + 1;
                 for (int j = 0; j < NJ; ++j) {
                     const int tt = sl + 32 * j;
                     const bool act = inblock && tt < nslot;
@@ -598,16 +597,15 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                 first = half_min(lo); last = half_max(hi);
             }
             if (inblock) {
-                // new band [min_k + 2 first - 1, min_k + 2 last + 1]; the previous-row entry of diagonal (new min_k) - 1 sits at
-                // ring position rlin + first - 1
+                // new band [min_k + 2 first - 1, min_k + 2 last + 1] = last - first + 2 diagonals; the previous-row entry of diagonal
+                // (new min_k) - 1 sits at ring position rlin + first - 1
                 pbase = rlin + 2u * (unsigned)(first - 1);
-                max_k = min_k + 2 * last + 1;
+                nslot = last - first + 2;
                 min_k = min_k + 2 * first - 1;
             }
         };
         int last_m0 = 0, last_mp = 0;
         while (true) {
-            const int nslot = ((max_k - min_k) >> 1) + 1;        // min_k and max_k have the same parity; exhausted halves: 0
             // :118 "max_k - min_k <= band_size"; the two conditions as masks (a ballot of their conjunction makes the compiler
             // turn the mask into a 0/1 vector and compare it again)
             const unsigned long long rmask = BALLOT(d < dlim) & BALLOT(nslot <= band_tol + 1);
@@ -618,7 +616,7 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
 #endif
             {                                // row record: band limits + linear ring position.  Every lane of the half stores the same
                 int2* rr = &S.rrec[d & (RROWS - 1)];      // two words to the same address (no exec juggling on the scalar unit)
-                rr->x = (int)__builtin_amdgcn_perm((unsigned)max_k, (unsigned)min_k, 0x05040100u); rr->y = (int)lin;
+                rr->x = (int)__builtin_amdgcn_perm((unsigned)nslot, (unsigned)min_k, 0x05040100u); rr->y = (int)lin;
             }
             const int ns_a = __builtin_amdgcn_readlane(nslot, 0), ns_b = __builtin_amdgcn_readlane(nslot, 32);
             NJ = (max(ns_a, ns_b) + 31) >> 5;
@@ -637,7 +635,7 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                     const int k = min_k + 2 * tt;
                     const unsigned int rp = pbase + 2u * (unsigned)tt;      // idle lanes read (and ignore) whatever the ring holds there
                     const int vl = ring_ld(rbase, rp), vr = ring_ld(rbase, rp + 2u);
-                    int x = (k == min_k || (k != max_k && vl < vr)) ? vr : vl + 1;       // :138-142
+                    int x = (tt == 0 || (tt != nslot - 1 && vl < vr)) ? vr : vl + 1;       // :138-142 (k == min_k, k != max_k)
                     // 0 <= y <= t_len and x <= q_len on every live diagonal (a diagonal at an end stops the block); idle lanes sit
                     // at (q_len, 0), where lim == 0
                     x = act ? x : q_len;
@@ -686,7 +684,6 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
             // Once per block, outside the row loop (inside it, the state written here costs register copies on every row): the
             // lowest diagonal that reached an end (:168-169), from the row just stored; then the rest of that row for the
             // other half.
-            const int nslot = ((max_k - min_k) >> 1) + 1;
             int hkey = 0x7fffffff;
             for (int jj = 0; jj < NJ; ++jj) {
                 const int tt = sl + 32 * jj, k = min_k + 2 * tt, kk = k + k_offset;
@@ -704,10 +701,7 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
             d += 1;
             __builtin_amdgcn_wave_barrier();
         }
-        {
-            const int nslot = ((max_k - min_k) >> 1) + 1;
-            row_ok = d < dlim && nslot <= band_tol + 1;
-        }
+        row_ok = d < dlim && nslot <= band_tol + 1;
 
         const bool fin = inblock && !row_ok;
 
@@ -728,7 +722,7 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                     const unsigned int plin = (unsigned int)pr.y;
                     if (d - 1 - r >= RROWS || lin - plin > 2 * RCAP) { handover = true; tracing = false; }
                     else {
-                        const int pmin = (int)(int16_t)pr.x, pmax = pr.x >> 16, cmin = (int)(int16_t)cr.x, cmax = cr.x >> 16;
+                        const int pmin = (int)(int16_t)pr.x, pmax = pmin + 2 * ((pr.x >> 16) - 1), cmin = (int)(int16_t)cr.x, cmax = cmin + 2 * ((cr.x >> 16) - 1);
                         const int kl = ck - 1, kr = ck + 1;
                         int vl = 0, vr = 0;
                         if (kl >= pmin && kl <= pmax) vl = ring_ld(rbase, plin + (unsigned)(kl - pmin));      // entry (kl - pmin) / 2, two bytes each

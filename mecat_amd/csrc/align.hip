@@ -635,7 +635,7 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                     const int k = min_k + 2 * tt;
                     const unsigned int rp = pbase + 2u * (unsigned)tt;      // idle lanes read (and ignore) whatever the ring holds there
                     const int vl = ring_ld(rbase, rp), vr = ring_ld(rbase, rp + 2u);
-                    int x = (tt == 0 || (tt != nslot - 1 && vl < vr)) ? vr : vl + 1;       // :138-142 (k == min_k, k != max_k)
+                    int x = (tt == 0 || (tt + 1 != nslot && vl < vr)) ? vr : vl + 1;       // :138-142 (k == min_k, k != max_k)
                     // 0 <= y <= t_len and x <= q_len on every live diagonal (a diagonal at an end stops the block); idle lanes sit
                     // at (q_len, 0), where lim == 0
                     x = act ? x : q_len;
@@ -662,7 +662,9 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                 rlin = lin;
                 lin += 2u * (unsigned)nslot;
                 __builtin_amdgcn_wave_barrier();
-                best_m = max(best_m, half_max(mmax));      // running maximum of x + y (:160-167)
+                // running maximum of x + y (:160-167) = the maximum of this row: the best diagonal k* of the row before qualifies for
+                // the band, so k* - 1 and k* + 1 are in this row and start at least one further along
+                best_m = half_max(mmax);
             };
             if (NJ == 1) {
                 row_passes(1);

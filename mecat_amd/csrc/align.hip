@@ -448,16 +448,17 @@ __device__ __forceinline__ void ring_st(uint32_t base, uint32_t pos, int x) { *(
 // max over each 32-lane half, returned in every lane of the half: four mirrored DPP steps leave each 16-lane row with its
 // maximum in every lane; v_permlane16_swap (gfx950) then exchanges rows 1 <-> 0 and 3 <-> 2 between two copies.
 __device__ __forceinline__ int half_max(int v) {
-    int w;
-    asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+    int r, w;      // out of place: the caller's value stays where it is (no copy in front of the chain)
+    asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
                  "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
                  "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
                  "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
                  "v_mov_b32 %1, %0\n\t"
                  "s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\t"
                  "s_nop 1\n\tv_max_i32 %0, %0, %1"
-                 : "+v"(v), "=&v"(w));
-    return v;
+                 : "=&v"(r), "=&v"(w)
+                 : "v"(v));
+    return r;
 }
 __device__ __forceinline__ int half_min(int v) { return -half_max(-v); }
 

@@ -427,7 +427,7 @@ def main():
                                "salu_achieved": im["salu_insts_per_launch"] / (avg_ms / 1e3) / 1e9,
                                "source": "profiles/%s_instruction_mix.json (SQ_INSTS_VALU / SQ_INSTS_SALU per launch, same sources)" % tag})
                     vi["note"] = ("peak = VALU rate of valu_peak's mix_dw_rowbody (independent streams, this kernel's instruction mix, best over 1-8 "
-                                  "waves per SIMD); dw_extend2 runs 4 waves per SIMD (125 VGPRs, 40 KB LDS per 4 waves)")
+                                  "waves per SIMD); dw_extend2 runs 7 waves per SIMD (72 VGPRs, 21.5 KB LDS per 4 waves)")
                     if f4 is not None:
                         vi["valu_4cycle_fraction_static"] = f4
                 except (OSError, ValueError, KeyError, TypeError):
@@ -532,7 +532,7 @@ def main():
                 v = C.c_int64()
                 M.lib().mhip_debug_counter(ctx.h, slot, C.byref(v))
                 dbg.append(v.value // args.steps)
-            log("[bench] dw debug/step: spills=%d rows=%d idle_rows=%d wide_rows=%d unaligned_blocks=%d (row counters need -DMECAT_DW_STATS)" % tuple(dbg))
+            log("[bench] dw per step: %d units handed over to the second launch (which ran %d rows, %d blocks without an end)" % (dbg[0], dbg[1], dbg[4]))
         except Exception as e:
             log("[bench] no debug counters: %r" % (e,))
         log("[bench] kernel ms/step: " + ", ".join("%s=%.2f" % (k, v[1] / args.steps) for k, v in sorted(kstats.items(), key=lambda kv: -kv[1][1])))

@@ -462,7 +462,14 @@ __device__ __forceinline__ int half_max(int v) {
 }
 __device__ __forceinline__ int half_min(int v) { return -half_max(-v); }
 
-__device__ __forceinline__ unsigned int lowbits32(int n) { return n >= 32 ? 0xffffffffu : n <= 0 ? 0u : (1u << n) - 1u; }
+// the low min(max(n, 0), 32) bits set; n wave-uniform (from v_readlane): three scalar instructions (written out: the compiler turns
+// the clamp into a vector v_med3)
+__device__ __forceinline__ unsigned int lowbits32(int n) {
+    unsigned long long r;
+    int c;
+    asm("s_min_i32 %1, %2, 32\n\ts_max_i32 %1, %1, 0\n\ts_bfm_b64 %0, %1, 0" : "=s"(r), "=&s"(c) : "s"(n) : "scc");
+    return (unsigned int)r;
+}
 
 #ifndef DW2_WAVES_PER_SIMD
 #define DW2_WAVES_PER_SIMD 7

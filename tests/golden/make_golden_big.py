@@ -7,7 +7,7 @@ files); the read sets are re-generated from their seeds by mecat_amd/bin/synth_r
     python tests/golden/make_golden_big.py config2            # ~4 min -j 0 + ~25 min -j 1 on 7 threads
     python tests/golden/make_golden_big.py config3            # 3 volumes, 6 grid cells, -j 0: about an hour
     python tests/golden/make_golden_big.py config3_ecoli      # same reads x length on a 4.6 Mb genome (1300x): row 2 only
-    python tests/golden/make_golden_big.py config5            # 19 volumes, -x 1 -j 0: rows 17 and 18 only (resume protocol)
+    python tests/golden/make_golden_big.py config5            # 19 volumes, -x 1: -j 0 rows 17 and 18, -j 1 row 18 (resume protocol)
 
 Rows that are not pinned are skipped with the reference's own resume protocol: an existing wrk/r_<i> means "volume i has been
 finished" (mecat2pw/pw.cpp:65-81), so empty r_<i> files are planted for them before the run.
@@ -151,7 +151,10 @@ def main():
             pinned = (17, 18)
             # 19 volumes expected (40 Gbase / 2.14 Gbase); the rows before the pinned ones are planted as finished
             m["j0_seconds"] = run_ref(fa, out, wrk, ["-j", "0", "-x", "1"], skip_rows=range(0, pinned[0]))
-            vols = volumes(wrk)
+            if all(os.path.exists(ln.strip()) for ln in open(os.path.join(wrk, "fileindex.txt")) if ln.strip()):
+                vols = volumes(wrk)
+            else:                                    # an earlier run's volume files were removed: keep what it recorded
+                vols = big[name]["volumes"]
             assert len(vols) == 19, len(vols)
             m["volumes"] = vols
             m["rows"] = {}
@@ -160,6 +163,12 @@ def main():
                 row = {}
                 row["lines"], row["sorted_sha256"] = sorted_sha(r)
                 m["rows"][str(i)] = row
+            # -j 1 (X-drop extension) of the last row only: cell (18, 18)
+            out1 = os.path.join(d, "c5.m4")
+            wrk1 = os.path.join(d, "w1")
+            m["j1_seconds"] = run_ref(fa, out1, wrk1, ["-j", "1", "-x", "1", "-g", "1"], skip_rows=range(0, 18))
+            m["m4_row18"] = {}
+            m["m4_row18"]["lines"], m["m4_row18"]["sorted_sha256"] = sorted_sha(os.path.join(wrk1, "r_18"))
         big[name] = m
         json.dump(big, open(OUT, "w"), indent=1, sort_keys=True)
         print(name, json.dumps({k: v for k, v in m.items() if k != "volumes"})[:600], file=sys.stderr)

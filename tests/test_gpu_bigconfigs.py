@@ -5,8 +5,9 @@ C ABI -> text output), against hashes of the UNMODIFIED reference's output on th
   config 2   100 000 x 15 kb @ 15 %, one volume:    `-j 0` and `-j 1 -g 1`, sorted-output SHA-256, line counts, aligned bases
   config 3   500 000 x 12 kb @ 15 %, three volumes: `-j 0`, every grid row r_<i> and every grid cell (i, j) hashed separately
              (real 2.14 Gbase volume limit, int32 coordinates up to the limit, no test knob)
-  config 5   2 000 000 x 20 kb ONT-style, 19 volumes, `-x 1 -j 0`: grid rows 17 and 18 against the reference (the rows before
-             them are planted as finished through the reference's own resume protocol, as the golden run did);
+  config 5   2 000 000 x 20 kb ONT-style, 19 volumes, `-x 1`: `-j 0` grid rows 17 and 18 and `-j 1 -g 1` (X-drop extension) row 18
+             against the reference (the rows before them are planted as finished through the reference's own resume protocol,
+             as the golden run did);
              MECAT_TEST_CONFIG5_FULL=1 runs all 190 cells and checks the size-independent properties on the whole output.
 
 Line order is not part of the contract: both sides are compared as `LC_ALL=C sort`-ed multisets.
@@ -150,6 +151,15 @@ def test_config5_nanopore_19_volume_grid(workdir):
         for i in range(pinned[0]):
             open(os.path.join(wrk, "r_%d" % i), "w").close()
     secs = _run(["-j", "0", "-x", "1"], fa, out, wrk, threads=64)
+    if "m4_row18" in g:
+        # X-drop extension at this scale: grid row 18 = cell (18, 18) with `-j 1 -x 1 -g 1`, the rows before it planted as finished
+        wrk1 = os.path.join(workdir, "w1")
+        os.makedirs(wrk1)
+        for i in range(18):
+            open(os.path.join(wrk1, "r_%d" % i), "w").close()
+        _run(["-j", "1", "-x", "1", "-g", "1"], fa, os.path.join(workdir, "o.m4"), wrk1, threads=64)
+        assert _sorted_sha(os.path.join(wrk1, "r_18")) == (g["m4_row18"]["lines"], g["m4_row18"]["sorted_sha256"])
+        shutil.rmtree(wrk1, ignore_errors=True)
     os.unlink(fa)
     vols = _volumes(wrk)
     assert len(vols) == 19

@@ -447,18 +447,21 @@ __device__ __forceinline__ void ring_st(uint32_t base, uint32_t pos, int x) { *(
 
 // max over each 32-lane half, returned in every lane of the half: four mirrored DPP steps leave each 16-lane row with its
 // maximum in every lane; v_permlane16_swap (gfx950) then exchanges rows 1 <-> 0 and 3 <-> 2 between two copies.
+// Written with the DPP builtin (old = the identity of max, so the DPP combiner fuses mov_dpp + max into one v_max_i32_dpp) rather
+// than as one asm block: the compiler then fills the two wait states each step needs with independent instructions of the row
+// (row record, masks) instead of s_nops.
+template <int CTRL> __device__ __forceinline__ int dpp_max_step(int v) {
+    return max(v, __builtin_amdgcn_update_dpp((int)0x80000000, v, CTRL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ int half_max(int v) {
-    int r, w;      // out of place: the caller's value stays where it is (no copy in front of the chain)
-    asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-                 "v_mov_b32 %1, %0\n\t"
-                 "s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\t"
-                 "s_nop 1\n\tv_max_i32 %0, %0, %1"
-                 : "=&v"(r), "=&v"(w)
-                 : "v"(v));
-    return r;
+    v = dpp_max_step<0xB1>(v);           // quad_perm:[1,0,3,2]
+    v = dpp_max_step<0x4E>(v);           // quad_perm:[2,3,0,1]
+    v = dpp_max_step<0x141>(v);          // row_half_mirror
+    v = dpp_max_step<0x140>(v);          // row_mirror: every lane of a 16-lane row holds the row's maximum
+    int r = v, w = v;
+    // rows 1 <-> 0 and 3 <-> 2 between the two copies (the wait states around it are not known to the compiler's hazard recogniser)
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(r), "+v"(w));
+    return max(r, w);
 }
 __device__ __forceinline__ int half_min(int v) { return -half_max(-v); }
 

@@ -583,19 +583,25 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                 // 32 diagonals per half: one ballot; first / last set bit of the half's 32 bits with the raw instructions
                 // (v_ffbl / v_ffbh return -1 for an empty mask: a half without a block, whose values are not used)
                 const unsigned long long q0 = BALLOT(m0 >= best_m - band_tol);
-                const unsigned int m32 = hh ? (unsigned int)(q0 >> 32) : (unsigned int)q0;
+                const unsigned int m32 = (unsigned int)(q0 >> (hh << 5));
                 int lz;
                 asm("v_ffbl_b32 %0, %1" : "=v"(first) : "v"(m32));
                 asm("v_ffbh_u32 %0, %1" : "=v"(lz) : "v"(m32));
                 last = 31 - lz;
             } else if (NJ == 2) {
-                // up to 64 diagonals per half: two ballots, the half's 2 x 32 qualification bits
+                // up to 64 diagonals per half: two ballots, the half's 2 x 32 qualification bits.  Branch-free: v_ffbl / v_ffbh return
+                // -1 for an empty word, which `| 32` leaves at 0xffffffff (first: unsigned min) and `^ 31` turns into -32 (last:
+                // signed max; x ^ 31 == 31 - x for x in 0..31)
                 const int thr = best_m - band_tol;
                 const unsigned long long q0 = BALLOT(mp >= thr), q1 = BALLOT(m0 >= thr);
-                const unsigned int lo32 = hh ? (unsigned int)(q0 >> 32) : (unsigned int)q0;
-                const unsigned int hi32 = hh ? (unsigned int)(q1 >> 32) : (unsigned int)q1;
-                first = lo32 ? __ffs((int)lo32) - 1 : 31 + __ffs((int)hi32);
-                last = hi32 ? 63 - __clz((int)hi32) : 31 - __clz((int)lo32);
+                const unsigned int lo32 = (unsigned int)(q0 >> (hh << 5)), hi32 = (unsigned int)(q1 >> (hh << 5));
+                unsigned int fl, fh, ll, lh;
+                asm("v_ffbl_b32 %0, %1" : "=v"(fl) : "v"(lo32));
+                asm("v_ffbl_b32 %0, %1" : "=v"(fh) : "v"(hi32));
+                asm("v_ffbh_u32 %0, %1" : "=v"(ll) : "v"(lo32));
+                asm("v_ffbh_u32 %0, %1" : "=v"(lh) : "v"(hi32));
+                first = (int)min(fl, fh | 32u);
+                last = max((int)(ll ^ 31u), (int)((lh ^ 31u) | 32u));
             } else {
                 int lo = 0x7fffffff, hi = -0x7fffffff;
                 for (int j = 0; j < NJ; ++j) {

@@ -652,7 +652,8 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                     const int k = min_k + 2 * tt;
                     const unsigned int rp = pbase + 2u * (unsigned)tt;      // idle lanes read (and ignore) whatever the ring holds there
                     const int vl = ring_ld(rbase, rp), vr = ring_ld(rbase, rp + 2u);
-                    int x = (tt == 0 || (tt + 1 != nslot && vl < vr)) ? vr : vl + 1;       // :138-142 (k == min_k, k != max_k)
+                    // :138-142 (k == min_k, k != max_k), without short circuits: both neighbours are always loaded
+                    int x = ((tt == 0) | ((tt + 1 != nslot) & (vl < vr))) ? vr : vl + 1;
                     // 0 <= y <= t_len and x <= q_len on every live diagonal (a diagonal at an end stops the block); idle lanes sit
                     // at (q_len, 0), where lim == 0
                     x = act ? x : q_len;

@@ -29,9 +29,13 @@ $(LIBDIR)/libmecat_hip.so: $(HIP_OBJS)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(HIP_OBJS) -o $@
 
-host: $(BINDIR)/mecat2pw $(BINDIR)/mecat2cns_partition $(BINDIR)/valu_peak
+host: $(BINDIR)/mecat2pw $(BINDIR)/mecat2cns_partition $(BINDIR)/valu_peak $(BINDIR)/gather_peak
 # issue-rate calibration for bench.py's dw roofline (measures, computes nothing of the path)
 $(BINDIR)/valu_peak: mecat_amd/tools/valu_peak.hip
+	@mkdir -p $(BINDIR)
+	$(HIPCC) --offload-arch=$(ARCH) -O3 $< -o $@
+# random short-run fetch ceiling for the bucket walks of the seeding kernels (measures, computes nothing of the path)
+$(BINDIR)/gather_peak: mecat_amd/tools/gather_peak.hip
 	@mkdir -p $(BINDIR)
 	$(HIPCC) --offload-arch=$(ARCH) -O3 $< -o $@
 $(BINDIR)/mecat2pw: $(HOST_SRCS) $(wildcard mecat_amd/host/*.h) include/mecat_hip.h $(LIBDIR)/libmecat_hip.so

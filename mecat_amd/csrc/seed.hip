@@ -59,6 +59,7 @@ struct SeedArrays {
     uint32_t* strand_hits;       // [ns]   hits kept (emitted, sorted, built)
     uint32_t* rel_bits;          // [ns * REL_WORDS] relevance bitmap of the strand (filtered strands only)
     int32_t* filtered;           // [ns]   1 = only relevant hits are kept, 0 = every hit is kept
+    int32_t* fused;              // [ns]   1 = the strand went through seed_strand (its tables live in the fused arrays)
     uint64_t* hit_base;          // [ns + 1]
     uint64_t* keysA;             // [Htot]
     uint64_t* keysB;             // [Htot]
@@ -248,6 +249,10 @@ __global__ __launch_bounds__(SEED_BLOCK) void seed_filter(const mhip_offset_t* _
     const int K = kmers_of(L);
     const uint32_t kb = A.km_base[s];
     const uint32_t Hall = A.strand_hits_all[s];
+    if (A.fused[s]) {                 // done by seed_strand: nothing for the kernels of this path
+        if (threadIdx.x == 0) { A.strand_hits[s] = 0; A.filtered[s] = 0; }
+        return;
+    }
     bool filtered = enable && Hall > 0;
     uint32_t kept = Hall;
     if (filtered) {
@@ -682,6 +687,522 @@ __global__ __launch_bounds__(SEED_BLOCK) void seed_build(SeedArrays A, int sorte
     }
 }
 
+// ------------------------------------------------------------------------------------------------ the strand-resident pipeline
+// seed_strand = seed_filter + seed_emit + seed_sort_pass x 2 + seed_build of one strand inside one workgroup, for the strands whose
+// kept hits fit the LDS of a CU (all of them at BASELINE config 2: ~4 k kept hits of ~39 k bucket hits per strand, ~2.7 k
+// segments).  The kept hits never travel through HBM: what leaves the workgroup is what seed_cand reads (recorded events, the
+// segment table in ascending segment order, the gated segments in first-touch order).  Everything else falls back to the
+// kernels above, strand by strand (A.fused[s] == 0): nanopore mode (no relevance filter), strands with more than FS_CAP kept
+// hits or FS_SEGCAP segments, repeats that pile > FS_BIGN hits into one table slot, and strands that find the shared output
+// arrays full.
+//
+//   walk 1  (slots[])    16-bit hit counters per hashed segment id ("table slot", 2^15 of them), LDS atomics, no return value
+//   relevance            as seed_filter; then occ = relevant & non-empty slots, compact index ci(slot) = word prefix + popcount,
+//                        region start of every occupied slot = prefix sum of its counter
+//   walk 2  (offsets[])  every kept hit takes the next place of its slot's region (LDS atomic): payload = seg_hi:6 | km:15 |
+//                        off:11, slot kept beside it.  Regions come out in slot order; inside a region the order is whatever
+//                        the atomics made it
+//   region sort          ascending payload inside each region = (segment, km, position) order, the order the reference visits
+//                        the hits of a segment in (keys are unique).  Regions are tiny (a hit or two) except where a read
+//                        meets itself (~200 hits per segment): a thread sorts a short region, a wave rank-sorts a long one
+//   build                phases A-E of seed_build on the LDS arrays.  The elements stay in slot-major order; only the segment
+//                        table is permuted to ascending segment id (stable split on the segment bits above the slot bits)
+//
+// Both walks are software pipelined: bucket headers two steps ahead, bucket data one step ahead of the hits being consumed —
+// the walks are gathers of ~50 / ~90 byte runs and live on the number of loads in flight (mecat_amd/tools/gather_peak.hip
+// measures the ceiling: 35 G runs/s of <= 64 bytes, 26 G runs/s of 128 bytes on an MI355X).
+#define FS_THREADS 1024
+#define FS_WAVES (FS_THREADS / WAVE)
+#define FS_CAP 8192                  // kept hits
+#define FS_SEGCAP 6144               // segments
+#define FS_SMALLN 16                 // regions up to this length: every element ranks itself
+#define FS_BIGN 512                  // longest region (8 elements per lane of a wave)
+#define FS_BIGCAP 768                // regions longer than FS_SMALLN (FS_CAP / (FS_SMALLN + 1) at most: 630)
+#define FS_GATECAP 1024              // gated segments
+#define FS_OVF16 0x8000u
+#ifndef FS_Q1
+#define FS_Q1 2                      // walk 1: buckets per 16-lane group and stage, stages in flight
+#define FS_D1 2
+#define FS_Q2 2                      // walk 2
+#define FS_D2 2
+#endif
+
+struct FsLds {
+    union {
+        uint32_t cnt32[FLT_M / 2];                       // walk 1 .. relevance: 16-bit counters, two per word (64 KB)
+        struct {
+            uint32_t pay[FS_CAP];                        // walk 2 ..: payload, then (phase A, in place) recorded events
+            uint16_t eslot[FS_CAP];
+            uint16_t big[FS_BIGCAP];                     // long regions (compact slot index); later: overflowed segments
+            uint32_t hist[FS_WAVES][64];                 // segment permutation: per-wave cursors
+            uint64_t tf[FS_GATECAP];                     // first-touch times of the gated segments
+        } e;
+    } x;
+    union {
+        uint32_t cur32[FS_CAP / 2];                      // region cursors, 16 bit each (walk 2, region sort)
+        uint16_t perm[FS_SEGCAP];                        // build: segment-order index -> slot-order index
+    } y;
+    uint32_t occ[REL_WORDS];
+    uint32_t rel[REL_WORDS];
+    uint16_t base_ci[REL_WORDS];
+    uint32_t sq_id[FS_SEGCAP];                           // segment table in slot-major order q
+    uint16_t sq_st[FS_SEGCAP + 2];                       // first recorded event of the segment; [nseg] = nrec
+    uint16_t sq_score[FS_SEGCAP];                        // live score | FS_OVF16
+    uint16_t gate[FS_GATECAP];
+    uint32_t wtot[FS_WAVES];
+    uint32_t misc[8];                                    // 0 big count, 1 overflow count, 2 gated count, 3 fail flag, 4/5 carry, 6 hb lo, 7 hb hi
+};
+static_assert(sizeof(FsLds) <= 160 * 1024 - 512, "one workgroup per CU");
+
+struct FusedCtl { unsigned long long alloc; unsigned int n_fallback; unsigned int pad; unsigned long long prof[32]; };
+#ifdef FS_PROF
+#define FS_MARK(i) do { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&ctl->prof[(i) + 16 * (blockIdx.x & 1)], t_ - t_prev); t_prev = t_; } } while (0)
+#else
+#define FS_MARK(i) do { } while (0)
+#endif
+
+// block-wide exclusive scan, FS_THREADS threads
+__device__ __forceinline__ uint32_t fs_excl_scan(uint32_t v, uint32_t* wtot, uint32_t* total) {
+    uint32_t incl = v;
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t n = __shfl_up(incl, o);
+        if (lane_id() >= o) incl += n;
+    }
+    __syncthreads();
+    if (lane_id() == 63) wtot[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < FS_WAVES; ++w) {
+        const uint32_t x = wtot[w];
+        if (w < (int)(threadIdx.x >> 6)) base += x;
+        tot += x;
+    }
+    *total = tot;
+    return base + incl - v;
+}
+
+// pipelined walk over the buckets of a strand; f(km, value) per hit.  16 lanes per bucket, Q buckets per group and stage, D stages
+// of bucket data in flight plus one stage of bucket headers (start, size) ahead of them.  The first 48 entries of a bucket are
+// loaded by the pipeline (three pieces of 16); a longer bucket reads the rest when it is consumed.
+template <int Q, int D, typename T, typename F>
+__device__ __forceinline__ void fs_walk(const uint32_t* __restrict__ kbs, const uint32_t* __restrict__ kcn, const T* __restrict__ arr, const int K, F f) {
+    constexpr int G = FS_THREADS / 16, STEP = Q * G;
+    const int g = threadIdx.x >> 4;
+    const uint32_t sub = threadIdx.x & 15u;
+    uint32_t hb[Q], hc[Q];                                        // headers of stage D (no data requested yet)
+    uint32_t sb[D][Q], sc[D][Q], s0[D][Q], s1[D][Q], s2[D][Q];    // stages 0 .. D-1: header and data
+#define FS_HDR(BASE, BS, CN)                                                      \
+    _Pragma("unroll") for (int q = 0; q < Q; ++q) {                               \
+        const int km_ = (BASE) + q * G + g;                                       \
+        BS[q] = km_ < K ? kbs[km_] : 0u;                                          \
+        CN[q] = km_ < K ? kcn[km_] : 0u;                                          \
+    }
+#define FS_DAT(BS, CN, DA, DB, DC)                                                \
+    _Pragma("unroll") for (int q = 0; q < Q; ++q) {                               \
+        DA[q] = sub < CN[q] ? (uint32_t)arr[BS[q] + sub] : 0u;                    \
+        DB[q] = sub + 16u < CN[q] ? (uint32_t)arr[BS[q] + 16u + sub] : 0u;        \
+        DC[q] = sub + 32u < CN[q] ? (uint32_t)arr[BS[q] + 32u + sub] : 0u;        \
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) { FS_HDR(d * STEP, sb[d], sc[d]) }
+    FS_HDR(D * STEP, hb, hc)
+#pragma unroll
+    for (int d = 0; d < D; ++d) { FS_DAT(sb[d], sc[d], s0[d], s1[d], s2[d]) }
+    for (int base = 0; base < K; base += STEP) {
+        uint32_t cb[Q], cc[Q], c0[Q], c1[Q], c2[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { cb[q] = sb[0][q]; cc[q] = sc[0][q]; c0[q] = s0[0][q]; c1[q] = s1[0][q]; c2[q] = s2[0][q]; }
+#pragma unroll
+        for (int d = 0; d + 1 < D; ++d)
+#pragma unroll
+            for (int q = 0; q < Q; ++q) { sb[d][q] = sb[d + 1][q]; sc[d][q] = sc[d + 1][q]; s0[d][q] = s0[d + 1][q]; s1[d][q] = s1[d + 1][q]; s2[d][q] = s2[d + 1][q]; }
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { sb[D - 1][q] = hb[q]; sc[D - 1][q] = hc[q]; }
+        FS_DAT(sb[D - 1], sc[D - 1], s0[D - 1], s1[D - 1], s2[D - 1])
+        FS_HDR(base + (D + 1) * STEP, hb, hc)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int km = base + q * G + g;
+            if (sub < cc[q]) f(km, c0[q]);
+            if (sub + 16u < cc[q]) f(km, c1[q]);
+            if (sub + 32u < cc[q]) f(km, c2[q]);
+            for (uint32_t r = 48u + sub; r < cc[q]; r += 16u) f(km, (uint32_t)arr[cb[q] + r]);
+        }
+    }
+#undef FS_HDR
+#undef FS_DAT
+}
+
+// ascending sort of p[0 .. n) (LDS, n <= 64 NQ) by one wave: bitonic network, element q * 64 + lane in register v[q]
+template <int NQ>
+__device__ __noinline__ void fs_bitonic(uint32_t* p, const uint32_t n, const int lane) {
+    uint32_t v[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { const uint32_t idx = q * 64 + lane; v[q] = idx < n ? p[idx] : 0xFFFFFFFFu; }
+#pragma unroll
+    for (int k = 2; k <= NQ * 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 64) {
+                const int dq = j >> 6;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    if ((q & dq) == 0) {
+                        const uint32_t a = v[q], b = v[q | dq];
+                        const bool asc = ((q * 64) & k) == 0;         // k > j >= 64: the k bit of the index is a bit of q
+                        v[q] = asc ? min(a, b) : max(a, b);
+                        v[q | dq] = asc ? max(a, b) : min(a, b);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const uint32_t o = (uint32_t)__shfl_xor((int)v[q], j);
+                    const bool asc = (((q * 64 + lane) & k) == 0), lower = (lane & j) == 0;
+                    v[q] = (asc == lower) ? min(v[q], o) : max(v[q], o);
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { const uint32_t idx = q * 64 + lane; if (idx < n) p[idx] = v[q]; }
+}
+
+__device__ __forceinline__ uint32_t fs_cnt(const uint32_t* cnt32, uint32_t e) { return (cnt32[e >> 1] >> ((e & 1u) * 16u)) & 0xFFFFu; }
+
+__global__ __launch_bounds__(FS_THREADS) void seed_strand(const mhip_offset_t* __restrict__ roffs, ReadSel sel, int ib,
+                                                          const uint16_t* __restrict__ slots, const int32_t* __restrict__ offsets, SeedArrays A,
+                                                          int gate, int hi_bits, int min_kmer_match, double cutoff, unsigned long long cap,
+                                                          FusedCtl* __restrict__ ctl, unsigned long long* __restrict__ counters) {
+    __shared__ FsLds L;
+    const int s = blockIdx.x;
+    const int tid = threadIdx.x, lane = lane_id(), wv = threadIdx.x >> 6;
+    const int rid = sel_rid(sel, ib + (s >> 1));
+    const int rlen = roffs[rid].size;
+    const int K = kmers_of(rlen);
+    const uint32_t kb = A.km_base[s];
+    const uint32_t Hall = A.strand_hits_all[s];
+    const uint32_t* __restrict__ kbs = A.km_bstart + kb;
+    const uint32_t* __restrict__ kcn = A.km_cnt + kb;
+    auto fail = [&]() {                     // called by all threads together
+        if (tid == 0) { A.fused[s] = 0; atomicAdd(&ctl->n_fallback, 1u); atomicAdd(&counters[14], 1ull); }      // debug slot 14: strands left to the kernel chain
+    };
+    if (Hall == 0) {
+        if (tid == 0) { A.fused[s] = 1; A.strand_hits[s] = 0; A.hit_base[s] = 0; A.nseg[s] = 0; A.nrec[s] = 0; A.ngated[s] = 0; }
+        return;
+    }
+    if (Hall >= 65536u || K > 32767) { fail(); return; }            // a 16-bit counter could wrap; km has 15 bits in the payload
+
+    unsigned long long t_prev = wall_clock64(); (void)t_prev;
+    // ---- walk 1: hits per table slot
+    for (int i = tid; i < FLT_M / 2; i += FS_THREADS) L.x.cnt32[i] = 0;
+    for (int i = tid; i < REL_WORDS; i += FS_THREADS) L.rel[i] = 0;
+    if (tid < 8) L.misc[tid] = 0;
+    __syncthreads();
+    FS_MARK(0);
+    fs_walk<FS_Q1, FS_D1>(kbs, kcn, slots, K, [&](int, uint32_t e) { atomicAdd(&L.x.cnt32[e >> 1], 1u << ((e & 1u) * 16u)); });
+    __syncthreads();
+    FS_MARK(1);
+
+    // ---- relevance: hot slots, +- reach (seed_filter).  A thread owns one word of the bitmaps = 32 slots = 16 counter words,
+    // which it keeps in registers from here to the region starts.
+    static_assert(FLT_M / FS_THREADS == 32, "one bitmap word per thread");
+    uint32_t cw[18];                   // cw[1 .. 16]: the thread's counters; cw[0], cw[17]: the neighbours' last / first word
+    {
+        const uint4* c4 = (const uint4*)&L.x.cnt32[16 * tid];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const uint4 v = c4[q]; cw[1 + 4 * q] = v.x; cw[2 + 4 * q] = v.y; cw[3 + 4 * q] = v.z; cw[4 + 4 * q] = v.w; }
+        cw[0] = L.x.cnt32[(16 * tid - 1) & (FLT_M / 2 - 1)];
+        cw[17] = L.x.cnt32[(16 * tid + 16) & (FLT_M / 2 - 1)];
+        uint32_t hot = 0;
+#pragma unroll
+        for (int j = 1; j <= 16; ++j) {
+            const int lo = (int)(cw[j] & 0xFFFFu), hi = (int)(cw[j] >> 16), pl = (int)(cw[j - 1] >> 16), nx = (int)(cw[j + 1] & 0xFFFFu);
+            const bool hl = lo > 0 && (lo + hi >= gate || lo + pl >= gate);
+            const bool hh = hi > 0 && (hi + nx >= gate || hi + lo >= gate);
+            hot |= (hl ? 1u : 0u) << (2 * (j - 1)) | (hh ? 1u : 0u) << (2 * (j - 1) + 1);
+        }
+        const uint32_t reach = (uint32_t)min(sweep_reach(rlen), FLT_M / 2 - 1);
+        for (uint32_t m = hot; m; m &= m - 1u) {
+            const uint32_t e = (uint32_t)tid * 32u + (uint32_t)__builtin_ctz(m);
+            uint32_t lo = (e - reach) & (FLT_M - 1), left = 2 * reach + 1;
+            while (left > 0) {
+                const uint32_t b = lo & 31u, take = min(32u - b, left);
+                const uint32_t msk = (take == 32u ? 0xFFFFFFFFu : ((1u << take) - 1u)) << b;
+                atomicOr(&L.rel[lo >> 5], msk);
+                lo = (lo + take) & (FLT_M - 1);
+                left -= take;
+            }
+        }
+    }
+    __syncthreads();
+    FS_MARK(2);
+    // ---- occupied relevant slots, region starts
+    uint32_t kept;
+    {
+        const uint32_t r = L.rel[tid];
+        uint32_t occ = 0, mine = 0;
+        bool toolong = false;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const uint32_t h = (cw[1 + (j >> 1)] >> ((j & 1) * 16)) & 0xFFFFu;
+            if (((r >> j) & 1u) && h) { occ |= 1u << j; mine += h; toolong |= h > FS_BIGN; }
+        }
+        uint32_t nci;
+        const uint32_t ex = fs_excl_scan(mine, L.wtot, &kept);
+        const uint32_t cx = fs_excl_scan((uint32_t)__popc(occ), L.wtot, &nci);
+        if (kept > FS_CAP) { fail(); return; }
+        L.occ[tid] = occ;
+        L.base_ci[tid] = (uint16_t)cx;
+        uint16_t* cur16 = (uint16_t*)L.y.cur32;
+        uint32_t at = ex, ci = cx;
+        if (occ) {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const uint32_t h = (cw[1 + (j >> 1)] >> ((j & 1) * 16)) & 0xFFFFu;
+                if ((occ >> j) & 1u) { cur16[ci++] = (uint16_t)at; at += h; }
+            }
+        }
+        if (toolong) L.misc[3] = 1;
+        __syncthreads();
+        if (L.misc[3]) { fail(); return; }
+    }
+    if (kept == 0) {
+        if (tid == 0) { A.fused[s] = 1; A.strand_hits[s] = 0; A.hit_base[s] = 0; A.nseg[s] = 0; A.nrec[s] = 0; A.ngated[s] = 0; }
+        return;
+    }
+    // room in the shared output arrays
+    if (tid == 0) {
+        const unsigned long long hb0 = atomicAdd(&ctl->alloc, (unsigned long long)kept);
+        if (hb0 + kept > cap) L.misc[3] = 1;
+        L.misc[6] = (uint32_t)hb0;
+        L.misc[7] = (uint32_t)(hb0 >> 32);
+    }
+    __syncthreads();                                      // also: cnt32 is dead from here, the payload arrays take its place
+    if (L.misc[3]) { fail(); return; }
+    const uint64_t hb = ((uint64_t)L.misc[7] << 32) | L.misc[6];
+
+    FS_MARK(3);
+    // ---- walk 2: kept hits into their slot's region
+    fs_walk<FS_Q2, FS_D2>(kbs, kcn, offsets, K, [&](int km, uint32_t pos) {
+        const uint32_t seg = pos / (uint32_t)ZV, off = pos - seg * (uint32_t)ZV;
+        const uint32_t e = seg & (FLT_M - 1), w = e >> 5, b = e & 31u;
+        const uint32_t oc = L.occ[w];
+        if ((oc >> b) & 1u) {
+            const uint32_t ci = (uint32_t)L.base_ci[w] + (uint32_t)__popc(oc & ((1u << b) - 1u));
+            const uint32_t sh = (ci & 1u) * 16u;
+            const uint32_t p = (atomicAdd(&L.y.cur32[ci >> 1], 1u << sh) >> sh) & 0xFFFFu;
+            L.x.e.pay[p] = ((seg >> FLT_BITS) << 26) | ((uint32_t)km << 11) | off;
+            L.x.e.eslot[p] = (uint16_t)e;
+        }
+    });
+    __syncthreads();
+
+    FS_MARK(4);
+    // ---- region sort.  After walk 2 cursor[ci] = end of region ci = start of region ci + 1.
+    {
+        const uint16_t* cur16 = (const uint16_t*)L.y.cur32;
+        // short regions: every element counts the smaller elements of its region (all reads, barrier, all writes)
+        uint32_t val[FS_CAP / FS_THREADS], dst[FS_CAP / FS_THREADS];
+#pragma unroll
+        for (int rd = 0; rd < FS_CAP / FS_THREADS; ++rd) {
+            const uint32_t i = (uint32_t)rd * FS_THREADS + tid;
+            dst[rd] = 0xFFFFFFFFu;
+            val[rd] = 0;
+            if ((uint32_t)rd * FS_THREADS < kept && i < kept) {
+                const uint32_t v = L.x.e.pay[i], e = L.x.e.eslot[i], w = e >> 5, oc = L.occ[w];
+                const uint32_t ci = (uint32_t)L.base_ci[w] + (uint32_t)__popc(oc & ((1u << (e & 31u)) - 1u));
+                const uint32_t st = ci ? cur16[ci - 1] : 0u, en = cur16[ci], n = en - st;
+                if (n > FS_SMALLN) {
+                    if (i == st) L.x.e.big[atomicAdd(&L.misc[0], 1u)] = (uint16_t)ci;
+                } else if (n > 1) {
+                    uint32_t rank = 0;
+                    for (uint32_t k = st; k < en; ++k) rank += L.x.e.pay[k] < v ? 1u : 0u;
+                    val[rd] = v;
+                    dst[rd] = st + rank;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rd = 0; rd < FS_CAP / FS_THREADS; ++rd)
+            if (dst[rd] != 0xFFFFFFFFu) L.x.e.pay[dst[rd]] = val[rd];
+        FS_MARK(11);
+        // long regions (a read meeting itself: ~200 hits per segment): one wave each, bitonic network in registers
+        const uint32_t nbig = L.misc[0];
+        for (uint32_t k = wv; k < nbig; k += FS_WAVES) {
+            const uint32_t ci = L.x.e.big[k];
+            const uint32_t st = ci ? cur16[ci - 1] : 0u, n = (uint32_t)cur16[ci] - st;      // FS_SMALLN < n <= FS_BIGN
+            if (n <= 64) fs_bitonic<1>(L.x.e.pay + st, n, lane);
+            else if (n <= 256) fs_bitonic<4>(L.x.e.pay + st, n, lane);
+            else fs_bitonic<8>(L.x.e.pay + st, n, lane);
+        }
+        __syncthreads();
+    }
+
+    FS_MARK(5);
+    // ---- build, phase A: recorded events (first hit of each (segment, km)) and segment heads, events compacted in place
+    uint32_t nrec, nseg;
+    {
+        uint32_t rec_run = 0, seg_run = 0;
+        for (uint32_t t0 = 0; t0 < kept; t0 += FS_THREADS) {
+            const uint32_t i = t0 + tid;
+            const bool in = i < kept;
+            const uint32_t pay = in ? L.x.e.pay[i] : 0u, sl = in ? L.x.e.eslot[i] : 0u;
+            uint32_t ppay = 0, psl = 0;
+            if (in && i > 0) {
+                if (tid > 0) { ppay = L.x.e.pay[i - 1]; psl = L.x.e.eslot[i - 1]; }
+                else { ppay = L.misc[4]; psl = L.misc[5]; }
+            }
+            const bool head = in && (i == 0 || sl != psl || (pay >> 26) != (ppay >> 26));
+            const bool rec = in && (head || ((pay >> 11) & 0x7FFFu) != ((ppay >> 11) & 0x7FFFu));
+            uint32_t both;
+            const uint32_t ex = fs_excl_scan((rec ? 1u : 0u) | (head ? 0x10000u : 0u), L.wtot, &both);     // all reads are before its barriers
+            const uint32_t rpos = rec_run + (ex & 0xFFFFu), spos = seg_run + (ex >> 16);
+            if (tid == FS_THREADS - 1) { L.misc[4] = pay; L.misc[5] = sl; }
+            if (rec) L.x.e.pay[rpos] = ((pay & 0x7FFu) << 16) | ((((pay >> 11) & 0x7FFFu) + 1u) & 0xFFFFu);
+            if (head && spos < FS_SEGCAP) {
+                L.sq_id[spos] = ((pay >> 26) << FLT_BITS) | sl;
+                L.sq_st[spos] = (uint16_t)rpos;
+            }
+            rec_run += both & 0xFFFFu;
+            seg_run += both >> 16;
+            __syncthreads();
+        }
+        nrec = rec_run;
+        nseg = seg_run;
+        if (nseg > FS_SEGCAP) { fail(); return; }
+        if (tid == 0) L.sq_st[nseg] = (uint16_t)nrec;
+    }
+    uint16_t* perm = L.y.perm;                           // the cursors are dead
+    __syncthreads();
+
+    FS_MARK(6);
+    // ---- segment order: stable split of the slot-major table on the segment bits above the slot bits
+    if (hi_bits == 0) {
+        for (uint32_t q = tid; q < nseg; q += FS_THREADS) perm[q] = (uint16_t)q;
+    } else {
+        uint32_t* hist = &L.x.e.hist[0][0];
+        hist[tid] = 0;                                    // FS_WAVES * 64 == FS_THREADS
+        __syncthreads();
+        const uint32_t chunk = (((nseg + FS_WAVES - 1) / FS_WAVES) + 63u) & ~63u;
+        const uint32_t lo = min(nseg, (uint32_t)wv * chunk), hi = min(nseg, lo + chunk);
+        for (uint32_t q = lo + lane; q < hi; q += 64) atomicAdd(&L.x.e.hist[wv][L.sq_id[q] >> FLT_BITS], 1u);
+        __syncthreads();
+        {
+            const uint32_t bin = tid >> 4, w = tid & 15;         // (bin major, wave minor)
+            static_assert(FS_WAVES == 16, "16 waves");
+            const uint32_t v = L.x.e.hist[w][bin];
+            uint32_t all;
+            const uint32_t ex = fs_excl_scan(v, L.wtot, &all);
+            L.x.e.hist[w][bin] = ex;
+        }
+        __syncthreads();
+        volatile uint32_t* cur = L.x.e.hist[wv];
+        const uint64_t lt = (1ull << lane) - 1ull;
+        for (uint32_t q0 = lo; q0 < hi; q0 += 64) {
+            const uint32_t q = q0 + lane;
+            const bool valid = q < hi;
+            const uint32_t d = valid ? L.sq_id[q] >> FLT_BITS : 0u;
+            uint64_t peers = __ballot(valid);
+            for (int b = 0; b < hi_bits; ++b) {
+                const uint64_t m = __ballot((d >> b) & 1u);
+                peers &= ((d >> b) & 1u) ? m : ~m;
+            }
+            const uint32_t rank = __popcll(peers & lt);
+            const uint32_t base = valid ? cur[d] : 0u;
+            if (valid) perm[base + rank] = (uint16_t)q;
+            if (valid && rank == 0) cur[d] = base + (uint32_t)__popcll(peers);
+        }
+    }
+    FS_MARK(7);
+    // ---- phase B: scores; overflowed segments
+    uint16_t* ovf = L.x.e.big;
+    for (uint32_t q = tid; q < nseg; q += FS_THREADS) {
+        const uint32_t c = (uint32_t)L.sq_st[q + 1] - (uint32_t)L.sq_st[q];
+        if (c > SM) {
+            const uint32_t k = atomicAdd(&L.misc[1], 1u);
+            if (k < FS_BIGCAP) ovf[k] = (uint16_t)q;
+            L.sq_score[q] = (uint16_t)FS_OVF16;
+        } else {
+            L.sq_score[q] = (uint16_t)c;
+        }
+    }
+    __syncthreads();
+    if (L.misc[1] > FS_BIGCAP) { fail(); return; }
+    // ---- phase C: insert_loc replay, one wave per overflowed segment (final lists and running scores go to HBM)
+    {
+        const uint32_t novf = L.misc[1];
+        for (uint32_t k = wv; k < novf; k += FS_WAVES) {
+            const uint32_t q = ovf[k];
+            const uint32_t st = L.sq_st[q], en = L.sq_st[q + 1];
+            int sc;
+            replay_overflow(L.x.e.pay + st, (int)(en - st), A.ent_fin + hb + st, A.escore + hb + st, cutoff, &sc);
+            if (lane == 0) L.sq_score[q] = (uint16_t)((uint32_t)sc | FS_OVF16);
+        }
+    }
+    __syncthreads();
+    FS_MARK(8);
+    // ---- phase D: index_score and the gate, in segment order
+    for (uint32_t g = tid; g < nseg; g += FS_THREADS) {
+        const uint32_t q = perm[g];
+        const uint32_t sid = L.sq_id[q];
+        int s_k = (int)(L.sq_score[q] & 0x7FFFu);
+        if (g > 0 && sid > 0) {
+            const uint32_t ql = perm[g - 1];
+            if (L.sq_id[ql] == sid - 1u) {
+                const uint32_t st = L.sq_st[ql], en = L.sq_st[ql + 1];
+                const uint32_t t = L.x.e.pay[(uint32_t)L.sq_st[q + 1] - 1u] & 0xFFFFu;       // km + 1 of this segment's last event
+                uint32_t lo = st, hi = en;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if ((L.x.e.pay[mid] & 0xFFFFu) <= t) lo = mid + 1; else hi = mid;
+                }
+                if (lo > st) s_k += (L.sq_score[ql] & FS_OVF16) ? (int)A.escore[hb + lo - 1] : (int)(lo - st);
+            }
+        }
+        if ((int)(int16_t)s_k >= 2 * min_kmer_match) {
+            const uint32_t k = atomicAdd(&L.misc[2], 1u);
+            if (k < FS_GATECAP) {
+                const uint32_t e0 = L.x.e.pay[L.sq_st[q]];
+                L.gate[k] = (uint16_t)g;
+                L.x.e.tf[k] = ((uint64_t)((e0 & 0xFFFFu) - 1u) << 32) | (uint64_t)(sid * (uint32_t)ZV + (e0 >> 16));
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t ng = L.misc[2];
+    if (ng > FS_GATECAP) { fail(); return; }
+    FS_MARK(9);
+    // ---- phase E + output
+    for (uint32_t a = tid; a < ng; a += FS_THREADS) {
+        const uint64_t ta = L.x.e.tf[a];
+        uint32_t rank = 0;
+        for (uint32_t b = 0; b < ng; ++b) rank += L.x.e.tf[b] < ta ? 1u : 0u;
+        A.gated[hb + rank] = (uint32_t)L.gate[a];
+    }
+    for (uint32_t i = tid; i < nrec; i += FS_THREADS) A.ent[hb + i] = L.x.e.pay[i];
+    for (uint32_t g = tid; g < nseg; g += FS_THREADS) {
+        const uint32_t q = perm[g];
+        const uint32_t sc = L.sq_score[q];
+        A.seg_id[hb + g] = L.sq_id[q];
+        A.seg_start[hb + g] = L.sq_st[q];
+        A.seg_score[hb + g] = (int32_t)((sc & 0x7FFFu) | ((sc & FS_OVF16) ? OVF_FLAG : 0u));
+    }
+    FS_MARK(10);
+    if (tid == 0) {
+        atomicAdd(&counters[13], 1ull);                   // debug slot 13: strands that went through this kernel with hits
+        A.fused[s] = 1;
+        A.strand_hits[s] = kept;
+        A.hit_base[s] = hb;
+        A.nseg[s] = nseg;
+        A.nrec[s] = nrec;
+        A.ngated[s] = ng;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ candidates
 struct CandLds {
     int t_loc[2 * SM + 10];
@@ -726,7 +1247,7 @@ __device__ __forceinline__ int read_id_lookup(const mhip_offset_t* __restrict__ 
 }
 
 // one wave per read: F strand then R strand into one top-MAXC list kept in LDS (12 ints per entry)
-__global__ __launch_bounds__(WAVE) void seed_cand(SeedArrays A, const mhip_offset_t* __restrict__ ref_offs, const uint32_t* __restrict__ ref_blk, int ref_nreads,
+__global__ __launch_bounds__(WAVE) void seed_cand(SeedArrays AF, SeedArrays AB, const mhip_offset_t* __restrict__ ref_offs, const uint32_t* __restrict__ ref_blk, int ref_nreads,
                                                   int ref_start_id, const mhip_offset_t* __restrict__ roffs, ReadSel sel, int ib,
                                                   int reads_start_id, mhip_params P, mhip_candidate* __restrict__ out,
                                                   int32_t* __restrict__ out_counts, unsigned long long* __restrict__ counters) {
@@ -744,6 +1265,7 @@ __global__ __launch_bounds__(WAVE) void seed_cand(SeedArrays A, const mhip_offse
 
     for (int strand = 0; strand < 2; ++strand) {
         const int s = 2 * r + strand;
+        const SeedArrays& A = AF.fused[s] ? AF : AB;          // the strand's tables: from seed_strand or from the kernel chain
         const uint64_t hb = A.hit_base[s];
         const int nseg = (int)A.nseg[s];
         const int ng = (int)A.ngated[s];
@@ -998,6 +1520,7 @@ static int bits_for(uint32_t maxv) {
 }
 
 static bool filter_enabled(const mhip_params* P);
+static bool fused_enabled(const mhip_params* P);
 
 // the reads with local index in [ib, ie) of the selection
 static int seed_batch(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref, const mhip_volume* reads, const ReadSel sel,
@@ -1018,57 +1541,95 @@ static int seed_batch(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref
     if (c->scratch("sd_kmbase", sizeof(uint32_t) * (size_t)ns, (void**)&d_kmb)) return -1;
     if (c->scratch("sd_kmbstart", sizeof(uint32_t) * (size_t)(sumK + 1), (void**)&A.km_bstart)) return -1;
     if (c->scratch("sd_kmcnt", sizeof(uint32_t) * (size_t)(sumK + 1), (void**)&A.km_cnt)) return -1;
-    if (c->scratch("sd_hits", sizeof(uint32_t) * (size_t)ns, (void**)&A.strand_hits)) return -1;
     if (c->scratch("sd_hitsall", sizeof(uint32_t) * (size_t)ns, (void**)&A.strand_hits_all)) return -1;
-    if (c->scratch("sd_filtered", sizeof(int32_t) * (size_t)ns, (void**)&A.filtered)) return -1;
-    if (c->scratch("sd_relbits", sizeof(uint32_t) * (size_t)ns * REL_WORDS, (void**)&A.rel_bits)) return -1;
-    if (c->scratch("sd_hbase", sizeof(uint64_t) * (size_t)(ns + 1), (void**)&A.hit_base)) return -1;
-    if (c->scratch("sd_nseg", sizeof(uint32_t) * (size_t)ns, (void**)&A.nseg)) return -1;
-    if (c->scratch("sd_nrec", sizeof(uint32_t) * (size_t)ns, (void**)&A.nrec)) return -1;
-    if (c->scratch("sd_ngated", sizeof(uint32_t) * (size_t)ns, (void**)&A.ngated)) return -1;
+    if (c->scratch("sd_fused", sizeof(int32_t) * (size_t)ns, (void**)&A.fused)) return -1;
     A.km_base = d_kmb;
     HIPCHK(hipMemcpyAsync(d_kmb, kmb.data(), sizeof(uint32_t) * (size_t)ns, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(A.fused, 0, sizeof(int32_t) * (size_t)ns, c->stream));
     LAUNCH(c, "seed_probe", seed_probe, ns, SEED_BLOCK, 0, (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs, sel, ib,
            (const uint32_t*)idx->d_starts, A, (unsigned long long*)c->d_counters);
-    {
-        const int gate = 2 * P->min_kmer_match;
-        const int enable = filter_enabled(P) ? 1 : 0;
+    const int gate = 2 * P->min_kmer_match;
+    const int nbits = bits_for((uint32_t)(ref->num_bases / ZV));
+
+    // ---- the strand-resident pipeline (seed_strand): tables of the strands it takes, in arrays handed out by an atomic cursor
+    SeedArrays F = A;
+    unsigned int nfallback = (unsigned int)ns;
+    if (fused_enabled(P)) {
+        // room: the relevance filter keeps about one bucket hit in nine; a strand that finds the arrays full takes the kernel chain
+        const double hits_per_lookup = (double)idx->num_kmers / (double)NKMER + 2.0;
+        const size_t capF = (size_t)((double)sumK * hits_per_lookup / 5.0) + (size_t)ns * 256 + 64;
+        FusedCtl* d_ctl;
+        if (c->scratch("sf_ctl", sizeof(FusedCtl), (void**)&d_ctl)) return -1;
+        if (c->scratch("sf_hits", sizeof(uint32_t) * (size_t)ns, (void**)&F.strand_hits)) return -1;
+        if (c->scratch("sf_hbase", sizeof(uint64_t) * (size_t)(ns + 1), (void**)&F.hit_base)) return -1;
+        if (c->scratch("sf_nseg", sizeof(uint32_t) * (size_t)ns, (void**)&F.nseg)) return -1;
+        if (c->scratch("sf_nrec", sizeof(uint32_t) * (size_t)ns, (void**)&F.nrec)) return -1;
+        if (c->scratch("sf_ngated", sizeof(uint32_t) * (size_t)ns, (void**)&F.ngated)) return -1;
+        if (c->scratch("sf_ent", sizeof(uint32_t) * capF, (void**)&F.ent)) return -1;
+        if (c->scratch("sf_entfin", sizeof(uint32_t) * capF, (void**)&F.ent_fin)) return -1;
+        if (c->scratch("sf_escore", sizeof(uint16_t) * capF, (void**)&F.escore)) return -1;
+        if (c->scratch("sf_segid", sizeof(uint32_t) * capF, (void**)&F.seg_id)) return -1;
+        if (c->scratch("sf_segstart", sizeof(uint32_t) * capF, (void**)&F.seg_start)) return -1;
+        if (c->scratch("sf_segscore", sizeof(int32_t) * capF, (void**)&F.seg_score)) return -1;
+        if (c->scratch("sf_gated", sizeof(uint32_t) * capF, (void**)&F.gated)) return -1;
+        HIPCHK(hipMemsetAsync(d_ctl, 0, sizeof(FusedCtl), c->stream));
+        LAUNCH(c, "seed_strand", seed_strand, ns, FS_THREADS, 0, (const mhip_offset_t*)reads->d_offs, sel, ib, (const uint16_t*)idx->d_slots,
+               (const int32_t*)idx->d_offsets, F, gate, std::max(0, nbits - FLT_BITS), (int)P->min_kmer_match, P->ddfs_cutoff,
+               (unsigned long long)capF, d_ctl, (unsigned long long*)c->d_counters);
+        FusedCtl ctl;
+        HIPCHK(hipMemcpyAsync(&ctl, d_ctl, sizeof(ctl), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));   // also orders the kmb host buffer
+        nfallback = ctl.n_fallback;
+#ifdef FS_PROF
+        for (int i = 0; i < 12; ++i) fprintf(stderr, "FS_PROF phase %d: F %.1f R %.1f us per strand\n", i, (double)ctl.prof[i] / 50.0 / ns, (double)ctl.prof[i + 16] / 50.0 / ns);
+#endif
+    }
+
+    // ---- the kernel chain for every other strand
+    SeedArrays B = A;
+    if (nfallback > 0) {
+        if (c->scratch("sd_hits", sizeof(uint32_t) * (size_t)ns, (void**)&B.strand_hits)) return -1;
+        if (c->scratch("sd_filtered", sizeof(int32_t) * (size_t)ns, (void**)&B.filtered)) return -1;
+        if (c->scratch("sd_relbits", sizeof(uint32_t) * (size_t)ns * REL_WORDS, (void**)&B.rel_bits)) return -1;
+        if (c->scratch("sd_hbase", sizeof(uint64_t) * (size_t)(ns + 1), (void**)&B.hit_base)) return -1;
+        if (c->scratch("sd_nseg", sizeof(uint32_t) * (size_t)ns, (void**)&B.nseg)) return -1;
+        if (c->scratch("sd_nrec", sizeof(uint32_t) * (size_t)ns, (void**)&B.nrec)) return -1;
+        if (c->scratch("sd_ngated", sizeof(uint32_t) * (size_t)ns, (void**)&B.ngated)) return -1;
         LAUNCH(c, "seed_filter", seed_filter, ns, SEED_BLOCK, 0, (const mhip_offset_t*)reads->d_offs, sel, ib,
-               (const uint16_t*)idx->d_slots, A, gate, enable);
-    }
-    LAUNCH(c, "seed_scan", seed_scan, 1, 1024, 0, (const uint32_t*)A.strand_hits, ns, A.hit_base);
-    uint64_t Htot = 0;
-    HIPCHK(hipMemcpyAsync(&Htot, A.hit_base + ns, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));   // also orders the kmb host buffer
-    const size_t Hc = (size_t)Htot + 64;
-    if (c->scratch("sd_keysA", sizeof(uint64_t) * Hc, (void**)&A.keysA)) return -1;
-    if (c->scratch("sd_keysB", sizeof(uint64_t) * Hc, (void**)&A.keysB)) return -1;
-    if (c->scratch("sd_ent", sizeof(uint32_t) * Hc, (void**)&A.ent)) return -1;
-    if (c->scratch("sd_entfin", sizeof(uint32_t) * Hc, (void**)&A.ent_fin)) return -1;
-    if (c->scratch("sd_escore", sizeof(uint16_t) * Hc, (void**)&A.escore)) return -1;
-    if (c->scratch("sd_segid", sizeof(uint32_t) * Hc, (void**)&A.seg_id)) return -1;
-    if (c->scratch("sd_segstart", sizeof(uint32_t) * Hc, (void**)&A.seg_start)) return -1;
-    if (c->scratch("sd_segscore", sizeof(int32_t) * Hc, (void**)&A.seg_score)) return -1;
-    if (c->scratch("sd_segkmlast", sizeof(uint32_t) * Hc, (void**)&A.seg_kmlast)) return -1;
-    if (c->scratch("sd_segtfirst", sizeof(uint64_t) * Hc, (void**)&A.seg_tfirst)) return -1;
-    if (c->scratch("sd_gated", sizeof(uint32_t) * Hc, (void**)&A.gated)) return -1;
-    int in_b = 0;
-    if (Htot > 0) {
-        LAUNCH(c, "seed_emit", seed_emit, ns, SEED_BLOCK, 0, (const mhip_offset_t*)reads->d_offs, sel, ib, (const int32_t*)idx->d_offsets, A);
-        const int nbits = bits_for((uint32_t)(ref->num_bases / ZV));
-        const int npass = (nbits + SORT_MAXBITS - 1) / SORT_MAXBITS;
-        const int per = (nbits + npass - 1) / npass;
-        int done = 0;
-        for (int p = 0; p < npass; ++p) {
-            int b = std::min(per, nbits - done);
-            LAUNCH(c, "seed_sort_pass", seed_sort_pass, ns, SEED_BLOCK, 0, A, in_b, KEY_SEG_SHIFT + done, b);
-            done += b;
-            in_b ^= 1;
+               (const uint16_t*)idx->d_slots, B, gate, filter_enabled(P) ? 1 : 0);
+        LAUNCH(c, "seed_scan", seed_scan, 1, 1024, 0, (const uint32_t*)B.strand_hits, ns, B.hit_base);
+        uint64_t Htot = 0;
+        HIPCHK(hipMemcpyAsync(&Htot, B.hit_base + ns, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));   // also orders the kmb host buffer
+        const size_t Hc = (size_t)Htot + 64;
+        if (c->scratch("sd_keysA", sizeof(uint64_t) * Hc, (void**)&B.keysA)) return -1;
+        if (c->scratch("sd_keysB", sizeof(uint64_t) * Hc, (void**)&B.keysB)) return -1;
+        if (c->scratch("sd_ent", sizeof(uint32_t) * Hc, (void**)&B.ent)) return -1;
+        if (c->scratch("sd_entfin", sizeof(uint32_t) * Hc, (void**)&B.ent_fin)) return -1;
+        if (c->scratch("sd_escore", sizeof(uint16_t) * Hc, (void**)&B.escore)) return -1;
+        if (c->scratch("sd_segid", sizeof(uint32_t) * Hc, (void**)&B.seg_id)) return -1;
+        if (c->scratch("sd_segstart", sizeof(uint32_t) * Hc, (void**)&B.seg_start)) return -1;
+        if (c->scratch("sd_segscore", sizeof(int32_t) * Hc, (void**)&B.seg_score)) return -1;
+        if (c->scratch("sd_segkmlast", sizeof(uint32_t) * Hc, (void**)&B.seg_kmlast)) return -1;
+        if (c->scratch("sd_segtfirst", sizeof(uint64_t) * Hc, (void**)&B.seg_tfirst)) return -1;
+        if (c->scratch("sd_gated", sizeof(uint32_t) * Hc, (void**)&B.gated)) return -1;
+        int in_b = 0;
+        if (Htot > 0) {
+            LAUNCH(c, "seed_emit", seed_emit, ns, SEED_BLOCK, 0, (const mhip_offset_t*)reads->d_offs, sel, ib, (const int32_t*)idx->d_offsets, B);
+            const int npass = (nbits + SORT_MAXBITS - 1) / SORT_MAXBITS;
+            const int per = (nbits + npass - 1) / npass;
+            int done = 0;
+            for (int p = 0; p < npass; ++p) {
+                int b = std::min(per, nbits - done);
+                LAUNCH(c, "seed_sort_pass", seed_sort_pass, ns, SEED_BLOCK, 0, B, in_b, KEY_SEG_SHIFT + done, b);
+                done += b;
+                in_b ^= 1;
+            }
         }
+        LAUNCH(c, "seed_build", seed_build, ns, SEED_BLOCK, 0, B, in_b, (int)P->min_kmer_match, P->ddfs_cutoff);
     }
-    LAUNCH(c, "seed_build", seed_build, ns, SEED_BLOCK, 0, A, in_b, (int)P->min_kmer_match, P->ddfs_cutoff);
     const size_t lds = sizeof(int) * 12 * (size_t)P->maxc + sizeof(CandLds);
-    LAUNCH(c, "seed_cand", seed_cand, nr, WAVE, lds, A, (const mhip_offset_t*)ref->d_offs, (const uint32_t*)ref->d_blk2read, ref->num_reads,
+    LAUNCH(c, "seed_cand", seed_cand, nr, WAVE, lds, F, B, (const mhip_offset_t*)ref->d_offs, (const uint32_t*)ref->d_blk2read, ref->num_reads,
            ref->start_read_id,
            (const mhip_offset_t*)reads->d_offs, sel, ib, reads->start_read_id, *P, d_out, d_counts, (unsigned long long*)c->d_counters);
     HIPCHK(hipGetLastError());
@@ -1079,6 +1640,11 @@ static bool filter_enabled(const mhip_params* P) {
     // the filter needs a gate high enough to separate signal from random hits; below that every hit is kept
     const char* fe = getenv("MECAT_SEED_FILTER");      // debug knob: 0 disables the relevance filter
     return 2 * P->min_kmer_match >= 6 && !(fe && atoi(fe) == 0);
+}
+
+static bool fused_enabled(const mhip_params* P) {
+    const char* fe = getenv("MECAT_SEED_FUSED");       // debug knob: 0 sends every strand through the kernel chain
+    return filter_enabled(P) && !(fe && atoi(fe) == 0);
 }
 
 // reads per launch: bounded by an estimate of the bucket hits they produce.  The batch arrays cost ~54 bytes per KEPT

@@ -74,6 +74,7 @@ def lib():
     L.mhip_ctx_kernel_names.argtypes = [vp, C.c_char_p, i32]
     L.mhip_ctx_reset_stats.argtypes = [vp]
     L.mhip_ctx_counters.argtypes = [vp, C.POINTER(i64)]
+    L.mhip_debug_counter.argtypes = [vp, i32, C.POINTER(i64)]
     L.mhip_volume_upload.argtypes = [vp, vp, vp, i32, i32, i32, C.POINTER(vp)]
     L.mhip_volume_free.argtypes = [vp]
     L.mhip_volume_num_reads.argtypes = [vp]
@@ -170,6 +171,12 @@ class Context:
         _chk(lib().mhip_ctx_counters(self.h, a))
         names = ("lookups", "hits", "candidates", "dw_blocks", "dw_cells", "snake_bases", "aligned_bases", "aln_ok")
         return dict(zip(names, [int(x) for x in a]))
+
+    def debug_counter(self, slot):
+        """development counters 8..15 (13 / 14: strands taken by seed_strand / left to the kernel chain)"""
+        v = C.c_int64()
+        _chk(lib().mhip_debug_counter(self.h, slot, C.byref(v)))
+        return int(v.value)
 
 
 class Volume:

@@ -107,6 +107,14 @@ def test_candidates_full_size(full):
     sc = np.where(mask, cands["score"], np.iinfo(np.int32).max)
     sc_next = np.where(mask[:, 1:], cands["score"][:, 1:], -1)
     assert np.all(sc[:, :-1] >= sc_next), "candidate lists are sorted by score, descending"
+    # the strand-resident pipeline took (practically) every strand with hits; the kernel chain gives the same lists
+    took, left = ctx.debug_counter(13), ctx.debug_counter(14)
+    assert took > 0 and left <= 0.01 * took, (took, left)
+    with _Env(MECAT_SEED_FUSED="0"):
+        c2, n2 = M.seed_reads(ctx, idx, vol, vol, 0, n, p)
+    assert np.array_equal(cnt, n2)
+    assert np.array_equal(cands[mask], c2[mask])
+    del c2
     # independent implementation: no relevance filter
     with _Env(MECAT_SEED_FILTER="0"):
         c2, n2 = M.seed_reads(ctx, idx, vol, vol, 0, n, p)

@@ -135,6 +135,27 @@ def test_can_lines_match_golden(name, hip, ctx):
     assert sha(("\n".join(lines) + "\n").encode()) == G["sets"][name]["can_sorted_sha256"]
 
 
+def test_strand_pipeline_equals_kernel_chain(hip, ctx):
+    """seed_strand (one workgroup per strand, hits resident in LDS) and the filter/emit/sort/build kernel chain are two
+    formulations of pw_impl.cpp:241-286; both must give the oracle's lists, and the first must be the one that runs"""
+    d = dataset("config1", hip, ctx)
+    p = hip.default_params(0)
+    ctx.reset_stats()
+    got, cnt = _gpu_cands(hip, ctx, d, p)
+    took, left = ctx.debug_counter(13), ctx.debug_counter(14)
+    assert took >= 0.8 * 2 * len(cnt) and took + left <= 2 * len(cnt), (took, left, len(cnt))      # (at this coverage ~1 strand in 9 exceeds the LDS budget)
+    os.environ["MECAT_SEED_FUSED"] = "0"
+    try:
+        ctx.reset_stats()
+        got2, cnt2 = _gpu_cands(hip, ctx, d, p)
+        assert ctx.debug_counter(13) == 0
+    finally:
+        del os.environ["MECAT_SEED_FUSED"]
+    assert np.array_equal(cnt, cnt2)
+    for r in range(len(cnt)):
+        assert np.array_equal(got[r][: cnt[r]], got2[r][: cnt[r]]), r
+
+
 def test_candidates_small_batches_equal_one_batch(hip, ctx):
     """the read range may be cut anywhere: per-read results do not depend on the batch"""
     d = dataset("tiny", hip, ctx)

@@ -481,77 +481,79 @@ __device__ __forceinline__ bool ddf_find_quarter(int dloc, int dseed) { return 2
 
 // insert_loc replay for one overflowed segment by one wave.  Events e = 40.. c-1 (0-based) arrive one by one.
 // lane i (< 40) holds list entry i.  Writes the final 40 entries to fin[] and the score after each event to esc[].
+//
+// While the 40-entry list is one exact chain (strictly increasing seed numbers, loc advancing by BC per seed from entry to
+// entry) an event that continues the chain after the last entry passes every pair test: the minimum is SM and the event just
+// replaces the last entry (pw_impl.cpp:121-159 with every score equal).  Runs of such events are skipped in one step — a read
+// against its own copy in the volume is the common overflow and is such a chain from end to end, bar the odd random hit,
+// which is looked at, thrown out again, and leaves the list the chain it was.
 __device__ void replay_overflow(const uint32_t* __restrict__ ev, int c, uint32_t* __restrict__ fin, uint16_t* __restrict__ esc,
                                 double cutoff, int* score_out) {
     const int lane = lane_id();
-    // The events up to the first one that leaves the exact diagonal of its predecessor (strictly increasing seed numbers, loc
-    // advancing by BC per seed) need no replay: while the working list is one exact chain every pair passes, the minimum
-    // is SM, and the new event just replaces the last entry (the fast path below).  A read against its own copy in the
-    // volume is the common overflow and is such a chain from end to end.  brk = length of that prefix.
-    int brk = c;
-    for (int i0 = 1; i0 < c && brk == c; i0 += 64) {
-        const int i = i0 + lane;
-        bool bad = false;
-        if (i < c) {
-            const uint32_t a = ev[i - 1], b = ev[i];
-            const int ds = ent_seed(b) - ent_seed(a), dl = ent_loc(b) - ent_loc(a);
-            bad = !(ds > 0 && dl == ds * BC);
-        }
-        const unsigned long long bm = __ballot(bad);
-        if (bm) brk = i0 + __builtin_ctzll(bm);
-    }
     int loc = 0, seed = 0;
-    int score = SM, start = SM;
-    if (brk > SM) {                          // state after the events SM .. brk - 1: entries 0 .. 38 and the last event of the prefix
-        start = brk;
-        score = brk;
-        if (lane < SM) { const uint32_t e = ev[lane < SM - 1 ? lane : brk - 1]; loc = ent_loc(e); seed = ent_seed(e); }
-        for (int e = lane; e < brk; e += 64) esc[e] = (uint16_t)(e + 1);
-    } else {
-        if (lane < SM) { const uint32_t e = ev[lane]; loc = ent_loc(e); seed = ent_seed(e); }
-        for (int e = lane; e < SM; e += 64) esc[e] = (uint16_t)(e + 1);
-    }
-    uint32_t evreg = 0;                      // events of the current 64-chunk, one per lane: no load latency inside the serial replay
-    for (int e = start; e < c; ++e) {
-        if (((e - SM) & 63) == 0 || e == start) {
-            const int base = SM + ((e - SM) & ~63);
-            evreg = base + lane < c ? ev[base + lane] : 0u;
+    if (lane < SM) { const uint32_t e0 = ev[lane]; loc = ent_loc(e0); seed = ent_seed(e0); }
+    if (lane < SM) esc[lane] = (uint16_t)(lane + 1);
+    int score = SM;
+    int e = SM;
+    auto is_chain = [&]() {
+        const int nl = __shfl_down(loc, 1), ns = __shfl_down(seed, 1);
+        return (bool)__all(lane >= SM - 1 || (ns - seed > 0 && nl - loc == (ns - seed) * BC));
+    };
+    bool chain = is_chain();
+    while (e < c) {
+        if (chain) {
+            const int lloc = __builtin_amdgcn_readlane(loc, SM - 1), lseed = __builtin_amdgcn_readlane(seed, SM - 1);
+            int nb = c;                              // first event that does not continue the chain
+            for (int i0 = e; i0 < c && nb == c; i0 += 64) {
+                const int i = i0 + lane;
+                bool bad = false;
+                if (i < c) {
+                    const uint32_t b = ev[i];
+                    int pl = lloc, ps = lseed;
+                    if (i > e) { const uint32_t a = ev[i - 1]; pl = ent_loc(a); ps = ent_seed(a); }
+                    const int ds = ent_seed(b) - ps, dl = ent_loc(b) - pl;
+                    bad = !(ds > 0 && dl == ds * BC);
+                }
+                const unsigned long long bm = __ballot(bad);
+                if (bm) nb = i0 + __builtin_ctzll(bm);
+            }
+            if (nb > e) {
+                for (int x = e + lane; x < nb; x += 64) esc[x] = (uint16_t)(score + (x - e) + 1);
+                score += nb - e;
+                if (lane == SM - 1) { const uint32_t le = ev[nb - 1]; loc = ent_loc(le); seed = ent_seed(le); }
+                e = nb;
+                if (e >= c) break;
+            }
         }
-        const uint32_t ne = (uint32_t)__builtin_amdgcn_readlane((int)evreg, (e - SM) & 63);
+        const uint32_t ne = ev[e];
         const int nloc = ent_loc(ne), nseed = ent_seed(ne);
         ++score;   // loc = ++spr->score (pw_impl.cpp:267)
         // element 40 of the 41-entry working list is the new seed
-        int myloc = lane < SM ? loc : nloc, myseed = lane < SM ? seed : nseed;
-        // fast path: all 41 entries on one exact diagonal with strictly increasing seed numbers -> every pair passes
-        int nxloc = __shfl_down(myloc, 1), nxseed = __shfl_down(myseed, 1);
-        bool chain_ok = lane >= SM || (nxseed - myseed > 0 && nxloc - myloc == (nxseed - myseed) * BC);
-        int minval, mini;
-        if (__all(chain_ok)) {
-            minval = SM; mini = 0;
-        } else {
-            int sc = 0;
-            for (int i = 0; i < SM; ++i) {
-                const int li = __builtin_amdgcn_readlane(myloc, i), si = __builtin_amdgcn_readlane(myseed, i);      // entry i lives in lane i
-                bool pass = lane > i && lane <= SM && myseed - si > 0 && myloc - li > 0 && ddf_insert(myloc - li, myseed - si, cutoff);
-                uint64_t b = __ballot(pass);
-                sc += pass ? 1 : 0;
-                if (lane == i) sc += __popcll(b);
-            }
-            int v = lane <= SM ? sc : 0x7fffffff;
-            int m = v;
-            for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o));
-            minval = m;
-            mini = __ffsll((unsigned long long)__ballot(v == m)) - 1;   // first index holding the minimum
+        const int myloc = lane < SM ? loc : nloc, myseed = lane < SM ? seed : nseed;
+        int sc = 0;
+        for (int i = 0; i < SM; ++i) {
+            const int li = __builtin_amdgcn_readlane(myloc, i), si = __builtin_amdgcn_readlane(myseed, i);      // entry i lives in lane i
+            const bool pass = lane > i && lane <= SM && myseed - si > 0 && myloc - li > 0 && ddf_insert(myloc - li, myseed - si, cutoff);
+            const uint64_t b = __ballot(pass);
+            sc += pass ? 1 : 0;
+            if (lane == i) sc += __popcll(b);
         }
+        const int v = lane <= SM ? sc : 0x7fffffff;
+        int m = v;
+        for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o));
+        const int minval = m;
+        const int mini = __ffsll((unsigned long long)__ballot(v == m)) - 1;   // first index holding the minimum
         if (minval == SM) {
             if (lane == SM - 1) { loc = nloc; seed = nseed; }
         } else if (minval < SM && mini < SM) {
             // delete entry mini, shift left, append the new one
-            int sl = __shfl_down(myloc, 1), ss = __shfl_down(myseed, 1);
+            const int sl = __shfl_down(myloc, 1), ss = __shfl_down(myseed, 1);
             if (lane >= mini && lane < SM) { loc = sl; seed = ss; }
             --score;
         }
         if (lane == 0) esc[e] = (uint16_t)score;
+        ++e;
+        chain = is_chain();
     }
     if (lane < SM) fin[lane] = ((uint32_t)loc << 16) | ((uint32_t)seed & 0xFFFFu);
     *score_out = score;
@@ -950,9 +952,11 @@ __global__ __launch_bounds__(FS_THREADS) void seed_strand(const mhip_offset_t* _
             const uint32_t h = (cw[1 + (j >> 1)] >> ((j & 1) * 16)) & 0xFFFFu;
             if (((r >> j) & 1u) && h) { occ |= 1u << j; mine += h; toolong |= h > FS_BIGN; }
         }
-        uint32_t nci;
-        const uint32_t ex = fs_excl_scan(mine, L.wtot, &kept);
-        const uint32_t cx = fs_excl_scan((uint32_t)__popc(occ), L.wtot, &nci);
+        // one scan for both prefixes: hits in the low half (Hall < 2^16), occupied slots in the high half (<= 2^15)
+        uint32_t both;
+        const uint32_t exb = fs_excl_scan(mine | ((uint32_t)__popc(occ) << 16), L.wtot, &both);
+        const uint32_t ex = exb & 0xFFFFu, cx = exb >> 16;
+        kept = both & 0xFFFFu;
         if (kept > FS_CAP) { fail(); return; }
         L.occ[tid] = occ;
         L.base_ci[tid] = (uint16_t)cx;
@@ -1043,37 +1047,46 @@ __global__ __launch_bounds__(FS_THREADS) void seed_strand(const mhip_offset_t* _
     }
 
     FS_MARK(5);
-    // ---- build, phase A: recorded events (first hit of each (segment, km)) and segment heads, events compacted in place
+    // ---- build, phase A: recorded events (first hit of each (segment, km)) and segment heads, events compacted in place.
+    // A thread takes a run of consecutive elements into registers; one scan; then everybody writes.
     uint32_t nrec, nseg;
     {
-        uint32_t rec_run = 0, seg_run = 0;
-        for (uint32_t t0 = 0; t0 < kept; t0 += FS_THREADS) {
-            const uint32_t i = t0 + tid;
-            const bool in = i < kept;
-            const uint32_t pay = in ? L.x.e.pay[i] : 0u, sl = in ? L.x.e.eslot[i] : 0u;
-            uint32_t ppay = 0, psl = 0;
-            if (in && i > 0) {
-                if (tid > 0) { ppay = L.x.e.pay[i - 1]; psl = L.x.e.eslot[i - 1]; }
-                else { ppay = L.misc[4]; psl = L.misc[5]; }
-            }
-            const bool head = in && (i == 0 || sl != psl || (pay >> 26) != (ppay >> 26));
-            const bool rec = in && (head || ((pay >> 11) & 0x7FFFu) != ((ppay >> 11) & 0x7FFFu));
-            uint32_t both;
-            const uint32_t ex = fs_excl_scan((rec ? 1u : 0u) | (head ? 0x10000u : 0u), L.wtot, &both);     // all reads are before its barriers
-            const uint32_t rpos = rec_run + (ex & 0xFFFFu), spos = seg_run + (ex >> 16);
-            if (tid == FS_THREADS - 1) { L.misc[4] = pay; L.misc[5] = sl; }
-            if (rec) L.x.e.pay[rpos] = ((pay & 0x7FFu) << 16) | ((((pay >> 11) & 0x7FFFu) + 1u) & 0xFFFFu);
-            if (head && spos < FS_SEGCAP) {
-                L.sq_id[spos] = ((pay >> 26) << FLT_BITS) | sl;
-                L.sq_st[spos] = (uint16_t)rpos;
-            }
-            rec_run += both & 0xFFFFu;
-            seg_run += both >> 16;
-            __syncthreads();
+        constexpr int CHMAX = FS_CAP / FS_THREADS;
+        const uint32_t ch = (kept + FS_THREADS - 1) / FS_THREADS;
+        const uint32_t i0 = (uint32_t)tid * ch;
+        uint32_t pv[CHMAX], sv[CHMAX];
+        uint32_t ppay = 0, psl = 0xFFFFFFFFu;                       // no element before the first: a head
+        if (i0 > 0 && i0 < kept) { ppay = L.x.e.pay[i0 - 1]; psl = L.x.e.eslot[i0 - 1]; }
+        uint32_t hm = 0, rm = 0;
+#pragma unroll
+        for (int c = 0; c < CHMAX; ++c) {
+            const uint32_t i = i0 + c;
+            const bool in = (uint32_t)c < ch && i < kept;
+            pv[c] = in ? L.x.e.pay[i] : 0u;
+            sv[c] = in ? L.x.e.eslot[i] : 0u;
+            const bool head = in && (sv[c] != psl || (pv[c] >> 26) != (ppay >> 26));
+            const bool rec = in && (head || ((pv[c] >> 11) & 0x7FFFu) != ((ppay >> 11) & 0x7FFFu));
+            hm |= (head ? 1u : 0u) << c;
+            rm |= (rec ? 1u : 0u) << c;
+            if (in) { ppay = pv[c]; psl = sv[c]; }
         }
-        nrec = rec_run;
-        nseg = seg_run;
+        uint32_t both;
+        const uint32_t ex = fs_excl_scan((uint32_t)__popc(rm) | ((uint32_t)__popc(hm) << 16), L.wtot, &both);     // its barriers come after all the reads
+        uint32_t rpos = ex & 0xFFFFu, spos = ex >> 16;
+        nrec = both & 0xFFFFu;
+        nseg = both >> 16;
         if (nseg > FS_SEGCAP) { fail(); return; }
+#pragma unroll
+        for (int c = 0; c < CHMAX; ++c) {
+            if ((rm >> c) & 1u) {
+                if ((hm >> c) & 1u) {
+                    L.sq_id[spos] = ((pv[c] >> 26) << FLT_BITS) | sv[c];
+                    L.sq_st[spos] = (uint16_t)rpos;
+                    ++spos;
+                }
+                L.x.e.pay[rpos++] = ((pv[c] & 0x7FFu) << 16) | ((((pv[c] >> 11) & 0x7FFFu) + 1u) & 0xFFFFu);
+            }
+        }
         if (tid == 0) L.sq_st[nseg] = (uint16_t)nrec;
     }
     uint16_t* perm = L.y.perm;                           // the cursors are dead

@@ -477,7 +477,9 @@ __device__ __forceinline__ bool ddf_find(int dloc, int dseed, double cutoff) {
 // integers, so x = dloc / (10 dseed) is never within a rounding error of 0.75 or 1.25 unless it equals them
 // (|x - 1.25| >= 1 / (40 dseed) >= 7.6e-7 for dseed < 32768, half an f32 ulp there is 6e-8): q = RN(x) satisfies
 // 0.75 < q < 1.25 exactly when x does; q - 1 is exact for q in [0.5, 2] (Sterbenz) and |RN(q - 1)| >= 0.5 outside.
-__device__ __forceinline__ bool ddf_find_quarter(int dloc, int dseed) { return 2 * dloc > 15 * dseed && 2 * dloc < 25 * dseed; }
+__device__ __forceinline__ bool ddf_find_quarter(int dloc, int dseed) {        // |dseed| < 2^15: 24-bit multiplies
+    return (int)(2 * dloc > __mul24(15, dseed)) & (int)(2 * dloc < __mul24(25, dseed));
+}
 
 // insert_loc replay for one overflowed segment by one wave.  Events e = 40.. c-1 (0-based) arrive one by one.
 // lane i (< 40) holds list entry i.  Writes the final 40 entries to fin[] and the score after each event to esc[].
@@ -1259,8 +1261,15 @@ __device__ __forceinline__ int read_id_lookup(const mhip_offset_t* __restrict__ 
     return read_id_from_offset(a, n, offset);
 }
 
+// lane `l` (wave-uniform) of `old` replaced by the wave-uniform value `v`
+__device__ __forceinline__ int write_lane(int v, int l, int old) {
+    // two scalar operands exceed the constant bus: the lane select goes through m0 (the compiler sets m0 anew before each of its own uses)
+    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(v), "s"(l));
+    return old;
+}
+
 // one wave per read: F strand then R strand into one top-MAXC list kept in LDS (12 ints per entry)
-__global__ __launch_bounds__(WAVE) void seed_cand(SeedArrays AF, SeedArrays AB, const mhip_offset_t* __restrict__ ref_offs, const uint32_t* __restrict__ ref_blk, int ref_nreads,
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(7, 7))) void seed_cand(SeedArrays AF, SeedArrays AB, const mhip_offset_t* __restrict__ ref_offs, const uint32_t* __restrict__ ref_blk, int ref_nreads,
                                                   int ref_start_id, const mhip_offset_t* __restrict__ roffs, ReadSel sel, int ib,
                                                   int reads_start_id, mhip_params P, mhip_candidate* __restrict__ out,
                                                   int32_t* __restrict__ out_counts, unsigned long long* __restrict__ counters) {
@@ -1336,26 +1345,34 @@ __global__ __launch_bounds__(WAVE) void seed_cand(SeedArrays AF, SeedArrays AB, 
             int temp0 = d0, temp1 = d1, sc0 = 0, sc1 = 0;
             // entries 64.. exist only when both lists are long (k <= 80); most segment pairs fit one entry per lane
             const int k0 = min(k, 64);
+            // Branch-free: every condition is evaluated for every lane and combined with &; the votes an entry receives from
+            // the entries before it go through a lane write (each j is written once) and are added after the loops.
+            int in0 = 0, in1 = 0;
             auto vote_loops = [&](auto ddf) {
                 for (int j = 1; j < k0; ++j) {
                     const int lj = __builtin_amdgcn_readlane(l0, j), dj = __builtin_amdgcn_readlane(d0, j);     // entry j lives in lane j
-                    bool v0 = i0 < j && temp0 != dj && dj - d0 > 0 && lj - l0 > 0 && lj - l0 < read_size && ddf(lj - l0, dj - d0);
-                    if (v0) { ++sc0; temp0 = dj; }
-                    const int votes = __popcll(__ballot(v0));
-                    if (lane == j) sc0 += votes;
+                    const int ds = dj - d0, dl = lj - l0;
+                    const bool v0 = (i0 < j) & (temp0 != dj) & (ds > 0) & (dl > 0) & (dl < read_size) & ddf(dl, ds);
+                    sc0 += v0 ? 1 : 0;
+                    temp0 = v0 ? dj : temp0;
+                    in0 = write_lane(__popcll(__ballot(v0)), j, in0);
                 }
                 for (int j = 64; j < k; ++j) {
                     const int lj = __builtin_amdgcn_readlane(l1, j - 64), dj = __builtin_amdgcn_readlane(d1, j - 64);
-                    bool v0 = temp0 != dj && dj - d0 > 0 && lj - l0 > 0 && lj - l0 < read_size && ddf(lj - l0, dj - d0);
-                    bool v1 = i1 < j && temp1 != dj && dj - d1 > 0 && lj - l1 > 0 && lj - l1 < read_size && ddf(lj - l1, dj - d1);
-                    if (v0) { ++sc0; temp0 = dj; }
-                    if (v1) { ++sc1; temp1 = dj; }
-                    const int votes = __popcll(__ballot(v0)) + __popcll(__ballot(v1));
-                    if (lane == j - 64) sc1 += votes;
+                    const int ds0 = dj - d0, dl0 = lj - l0, ds1 = dj - d1, dl1 = lj - l1;
+                    const bool v0 = (temp0 != dj) & (ds0 > 0) & (dl0 > 0) & (dl0 < read_size) & ddf(dl0, ds0);
+                    const bool v1 = (i1 < j) & (temp1 != dj) & (ds1 > 0) & (dl1 > 0) & (dl1 < read_size) & ddf(dl1, ds1);
+                    sc0 += v0 ? 1 : 0;
+                    temp0 = v0 ? dj : temp0;
+                    sc1 += v1 ? 1 : 0;
+                    temp1 = v1 ? dj : temp1;
+                    in1 = write_lane(__popcll(__ballot(v0)) + __popcll(__ballot(v1)), j - 64, in1);
                 }
             };
             if (cutoff == 0.25) vote_loops([](int dloc, int dseed) { return ddf_find_quarter(dloc, dseed); });
-            else vote_loops([&](int dloc, int dseed) { return ddf_find(dloc, dseed, cutoff); });
+            else vote_loops([&](int dloc, int dseed) { return (dloc > 0) & (dseed > 0) & ddf_find(dloc, dseed, cutoff); });
+            sc0 += in0;
+            sc1 += in1;
             int mv = max(i0 < k ? sc0 : -1, i1 < k ? sc1 : -1);
             for (int o = 32; o > 0; o >>= 1) mv = max(mv, __shfl_xor(mv, o));
             const int maxval = mv;
@@ -1641,7 +1658,8 @@ static int seed_batch(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref
         }
         LAUNCH(c, "seed_build", seed_build, ns, SEED_BLOCK, 0, B, in_b, (int)P->min_kmer_match, P->ddfs_cutoff);
     }
-    const size_t lds = sizeof(int) * 12 * (size_t)P->maxc + sizeof(CandLds);
+    size_t lds = sizeof(int) * 12 * (size_t)P->maxc + sizeof(CandLds);
+    if (const char* e = getenv("MECAT_CAND_LDS_PAD")) lds += (size_t)atoi(e);      // development: fewer waves per CU
     LAUNCH(c, "seed_cand", seed_cand, nr, WAVE, lds, F, B, (const mhip_offset_t*)ref->d_offs, (const uint32_t*)ref->d_blk2read, ref->num_reads,
            ref->start_read_id,
            (const mhip_offset_t*)reads->d_offs, sel, ib, reads->start_read_id, *P, d_out, d_counts, (unsigned long long*)c->d_counters);

@@ -753,6 +753,8 @@ struct FsLds {
     uint16_t sq_st[FS_SEGCAP + 2];                       // first recorded event of the segment; [nseg] = nrec
     uint16_t sq_score[FS_SEGCAP];                        // live score | FS_OVF16
     uint16_t gate[FS_GATECAP];
+    uint32_t qpos[FS_WAVES][128];                        // walk 2: kept hits waiting for a full wave (position, km)
+    uint16_t qkm[FS_WAVES][128];
     uint32_t wtot[FS_WAVES];
     uint32_t misc[8];                                    // 0 big count, 1 overflow count, 2 gated count, 3 fail flag, 4/5 carry, 6 hb lo, 7 hb hi
 };
@@ -789,7 +791,7 @@ __device__ __forceinline__ uint32_t fs_excl_scan(uint32_t v, uint32_t* wtot, uin
 // pipelined walk over the buckets of a strand; f(km, value) per hit.  16 lanes per bucket, Q buckets per group and stage, D stages
 // of bucket data in flight plus one stage of bucket headers (start, size) ahead of them.  The first 48 entries of a bucket are
 // loaded by the pipeline (three pieces of 16); a longer bucket reads the rest when it is consumed.
-template <int Q, int D, typename T, typename F>
+template <int Q, int D, bool UNIFORM, typename T, typename F>
 __device__ __forceinline__ void fs_walk(const uint32_t* __restrict__ kbs, const uint32_t* __restrict__ kcn, const T* __restrict__ arr, const int K, F f) {
     constexpr int G = FS_THREADS / 16, STEP = Q * G;
     const int g = threadIdx.x >> 4;
@@ -828,10 +830,17 @@ __device__ __forceinline__ void fs_walk(const uint32_t* __restrict__ kbs, const 
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             const int km = base + q * G + g;
-            if (sub < cc[q]) f(km, c0[q]);
-            if (sub + 16u < cc[q]) f(km, c1[q]);
-            if (sub + 32u < cc[q]) f(km, c2[q]);
-            for (uint32_t r = 48u + sub; r < cc[q]; r += 16u) f(km, (uint32_t)arr[cb[q] + r]);
+            if constexpr (UNIFORM) {            // f(km, value, valid) is called by the whole wave together
+                if (__any(sub < cc[q])) f(km, c0[q], sub < cc[q]);
+                if (__any(sub + 16u < cc[q])) f(km, c1[q], sub + 16u < cc[q]);
+                if (__any(sub + 32u < cc[q])) f(km, c2[q], sub + 32u < cc[q]);
+                for (uint32_t r = 48u + sub; __any(r < cc[q]); r += 16u) f(km, r < cc[q] ? (uint32_t)arr[cb[q] + r] : 0u, r < cc[q]);
+            } else {
+                if (sub < cc[q]) f(km, c0[q]);
+                if (sub + 16u < cc[q]) f(km, c1[q]);
+                if (sub + 32u < cc[q]) f(km, c2[q]);
+                for (uint32_t r = 48u + sub; r < cc[q]; r += 16u) f(km, (uint32_t)arr[cb[q] + r]);
+            }
         }
     }
 #undef FS_HDR
@@ -906,7 +915,7 @@ __global__ __launch_bounds__(FS_THREADS) void seed_strand(const mhip_offset_t* _
     if (tid < 8) L.misc[tid] = 0;
     __syncthreads();
     FS_MARK(0);
-    fs_walk<FS_Q1, FS_D1>(kbs, kcn, slots, K, [&](int, uint32_t e) { atomicAdd(&L.x.cnt32[e >> 1], 1u << ((e & 1u) * 16u)); });
+    fs_walk<FS_Q1, FS_D1, false>(kbs, kcn, slots, K, [&](int, uint32_t e) { atomicAdd(&L.x.cnt32[e >> 1], 1u << ((e & 1u) * 16u)); });
     __syncthreads();
     FS_MARK(1);
 
@@ -992,20 +1001,40 @@ __global__ __launch_bounds__(FS_THREADS) void seed_strand(const mhip_offset_t* _
 
     FS_MARK(3);
     // ---- walk 2: kept hits into their slot's region
-    fs_walk<FS_Q2, FS_D2>(kbs, kcn, offsets, K, [&](int km, uint32_t pos) {
-        const uint32_t seg = pos / (uint32_t)ZV, off = pos - seg * (uint32_t)ZV;
-        const uint32_t e = seg & (FLT_M - 1), w = e >> 5, b = e & 31u;
-        const uint32_t oc = L.occ[w];
-        if ((oc >> b) & 1u) {
+    // A kept hit is rare (one in nine): the wave parks kept hits in its queue and places 64 of them at a time, so that the
+    // cursor arithmetic runs with every lane busy.
+    {
+        uint32_t qn = 0;                                  // wave-uniform: hits in this wave's queue
+        auto place = [&](uint32_t qi) {
+            const uint32_t pos = L.qpos[wv][qi], km = L.qkm[wv][qi];
+            const uint32_t seg = pos / (uint32_t)ZV, off = pos - seg * (uint32_t)ZV;
+            const uint32_t e = seg & (FLT_M - 1), w = e >> 5, b = e & 31u;
+            const uint32_t oc = L.occ[w];
             const uint32_t ci = (uint32_t)L.base_ci[w] + (uint32_t)__popc(oc & ((1u << b) - 1u));
             const uint32_t sh = (ci & 1u) * 16u;
             const uint32_t p = (atomicAdd(&L.y.cur32[ci >> 1], 1u << sh) >> sh) & 0xFFFFu;
-            L.x.e.pay[p] = ((seg >> FLT_BITS) << 26) | ((uint32_t)km << 11) | off;
+            L.x.e.pay[p] = ((seg >> FLT_BITS) << 26) | (km << 11) | off;
             L.x.e.eslot[p] = (uint16_t)e;
-        }
-    });
+        };
+        fs_walk<FS_Q2, FS_D2, true>(kbs, kcn, offsets, K, [&](int km, uint32_t pos, bool valid) {
+            const uint32_t seg = pos / (uint32_t)ZV;
+            const uint32_t e = seg & (FLT_M - 1);
+            const uint32_t oc = valid ? L.occ[e >> 5] : 0u;
+            const bool keep = (oc >> (e & 31u)) & 1u;
+            const unsigned long long m = __ballot(keep);
+            if (m) {
+                if (keep) {
+                    const uint32_t at = qn + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    L.qpos[wv][at] = pos;
+                    L.qkm[wv][at] = (uint16_t)km;
+                }
+                qn += (uint32_t)__popcll(m);
+                if (qn >= 64u) { qn -= 64u; place(qn + (uint32_t)lane); }
+            }
+        });
+        if ((uint32_t)lane < qn) place((uint32_t)lane);
+    }
     __syncthreads();
-
     FS_MARK(4);
     // ---- region sort.  After walk 2 cursor[ci] = end of region ci = start of region ci + 1.
     {

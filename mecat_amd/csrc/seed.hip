@@ -1021,7 +1021,7 @@ __global__ __launch_bounds__(FS_THREADS) void seed_strand(const mhip_offset_t* _
             const uint32_t e = seg & (FLT_M - 1);
             const uint32_t oc = valid ? L.occ[e >> 5] : 0u;
             const bool keep = (oc >> (e & 31u)) & 1u;
-            const unsigned long long m = __ballot(keep);
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
             if (m) {
                 if (keep) {
                     const uint32_t at = qn + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
@@ -1384,7 +1384,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(7, 7))) vo
                     const bool v0 = (i0 < j) & (temp0 != dj) & (ds > 0) & (dl > 0) & (dl < read_size) & ddf(dl, ds);
                     sc0 += v0 ? 1 : 0;
                     temp0 = v0 ? dj : temp0;
-                    in0 = write_lane(__popcll(__ballot(v0)), j, in0);
+                    in0 = write_lane(__popcll(__builtin_amdgcn_ballot_w64(v0)), j, in0);
                 }
                 for (int j = 64; j < k; ++j) {
                     const int lj = __builtin_amdgcn_readlane(l1, j - 64), dj = __builtin_amdgcn_readlane(d1, j - 64);
@@ -1395,7 +1395,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(7, 7))) vo
                     temp0 = v0 ? dj : temp0;
                     sc1 += v1 ? 1 : 0;
                     temp1 = v1 ? dj : temp1;
-                    in1 = write_lane(__popcll(__ballot(v0)) + __popcll(__ballot(v1)), j - 64, in1);
+                    in1 = write_lane(__popcll(__builtin_amdgcn_ballot_w64(v0)) + __popcll(__builtin_amdgcn_ballot_w64(v1)), j - 64, in1);
                 }
             };
             if (cutoff == 0.25) vote_loops([](int dloc, int dseed) { return ddf_find_quarter(dloc, dseed); });

@@ -681,7 +681,11 @@ int main(int argc, char* argv[]) {
         mhip_comm_destroy(comm);
     }
     gpu_setup.join();
-    mhip_ctx_destroy(ctx);
+    {
+        TraceTimer tt("ctx_destroy");
+        mhip_ctx_destroy(ctx);
+    }
+    if (getenv("MECAT_TRACE")) fprintf(stderr, "[trace] main up to here     %.3f s\n", now_s() - t_start);
     if (rank != 0) return 0;
 
     // merge_results, pw.cpp:34-46 (rank 0; in rows mode it waits for the rows of the other ranks, but not for a dead one)

@@ -144,10 +144,15 @@ def e2e_cli(workload, codes, lens, threads):
             best = None
             for rep in range(2):                     # the first run also pays the one-off page-in of the device libraries
                 w = os.path.join(d, "w_%s_%d" % (name, rep))
+                # the driver takes a second or two to take back the ~60 GB of a process that has just exited; a CLI started inside
+                # that window spends 20-30 ms per GB in hipMalloc (0.6 -> 1.5 s wall): the runs are spaced so that each measures itself
+                time.sleep(3.0)
                 t0 = time.time()
                 p = subprocess.run([exe, "-j", str(task), "-d", fa, "-o", o, "-w", w, "-t", str(threads), "-g", "1"],
-                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(os.environ, MECAT_TRACE="1"))
                 wall = time.time() - t0
+                log("e2e -j %d run %d: %.3f s; %s" % (task, rep, wall, "; ".join(
+                    l.strip() for l in p.stderr.splitlines() if "[trace]" in l or "takes" in l)))
                 if p.returncode != 0:
                     res["error"] = p.stderr[-300:]
                     return res
@@ -277,6 +282,7 @@ def main():
         d_res = torch.empty((d_jobs.shape[0], 8), dtype=torch.int32, device=dev)
 
     keep = {}
+    released = False
 
     def one_step():
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -536,6 +542,11 @@ def main():
         except Exception as e:
             log("[bench] no debug counters: %r" % (e,))
         log("[bench] kernel ms/step: " + ", ".join("%s=%.2f" % (k, v[1] / args.steps) for k, v in sorted(kstats.items(), key=lambda kv: -kv[1][1])))
+        if world == 1:
+            # the CLI leg is another process on the same GPU: give this process's device memory (tens of GB of scratch) back first
+            vol.free()
+            ctx.close()
+            released = True
         if world == 1 and not args.no_e2e:
             try:
                 line["e2e"] = e2e_cli(args.workload, codes, lens, min(32, os.cpu_count() or 1))
@@ -554,11 +565,13 @@ def main():
                 line["cpu_baseline"] = {"value": None, "unit": "candidates/s", "cores": os.cpu_count(), "kind": "reference",
                                         "sample": "failed: %r" % (e,)}
         print(json.dumps(line), flush=True)
-    vol.free()
+    if not released:
+        vol.free()
     if comm is not None:
         comm.barrier()
         comm.close()
-    ctx.close()
+    if not released:
+        ctx.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -1616,7 +1616,8 @@ static int seed_batch(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref
     if (fused_enabled(P)) {
         // room: the relevance filter keeps about one bucket hit in nine; a strand that finds the arrays full takes the kernel chain
         const double hits_per_lookup = (double)idx->num_kmers / (double)NKMER + 2.0;
-        const size_t capF = (size_t)((double)sumK * hits_per_lookup / 5.0) + (size_t)ns * 256 + 64;
+        size_t capF = (size_t)((double)sumK * hits_per_lookup / 5.0) + (size_t)ns * 256 + 64;
+        if (const char* e = getenv("MECAT_SEED_FUSED_ROOM")) capF = (size_t)std::max(64.0, atof(e));      // test knob: entries in the shared arrays
         FusedCtl* d_ctl;
         if (c->scratch("sf_ctl", sizeof(FusedCtl), (void**)&d_ctl)) return -1;
         if (c->scratch("sf_hits", sizeof(uint32_t) * (size_t)ns, (void**)&F.strand_hits)) return -1;

@@ -156,6 +156,26 @@ def test_strand_pipeline_equals_kernel_chain(hip, ctx):
         assert np.array_equal(got[r][: cnt[r]], got2[r][: cnt[r]]), r
 
 
+def test_strand_pipeline_out_of_room_falls_back(hip, ctx):
+    """the tables of the strands seed_strand takes live in arrays handed out by an atomic cursor; a strand that finds them full
+    is left to the kernel chain: same lists whatever the room"""
+    d = dataset("config1", hip, ctx)
+    p = hip.default_params(0)
+    full, cnt = _gpu_cands(hip, ctx, d, p)
+    for room in (64, 20000, 300000):
+        os.environ["MECAT_SEED_FUSED_ROOM"] = str(room)
+        try:
+            ctx.reset_stats()
+            got, c2 = _gpu_cands(hip, ctx, d, p)
+            took, left = ctx.debug_counter(13), ctx.debug_counter(14)
+        finally:
+            del os.environ["MECAT_SEED_FUSED_ROOM"]
+        assert left > 0 and (room > 64 or took == 0), (room, took, left)
+        assert np.array_equal(cnt, c2)
+        for r in range(len(cnt)):
+            assert np.array_equal(got[r][: cnt[r]], full[r][: cnt[r]]), (room, r)
+
+
 def test_candidates_small_batches_equal_one_batch(hip, ctx):
     """the read range may be cut anywhere: per-read results do not depend on the batch"""
     d = dataset("tiny", hip, ctx)

@@ -430,6 +430,7 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
     }
     mhip_index_free(idx);
     mhip_volume_free(dref);
+    volume_wait_pending();       // the volume's file is written from `ref`'s buffers
 }
 
 static std::string results_name(const char* wrk_dir, int vid, bool working) {
@@ -580,6 +581,7 @@ int main(int argc, char* argv[]) {
     memset(comm_id, 0, sizeof(comm_id));
     if (rank == 0) {
         if (world > 1) unlink(marker.c_str());
+        volume_set_async_dump(world == 1);       // other ranks read the volume files as soon as the run marker exists
         num_vols = split_raw_dataset(opt.reads, opt.wrk_dir, opt.num_threads);
         for (int i = 0; i < num_vols; ++i)
             if (access(results_name(opt.wrk_dir, i, false).c_str(), F_OK) != 0) todo.push_back(i);

@@ -168,6 +168,8 @@ long read_one_seq(LineReader& r, std::string& seq, bool* have_header) {
 // that was just written)
 std::string g_kept_path;
 HostVolume g_kept;
+bool g_async_dump = false;
+std::thread g_pending;           // writes the kept volume's file / unmaps the input
 
 void dump_volume(const std::string& path, const HostVolume& v) {
     FILE* out = fopen(path.c_str(), "wb");
@@ -188,7 +190,15 @@ void run_threads(int nt, F f) {
     for (auto& x : th) x.join();
 }
 
-struct PlainRec { size_t data; int len; };     // first byte after the header line, number of residues
+struct PlainRec { size_t data; int len; };
+
+// MECAT_TRACE: seconds per stage of the threaded split on stderr
+struct SplitClock {
+    bool on; double t0;
+    static double now() { struct timeval t; gettimeofday(&t, NULL); return t.tv_sec + 1e-6 * t.tv_usec; }
+    SplitClock() : on(getenv("MECAT_TRACE") != NULL), t0(now()) {}
+    void mark(const char* what) { if (!on) return; const double t = now(); fprintf(stderr, "[trace] split: %-14s %.3f s\n", what, t - t0); t0 = t; }
+};     // first byte after the header line, number of residues
 
 // Parallel reader for plain FASTA (see volume.h).  Returns false, touching nothing, if the file is anything else.
 bool split_plain_fasta(const char* reads, const char* wrk_dir, long max_volume_bases, int nt, int* out_vols, long long* out_reads,
@@ -201,6 +211,7 @@ bool split_plain_fasta(const char* reads, const char* wrk_dir, long max_volume_b
     const char* txt = (const char*)mmap(NULL, size, PROT_READ, MAP_PRIVATE, fd, 0);
     close(fd);
     if (txt == MAP_FAILED) return false;
+    SplitClock clk;
     bool ok = txt[0] == '>';
     nt = std::max(1, std::min(nt, 64));
     // chunk t = records whose '>' lies in [cut[t], cut[t+1])
@@ -245,6 +256,7 @@ bool split_plain_fasta(const char* reads, const char* wrk_dir, long max_volume_b
         }
     });
     if (!plain.load()) { munmap((void*)txt, size); return false; }
+    clk.mark("scan");
 
     // volume layout: the reference's loop (split_database.cpp:240-250)
     struct Vol { size_t first, count; long bases; };
@@ -276,7 +288,14 @@ bool split_plain_fasta(const char* reads, const char* wrk_dir, long max_volume_b
         v.start_read_id = rid;
         rid += v.num_reads;
         v.offs.resize(vo.count);
-        v.pac.assign(((size_t)vo.bases + 3) / 4, 0);
+        const size_t pac_bytes = ((size_t)vo.bases + 3) / 4;
+        v.pac.clear();
+        v.pac.resize(pac_bytes);                  // uninitialised
+        run_threads(nt, [&](int t) {              // zero (first touch) in parallel: the packers OR into the bytes at read boundaries
+            const size_t lo = pac_bytes * (size_t)t / (size_t)nt, hi = pac_bytes * (size_t)(t + 1) / (size_t)nt;
+            if (hi > lo) memset(v.pac.data() + lo, 0, hi - lo);
+        });
+        clk.mark("layout+zero");
         // thread t packs a contiguous range of reads holding ~1/nt of the volume's bases
         std::vector<size_t> rcut((size_t)nt + 1, vo.count);
         rcut[0] = 0;
@@ -315,13 +334,39 @@ bool split_plain_fasta(const char* reads, const char* wrk_dir, long max_volume_b
                 put();
             }
         });
+        clk.mark("pack");
         const std::string name = volume_file_name(wrk_dir, (int)k);
         fprintf(idx_file, "%s\n", name.c_str());
-        dump_volume(name, v);
-        if (k + 1 == vols.size()) { g_kept_path = name; g_kept = std::move(v); }
+        if (k + 1 == vols.size()) {
+            g_kept_path = name;
+            g_kept = std::move(v);
+            if (g_async_dump) {
+                // the buffers of g_kept stay where they are when load_volume() moves them into the caller's volume
+                const HostVolume* kv = &g_kept;
+                const int nr = kv->num_reads, nb = kv->num_bases, sid = kv->start_read_id;
+                const mhip_offset_t* offs = kv->offs.data();
+                const uint8_t* pac = kv->pac.data();
+                g_pending = std::thread([=]() {
+                    FILE* out = fopen(name.c_str(), "wb");
+                    if (!out) DIE("cannot open '%s' for writing", name.c_str());
+                    bool ok = fwrite(&nr, sizeof(int), 1, out) == 1 && fwrite(&nb, sizeof(int), 1, out) == 1 && fwrite(&sid, sizeof(int), 1, out) == 1;
+                    if (nr) ok = ok && fwrite(offs, sizeof(mhip_offset_t), (size_t)nr, out) == (size_t)nr;
+                    const size_t bytes = ((size_t)nb + 3) / 4;
+                    if (bytes) ok = ok && fwrite(pac, 1, bytes, out) == bytes;
+                    if (fclose(out) != 0 || !ok) DIE("write error!");
+                    munmap((void*)txt, size);
+                });
+            } else {
+                dump_volume(name, g_kept);
+            }
+        } else {
+            dump_volume(name, v);
+        }
+        clk.mark("dump");
     }
     fclose(idx_file);
-    munmap((void*)txt, size);
+    if (!g_pending.joinable()) munmap((void*)txt, size);
+    clk.mark("unmap");
     *out_vols = (int)vols.size();
     *out_reads = (long long)all.size();
     *out_nucls = nucls;
@@ -412,6 +457,16 @@ int split_raw_dataset(const char* reads, const char* wrk_dir, int num_threads) {
     return vol;
 }
 
+void volume_set_async_dump(bool on) {
+    static bool registered = false;
+    g_async_dump = on;
+    if (on && !registered) { registered = true; atexit(volume_wait_pending); }
+}
+
+void volume_wait_pending() {
+    if (g_pending.joinable()) g_pending.join();
+}
+
 std::vector<std::string> load_volume_names(const std::string& idx_file) {
     std::vector<std::string> names;
     FILE* f = fopen(idx_file.c_str(), "r");
@@ -435,6 +490,7 @@ void load_volume(const std::string& path, HostVolume* v) {
         g_kept_path.clear();
         return;
     }
+    volume_wait_pending();
     FILE* in = fopen(path.c_str(), "rb");
     if (!in) { fprintf(stderr, "[%s, %u] failed to open file '%s'.\n", __func__, __LINE__, path.c_str()); exit(1); }
     bool ok = fread(&v->num_reads, sizeof(int), 1, in) == 1 && fread(&v->num_bases, sizeof(int), 1, in) == 1 &&

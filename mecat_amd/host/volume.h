@@ -6,18 +6,34 @@
 #include <stdint.h>
 
 #include <string>
+#include <memory>
+#include <utility>
 #include <vector>
 
 #include "mecat_hip.h"
 
 static const long kMaxVolumeBases = 2140000000L;   // MCS, common/split_database.h:6
 
+// std::allocator whose value-less construct() default-initialises: vector::resize(n) does not zero-fill (the packers write every
+// byte themselves; zeroing 400 MB on one thread costs 70 ms), resize(n, 0) / assign(n, 0) still do
+template <typename T>
+struct NoInitAlloc : std::allocator<T> {
+    template <typename U> struct rebind { using other = NoInitAlloc<U>; };
+    NoInitAlloc() = default;
+    template <typename U> NoInitAlloc(const NoInitAlloc<U>&) {}
+    template <typename U, typename... A>
+    void construct(U* p, A&&... a) {
+        if constexpr (sizeof...(A) == 0) ::new ((void*)p) U;
+        else ::new ((void*)p) U(std::forward<A>(a)...);
+    }
+};
+
 struct HostVolume {
     int num_reads = 0;
     int num_bases = 0;         // incl. one pad base per read
     int start_read_id = 0;
     std::vector<mhip_offset_t> offs;
-    std::vector<uint8_t> pac;  // (num_bases + 3) / 4 bytes
+    std::vector<uint8_t, NoInitAlloc<uint8_t>> pac;  // (num_bases + 3) / 4 bytes; resize(n) leaves new bytes uninitialised
 };
 
 // Splits `reads` into volumes inside `wrk_dir`; returns the number of volumes.  Aborts with the reference's messages on
@@ -30,4 +46,9 @@ int split_raw_dataset(const char* reads, const char* wrk_dir, int num_threads = 
 std::string volume_file_name(const char* wrk_dir, int vol);      // generate_vol_file_name, split_database.cpp:183-192
 std::string index_file_name(const char* wrk_dir);                // generate_idx_file_name, split_database.cpp:194-200
 std::vector<std::string> load_volume_names(const std::string& idx_file);   // split_database.cpp:373-392
+// One-process runs: the file of the volume that stays in memory is written, and the input unmapped, on a second thread while the
+// caller goes on; volume_wait_pending() returns when that is done (called before a volume file is read back, before the volume's
+// memory is released and at exit).  Multi-process runs keep the write synchronous: other ranks read the file.
+void volume_set_async_dump(bool on);
+void volume_wait_pending();
 void load_volume(const std::string& path, HostVolume* v);        // split_database.cpp:155-181 (exit(1) if missing)

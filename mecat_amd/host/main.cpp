@@ -407,6 +407,7 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
                     else MCHK(mhip_align_candidates(ctx, dref, dreads, jobs.data(), (int)jobs.size(), P.min_align_size, res.data()));
                 }
             }
+            if (sno == 0) volume_release_input();      // every scratch array of the volume exists by now
             if (writes) {
                 std::lock_guard<std::mutex> lk(pm);
                 ++produced;

@@ -169,7 +169,10 @@ long read_one_seq(LineReader& r, std::string& seq, bool* have_header) {
 std::string g_kept_path;
 HostVolume g_kept;
 bool g_async_dump = false;
-std::thread g_pending;           // writes the kept volume's file / unmaps the input
+std::thread g_pending;           // writes the kept volume's file
+std::thread g_unmapper;          // unmaps the input (volume_release_input)
+const void* g_map = NULL;        // the input mapping of an asynchronous split, until it is released
+size_t g_map_size = 0;
 
 void dump_volume(const std::string& path, const HostVolume& v) {
     FILE* out = fopen(path.c_str(), "wb");
@@ -354,8 +357,9 @@ bool split_plain_fasta(const char* reads, const char* wrk_dir, long max_volume_b
                     const size_t bytes = ((size_t)nb + 3) / 4;
                     if (bytes) ok = ok && fwrite(pac, 1, bytes, out) == bytes;
                     if (fclose(out) != 0 || !ok) DIE("write error!");
-                    munmap((void*)txt, size);
                 });
+                g_map = txt;
+                g_map_size = size;
             } else {
                 dump_volume(name, g_kept);
             }
@@ -365,7 +369,7 @@ bool split_plain_fasta(const char* reads, const char* wrk_dir, long max_volume_b
         clk.mark("dump");
     }
     fclose(idx_file);
-    if (!g_pending.joinable()) munmap((void*)txt, size);
+    if (!g_map) munmap((void*)txt, size);
     clk.mark("unmap");
     *out_vols = (int)vols.size();
     *out_reads = (long long)all.size();
@@ -465,6 +469,15 @@ void volume_set_async_dump(bool on) {
 
 void volume_wait_pending() {
     if (g_pending.joinable()) g_pending.join();
+    if (g_unmapper.joinable()) g_unmapper.join();
+}
+
+void volume_release_input() {
+    if (!g_map || g_unmapper.joinable()) return;
+    const void* m = g_map;
+    const size_t n = g_map_size;
+    g_map = NULL;
+    g_unmapper = std::thread([m, n]() { munmap((void*)m, n); });
 }
 
 std::vector<std::string> load_volume_names(const std::string& idx_file) {

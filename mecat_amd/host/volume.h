@@ -51,4 +51,8 @@ std::vector<std::string> load_volume_names(const std::string& idx_file);   // sp
 // memory is released and at exit).  Multi-process runs keep the write synchronous: other ranks read the file.
 void volume_set_async_dump(bool on);
 void volume_wait_pending();
+// Unmapping a multi-GB input holds the process's mmap lock for tens of milliseconds, which every hipMalloc needs: the mapping of an
+// asynchronous split is let go (on its own thread) only when the caller says the device allocations are made.  Without the call it
+// goes with the process.
+void volume_release_input();
 void load_volume(const std::string& path, HostVolume* v);        // split_database.cpp:155-181 (exit(1) if missing)

@@ -722,5 +722,6 @@ int main(int argc, char* argv[]) {
         if (opt.task == TASK_SEED) partition_candidates_text(opt.output, part_batch, part_min, opt.num_threads);
         else partition_m4_text(opt.output, part_ratio, part_batch, part_min, opt.num_threads);
     }
+    if (getenv("MECAT_TRACE")) fprintf(stderr, "[trace] main returns at    %.3f s\n", now_s() - t_start);
     return 0;
 }

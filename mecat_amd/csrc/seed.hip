@@ -561,7 +561,21 @@ __device__ void replay_overflow(const uint32_t* __restrict__ ev, int c, uint32_t
     *score_out = score;
 }
 
-__global__ __launch_bounds__(SEED_BLOCK) void seed_build(SeedArrays A, int sorted_in_b, int min_kmer_match, double cutoff) {
+__device__ __forceinline__ int read_id_lookup(const mhip_offset_t* __restrict__ a, int n, const uint32_t* __restrict__ blk, int offset);
+
+// what the segment builders need to know about the reference volume: a gated segment whose every possible subject read has a
+// higher id than the query read is not listed (get_candidates would vote on it and then drop it at `sid > read_id`,
+// pw_impl.cpp:370, before anything is written: half of the gated segments of a diagonal grid cell)
+struct RefReads { const mhip_offset_t* offs; const uint32_t* blk; int nreads, start_id, reads_start_id, enable; };
+// every location find_location can return for segment `seg` (with its left neighbour) lies at or behind the start of segment
+// seg - 1, and the read lookup is monotone in the position (a pad base belongs to the read before it)
+__device__ __forceinline__ bool subjects_all_higher(const RefReads& R, uint32_t seg, int rid) {
+    const int lo = (int)((seg > 0 ? seg - 1u : 0u) * (uint32_t)ZV);
+    return read_id_lookup(R.offs, R.nreads, R.blk, lo) + R.start_id > rid + R.reads_start_id;
+}
+
+__global__ __launch_bounds__(SEED_BLOCK) void seed_build(SeedArrays A, int sorted_in_b, int min_kmer_match, double cutoff, ReadSel sel, int ib,
+                                                         RefReads R) {
     __shared__ uint32_t wtot[SEED_WAVES];
     __shared__ uint32_t s_cnt[4];          // 0: overflow count, 1: gated count
     __shared__ uint64_t s_tf[GATE_LDS];    // first-touch times of the gated segments (phase E)
@@ -659,7 +673,7 @@ __global__ __launch_bounds__(SEED_BLOCK) void seed_build(SeedArrays A, int sorte
             if (lo > st) left = (seg_score[g - 1] & OVF_FLAG) ? (int)esc[lo - 1] : (int)(lo - st);
             s_k += left;
         }
-        if ((int)(int16_t)s_k >= 2 * min_kmer_match) {
+        if ((int)(int16_t)s_k >= 2 * min_kmer_match && !(R.enable && subjects_all_higher(R, sid, sel_rid(sel, ib + (s >> 1))))) {
             uint32_t k = atomicAdd(&s_cnt[1], 1u);
             gate_tmp[k] = (uint64_t)g;   // index only; ordered below by seg_tfirst
         }
@@ -888,7 +902,7 @@ __device__ __forceinline__ uint32_t fs_cnt(const uint32_t* cnt32, uint32_t e) { 
 __global__ __launch_bounds__(FS_THREADS) void seed_strand(const mhip_offset_t* __restrict__ roffs, ReadSel sel, int ib,
                                                           const uint16_t* __restrict__ slots, const int32_t* __restrict__ offsets, SeedArrays A,
                                                           int gate, int hi_bits, int min_kmer_match, double cutoff, unsigned long long cap,
-                                                          FusedCtl* __restrict__ ctl, unsigned long long* __restrict__ counters) {
+                                                          FusedCtl* __restrict__ ctl, unsigned long long* __restrict__ counters, RefReads R) {
     __shared__ FsLds L;
     const int s = blockIdx.x;
     const int tid = threadIdx.x, lane = lane_id(), wv = threadIdx.x >> 6;
@@ -1207,7 +1221,9 @@ __global__ __launch_bounds__(FS_THREADS) void seed_strand(const mhip_offset_t* _
                 if (lo > st) s_k += (L.sq_score[ql] & FS_OVF16) ? (int)A.escore[hb + lo - 1] : (int)(lo - st);
             }
         }
-        if ((int)(int16_t)s_k >= 2 * min_kmer_match) {
+        bool listed = (int)(int16_t)s_k >= 2 * min_kmer_match;
+        if (listed && R.enable) listed = !subjects_all_higher(R, sid, rid);
+        if (listed) {
             const uint32_t k = atomicAdd(&L.misc[2], 1u);
             if (k < FS_GATECAP) {
                 const uint32_t e0 = L.x.e.pay[L.sq_st[q]];
@@ -1348,9 +1364,15 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(7, 7))) vo
             const int g = g_n, seg = seg_n, segm1 = segm1_n;
             const uint32_t st_g = st_n, st_gm1 = stm1_n;
             if (gi + 1 < ng) prefetch(gi + 1);
+#ifdef CAND_STATS
+            if (lane == 0) atomicAdd(&counters[9], 1ull);
+#endif
             const int raw_g = seg_score[g];
             int s_k = raw_g & ~OVF_FLAG;
             if (s_k == 0) continue;
+#ifdef CAND_STATS
+            if (lane == 0) atomicAdd(&counters[10], 1ull);
+#endif
             int start_loc = seg * ZV;
             int loc = 0, raw_gm1 = 0;
             const bool has_left = seg > 0 && g > 0 && segm1 == seg - 1;
@@ -1405,6 +1427,10 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(7, 7))) vo
             int mv = max(i0 < k ? sc0 : -1, i1 < k ? sc1 : -1);
             for (int o = 32; o > 0; o >>= 1) mv = max(mv, __shfl_xor(mv, o));
             const int maxval = mv;
+#ifdef CAND_STATS
+            if (lane == 0 && maxval < 5) atomicAdd(&counters[11], 1ull);
+            if (lane == 0) atomicAdd(&counters[12], (unsigned long long)k);
+#endif
             if (maxval < 5) continue;
             const uint64_t eq0 = __ballot(i0 < k && sc0 == maxval), eq1 = __ballot(i1 < k && sc1 == maxval);
             const int maxi = eq0 ? __ffsll((unsigned long long)eq0) - 1 : 64 + __ffsll((unsigned long long)eq1) - 1;
@@ -1580,6 +1606,7 @@ static int bits_for(uint32_t maxv) {
 
 static bool filter_enabled(const mhip_params* P);
 static bool fused_enabled(const mhip_params* P);
+static bool predrop_enabled();
 
 // the reads with local index in [ib, ie) of the selection
 static int seed_batch(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref, const mhip_volume* reads, const ReadSel sel,
@@ -1609,6 +1636,8 @@ static int seed_batch(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref
            (const uint32_t*)idx->d_starts, A, (unsigned long long*)c->d_counters);
     const int gate = 2 * P->min_kmer_match;
     const int nbits = bits_for((uint32_t)(ref->num_bases / ZV));
+    const RefReads RR{(const mhip_offset_t*)ref->d_offs, (const uint32_t*)ref->d_blk2read, ref->num_reads, ref->start_read_id, reads->start_read_id,
+                      predrop_enabled() ? 1 : 0};
 
     // ---- the strand-resident pipeline (seed_strand): tables of the strands it takes, in arrays handed out by an atomic cursor
     SeedArrays F = A;
@@ -1635,7 +1664,7 @@ static int seed_batch(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref
         HIPCHK(hipMemsetAsync(d_ctl, 0, sizeof(FusedCtl), c->stream));
         LAUNCH(c, "seed_strand", seed_strand, ns, FS_THREADS, 0, (const mhip_offset_t*)reads->d_offs, sel, ib, (const uint16_t*)idx->d_slots,
                (const int32_t*)idx->d_offsets, F, gate, std::max(0, nbits - FLT_BITS), (int)P->min_kmer_match, P->ddfs_cutoff,
-               (unsigned long long)capF, d_ctl, (unsigned long long*)c->d_counters);
+               (unsigned long long)capF, d_ctl, (unsigned long long*)c->d_counters, RR);
         FusedCtl ctl;
         HIPCHK(hipMemcpyAsync(&ctl, d_ctl, sizeof(ctl), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));   // also orders the kmb host buffer
@@ -1686,7 +1715,7 @@ static int seed_batch(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref
                 in_b ^= 1;
             }
         }
-        LAUNCH(c, "seed_build", seed_build, ns, SEED_BLOCK, 0, B, in_b, (int)P->min_kmer_match, P->ddfs_cutoff);
+        LAUNCH(c, "seed_build", seed_build, ns, SEED_BLOCK, 0, B, in_b, (int)P->min_kmer_match, P->ddfs_cutoff, sel, ib, RR);
     }
     size_t lds = sizeof(int) * 12 * (size_t)P->maxc + sizeof(CandLds);
     if (const char* e = getenv("MECAT_CAND_LDS_PAD")) lds += (size_t)atoi(e);      // development: fewer waves per CU
@@ -1701,6 +1730,11 @@ static bool filter_enabled(const mhip_params* P) {
     // the filter needs a gate high enough to separate signal from random hits; below that every hit is kept
     const char* fe = getenv("MECAT_SEED_FILTER");      // debug knob: 0 disables the relevance filter
     return 2 * P->min_kmer_match >= 6 && !(fe && atoi(fe) == 0);
+}
+
+static bool predrop_enabled() {
+    const char* e = getenv("MECAT_SEED_PREDROP");      // debug knob: 0 lists every gated segment
+    return !(e && atoi(e) == 0);
 }
 
 static bool fused_enabled(const mhip_params* P) {

@@ -18,3 +18,5 @@ for it in range(2):
 for k, (c, ms) in sorted(ctx.kernel_stats().items(), key=lambda kv: -kv[1][1]):
     print("  %-16s %3d launches %8.2f ms" % (k, c, ms))
 print("fused", ctx.debug_counter(13), "chain", ctx.debug_counter(14))
+if os.environ.get("CAND_STATS"):
+    print("cand: gated iterations %d, reached the vote %d, maxval < 5: %d, entries voted on %d" % tuple(ctx.debug_counter(i) for i in (9, 10, 11, 12)))

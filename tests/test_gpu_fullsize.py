@@ -115,6 +115,12 @@ def test_candidates_full_size(full):
     assert np.array_equal(cnt, n2)
     assert np.array_equal(cands[mask], c2[mask])
     del c2
+    # every gated segment listed (no early drop of the segments whose subjects all have higher ids)
+    with _Env(MECAT_SEED_PREDROP="0"):
+        c2, n2 = M.seed_reads(ctx, idx, vol, vol, 0, n, p)
+    assert np.array_equal(cnt, n2)
+    assert np.array_equal(cands[mask], c2[mask])
+    del c2
     # independent implementation: no relevance filter
     with _Env(MECAT_SEED_FILTER="0"):
         c2, n2 = M.seed_reads(ctx, idx, vol, vol, 0, n, p)

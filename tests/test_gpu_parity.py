@@ -156,6 +156,23 @@ def test_strand_pipeline_equals_kernel_chain(hip, ctx):
         assert np.array_equal(got[r][: cnt[r]], got2[r][: cnt[r]]), r
 
 
+@pytest.mark.parametrize("name", ["tiny", "tiny_ont", "config1"])
+def test_early_drop_of_higher_id_subjects_changes_nothing(name, hip, ctx):
+    """gated segments whose possible subject reads all have a higher id than the query are not listed for get_candidates (it
+    drops them at `sid > read_id`, pw_impl.cpp:370, after the vote and before any write): same lists with and without"""
+    d = dataset(name, hip, ctx)
+    p = hip.default_params(d["tech"])
+    got, cnt = _gpu_cands(hip, ctx, d, p)
+    os.environ["MECAT_SEED_PREDROP"] = "0"
+    try:
+        got2, cnt2 = _gpu_cands(hip, ctx, d, p)
+    finally:
+        del os.environ["MECAT_SEED_PREDROP"]
+    assert np.array_equal(cnt, cnt2)
+    for r in range(len(cnt)):
+        assert np.array_equal(got[r][: cnt[r]], got2[r][: cnt[r]]), r
+
+
 def test_strand_pipeline_out_of_room_falls_back(hip, ctx):
     """the tables of the strands seed_strand takes live in arrays handed out by an atomic cursor; a strand that finds them full
     is left to the kernel chain: same lists whatever the room"""

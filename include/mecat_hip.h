@@ -113,6 +113,9 @@ int  mhip_volume_num_bases(const mhip_volume* v);
 
 /* index of one volume (k = 13).  Buckets with more than 128 occurrences are empty; bucket contents ascend. */
 int  mhip_index_build(mhip_ctx* ctx, const mhip_volume* v, mhip_index** out);
+/* the same table with another bucket cap (1..256): mecat2canu's overlappers drop buckets of more than 256 occurrences
+   (mecat2asmpw.c:307-314 sumvalue_x) where mecat2pw drops those above 128; everything else about the table is the same */
+int  mhip_index_build_ex(mhip_ctx* ctx, const mhip_volume* v, int max_bucket, mhip_index** out);
 void mhip_index_free(mhip_index* idx);                       /* waits for the device: work queued through *_dev calls may still read it */
 int64_t mhip_index_num_kmers(const mhip_index* idx);
 /* parity/debug: counts[4^13] (kept occurrences) and/or offsets[num_kmers]; either may be NULL */

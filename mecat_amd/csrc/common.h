@@ -83,6 +83,7 @@ struct mhip_index {
     uint16_t* d_slots = nullptr;    // [num_kmers] (position / 2000) mod 2^15: all the relevance filter's bucket walk needs, at half the bytes
     int64_t num_kmers = 0;
     int num_bases = 0;
+    int max_bucket = MAX_BUCKET;    // buckets with more occurrences are empty (128: lookup_table.cpp:97; 256: mecat2asmpw.c:311)
     size_t cap_starts = 0, cap_offsets = 0, cap_slots = 0;   // allocation sizes, for the recycler below
 };
 

@@ -235,6 +235,7 @@ __device__ __forceinline__ void sort_small_buckets(unsigned long long todo, uint
 }
 
 __device__ __forceinline__ void bitonic128(int& a, int& b);
+__device__ __noinline__ void bitonic256(int32_t* p, const int n);
 
 // every bucket of the wave's 64 lanes ([s0, e1) per lane, <= 128 entries) ascending: the reference's fill order
 __device__ __forceinline__ void sort_wave_buckets(uint32_t s0, uint32_t e1, int32_t* data) {
@@ -253,14 +254,52 @@ __device__ __forceinline__ void sort_wave_buckets(uint32_t s0, uint32_t e1, int3
             int x = lane < n ? data[st + lane] : 0x7fffffff;
             x = bitonic64(x);
             if (lane < n) data[st + lane] = x;
-        } else {
+        } else if (n <= 128) {
             int a = data[st + lane];
             int c2 = lane + 64 < n ? data[st + 64 + lane] : 0x7fffffff;
             bitonic128(a, c2);
             data[st + lane] = a;
             if (lane + 64 < n) data[st + 64 + lane] = c2;
+        } else {
+            bitonic256(data + st, n);       // only an index built with a bucket cap above 128 has these (mhip_index_build_ex)
         }
     }
+}
+
+// ascending sort of n <= 256 non-negative values by one wave: bitonic network, element q * 64 + lane in register v[q]
+__device__ __noinline__ void bitonic256(int32_t* p, const int n) {
+    const int lane = lane_id();
+    int v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int i = q * 64 + lane; v[q] = i < n ? p[i] : 0x7fffffff; }
+#pragma unroll
+    for (int k = 2; k <= 256; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 64) {
+                const int dq = j >> 6;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if ((q & dq) == 0) {
+                        const int a = v[q], b = v[q | dq];
+                        const bool asc = ((q * 64) & k) == 0;
+                        v[q] = asc ? min(a, b) : max(a, b);
+                        v[q | dq] = asc ? max(a, b) : min(a, b);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int o = __shfl_xor(v[q], j);
+                    const bool asc = (((q * 64 + lane) & k) == 0), lower = (lane & j) == 0;
+                    v[q] = (asc == lower) ? min(v[q], o) : max(v[q], o);
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int i = q * 64 + lane; if (i < n) p[i] = v[q]; }
 }
 
 // ascending bitonic sort of 128 values: element i in lane i (a) and element 64+i in lane i (b)
@@ -496,7 +535,8 @@ __global__ __launch_bounds__(IDX_BLOCK) void idx_scatter2(const uint64_t* __rest
 // total, and the entry ranges of its 64 sub-bins (all occurrences, dropped buckets included) for the level-3 scatter
 __global__ __launch_bounds__(BIN_THREADS) void idx_bin_count(const uint64_t* __restrict__ ent2, const uint32_t* __restrict__ fine_base,
                                                              uint32_t* __restrict__ starts, uint32_t* __restrict__ bintot,
-                                                             uint32_t* __restrict__ sub_base, uint32_t* __restrict__ cur3, int fine0) {
+                                                             uint32_t* __restrict__ sub_base, uint32_t* __restrict__ cur3, int fine0,
+                                                             uint32_t max_bucket) {
     __shared__ uint32_t cnt[IDS_PER_FINE];     // 64 KB
     __shared__ uint32_t wtot[BIN_THREADS / WAVE];
     __shared__ uint32_t subtot[NSUB];
@@ -508,7 +548,7 @@ __global__ __launch_bounds__(BIN_THREADS) void idx_bin_count(const uint64_t* __r
     __syncthreads();
     uint32_t s = 0;
     for (int i = threadIdx.x; i < IDS_PER_FINE; i += BIN_THREADS) {
-        const uint32_t k = kept(cnt[i]);
+        const uint32_t k = cnt[i] > max_bucket ? 0u : cnt[i];
         starts[(size_t)b * IDS_PER_FINE + i] = k;
         s += k;
     }
@@ -711,7 +751,7 @@ static int index_build_binned(mhip_ctx* c, const mhip_volume* v, mhip_index* idx
         uint64_t* e2v = d_e2 - gbase;                    // the kernels index ent2 by volume-wide entry positions
         if (gx) LAUNCH(c, "idx_scatter2", idx_scatter2, dim3(gx, IDX_GROUP), IDX_BLOCK, 0, (const uint64_t*)d_e1, (const uint32_t*)d_fbase, d_cur2, e2v, c0);
         LAUNCH(c, "idx_bin_count", idx_bin_count, nf, BIN_THREADS, 0, (const uint64_t*)e2v, (const uint32_t*)d_fbase, idx->d_starts, d_bintot,
-               d_subbase, d_cur3, f0);
+               d_subbase, d_cur3, f0, (uint32_t)idx->max_bucket);
         if (gx3) LAUNCH(c, "idx_scatter3", idx_scatter3, dim3(gx3, nf), IDX_BLOCK, 0, (const uint64_t*)e2v, (const uint32_t*)d_fbase, d_cur3, d_e1, f0);
     }
     TRACE("scatter");
@@ -761,13 +801,21 @@ static int index_add_slots(mhip_ctx* c, mhip_index* idx) {
 
 extern "C" {
 
-int mhip_index_build(mhip_ctx* c, const mhip_volume* v, mhip_index** out) {
+int mhip_index_build(mhip_ctx* c, const mhip_volume* v, mhip_index** out) { return mhip_index_build_ex(c, v, MAX_BUCKET, out); }
+
+int mhip_index_build_ex(mhip_ctx* c, const mhip_volume* v, int max_bucket, mhip_index** out) {
     *out = nullptr;
     HIPCHK(hipSetDevice(c->device));
+    if (max_bucket < 1 || max_bucket > 256) { mhip_set_error("bucket cap %d outside 1..256", max_bucket); return -1; }
+    {
+        const char* e = getenv("MECAT_IDX_BUILD");
+        if (e && atoi(e) == 1 && max_bucket != MAX_BUCKET) { mhip_set_error("MECAT_IDX_BUILD=1 (direct atomic walks) only builds with the default bucket cap"); return -1; }
+    }
     const double tb0 = now_ms();
     mhip_index* idx = new mhip_index();
     idx->device = c->device;
     idx->num_bases = v->num_bases;
+    idx->max_bucket = max_bucket;
     uint32_t* d_counts = nullptr;
     uint32_t* d_partial = nullptr;
     if (c->scratch("idx_counts", sizeof(uint32_t) * (size_t)NKMER, (void**)&d_counts)) { delete idx; return -1; }

@@ -80,6 +80,7 @@ def lib():
     L.mhip_volume_num_reads.argtypes = [vp]
     L.mhip_volume_num_bases.argtypes = [vp]
     L.mhip_index_build.argtypes = [vp, vp, C.POINTER(vp)]
+    L.mhip_index_build_ex.argtypes = [vp, vp, i32, C.POINTER(vp)]
     L.mhip_index_free.argtypes = [vp]
     L.mhip_index_num_kmers.restype = i64
     L.mhip_index_num_kmers.argtypes = [vp]
@@ -210,10 +211,13 @@ class Volume:
 
 
 class Index:
-    def __init__(self, ctx, vol):
+    def __init__(self, ctx, vol, max_bucket=None):
         self.h = C.c_void_p()
         self.ctx = ctx
-        _chk(lib().mhip_index_build(ctx.h, vol.h, C.byref(self.h)))
+        if max_bucket is None:
+            _chk(lib().mhip_index_build(ctx.h, vol.h, C.byref(self.h)))
+        else:
+            _chk(lib().mhip_index_build_ex(ctx.h, vol.h, int(max_bucket), C.byref(self.h)))
 
     @property
     def num_kmers(self):

@@ -1717,8 +1717,7 @@ static int seed_batch(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref
         }
         LAUNCH(c, "seed_build", seed_build, ns, SEED_BLOCK, 0, B, in_b, (int)P->min_kmer_match, P->ddfs_cutoff, sel, ib, RR);
     }
-    size_t lds = sizeof(int) * 12 * (size_t)P->maxc + sizeof(CandLds);
-    if (const char* e = getenv("MECAT_CAND_LDS_PAD")) lds += (size_t)atoi(e);      // development: fewer waves per CU
+    const size_t lds = sizeof(int) * 12 * (size_t)P->maxc + sizeof(CandLds);
     LAUNCH(c, "seed_cand", seed_cand, nr, WAVE, lds, F, B, (const mhip_offset_t*)ref->d_offs, (const uint32_t*)ref->d_blk2read, ref->num_reads,
            ref->start_read_id,
            (const mhip_offset_t*)reads->d_offs, sel, ib, reads->start_read_id, *P, d_out, d_counts, (unsigned long long*)c->d_counters);

@@ -468,8 +468,9 @@ void volume_set_async_dump(bool on) {
 }
 
 void volume_wait_pending() {
-    if (g_pending.joinable()) g_pending.join();
-    if (g_unmapper.joinable()) g_unmapper.join();
+    // (an error exit from the writer thread itself runs the atexit handler on that thread: nothing to wait for then)
+    if (g_pending.joinable() && g_pending.get_id() != std::this_thread::get_id()) g_pending.join();
+    if (g_unmapper.joinable() && g_unmapper.get_id() != std::this_thread::get_id()) g_unmapper.join();
 }
 
 void volume_release_input() {

@@ -280,7 +280,7 @@ void dev_free_recycled(int device, void* p, size_t cap) {
         size_t n = 0, smallest = (size_t)-1;
         for (size_t i = 0; i < g_parked.size(); ++i)
             if (g_parked[i].device == device) { ++n; if (smallest == (size_t)-1 || g_parked[i].cap < g_parked[smallest].cap) smallest = i; }
-        if (n >= 3) {
+        if (n >= 4) {
             if (g_parked[smallest].cap < cap) { drop = g_parked[smallest].p; g_parked[smallest] = Parked{device, p, cap}; }
             else drop = p;
         } else g_parked.push_back(Parked{device, p, cap});

@@ -83,16 +83,23 @@ struct mhip_index {
     uint16_t* d_slots = nullptr;    // [num_kmers] (position / 2000) mod 2^15: all the relevance filter's bucket walk needs, at half the bytes
     int64_t num_kmers = 0;
     int num_bases = 0;
+    // bucket records for the seeding of a diagonal grid cell (index.hip: index_ensure_cuts): per k-mer id {start, occurrences below
+    // each of seven position cuts, occurrences}; built on first use
+    uint4* d_recs = nullptr;
+    int cut_step = 0;               // cut t (1..7) = position t * cut_step
+    std::mutex recs_mu;
     int max_bucket = MAX_BUCKET;    // buckets with more occurrences are empty (128: lookup_table.cpp:97; 256: mecat2asmpw.c:311)
-    size_t cap_starts = 0, cap_offsets = 0, cap_slots = 0;   // allocation sizes, for the recycler below
+    size_t cap_starts = 0, cap_offsets = 0, cap_slots = 0, cap_recs = 0;   // allocation sizes, for the recycler below
 };
 
 // Recycler for the index's two large device arrays: a per-read-volume rebuild (one per `-j` grid row) otherwise pays a
-// multi-GB hipMalloc + hipFree (~0.2 s) every time.  Freed blocks are parked per device (at most three) and handed back
+// multi-GB hipMalloc + hipFree (~0.2 s) every time.  Freed blocks are parked per device (at most four) and handed back
 // to the next request they fit without more than 2x slack; mhip_ctx_destroy releases what is parked.
 int dev_alloc_recycled(int device, size_t bytes, void** p, size_t* cap);
 void dev_free_recycled(int device, void* p, size_t cap);
 void dev_recycler_release(int device);
+// the bucket records of `idx` (built by the first caller; nullptr when the index cannot have them: bucket cap above 255)
+const uint4* index_ensure_cuts(mhip_ctx* c, const mhip_index* idx);
 
 // launch helper: optional HIP-event timing per kernel name on the context's stream
 struct LaunchTimer {

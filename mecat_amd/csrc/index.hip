@@ -647,7 +647,7 @@ __global__ __launch_bounds__(BIN_THREADS) void idx_bin_starts(const uint32_t* __
 // sweep.  A sub-bin with more kept positions than SUB_CAP (possible up to 256 x 128) does the same directly in global memory.
 __global__ __launch_bounds__(SUB_THREADS) void idx_sub_fill(const uint64_t* __restrict__ ent3, const uint32_t* __restrict__ sub_base,
                                                             const uint32_t* __restrict__ starts, int32_t* __restrict__ offsets,
-                                                            uint16_t* __restrict__ slots) {
+                                                            uint16_t* __restrict__ slots, uint4* __restrict__ recs, int cut_step) {
     __shared__ uint32_t lstart[IDS_PER_SUB + 1];
     __shared__ uint32_t cursor[IDS_PER_SUB];
     __shared__ int32_t buf[SUB_CAP];
@@ -660,7 +660,10 @@ __global__ __launch_bounds__(SUB_THREADS) void idx_sub_fill(const uint64_t* __re
     if (threadIdx.x == 0) lstart[IDS_PER_SUB] = starts[id0 + IDS_PER_SUB] - first;
     __syncthreads();
     const uint32_t total = lstart[IDS_PER_SUB];
-    if (total == 0) return;
+    if (total == 0) {
+        if (recs) recs[id0 + threadIdx.x] = make_uint4(first, 0u, 0u, 0u);
+        return;
+    }
     const bool in_lds = total <= SUB_CAP;
     int32_t* gdst = offsets + first;
     const uint32_t eb = sub_base[sb], ee = sub_base[sb + 1];
@@ -682,6 +685,24 @@ __global__ __launch_bounds__(SUB_THREADS) void idx_sub_fill(const uint64_t* __re
     }
     // positions out, and with them each position's slot in the seeding stage's relevance table: (position / ZV) mod 2^15, ZV = 2000
     __syncthreads();
+    if (recs) {
+        // the bucket record of this thread's k-mer id (see idx_cut_records): the sorted bucket is at hand, one pass against the
+        // ascending cuts
+        const uint32_t b0 = lstart[threadIdx.x], b1 = lstart[threadIdx.x + 1];
+        uint32_t below[7];
+        int t = 0;
+        for (uint32_t i = b0; i < b1 && t < 7; ++i) {
+            const int pos = in_lds ? buf[i] : gdst[i];
+            while (t < 7 && pos >= (t + 1) * cut_step) below[t++] = i - b0;
+        }
+        while (t < 7) below[t++] = b1 - b0;
+        uint4 r;
+        r.x = first + b0;
+        r.y = below[0] | (below[1] << 8) | (below[2] << 16) | (below[3] << 24);
+        r.z = below[4] | (below[5] << 8) | (below[6] << 16) | ((b1 - b0) << 24);
+        r.w = 0;
+        recs[id0 + threadIdx.x] = r;
+    }
     if (in_lds) {
         for (uint32_t i = threadIdx.x; i < total; i += SUB_THREADS) {
             const int32_t pos = buf[i];
@@ -766,8 +787,16 @@ static int index_build_binned(mhip_ctx* c, const mhip_volume* v, mhip_index* idx
     TRACE("malloc offsets");
     HIPCHK(hipMemcpyAsync(idx->d_starts + NKMER, d_binout + NFINE, sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
     if (dev_alloc_recycled(c->device, sizeof(uint16_t) * ((size_t)total + 64), (void**)&idx->d_slots, &idx->cap_slots)) return -1;
+    // bucket records with the prefix counts at seven position cuts (idx_cut_records): written by the kernel that has every sorted
+    // bucket in LDS anyway
+    if (idx->max_bucket <= 255 && dev_alloc_recycled(c->device, sizeof(uint4) * (size_t)NKMER, (void**)&idx->d_recs, &idx->cap_recs) == 0) {
+        const int segs = (idx->num_bases + 2000 - 1) / 2000;
+        idx->cut_step = ((segs + 7) / 8) * 2000;
+    } else {
+        idx->d_recs = nullptr;
+    }
     LAUNCH(c, "idx_sub_fill", idx_sub_fill, NFINE * NSUB, SUB_THREADS, 0, (const uint64_t*)d_e1, (const uint32_t*)d_subbase,
-           (const uint32_t*)idx->d_starts, idx->d_offsets, idx->d_slots);
+           (const uint32_t*)idx->d_starts, idx->d_offsets, idx->d_slots, idx->d_recs, idx->cut_step);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     TRACE("bin_fill");
@@ -790,6 +819,47 @@ __global__ __launch_bounds__(256) void idx_slots(const int32_t* __restrict__ off
 
 // The relevance filter of the seeding stage only needs each position's 2 kb-segment slot (15 bits): a second array at half the
 // bytes halves the sectors its bucket walk touches.
+// ---- bucket records with prefix counts at seven position cuts (seed.hip: the probe of a diagonal grid cell).
+// A query read of the reference volume itself only needs the bucket entries in front of its own copy (+ a few segments):
+// everything behind belongs to reads with higher ids, whose candidates get_candidates drops (pw_impl.cpp:370).  Bucket entries are
+// ascending positions, so "in front of position P" is a prefix of every bucket, and its length for seven fixed cuts P fits the
+// 16-byte record the probe reads anyway instead of two words of starts[]: x = start, the bytes of y:z = occurrences below cut
+// 1..7 and, last, all occurrences (<= 255), w = 0.
+__global__ __launch_bounds__(256) void idx_cut_records(const uint32_t* __restrict__ starts, const int32_t* __restrict__ offsets, int cut_step,
+                                                      uint4* __restrict__ recs) {
+    const uint32_t id = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t s0 = starts[id], s1 = starts[id + 1];
+    uint32_t below[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t i = s0; i < s1; ++i) {
+        const int pos = offsets[i];
+#pragma unroll
+        for (int t = 0; t < 7; ++t) below[t] += pos < (t + 1) * cut_step ? 1u : 0u;
+    }
+    uint4 r;
+    r.x = s0;
+    r.y = below[0] | (below[1] << 8) | (below[2] << 16) | (below[3] << 24);
+    r.z = below[4] | (below[5] << 8) | (below[6] << 16) | ((s1 - s0) << 24);
+    r.w = 0;
+    recs[id] = r;
+}
+
+const uint4* index_ensure_cuts(mhip_ctx* c, const mhip_index* cidx) {
+    mhip_index* idx = const_cast<mhip_index*>(cidx);          // a cache inside the handle
+    if (idx->max_bucket > 255) return nullptr;
+    std::lock_guard<std::mutex> lk(idx->recs_mu);
+    if (idx->d_recs) return idx->d_recs;
+    if (hipSetDevice(c->device) != hipSuccess) return nullptr;
+    uint4* p = nullptr;
+    if (dev_alloc_recycled(c->device, sizeof(uint4) * (size_t)NKMER, (void**)&p, &idx->cap_recs)) return nullptr;   // no room: no cuts
+    // cuts at multiples of a whole number of segments, the eighth at or behind the end of the volume
+    const int segs = (idx->num_bases + 2000 - 1) / 2000;
+    idx->cut_step = ((segs + 7) / 8) * 2000;
+    LAUNCH(c, "idx_cut_records", idx_cut_records, NKMER / 256, 256, 0, (const uint32_t*)idx->d_starts, (const int32_t*)idx->d_offsets, idx->cut_step, p);
+    if (hipStreamSynchronize(c->stream) != hipSuccess) { dev_free_recycled(c->device, p, idx->cap_recs); return nullptr; }
+    idx->d_recs = p;
+    return p;
+}
+
 static int index_add_slots(mhip_ctx* c, mhip_index* idx) {
     if (idx->num_kmers <= 0 || idx->d_slots) return 0;      // the binned build writes the slots with the positions
     if (dev_alloc_recycled(c->device, sizeof(uint16_t) * ((size_t)idx->num_kmers + 64), (void**)&idx->d_slots, &idx->cap_slots)) return -1;
@@ -872,6 +942,7 @@ void mhip_index_free(mhip_index* idx) {
     dev_free_recycled(idx->device, idx->d_starts, idx->cap_starts);
     dev_free_recycled(idx->device, idx->d_offsets, idx->cap_offsets);
     dev_free_recycled(idx->device, idx->d_slots, idx->cap_slots);
+    dev_free_recycled(idx->device, idx->d_recs, idx->cap_recs);
     delete idx;
 }
 

@@ -111,9 +111,15 @@ __host__ __device__ __forceinline__ int sel_rid(const ReadSel& s, int i) {
 }
 
 // ------------------------------------------------------------------------------------------------ probe
+// `recs` (index.hip: idx_cut_records) replaces starts[] when reference and query volume are the same one (a diagonal grid cell):
+// the bucket of a query k-mer is cut at the first of seven fixed positions behind the read's own copy + 5 segments.  What lies
+// behind belongs to reads with higher ids: get_candidates drops their candidates at `sid > read_id` (pw_impl.cpp:370) before it writes
+// anything, the sweeps of a kept candidate stay within 3 segments of its subject read's end (num2 <= send - loc_list, :399-403,
+// 424-438), index_score looks at the left neighbour only (:270-280) — so those hits cannot reach the output, and half of the
+// bucket walk of a diagonal cell is not done.  counters[1] still counts every bucket hit (the H of SURVEY.md §8d).
 __global__ __launch_bounds__(SEED_BLOCK) void seed_probe(const uint32_t* __restrict__ pac, const mhip_offset_t* __restrict__ roffs,
                                                          ReadSel sel, int ib, const uint32_t* __restrict__ starts, SeedArrays A,
-                                                         unsigned long long* __restrict__ counters) {
+                                                         unsigned long long* __restrict__ counters, const uint4* __restrict__ recs, int cut_step) {
     __shared__ uint32_t wtot[SEED_WAVES];
     const int s = blockIdx.x;
     const int rid = sel_rid(sel, ib + (s >> 1));
@@ -121,29 +127,52 @@ __global__ __launch_bounds__(SEED_BLOCK) void seed_probe(const uint32_t* __restr
     const int off = roffs[rid].offset, L = roffs[rid].size;
     const int K = kmers_of(L);
     const uint32_t kb = A.km_base[s];
-    uint32_t run = 0;
+    // byte of the record's y:z that holds the bucket length for this read: cut t = ceil((end of the read + 5 segments) / step)
+    int cut_byte = 7;
+    if (recs) {
+        const long long need = (long long)off + L + 1 + 5 * ZV;
+        const long long t = (need + cut_step - 1) / cut_step;
+        if (t <= 7) cut_byte = (int)t - 1;
+    }
+    uint32_t run = 0, run_all = 0;
     for (int t0 = 0; t0 < K; t0 += SEED_BLOCK) {
         int km = t0 + threadIdx.x;
-        uint32_t cnt = 0, bs = 0;
+        uint32_t cnt = 0, all = 0, bs = 0;
         if (km < K) {
             uint32_t id;
             if (!rev) id = pac_kmer(pac, (int64_t)off + (int64_t)km * BC);
             else id = kmer_revcomp(pac_kmer(pac, (int64_t)off + L - MHIP_KMER_SIZE - (int64_t)km * BC));
-            bs = starts[id];
-            cnt = starts[id + 1] - bs;
+            if (recs) {
+                const uint4 r = recs[id];
+                const unsigned long long yz = ((unsigned long long)r.z << 32) | r.y;
+                bs = r.x;
+                all = r.z >> 24;
+                cnt = (uint32_t)(yz >> (8 * cut_byte)) & 0xFFu;
+            } else {
+                bs = starts[id];
+                all = cnt = starts[id + 1] - bs;
+            }
         }
         uint32_t tot;
-        (void)block_excl_scan(cnt, wtot, &tot);
+        if (recs) {
+            (void)block_excl_scan(cnt | (all << 16), wtot, &tot);      // both sums in one scan: <= 256 x 255 each
+            run += tot & 0xFFFFu;
+            run_all += tot >> 16;
+        } else {
+            (void)block_excl_scan(cnt, wtot, &tot);
+            run += tot;
+            run_all += tot;
+        }
         if (km < K) {
             A.km_bstart[kb + km] = bs;
             A.km_cnt[kb + km] = cnt;
         }
-        run += tot;
     }
     if (threadIdx.x == 0) {
         A.strand_hits_all[s] = run;
         atomicAdd(&counters[0], (unsigned long long)K);
-        atomicAdd(&counters[1], (unsigned long long)run);
+        atomicAdd(&counters[1], (unsigned long long)run_all);
+        if (recs) atomicAdd(&counters[15], (unsigned long long)run);      // debug slot 15: bucket hits walked with the cuts on
     }
 }
 
@@ -1607,6 +1636,7 @@ static int bits_for(uint32_t maxv) {
 static bool filter_enabled(const mhip_params* P);
 static bool fused_enabled(const mhip_params* P);
 static bool predrop_enabled();
+static bool cuts_enabled(const mhip_params* P);
 
 // the reads with local index in [ib, ie) of the selection
 static int seed_batch(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref, const mhip_volume* reads, const ReadSel sel,
@@ -1632,8 +1662,10 @@ static int seed_batch(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref
     A.km_base = d_kmb;
     HIPCHK(hipMemcpyAsync(d_kmb, kmb.data(), sizeof(uint32_t) * (size_t)ns, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemsetAsync(A.fused, 0, sizeof(int32_t) * (size_t)ns, c->stream));
+    // a diagonal grid cell (the query volume IS the reference volume): buckets cut behind each read's own copy
+    const uint4* recs = (ref == reads && cuts_enabled(P)) ? index_ensure_cuts(c, idx) : nullptr;
     LAUNCH(c, "seed_probe", seed_probe, ns, SEED_BLOCK, 0, (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs, sel, ib,
-           (const uint32_t*)idx->d_starts, A, (unsigned long long*)c->d_counters);
+           (const uint32_t*)idx->d_starts, A, (unsigned long long*)c->d_counters, recs, recs ? idx->cut_step : 1);
     const int gate = 2 * P->min_kmer_match;
     const int nbits = bits_for((uint32_t)(ref->num_bases / ZV));
     const RefReads RR{(const mhip_offset_t*)ref->d_offs, (const uint32_t*)ref->d_blk2read, ref->num_reads, ref->start_read_id, reads->start_read_id,
@@ -1729,6 +1761,12 @@ static bool filter_enabled(const mhip_params* P) {
     // the filter needs a gate high enough to separate signal from random hits; below that every hit is kept
     const char* fe = getenv("MECAT_SEED_FILTER");      // debug knob: 0 disables the relevance filter
     return 2 * P->min_kmer_match >= 6 && !(fe && atoi(fe) == 0);
+}
+
+static bool cuts_enabled(const mhip_params* P) {
+    (void)P;
+    const char* e = getenv("MECAT_SEED_CUTS");         // debug knob: 0 walks every bucket to its end
+    return !(e && atoi(e) == 0);
 }
 
 static bool predrop_enabled() {

@@ -115,6 +115,14 @@ def test_candidates_full_size(full):
     assert np.array_equal(cnt, n2)
     assert np.array_equal(cands[mask], c2[mask])
     del c2
+    # buckets walked to their ends (no cut behind the read's own copy)
+    walked, hits = ctx.debug_counter(15), ctx.counters()["hits"]
+    assert 0.4 * hits < walked < 0.7 * hits, (walked, hits)
+    with _Env(MECAT_SEED_CUTS="0"):
+        c2, n2 = M.seed_reads(ctx, idx, vol, vol, 0, n, p)
+    assert np.array_equal(cnt, n2)
+    assert np.array_equal(cands[mask], c2[mask])
+    del c2
     # every gated segment listed (no early drop of the segments whose subjects all have higher ids)
     with _Env(MECAT_SEED_PREDROP="0"):
         c2, n2 = M.seed_reads(ctx, idx, vol, vol, 0, n, p)

@@ -163,14 +163,15 @@ def test_early_drop_of_higher_id_subjects_changes_nothing(name, hip, ctx):
     d = dataset(name, hip, ctx)
     p = hip.default_params(d["tech"])
     got, cnt = _gpu_cands(hip, ctx, d, p)
-    os.environ["MECAT_SEED_PREDROP"] = "0"
-    try:
-        got2, cnt2 = _gpu_cands(hip, ctx, d, p)
-    finally:
-        del os.environ["MECAT_SEED_PREDROP"]
-    assert np.array_equal(cnt, cnt2)
-    for r in range(len(cnt)):
-        assert np.array_equal(got[r][: cnt[r]], got2[r][: cnt[r]]), r
+    for knob in ("MECAT_SEED_PREDROP", "MECAT_SEED_CUTS"):      # (the second: buckets not cut behind the read's own copy)
+        os.environ[knob] = "0"
+        try:
+            got2, cnt2 = _gpu_cands(hip, ctx, d, p)
+        finally:
+            del os.environ[knob]
+        assert np.array_equal(cnt, cnt2)
+        for r in range(len(cnt)):
+            assert np.array_equal(got[r][: cnt[r]], got2[r][: cnt[r]]), (knob, r)
 
 
 def test_strand_pipeline_out_of_room_falls_back(hip, ctx):
@@ -187,7 +188,7 @@ def test_strand_pipeline_out_of_room_falls_back(hip, ctx):
             took, left = ctx.debug_counter(13), ctx.debug_counter(14)
         finally:
             del os.environ["MECAT_SEED_FUSED_ROOM"]
-        assert left > 0 and (room > 64 or took == 0), (room, took, left)
+        assert left > 0 and (room > 64 or took <= 0.01 * left), (room, took, left)      # (a handful of early reads keep fewer than 64 hits: their buckets are cut right behind them)
         assert np.array_equal(cnt, c2)
         for r in range(len(cnt)):
             assert np.array_equal(got[r][: cnt[r]], full[r][: cnt[r]]), (room, r)

@@ -768,9 +768,16 @@ __global__ __launch_bounds__(SEED_BLOCK) void seed_build(SeedArrays A, int sorte
 #define FS_GATECAP 1024              // gated segments
 #define FS_OVF16 0x8000u
 #ifndef FS_Q1
-#define FS_Q1 2                      // walk 1: buckets per 16-lane group and stage, stages in flight
+// walk 1 / walk 2: lanes per bucket, pieces of a bucket loaded ahead, buckets per group and stage, stages in flight.  Measured at
+// config 2 (seed_strand per pass): 16 lanes x 3 pieces 46.1 ms, 8 x 4 43.4 ms, 8 x 3 45.0, 8 x 2 48.9, 4 x 8 50.4; three buckets per
+// stage or three stages in flight 45.3 - 45.8: a walk costs per bucket (its loads are issued whatever the bucket holds), not per hit
+#define FS_LPB1 8
+#define FS_NP1 4
+#define FS_Q1 2
 #define FS_D1 2
-#define FS_Q2 2                      // walk 2
+#define FS_LPB2 8
+#define FS_NP2 4
+#define FS_Q2 2
 #define FS_D2 2
 #endif
 
@@ -831,58 +838,66 @@ __device__ __forceinline__ uint32_t fs_excl_scan(uint32_t v, uint32_t* wtot, uin
     return base + incl - v;
 }
 
-// pipelined walk over the buckets of a strand; f(km, value) per hit.  16 lanes per bucket, Q buckets per group and stage, D stages
-// of bucket data in flight plus one stage of bucket headers (start, size) ahead of them.  The first 48 entries of a bucket are
-// loaded by the pipeline (three pieces of 16); a longer bucket reads the rest when it is consumed.
-template <int Q, int D, bool UNIFORM, typename T, typename F>
+// pipelined walk over the buckets of a strand; f(km, value) per hit.  LPB lanes per bucket, Q buckets per group and stage, D stages
+// of bucket data in flight plus one stage of bucket headers (start, size) ahead of them.  The first NP * LPB entries of a bucket are
+// loaded by the pipeline (NP pieces of LPB); a longer bucket reads the rest when it is consumed.
+template <int LPB, int NP, int Q, int D, bool UNIFORM, typename T, typename F>
 __device__ __forceinline__ void fs_walk(const uint32_t* __restrict__ kbs, const uint32_t* __restrict__ kcn, const T* __restrict__ arr, const int K, F f) {
-    constexpr int G = FS_THREADS / 16, STEP = Q * G;
-    const int g = threadIdx.x >> 4;
-    const uint32_t sub = threadIdx.x & 15u;
-    uint32_t hb[Q], hc[Q];                                        // headers of stage D (no data requested yet)
-    uint32_t sb[D][Q], sc[D][Q], s0[D][Q], s1[D][Q], s2[D][Q];    // stages 0 .. D-1: header and data
+    constexpr int G = FS_THREADS / LPB, STEP = Q * G;
+    const int g = threadIdx.x / LPB;
+    const uint32_t sub = threadIdx.x % LPB;
+    uint32_t hb[Q], hc[Q];                          // headers of stage D (no data requested yet)
+    uint32_t sb[D][Q], sc[D][Q], sd[D][Q][NP];      // stages 0 .. D-1: header and data
 #define FS_HDR(BASE, BS, CN)                                                      \
     _Pragma("unroll") for (int q = 0; q < Q; ++q) {                               \
         const int km_ = (BASE) + q * G + g;                                       \
         BS[q] = km_ < K ? kbs[km_] : 0u;                                          \
         CN[q] = km_ < K ? kcn[km_] : 0u;                                          \
     }
-#define FS_DAT(BS, CN, DA, DB, DC)                                                \
-    _Pragma("unroll") for (int q = 0; q < Q; ++q) {                               \
-        DA[q] = sub < CN[q] ? (uint32_t)arr[BS[q] + sub] : 0u;                    \
-        DB[q] = sub + 16u < CN[q] ? (uint32_t)arr[BS[q] + 16u + sub] : 0u;        \
-        DC[q] = sub + 32u < CN[q] ? (uint32_t)arr[BS[q] + 32u + sub] : 0u;        \
-    }
+#define FS_DAT(BS, CN, DD)                                                        \
+    _Pragma("unroll") for (int q = 0; q < Q; ++q)                                 \
+        _Pragma("unroll") for (int p = 0; p < NP; ++p)                            \
+            DD[q][p] = sub + (uint32_t)(p * LPB) < CN[q] ? (uint32_t)arr[BS[q] + (uint32_t)(p * LPB) + sub] : 0u;
 #pragma unroll
     for (int d = 0; d < D; ++d) { FS_HDR(d * STEP, sb[d], sc[d]) }
     FS_HDR(D * STEP, hb, hc)
 #pragma unroll
-    for (int d = 0; d < D; ++d) { FS_DAT(sb[d], sc[d], s0[d], s1[d], s2[d]) }
+    for (int d = 0; d < D; ++d) { FS_DAT(sb[d], sc[d], sd[d]) }
     for (int base = 0; base < K; base += STEP) {
-        uint32_t cb[Q], cc[Q], c0[Q], c1[Q], c2[Q];
+        uint32_t cb[Q], cc[Q], cd[Q][NP];
 #pragma unroll
-        for (int q = 0; q < Q; ++q) { cb[q] = sb[0][q]; cc[q] = sc[0][q]; c0[q] = s0[0][q]; c1[q] = s1[0][q]; c2[q] = s2[0][q]; }
+        for (int q = 0; q < Q; ++q) {
+            cb[q] = sb[0][q]; cc[q] = sc[0][q];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) cd[q][p] = sd[0][q][p];
+        }
 #pragma unroll
         for (int d = 0; d + 1 < D; ++d)
 #pragma unroll
-            for (int q = 0; q < Q; ++q) { sb[d][q] = sb[d + 1][q]; sc[d][q] = sc[d + 1][q]; s0[d][q] = s0[d + 1][q]; s1[d][q] = s1[d + 1][q]; s2[d][q] = s2[d + 1][q]; }
+            for (int q = 0; q < Q; ++q) {
+                sb[d][q] = sb[d + 1][q]; sc[d][q] = sc[d + 1][q];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) sd[d][q][p] = sd[d + 1][q][p];
+            }
 #pragma unroll
         for (int q = 0; q < Q; ++q) { sb[D - 1][q] = hb[q]; sc[D - 1][q] = hc[q]; }
-        FS_DAT(sb[D - 1], sc[D - 1], s0[D - 1], s1[D - 1], s2[D - 1])
+        FS_DAT(sb[D - 1], sc[D - 1], sd[D - 1])
         FS_HDR(base + (D + 1) * STEP, hb, hc)
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             const int km = base + q * G + g;
             if constexpr (UNIFORM) {            // f(km, value, valid) is called by the whole wave together
-                if (__any(sub < cc[q])) f(km, c0[q], sub < cc[q]);
-                if (__any(sub + 16u < cc[q])) f(km, c1[q], sub + 16u < cc[q]);
-                if (__any(sub + 32u < cc[q])) f(km, c2[q], sub + 32u < cc[q]);
-                for (uint32_t r = 48u + sub; __any(r < cc[q]); r += 16u) f(km, r < cc[q] ? (uint32_t)arr[cb[q] + r] : 0u, r < cc[q]);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const bool v = sub + (uint32_t)(p * LPB) < cc[q];
+                    if (__any(v)) f(km, cd[q][p], v);
+                }
+                for (uint32_t r = (uint32_t)(NP * LPB) + sub; __any(r < cc[q]); r += LPB) f(km, r < cc[q] ? (uint32_t)arr[cb[q] + r] : 0u, r < cc[q]);
             } else {
-                if (sub < cc[q]) f(km, c0[q]);
-                if (sub + 16u < cc[q]) f(km, c1[q]);
-                if (sub + 32u < cc[q]) f(km, c2[q]);
-                for (uint32_t r = 48u + sub; r < cc[q]; r += 16u) f(km, (uint32_t)arr[cb[q] + r]);
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+                    if (sub + (uint32_t)(p * LPB) < cc[q]) f(km, cd[q][p]);
+                for (uint32_t r = (uint32_t)(NP * LPB) + sub; r < cc[q]; r += LPB) f(km, (uint32_t)arr[cb[q] + r]);
             }
         }
     }
@@ -958,7 +973,7 @@ __global__ __launch_bounds__(FS_THREADS) void seed_strand(const mhip_offset_t* _
     if (tid < 8) L.misc[tid] = 0;
     __syncthreads();
     FS_MARK(0);
-    fs_walk<FS_Q1, FS_D1, false>(kbs, kcn, slots, K, [&](int, uint32_t e) { atomicAdd(&L.x.cnt32[e >> 1], 1u << ((e & 1u) * 16u)); });
+    fs_walk<FS_LPB1, FS_NP1, FS_Q1, FS_D1, false>(kbs, kcn, slots, K, [&](int, uint32_t e) { atomicAdd(&L.x.cnt32[e >> 1], 1u << ((e & 1u) * 16u)); });
     __syncthreads();
     FS_MARK(1);
 
@@ -1059,7 +1074,7 @@ __global__ __launch_bounds__(FS_THREADS) void seed_strand(const mhip_offset_t* _
             L.x.e.pay[p] = ((seg >> FLT_BITS) << 26) | (km << 11) | off;
             L.x.e.eslot[p] = (uint16_t)e;
         };
-        fs_walk<FS_Q2, FS_D2, true>(kbs, kcn, offsets, K, [&](int km, uint32_t pos, bool valid) {
+        fs_walk<FS_LPB2, FS_NP2, FS_Q2, FS_D2, true>(kbs, kcn, offsets, K, [&](int km, uint32_t pos, bool valid) {
             const uint32_t seg = pos / (uint32_t)ZV;
             const uint32_t e = seg & (FLT_M - 1);
             const uint32_t oc = valid ? L.occ[e >> 5] : 0u;

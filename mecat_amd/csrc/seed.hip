@@ -595,11 +595,13 @@ __device__ __forceinline__ int read_id_lookup(const mhip_offset_t* __restrict__ 
 // what the segment builders need to know about the reference volume: a gated segment whose every possible subject read has a
 // higher id than the query read is not listed (get_candidates would vote on it and then drop it at `sid > read_id`,
 // pw_impl.cpp:370, before anything is written: half of the gated segments of a diagonal grid cell)
-struct RefReads { const mhip_offset_t* offs; const uint32_t* blk; int nreads, start_id, reads_start_id, enable; };
+struct RefReads { const mhip_offset_t* offs; const uint32_t* blk; int nreads, start_id, reads_start_id, enable, same_volume; };
 // every location find_location can return for segment `seg` (with its left neighbour) lies at or behind the start of segment
-// seg - 1, and the read lookup is monotone in the position (a pad base belongs to the read before it)
-__device__ __forceinline__ bool subjects_all_higher(const RefReads& R, uint32_t seg, int rid) {
+// seg - 1, and the read lookup is monotone in the position (a pad base belongs to the read before it).  own_end = the first position
+// behind the query read's own copy and its pad, when the query volume is the reference volume: no lookup needed then.
+__device__ __forceinline__ bool subjects_all_higher(const RefReads& R, uint32_t seg, int rid, int own_end) {
     const int lo = (int)((seg > 0 ? seg - 1u : 0u) * (uint32_t)ZV);
+    if (R.same_volume) return lo >= own_end;
     return read_id_lookup(R.offs, R.nreads, R.blk, lo) + R.start_id > rid + R.reads_start_id;
 }
 
@@ -610,6 +612,8 @@ __global__ __launch_bounds__(SEED_BLOCK) void seed_build(SeedArrays A, int sorte
     __shared__ uint64_t s_tf[GATE_LDS];    // first-touch times of the gated segments (phase E)
     const int s = blockIdx.x;
     const uint32_t H = A.strand_hits[s];
+    const int own_rid = sel_rid(sel, ib + (s >> 1));
+    const int own_end = R.same_volume ? R.offs[own_rid].offset + R.offs[own_rid].size + 1 : 0;
     const uint64_t hb = A.hit_base[s];
     if (H == 0) {
         if (threadIdx.x == 0) { A.nseg[s] = 0; A.nrec[s] = 0; A.ngated[s] = 0; }
@@ -702,7 +706,7 @@ __global__ __launch_bounds__(SEED_BLOCK) void seed_build(SeedArrays A, int sorte
             if (lo > st) left = (seg_score[g - 1] & OVF_FLAG) ? (int)esc[lo - 1] : (int)(lo - st);
             s_k += left;
         }
-        if ((int)(int16_t)s_k >= 2 * min_kmer_match && !(R.enable && subjects_all_higher(R, sid, sel_rid(sel, ib + (s >> 1))))) {
+        if ((int)(int16_t)s_k >= 2 * min_kmer_match && !(R.enable && subjects_all_higher(R, sid, own_rid, own_end))) {
             uint32_t k = atomicAdd(&s_cnt[1], 1u);
             gate_tmp[k] = (uint64_t)g;   // index only; ordered below by seg_tfirst
         }
@@ -1266,7 +1270,7 @@ __global__ __launch_bounds__(FS_THREADS) void seed_strand(const mhip_offset_t* _
             }
         }
         bool listed = (int)(int16_t)s_k >= 2 * min_kmer_match;
-        if (listed && R.enable) listed = !subjects_all_higher(R, sid, rid);
+        if (listed && R.enable) listed = !subjects_all_higher(R, sid, rid, roffs[rid].offset + rlen + 1);
         if (listed) {
             const uint32_t k = atomicAdd(&L.misc[2], 1u);
             if (k < FS_GATECAP) {
@@ -1683,8 +1687,9 @@ static int seed_batch(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref
            (const uint32_t*)idx->d_starts, A, (unsigned long long*)c->d_counters, recs, recs ? idx->cut_step : 1);
     const int gate = 2 * P->min_kmer_match;
     const int nbits = bits_for((uint32_t)(ref->num_bases / ZV));
+    // (no subject can have a higher id than a query when the reference volume lies entirely before the query volume: nothing to drop)
     const RefReads RR{(const mhip_offset_t*)ref->d_offs, (const uint32_t*)ref->d_blk2read, ref->num_reads, ref->start_read_id, reads->start_read_id,
-                      predrop_enabled() ? 1 : 0};
+                      predrop_enabled() && !(ref != reads && ref->start_read_id + ref->num_reads <= reads->start_read_id) ? 1 : 0, ref == reads ? 1 : 0};
 
     // ---- the strand-resident pipeline (seed_strand): tables of the strands it takes, in arrays handed out by an atomic cursor
     SeedArrays F = A;

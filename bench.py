@@ -436,6 +436,13 @@ def main():
                                   "waves per SIMD); dw_extend2 runs 7 waves per SIMD (72 VGPRs, 21.5 KB LDS per 4 waves)")
                     if f4 is not None:
                         vi["valu_4cycle_fraction_static"] = f4
+                        # the guide's nominal issue rates (one wave64 VALU instruction per SIMD every 2 cycles for the simple class,
+                        # every 4 for the rest; 1024 SIMDs x 2.4 GHz), weighted by the kernel's static mix: the calibrated ceiling
+                        # above is what independent streams of that mix reach on this chip (the kernel, with scalar work co-issued,
+                        # runs past it), this one is what the data sheet allows
+                        nominal = 1.0 / (f4 / (1024 * 2.4 / 4) + (1.0 - f4) / (1024 * 2.4 / 2))
+                        vi["nominal_mix_ceiling"] = nominal
+                        vi["frac_of_nominal"] = ach / nominal
                 except (OSError, ValueError, KeyError, TypeError):
                     pass
             roof["valu_issue"] = vi

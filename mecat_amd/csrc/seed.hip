@@ -755,13 +755,14 @@ __global__ __launch_bounds__(SEED_BLOCK) void seed_build(SeedArrays A, int sorte
 //                        the atomics made it
 //   region sort          ascending payload inside each region = (segment, km, position) order, the order the reference visits
 //                        the hits of a segment in (keys are unique).  Regions are tiny (a hit or two) except where a read
-//                        meets itself (~200 hits per segment): a thread sorts a short region, a wave rank-sorts a long one
+//                        meets itself (~200 hits per segment): every element of a short region counts the smaller ones (all reads,
+//                        barrier, all writes); a wave sorts a long region in registers (bitonic network)
 //   build                phases A-E of seed_build on the LDS arrays.  The elements stay in slot-major order; only the segment
 //                        table is permuted to ascending segment id (stable split on the segment bits above the slot bits)
 //
-// Both walks are software pipelined: bucket headers two steps ahead, bucket data one step ahead of the hits being consumed —
-// the walks are gathers of ~50 / ~90 byte runs and live on the number of loads in flight (mecat_amd/tools/gather_peak.hip
-// measures the ceiling: 35 G runs/s of <= 64 bytes, 26 G runs/s of 128 bytes on an MI355X).
+// Both walks are software pipelined: bucket headers two steps ahead, bucket data one step ahead of the hits being consumed.
+// They are gathers of ~50 / ~90 byte runs (mecat_amd/tools/gather_peak.hip measures what the chip delivers on such runs: 35 G / s of
+// <= 64 bytes, 26 G / s of 128 bytes), and they cost per bucket rather than per hit: see the FS_LPB / FS_NP table below.
 #define FS_THREADS 1024
 #define FS_WAVES (FS_THREADS / WAVE)
 #define FS_CAP 8192                  // kept hits

@@ -90,6 +90,11 @@ int  mhip_ctx_sync(mhip_ctx* ctx);
  * (two arrays of 8 bytes per base; tens of GB take hundreds of milliseconds to map).  May run on another thread while the
  * caller still parses its input; every other call on the context that needs scratch waits for it. */
 int  mhip_ctx_reserve_index(mhip_ctx* ctx, int64_t bases);
+/* for callers that keep tables in HBM between calls (the mecat2pw driver keeps the candidate lists of a whole grid cell there):
+   a named device buffer of the context, grown on demand (contents are lost when it grows), freed with the context; and a copy
+   from device memory to the host on the context's stream that returns when the bytes have arrived */
+int  mhip_ctx_buffer(mhip_ctx* ctx, const char* name, size_t bytes, void** d_ptr);
+int  mhip_download(mhip_ctx* ctx, void* host_dst, const void* d_src, size_t bytes);
 void mhip_params_default(mhip_params* p, int tech);           /* pw_options.cpp:30-50 + pw_impl.cpp:843-851 */
 
 /* per-kernel timing with HIP events on the context's stream (for bench.py's roofline block).

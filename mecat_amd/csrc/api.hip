@@ -124,6 +124,21 @@ int mhip_ctx_reserve_index(mhip_ctx* c, int64_t bases) {
     return rc;
 }
 
+int mhip_ctx_buffer(mhip_ctx* c, const char* name, size_t bytes, void** d_ptr) {
+    HIPCHK(hipSetDevice(c->device));
+    if (!name || !*name) { mhip_set_error("buffer without a name"); return -1; }
+    const std::string key = std::string("user_") + name;       // kept apart from the library's own scratch names
+    return c->scratch(key.c_str(), bytes ? bytes : 1, d_ptr);
+}
+
+int mhip_download(mhip_ctx* c, void* host_dst, const void* d_src, size_t bytes) {
+    HIPCHK(hipSetDevice(c->device));
+    if (bytes == 0) return 0;
+    HIPCHK(hipMemcpyAsync(host_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int mhip_ctx_sync(mhip_ctx* c) {
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));

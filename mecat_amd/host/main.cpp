@@ -157,14 +157,6 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
 
     HostVolume ref;
     { TraceTimer tt("load_volume"); load_volume(vn[svid], &ref); }
-    mhip_volume* dref = NULL;
-    { TraceTimer tt("volume_upload"); MCHK(mhip_volume_upload(ctx, ref.pac.data(), ref.offs.data(), ref.num_reads, ref.num_bases, ref.start_read_id, &dref)); }
-    mhip_index* idx = NULL;
-    {
-        ScopedTimer t("create_ref_index");
-        MCHK(mhip_index_build(ctx, dref, &idx));
-    }
-    printf("number of kmers: %lld\n", (long long)mhip_index_num_kmers(idx));
 
     const char* slab_env = getenv("MECAT_HIP_SLAB");
     int slab = slab_env ? std::max(1, atoi(slab_env)) : 20000;
@@ -180,6 +172,27 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
         int rb = 0, nr = 0;
     };
     SlabBuf slabs[2];                         // slab s is written out while slab s + 1 is on the GPU
+    // page-locking ~100 MB per slab buffer takes 30-60 ms each: done on a second thread while the volume goes up and is indexed
+    std::thread prealloc;
+    if (writes)
+        prealloc = std::thread([&]() {
+            const size_t rows = (size_t)std::min(slab, std::max(ref.num_reads, 1));
+            for (SlabBuf& B : slabs) {
+                B.cands.resize(rows * (size_t)P.maxc);
+                B.counts.resize(rows);
+                if (opt.task != TASK_SEED) B.res.resize(rows * 32);       // (grown when a slab holds more candidates)
+            }
+        });
+    mhip_volume* dref = NULL;
+    { TraceTimer tt("volume_upload"); MCHK(mhip_volume_upload(ctx, ref.pac.data(), ref.offs.data(), ref.num_reads, ref.num_bases, ref.start_read_id, &dref)); }
+    mhip_index* idx = NULL;
+    {
+        ScopedTimer t("create_ref_index");
+        MCHK(mhip_index_build(ctx, dref, &idx));
+    }
+    printf("number of kmers: %lld\n", (long long)mhip_index_num_kmers(idx));
+
+    if (prealloc.joinable()) prealloc.join();
 
     for (int vid = svid; vid < (int)vn.size(); ++vid) {
         char info[64];
@@ -202,7 +215,7 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
                 fflush(stdout);
                 abort();
             }
-        double st[5] = {0, 0, 0, 0, 0};      // MECAT_TRACE: seconds in seeding, job assembly, extension, formatting, writing
+        double st[6] = {0, 0, 0, 0, 0, 0};      // MECAT_TRACE: seconds in seeding, job assembly, extension, formatting, writing, page-locked buffers
         struct StageClock {
             double* acc; double t0;
             static double now() { struct timeval t; gettimeofday(&t, NULL); return t.tv_sec + 1e-6 * t.tv_usec; }
@@ -215,7 +228,6 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
         auto emit = [&](SlabBuf& B) {
             PinnedBuf<mhip_candidate>& cands = B.cands;
             PinnedBuf<int32_t>& counts = B.counts;
-            PinnedBuf<mhip_aln_job>& jobs = B.jobs;
             PinnedBuf<mhip_aln_result>& res = B.res;
             std::vector<size_t>& jfirst = B.jfirst;
             const int rb = B.rb, nr = B.nr;
@@ -268,7 +280,13 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
                         const mhip_aln_result& a = res[ji];
                         if (!a.ok) continue;
                         const mhip_candidate& c = cands[(size_t)r * P.maxc + k];
-                        const mhip_aln_job& j = jobs[ji];
+                        // the job of this candidate (the loop head of pairwise_mapping, pw_impl.cpp:674-686): made on the device when
+                        // the candidate lists stay there, so its fields are derived here rather than read
+                        mhip_aln_job j;
+                        j.sid_local = c.readno - ref.start_read_id;
+                        j.qstart = c.loc2;
+                        j.sstart = c.loc1;
+                        if (j.qstart && j.sstart) { j.qstart += MHIP_KMER_SIZE / 2; j.sstart += MHIP_KMER_SIZE / 2; }
                         const int ssize = ref.offs[(size_t)j.sid_local].size;
                         M4Record m;     // fill_m4record, pw_impl.cpp:467-506
                         m.qid = c.readno;
@@ -342,6 +360,17 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
                 pcv.notify_all();
             }
         });
+        // One process: the candidate lists of the whole cell are made in one go and stay in HBM; a slab is then job assembly and
+        // extension on the device plus the copies the text needs (a seeding call per slab cost 5 x 17 ms instead of 59 at config 2,
+        // and the host-side job assembly kept the GPU waiting).  With a communicator the sharded calls below do all of this.
+        void *d_cell_cands = NULL, *d_cell_counts = NULL;
+        if (!comm) {
+            StageClock sc(&st[0]);
+            MCHK(mhip_ctx_buffer(ctx, "cell_cands", sizeof(mhip_candidate) * (size_t)rd->num_reads * P.maxc, &d_cell_cands));
+            MCHK(mhip_ctx_buffer(ctx, "cell_counts", sizeof(int32_t) * (size_t)rd->num_reads, &d_cell_counts));
+            MCHK(mhip_seed_reads_dev(ctx, idx, dref, dreads, 0, rd->num_reads, &P, d_cell_cands, d_cell_counts));
+            MCHK(mhip_ctx_sync(ctx));
+        }
         int sno = 0;
         for (int rb = 0; rb < rd->num_reads; rb += slab, ++sno) {
             const int re = std::min(rd->num_reads, rb + slab), nr = re - rb;
@@ -352,12 +381,12 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
             SlabBuf& B = slabs[sno & 1];
             PinnedBuf<mhip_candidate>& cands = B.cands;
             PinnedBuf<int32_t>& counts = B.counts;
-            PinnedBuf<mhip_aln_job>& jobs = B.jobs;
             PinnedBuf<mhip_aln_result>& res = B.res;
             std::vector<size_t>& jfirst = B.jfirst;
             B.rb = rb;
             B.nr = nr;
             if (writes) {
+                StageClock sc(&st[5]);
                 cands.resize((size_t)nr * P.maxc);
                 counts.resize((size_t)nr);
             }
@@ -365,12 +394,39 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
                 StageClock sc(&st[0]);
                 MCHK(mhip_seed_reads_sharded(comm, idx, dref, dreads, rb, re, shard_chunk, vid, &P, writes ? cands.data() : NULL,
                                              writes ? counts.data() : NULL));
-            } else { StageClock sc(&st[0]); MCHK(mhip_seed_reads(ctx, idx, dref, dreads, rb, re, &P, cands.data(), counts.data())); }
+            } else {
+                StageClock sc(&st[4]);      // (copies: booked with the writing)
+                MCHK(mhip_download(ctx, counts.data(), (const int32_t*)d_cell_counts + rb, sizeof(int32_t) * (size_t)nr));
+                MCHK(mhip_download(ctx, cands.data(), (const mhip_candidate*)d_cell_cands + (size_t)rb * P.maxc, sizeof(mhip_candidate) * (size_t)nr * P.maxc));
+            }
             if (opt.task != TASK_SEED && comm && !writes) {
                 StageClock sc(&st[2]);
                 int64_t nj = 0;
                 MCHK(mhip_align_sharded(comm, dref, dreads, opt.tech == TECH_NANOPORE ? 1 : 0, P.min_align_size, NULL, &nj));
+            } else if (opt.task != TASK_SEED && !comm) {
+                // pairwise_mapping, pw_impl.cpp:674-700, with the jobs made on the device from the lists that are there
+                jfirst.assign((size_t)nr + 1, 0);
+                for (int r = 0; r < nr; ++r) jfirst[(size_t)r + 1] = jfirst[(size_t)r] + (size_t)counts[(size_t)r];
+                { StageClock sc(&st[5]); res.resize(jfirst[(size_t)nr]); }
+                void *d_jobs = NULL, *d_res = NULL;
+                int nj = 0;
+                {
+                    StageClock sc(&st[1]);
+                    MCHK(mhip_ctx_buffer(ctx, "slab_jobs", sizeof(mhip_aln_job) * (size_t)nr * P.maxc, &d_jobs));
+                    MCHK(mhip_jobs_from_candidates_dev(ctx, (const mhip_candidate*)d_cell_cands + (size_t)rb * P.maxc, (const int32_t*)d_cell_counts + rb, nr,
+                                                       P.maxc, rb, 1, ref.start_read_id, 0, 1, d_jobs, &nj));
+                    if ((size_t)nj != jfirst[(size_t)nr]) DIE("%d jobs for %zu candidates", nj, jfirst[(size_t)nr]);
+                }
+                {
+                    StageClock sc(&st[2]);
+                    MCHK(mhip_ctx_buffer(ctx, "slab_results", sizeof(mhip_aln_result) * (size_t)std::max(nj, 1), &d_res));
+                    // aligner by technology (pw_impl.cpp:638-644): DiffAligner (dw) for PacBio, XdropAligner for nanopore
+                    if (opt.tech == TECH_NANOPORE) MCHK(mhip_xalign_candidates_dev(ctx, dref, dreads, d_jobs, nj, P.min_align_size, d_res));
+                    else MCHK(mhip_align_candidates_dev(ctx, dref, dreads, d_jobs, nj, P.min_align_size, d_res));
+                    MCHK(mhip_download(ctx, res.data(), d_res, sizeof(mhip_aln_result) * (size_t)nj));
+                }
             } else if (opt.task != TASK_SEED) {
+                PinnedBuf<mhip_aln_job>& jobs = B.jobs;
                 auto range_of = [&](int t, int* lo, int* hi) { *lo = (int)((long long)nr * t / nt); *hi = (int)((long long)nr * (t + 1) / nt); };
                 // pairwise_mapping, pw_impl.cpp:674-700
                 StageClock* sc_jobs = new StageClock(&st[1]);
@@ -426,8 +482,8 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
         pcv.notify_all();
         writer.join();
         if (getenv("MECAT_TRACE"))
-            fprintf(stderr, "[trace] volume %d stages: seed %.3f s, jobs %.3f s, extend %.3f s, format %.3f s, write %.3f s\n", vid, st[0], st[1],
-                    st[2], st[3], st[4]);
+            fprintf(stderr, "[trace] volume %d stages: seed %.3f s, jobs %.3f s, extend %.3f s, format %.3f s, write + copies %.3f s, page-locked buffers %.3f s\n",
+                    vid, st[0], st[1], st[2], st[3], st[4], st[5]);
         if (dreads != dref) mhip_volume_free(dreads);
     }
     mhip_index_free(idx);

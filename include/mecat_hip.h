@@ -150,6 +150,10 @@ int  mhip_jobs_from_candidates_dev(mhip_ctx* ctx, const void* d_cands, const voi
                                    int rid_begin, int rid_stride, int ref_start_read_id, int part_index, int part_count,
                                    void* d_jobs, int* num_jobs);
 
+/* the occupied entries of a candidate table, dense and read-major: d_pack[first(i) + k] = d_cands[i][k] with first = exclusive prefix
+   sum of d_counts; *total = number of entries.  d_pack must hold them (n_reads * maxc entries always suffice). */
+int  mhip_pack_candidates_dev(mhip_ctx* ctx, const void* d_cands, const void* d_counts, int n_reads, int maxc, void* d_pack, int64_t* total);
+
 /* dw extension of n jobs (PacBio / DiffAligner semantics); jobs/out are HOST pointers (_dev: DEVICE pointers) */
 int  mhip_align_candidates(mhip_ctx* ctx, const mhip_volume* ref, const mhip_volume* reads, const mhip_aln_job* jobs,
                            int n, int min_align_size, mhip_aln_result* out);

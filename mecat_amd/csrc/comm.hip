@@ -291,6 +291,28 @@ int allgatherv(mhip_comm* cm, const void* d_send, void* d_recv, const std::vecto
 
 extern "C" {
 
+// the occupied entries of a candidate table, dense and read-major (what crosses the PCIe link for the text output: a list is
+// ~22 of its 100 slots at config 2)
+int mhip_pack_candidates_dev(mhip_ctx* c, const void* d_cands, const void* d_counts, int n_reads, int maxc, void* d_pack, int64_t* total) {
+    HIPCHK(hipSetDevice(c->device));
+    *total = 0;
+    if (n_reads <= 0) return 0;
+    uint32_t* d_pref;
+    long long* d_tot;
+    if (c->scratch("pk_pref", sizeof(uint32_t) * (size_t)n_reads, (void**)&d_pref)) return -1;
+    if (c->scratch("pk_total", sizeof(long long), (void**)&d_tot)) return -1;
+    LAUNCH(c, "xg_prefix", xg_prefix, 1, 1024, 0, (const int32_t*)d_counts, n_reads, d_pref, d_tot);
+    const size_t nt = (size_t)n_reads * (size_t)maxc;
+    LAUNCH(c, "xg_pack", xg_pack, (unsigned)((nt + 255) / 256), 256, 0, (const mhip_candidate*)d_cands, (const int32_t*)d_counts,
+           (const uint32_t*)d_pref, n_reads, maxc, (mhip_candidate*)d_pack);
+    long long t = 0;
+    HIPCHK(hipMemcpyAsync(&t, d_tot, sizeof(t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *total = (int64_t)t;
+    return 0;
+}
+
+
 int mhip_comm_unique_id(uint8_t id[MHIP_COMM_ID_BYTES]) {
     static_assert(sizeof(ncclUniqueId) == MHIP_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
     RcclApi* R = rccl();

@@ -168,8 +168,9 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
         PinnedBuf<int32_t> counts;
         PinnedBuf<mhip_aln_job> jobs;
         PinnedBuf<mhip_aln_result> res;
-        std::vector<size_t> jfirst;
+        std::vector<size_t> jfirst;       // first entry of read r's list in res[] (and in cands[] when packed)
         int rb = 0, nr = 0;
+        bool packed = false;              // cands[] holds only the occupied entries, read-major (one process); else [nr][maxc]
     };
     SlabBuf slabs[2];                         // slab s is written out while slab s + 1 is on the GPU
     // page-locking ~100 MB per slab buffer takes 30-60 ms each: done on a second thread while the volume goes up and is indexed
@@ -178,7 +179,7 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
         prealloc = std::thread([&]() {
             const size_t rows = (size_t)std::min(slab, std::max(ref.num_reads, 1));
             for (SlabBuf& B : slabs) {
-                B.cands.resize(rows * (size_t)P.maxc);
+                B.cands.resize(comm ? rows * (size_t)P.maxc : rows * 32);       // packed lists in a one-process run (grown when a slab holds more)
                 B.counts.resize(rows);
                 if (opt.task != TASK_SEED) B.res.resize(rows * 32);       // (grown when a slab holds more candidates)
             }
@@ -244,8 +245,9 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
                     char line[160];
                     for (int r = lo; r < hi; ++r) {
                         const int qsize = rd->offs[(size_t)(rb + r)].size, qid = rb + r + rd->start_read_id;
+                        const size_t c0 = B.packed ? jfirst[(size_t)r] : (size_t)r * P.maxc;
                         for (int k = 0; k < counts[(size_t)r]; ++k) {
-                            const mhip_candidate& c = cands[(size_t)r * P.maxc + k];
+                            const mhip_candidate& c = cands[c0 + k];
                             int qext = c.loc2, sext = c.loc1;
                             if (qext && sext) { qext += MHIP_KMER_SIZE / 2; sext += MHIP_KMER_SIZE / 2; }
                             const int ssize = ref.offs[(size_t)(c.readno - ref.start_read_id)].size;
@@ -275,11 +277,12 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
                 for (int r = lo; r < hi; ++r) {
                     const int qsize = rd->offs[(size_t)(rb + r)].size, qid = rb + r + rd->start_read_id;
                     size_t ji = jfirst[(size_t)r];
+                    const size_t c0 = B.packed ? jfirst[(size_t)r] : (size_t)r * P.maxc;
                     m4v.clear();
                     for (int k = 0; k < counts[(size_t)r]; ++k, ++ji) {
                         const mhip_aln_result& a = res[ji];
                         if (!a.ok) continue;
-                        const mhip_candidate& c = cands[(size_t)r * P.maxc + k];
+                        const mhip_candidate& c = cands[c0 + k];
                         // the job of this candidate (the loop head of pairwise_mapping, pw_impl.cpp:674-686): made on the device when
                         // the candidate lists stay there, so its fields are derived here rather than read
                         mhip_aln_job j;
@@ -385,9 +388,10 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
             std::vector<size_t>& jfirst = B.jfirst;
             B.rb = rb;
             B.nr = nr;
+            B.packed = !comm;
             if (writes) {
                 StageClock sc(&st[5]);
-                cands.resize((size_t)nr * P.maxc);
+                if (comm) cands.resize((size_t)nr * P.maxc);
                 counts.resize((size_t)nr);
             }
             if (comm) {
@@ -396,8 +400,18 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
                                              writes ? counts.data() : NULL));
             } else {
                 StageClock sc(&st[4]);      // (copies: booked with the writing)
+                // the counts, and the occupied entries of the lists packed on the device (a list is ~22 of its 100 slots)
                 MCHK(mhip_download(ctx, counts.data(), (const int32_t*)d_cell_counts + rb, sizeof(int32_t) * (size_t)nr));
-                MCHK(mhip_download(ctx, cands.data(), (const mhip_candidate*)d_cell_cands + (size_t)rb * P.maxc, sizeof(mhip_candidate) * (size_t)nr * P.maxc));
+                jfirst.assign((size_t)nr + 1, 0);
+                for (int r = 0; r < nr; ++r) jfirst[(size_t)r + 1] = jfirst[(size_t)r] + (size_t)counts[(size_t)r];
+                void* d_pack = NULL;
+                int64_t total = 0;
+                MCHK(mhip_ctx_buffer(ctx, "slab_pack", sizeof(mhip_candidate) * (size_t)nr * P.maxc, &d_pack));
+                MCHK(mhip_pack_candidates_dev(ctx, (const mhip_candidate*)d_cell_cands + (size_t)rb * P.maxc, (const int32_t*)d_cell_counts + rb, nr, P.maxc,
+                                              d_pack, &total));
+                if ((size_t)total != jfirst[(size_t)nr]) DIE("%lld packed candidates for %zu counted", (long long)total, jfirst[(size_t)nr]);
+                cands.resize((size_t)total);
+                MCHK(mhip_download(ctx, cands.data(), d_pack, sizeof(mhip_candidate) * (size_t)total));
             }
             if (opt.task != TASK_SEED && comm && !writes) {
                 StageClock sc(&st[2]);
@@ -405,8 +419,6 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
                 MCHK(mhip_align_sharded(comm, dref, dreads, opt.tech == TECH_NANOPORE ? 1 : 0, P.min_align_size, NULL, &nj));
             } else if (opt.task != TASK_SEED && !comm) {
                 // pairwise_mapping, pw_impl.cpp:674-700, with the jobs made on the device from the lists that are there
-                jfirst.assign((size_t)nr + 1, 0);
-                for (int r = 0; r < nr; ++r) jfirst[(size_t)r + 1] = jfirst[(size_t)r] + (size_t)counts[(size_t)r];
                 { StageClock sc(&st[5]); res.resize(jfirst[(size_t)nr]); }
                 void *d_jobs = NULL, *d_res = NULL;
                 int nj = 0;

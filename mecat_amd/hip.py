@@ -94,6 +94,9 @@ def lib():
     L.mhip_xalign_candidates.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     L.mhip_xalign_candidates_dev.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     L.mhip_ctx_reserve_index.argtypes = [vp, C.c_int64]
+    L.mhip_ctx_buffer.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(vp)]
+    L.mhip_download.argtypes = [vp, vp, vp, C.c_size_t]
+    L.mhip_pack_candidates_dev.argtypes = [vp, vp, vp, i32, i32, vp, C.POINTER(i64)]
     L.mhip_cns_align_candidates.argtypes = [vp, vp, vp, vp, i32, C.c_double, i32, i32, vp, vp]
     L.mhip_cns_align_candidates_dev.argtypes = [vp, vp, vp, vp, i32, C.c_double, i32, i32, vp, vp]
     # multi-GPU

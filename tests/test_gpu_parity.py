@@ -194,6 +194,34 @@ def test_strand_pipeline_out_of_room_falls_back(hip, ctx):
             assert np.array_equal(got[r][: cnt[r]], full[r][: cnt[r]]), (room, r)
 
 
+def test_lists_kept_on_the_device_and_packed(hip, ctx):
+    """the driver's path: candidate lists of a cell made into a context buffer (mhip_ctx_buffer, mhip_seed_reads_dev), the occupied
+    entries packed (mhip_pack_candidates_dev) and copied out (mhip_download) == the lists mhip_seed_reads returns"""
+    d = dataset("tiny", hip, ctx)
+    p = hip.default_params(0)
+    want, cnt = _gpu_cands(hip, ctx, d, p)
+    n, L = len(cnt), hip.lib()
+    dc, dn, dp = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    hip._chk(L.mhip_ctx_buffer(ctx.h, b"t_cands", 48 * n * p.maxc, C.byref(dc)))
+    hip._chk(L.mhip_ctx_buffer(ctx.h, b"t_counts", 4 * n, C.byref(dn)))
+    hip._chk(L.mhip_ctx_buffer(ctx.h, b"t_pack", 48 * n * p.maxc, C.byref(dp)))
+    hip._chk(L.mhip_seed_reads_dev(ctx.h, d["gidx"].h, d["gv"].h, d["gv"].h, 0, n, C.byref(p), dc, dn))
+    got_cnt = np.empty(n, dtype=np.int32)
+    hip._chk(L.mhip_download(ctx.h, got_cnt.ctypes.data, dn, got_cnt.nbytes))
+    assert np.array_equal(got_cnt, cnt)
+    total = C.c_int64()
+    hip._chk(L.mhip_pack_candidates_dev(ctx.h, dc, dn, n, p.maxc, dp, C.byref(total)))
+    assert total.value == int(cnt.sum()) > 0
+    packed = np.empty(total.value, dtype=hip.CAND_DTYPE)
+    hip._chk(L.mhip_download(ctx.h, packed.ctypes.data, dp, packed.nbytes))
+    first = np.concatenate([[0], np.cumsum(cnt)])
+    for r in range(n):
+        assert np.array_equal(packed[first[r]: first[r + 1]], want[r][: cnt[r]]), r
+    # an empty range packs to nothing
+    hip._chk(L.mhip_pack_candidates_dev(ctx.h, dc, dn, 0, p.maxc, dp, C.byref(total)))
+    assert total.value == 0
+
+
 def test_candidates_small_batches_equal_one_batch(hip, ctx):
     """the read range may be cut anywhere: per-read results do not depend on the batch"""
     d = dataset("tiny", hip, ctx)

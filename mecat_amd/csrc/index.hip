@@ -378,12 +378,15 @@ __global__ __launch_bounds__(IDX_BLOCK) void idx_sort(const uint32_t* __restrict
 // the 16 k-mer start positions of aligned window t (positions 16t .. 16t+15): f(j, kmer, pos) for each valid one (j = slot 0..15)
 template <typename F>
 __device__ __forceinline__ void walk16(const uint32_t* __restrict__ pac, const mhip_offset_t* __restrict__ offs, int num_reads,
-                                       int num_bases, int64_t t, F f) {
+                                       int num_bases, int64_t t, const uint32_t* __restrict__ blk, F f) {
     const int64_t p0 = t << 4;
     const bool live = p0 < num_bases && num_reads != 0;
     const uint64_t W = live ? ((uint64_t)pac_word(pac, t) << 32) | pac_word(pac, t + 1) : 0ull;
-    int r = find_read_wave(offs, num_reads, live ? (int)p0 : num_bases - 1);    // whole wave takes part
     if (!live) return;
+    // the read of the window's first base: the volume's block table (entry b = the read that holds base 1024 b, or the one before
+    // it) and a step or two forward, instead of a 17-step binary search over the offsets per wave
+    int r = (int)blk[p0 >> 10];
+    while (r + 1 < num_reads && offs[r + 1].offset <= (int)p0) ++r;
     int rend = r >= 0 ? offs[r].offset + offs[r].size : -1;
     int next_off = (r + 1 < num_reads) ? offs[r + 1].offset : 0x7fffffff;
 #pragma unroll
@@ -400,13 +403,13 @@ __device__ __forceinline__ void walk16(const uint32_t* __restrict__ pac, const m
 
 // occurrences per fine bin
 __global__ __launch_bounds__(IDX_BLOCK) void idx_hist(const uint32_t* __restrict__ pac, const mhip_offset_t* __restrict__ offs,
-                                                      int num_reads, int num_bases, uint32_t* __restrict__ fine_hist) {
+                                                      int num_reads, int num_bases, uint32_t* __restrict__ fine_hist, const uint32_t* __restrict__ blk) {
     __shared__ uint32_t h[NFINE];
     for (int i = threadIdx.x; i < NFINE; i += IDX_BLOCK) h[i] = 0;
     __syncthreads();
     for (int tile = 0; tile < HIST_TILES; ++tile) {
         const int64_t t = ((int64_t)blockIdx.x * HIST_TILES + tile) * IDX_BLOCK + threadIdx.x;
-        walk16(pac, offs, num_reads, num_bases, t, [&](int, uint32_t k, int) { atomicAdd(&h[k >> (26 - FINE_BITS)], 1u); });
+        walk16(pac, offs, num_reads, num_bases, t, blk, [&](int, uint32_t k, int) { atomicAdd(&h[k >> (26 - FINE_BITS)], 1u); });
     }
     __syncthreads();
     for (int i = threadIdx.x; i < NFINE; i += IDX_BLOCK)
@@ -483,7 +486,7 @@ __device__ __forceinline__ void scatter_tile64(const uint64_t* ent, const uint32
 // level 1: volume walk -> entries (kmer << 32 | pos) partitioned by the top 6 k-mer bits
 __global__ __launch_bounds__(IDX_BLOCK) void idx_scatter1(const uint32_t* __restrict__ pac, const mhip_offset_t* __restrict__ offs,
                                                           int num_reads, int num_bases, uint32_t* __restrict__ cur1,
-                                                          uint64_t* __restrict__ ent1) {
+                                                          uint64_t* __restrict__ ent1, const uint32_t* __restrict__ blk) {
     __shared__ uint32_t hist[NCOARSE], lbase[NCOARSE + 1], gbase[NCOARSE];
     __shared__ uint64_t stage[TILE_POS];
     __shared__ uint8_t sbin[TILE_POS];
@@ -493,7 +496,7 @@ __global__ __launch_bounds__(IDX_BLOCK) void idx_scatter1(const uint32_t* __rest
 #pragma unroll
     for (int j = 0; j < 16; ++j) { ent[j] = 0; binv[j] = 0; }
     const int64_t t = (int64_t)blockIdx.x * IDX_BLOCK + threadIdx.x;
-    walk16(pac, offs, num_reads, num_bases, t, [&](int j, uint32_t k, int p) {
+    walk16(pac, offs, num_reads, num_bases, t, blk, [&](int j, uint32_t k, int p) {
         ent[j] = ((uint64_t)k << 32) | (uint32_t)p;
         binv[j] = k >> 20;
         vmask |= 1u << j;
@@ -738,7 +741,7 @@ static int index_build_binned(mhip_ctx* c, const mhip_volume* v, mhip_index* idx
         return 0;
     }
     LAUNCH(c, "idx_hist", idx_hist, (tiles + HIST_TILES - 1) / HIST_TILES, IDX_BLOCK, 0, (const uint32_t*)v->d_pac, (const mhip_offset_t*)v->d_offs,
-           v->num_reads, v->num_bases, d_hist);
+           v->num_reads, v->num_bases, d_hist, (const uint32_t*)v->d_blk2read);
     LAUNCH(c, "idx_scan4096", idx_scan4096, 1, 1024, 0, (const uint32_t*)d_hist, d_fbase);
     TRACE("hist+scan");
     // Entries: level 1 scatters the whole volume into ent1 (64 coarse bins).  Levels 2 and 3 run per group of IDX_GROUP coarse
@@ -760,7 +763,7 @@ static int index_build_binned(mhip_ctx* c, const mhip_volume* v, mhip_index* idx
     if (c->scratch("ix_cur3", sizeof(uint32_t) * (size_t)NFINE * NSUB, (void**)&d_cur3)) return -1;
     LAUNCH(c, "idx_init_cursors", idx_init_cursors, NFINE / 256, 256, 0, (const uint32_t*)d_fbase, d_cur1, d_cur2);
     LAUNCH(c, "idx_scatter1", idx_scatter1, tiles, IDX_BLOCK, 0, (const uint32_t*)v->d_pac, (const mhip_offset_t*)v->d_offs, v->num_reads,
-           v->num_bases, d_cur1, d_e1);
+           v->num_bases, d_cur1, d_e1, (const uint32_t*)v->d_blk2read);
     for (int g = 0; g < NGROUP; ++g) {
         const int c0 = g * IDX_GROUP, f0 = c0 * 64, nf = IDX_GROUP * 64;
         const uint32_t gbase = fb[(size_t)f0];

@@ -60,6 +60,8 @@ struct SeedArrays {
     uint32_t* rel_bits;          // [ns * REL_WORDS] relevance bitmap of the strand (filtered strands only)
     int32_t* filtered;           // [ns]   1 = only relevant hits are kept, 0 = every hit is kept
     int32_t* fused;              // [ns]   1 = the strand went through seed_strand (its tables live in the fused arrays)
+    uint32_t rel_mask;           // relevance bitmap bit of segment seg: ((seg & rel_mask) >> rel_shift): 2^15 - 1 and 0 for seed_filter,
+    uint32_t rel_shift;          //   2^18 - 1 and 3 for seed_filter_wide
     uint64_t* hit_base;          // [ns + 1]
     uint64_t* keysA;             // [Htot]
     uint64_t* keysB;             // [Htot]
@@ -253,6 +255,11 @@ __device__ __forceinline__ bool rel_test(const uint32_t* rel, uint32_t seg) {
     const uint32_t e = seg & (FLT_M - 1);
     return (rel[e >> 5] >> (e & 31u)) & 1u;
 }
+// the same with the bitmap's geometry as data (seed_emit: bitmaps of seed_filter and of seed_filter_wide)
+__device__ __forceinline__ bool rel_test(const uint32_t* rel, uint32_t seg, uint32_t mask, uint32_t shift) {
+    const uint32_t e = (seg & mask) >> shift;
+    return (rel[e >> 5] >> (e & 31u)) & 1u;
+}
 
 // ------------------------------------------------------------------------------------------------ relevance filter
 // Most bucket hits are random 13-mer matches that land alone in their 2 kb segment and can never matter:
@@ -375,13 +382,13 @@ __global__ __launch_bounds__(SEED_BLOCK) void seed_emit(const mhip_offset_t* __r
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             uint32_t kept = 0;
-            if (cn[q] > 0) kept += __popc(group_bits(__ballot(sub < cn[q] && (!flt || rel_test(rel, p0[q] / ZV)))));
-            if (cn[q] > 16) kept += __popc(group_bits(__ballot(sub + 16u < cn[q] && (!flt || rel_test(rel, p1[q] / ZV)))));
+            if (cn[q] > 0) kept += __popc(group_bits(__ballot(sub < cn[q] && (!flt || rel_test(rel, p0[q] / ZV, A.rel_mask, A.rel_shift)))));
+            if (cn[q] > 16) kept += __popc(group_bits(__ballot(sub + 16u < cn[q] && (!flt || rel_test(rel, p1[q] / ZV, A.rel_mask, A.rel_shift)))));
             for (uint32_t r0 = 32; r0 < cn[q]; r0 += 16) {
                 const uint32_t r = r0 + sub;
                 const bool valid = r < cn[q];
                 const uint32_t pos = valid ? (uint32_t)offsets[bs[q] + r] : 0u;
-                kept += __popc(group_bits(__ballot(valid && (!flt || rel_test(rel, pos / ZV)))));
+                kept += __popc(group_bits(__ballot(valid && (!flt || rel_test(rel, pos / ZV, A.rel_mask, A.rel_shift)))));
             }
             if (sub == 0) ccnt[q * 16 + g] = kept;
         }
@@ -404,7 +411,7 @@ __global__ __launch_bounds__(SEED_BLOCK) void seed_emit(const mhip_offset_t* __r
             uint32_t at = run + coff[q * 16 + g];
             auto put = [&](uint32_t pos, bool valid) {
                 const uint32_t seg = pos / ZV, so = pos - seg * ZV;
-                const bool k1 = valid && (!flt || rel_test(rel, seg));
+                const bool k1 = valid && (!flt || rel_test(rel, seg, A.rel_mask, A.rel_shift));
                 const uint32_t bits = group_bits(__ballot(k1));
                 if (k1) out[at + __popc(bits & below)] = ((uint64_t)seg << KEY_SEG_SHIFT) | ((uint64_t)km << KEY_OFF_BITS) | so;
                 at += __popc(bits);
@@ -419,6 +426,8 @@ __global__ __launch_bounds__(SEED_BLOCK) void seed_emit(const mhip_offset_t* __r
         }
         run += s_tot;
     }
+    // the number of keys written: exact, where seed_filter_wide's strand_hits was the room it asked for (an upper bound)
+    if (threadIdx.x == 0) A.strand_hits[s] = run;
 }
 
 // ------------------------------------------------------------------------------------------------ sort (one LSD pass)
@@ -947,6 +956,116 @@ __device__ __noinline__ void fs_bitonic(uint32_t* p, const uint32_t n, const int
 }
 
 __device__ __forceinline__ uint32_t fs_cnt(const uint32_t* cnt32, uint32_t e) { return (cnt32[e >> 1] >> ((e & 1u) * 16u)) & 0xFFFFu; }
+
+// ------------------------------------------------------------------------------------------------ relevance filter, low gates
+// Nanopore mode gates at index_score >= 4 (min_kmer_match 2), and a 2.14 Gbase volume puts ~64 k bucket hits of a strand on ~1.07 M
+// segments: folded onto seed_filter's 2^15 slots that is two hits per slot, every second slot pair passes a gate of 4, and the reach
+// of the sweeps (+- 11 segments for a 20 kb read) makes everything relevant — which is why that filter is only used from a gate of 6
+// up, and why nanopore strands used to sort and build all of their hits in HBM (0.66 of the 0.73 s of a config-5 grid cell).
+// Same construction with 2^18 slots (a quarter hit per slot: 0.2 % of the slot pairs pass by chance) and 4-bit counters in the LDS of
+// a whole CU; the relevance bitmap has one bit per 8 slots, so it is the 4 KB per strand seed_emit already reads.  A slot of a true
+// overlap collects 20-30 hits, so a 4-bit counter wraps there: the add that wraps it (its return value says so, and which neighbours
+// the carry ran into) marks the slot relevant on the spot and counts the wrap.  Counters next to a wrapped one are too high by the
+// carry: the bitmap only grows, and the number of kept hits becomes an upper bound (sum over the relevant slots + 16 per wrap) — the
+// room of the strand in the key arrays; seed_emit writes the exact number when it has placed the keys.
+#define WF_BITS 18
+#define WF_M (1 << WF_BITS)
+#define WF_CELL 3                    // log2 slots per relevance bit
+static_assert((WF_M >> WF_CELL) == FLT_M, "the bitmap is REL_WORDS words");
+__global__ __launch_bounds__(FS_THREADS) void seed_filter_wide(const mhip_offset_t* __restrict__ roffs, ReadSel sel, int ib,
+                                                               const int32_t* __restrict__ offsets, SeedArrays A, int gate, int same_volume,
+                                                               unsigned long long* __restrict__ counters) {
+    __shared__ uint32_t cnt[WF_M / 8];           // 128 KB: eight 4-bit counters per word
+    __shared__ uint32_t rel[REL_WORDS];
+    __shared__ uint32_t wtot[FS_WAVES];
+    __shared__ uint32_t s_wraps, s_self;
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const int rid = sel_rid(sel, ib + (s >> 1));
+    const int L = roffs[rid].size;
+    const int K = kmers_of(L);
+    const uint32_t kb = A.km_base[s];
+    const uint32_t Hall = A.strand_hits_all[s];
+    if (A.fused[s] || Hall == 0) {
+        if (tid == 0) { A.strand_hits[s] = 0; A.filtered[s] = 0; }
+        return;
+    }
+    for (int i = tid; i < WF_M / 8; i += FS_THREADS) cnt[i] = 0;
+    rel[tid] = 0;                                 // REL_WORDS == FS_THREADS
+    static_assert(REL_WORDS == FS_THREADS, "one bitmap word per thread");
+    if (tid == 0) { s_wraps = 0; s_self = 0; }
+    __syncthreads();
+    const uint32_t reach = (uint32_t)min(sweep_reach(L), WF_M / 2 - 1);
+    auto mark = [&](int lo, int hi) {            // slots lo .. hi (unwrapped, hi - lo < WF_M) -> their bitmap bits
+        uint32_t cell = (uint32_t)(lo >> WF_CELL) & (FLT_M - 1), left = min((uint32_t)((hi >> WF_CELL) - (lo >> WF_CELL) + 1), (uint32_t)FLT_M);
+        while (left > 0) {
+            const uint32_t b = cell & 31u, take = min(32u - b, left);
+            const uint32_t m = (take == 32u ? 0xFFFFFFFFu : ((1u << take) - 1u)) << b;
+            atomicOr(&rel[cell >> 5], m);
+            cell = (cell + take) & (FLT_M - 1);
+            left -= take;
+        }
+    };
+    // The forward strand of a read against the volume it comes from hits its own copy with every k-mer (200 hits per segment: every
+    // counter there would wrap).  Those hits are known without counting them: position = the read's offset + 10 km.  They are
+    // counted apart, and the read's own segments are relevant whatever the counters say.
+    const bool own = same_volume && !(s & 1);
+    const uint32_t own_off = (uint32_t)roffs[rid].offset;
+    fs_walk<FS_LPB2, FS_NP2, FS_Q2, FS_D2, false>(A.km_bstart + kb, A.km_cnt + kb, offsets, K, [&](int km, uint32_t pos) {
+        if (own && pos == own_off + (uint32_t)km * BC) { atomicAdd(&s_self, 1u); return; }
+        const uint32_t e = (pos / (uint32_t)ZV) & (WF_M - 1);
+        const uint32_t old = atomicAdd(&cnt[e >> 3], 1u << ((e & 7u) * 4u));
+        // the counters this add wrapped: slot e if it stood at 15, and the neighbours at 15 the carry went on through
+        for (uint32_t n = e & 7u; n < 8u && ((old >> (4u * n)) & 15u) == 15u; ++n) {
+            const int w = (int)((e & ~7u) + n);
+            mark(w - (int)reach, w + (int)reach);
+            atomicAdd(&s_wraps, 1u);
+        }
+    });
+    __syncthreads();
+    // hot slots: thread t owns slots 256 t .. 256 t + 255 = words 32 t .. 32 t + 31 = bitmap word t
+    if (own && tid == 0) mark((int)(own_off / (uint32_t)ZV) - (int)reach, (int)((own_off + (uint32_t)L) / (uint32_t)ZV) + (int)reach);
+    {
+        uint32_t wprev = cnt[(32 * tid - 1) & (WF_M / 8 - 1)], w = cnt[32 * tid];
+        for (int j = 0; j < 32; ++j) {
+            const uint32_t wnext = cnt[(32 * tid + j + 1) & (WF_M / 8 - 1)];
+            if (w) {
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    const int c = (int)((w >> (4 * n)) & 15u);
+                    const int pv = n ? (int)((w >> (4 * n - 4)) & 15u) : (int)(wprev >> 28);
+                    const int nx = n < 7 ? (int)((w >> (4 * n + 4)) & 15u) : (int)(wnext & 15u);
+                    if (c > 0 && (c + nx >= gate || c + pv >= gate)) {
+                        const int e = (32 * tid + j) * 8 + n;
+                        mark(e - (int)reach, e + (int)reach);
+                    }
+                }
+            }
+            wprev = w;
+            w = wnext;
+        }
+    }
+    __syncthreads();
+    // kept hits = hits of the slots whose bit is set
+    uint32_t mine = 0;
+    {
+        const uint32_t r = rel[tid];
+        for (uint32_t m = r; m; m &= m - 1u) {
+            const uint32_t w = cnt[32 * tid + (uint32_t)__builtin_ctz(m)];
+            // sum of the eight nibbles
+            const uint32_t a = (w & 0x0F0F0F0Fu) + ((w >> 4) & 0x0F0F0F0Fu);
+            mine += (a * 0x01010101u) >> 24;
+        }
+    }
+    uint32_t kept;
+    (void)fs_excl_scan(mine, wtot, &kept);
+    A.rel_bits[(size_t)s * REL_WORDS + tid] = rel[tid];
+    if (tid == 0) {
+        const uint32_t room = min(Hall, kept + s_self + 16u * s_wraps);
+        A.strand_hits[s] = room;
+        A.filtered[s] = 1;
+        atomicAdd(&counters[12], (unsigned long long)room);      // debug slot 12: room asked for by this filter
+    }
+}
 
 __global__ __launch_bounds__(FS_THREADS) void seed_strand(const mhip_offset_t* __restrict__ roffs, ReadSel sel, int ib,
                                                           const uint16_t* __restrict__ slots, const int32_t* __restrict__ offsets, SeedArrays A,
@@ -1655,6 +1774,7 @@ static int bits_for(uint32_t maxv) {
 
 static bool filter_enabled(const mhip_params* P);
 static bool fused_enabled(const mhip_params* P);
+static bool wide_filter_enabled(const mhip_params* P);
 static bool predrop_enabled();
 static bool cuts_enabled(const mhip_params* P);
 
@@ -1737,8 +1857,17 @@ static int seed_batch(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref
         if (c->scratch("sd_nseg", sizeof(uint32_t) * (size_t)ns, (void**)&B.nseg)) return -1;
         if (c->scratch("sd_nrec", sizeof(uint32_t) * (size_t)ns, (void**)&B.nrec)) return -1;
         if (c->scratch("sd_ngated", sizeof(uint32_t) * (size_t)ns, (void**)&B.ngated)) return -1;
-        LAUNCH(c, "seed_filter", seed_filter, ns, SEED_BLOCK, 0, (const mhip_offset_t*)reads->d_offs, sel, ib,
-               (const uint16_t*)idx->d_slots, B, gate, filter_enabled(P) ? 1 : 0);
+        if (wide_filter_enabled(P)) {           // low gates (nanopore mode): 2^18 slots, one workgroup per strand and CU
+            B.rel_mask = WF_M - 1;
+            B.rel_shift = WF_CELL;
+            LAUNCH(c, "seed_filter_wide", seed_filter_wide, ns, FS_THREADS, 0, (const mhip_offset_t*)reads->d_offs, sel, ib,
+                   (const int32_t*)idx->d_offsets, B, gate, ref == reads ? 1 : 0, (unsigned long long*)c->d_counters);
+        } else {
+            B.rel_mask = FLT_M - 1;
+            B.rel_shift = 0;
+            LAUNCH(c, "seed_filter", seed_filter, ns, SEED_BLOCK, 0, (const mhip_offset_t*)reads->d_offs, sel, ib,
+                   (const uint16_t*)idx->d_slots, B, gate, filter_enabled(P) ? 1 : 0);
+        }
         LAUNCH(c, "seed_scan", seed_scan, 1, 1024, 0, (const uint32_t*)B.strand_hits, ns, B.hit_base);
         uint64_t Htot = 0;
         HIPCHK(hipMemcpyAsync(&Htot, B.hit_base + ns, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
@@ -1795,6 +1924,12 @@ static bool predrop_enabled() {
     return !(e && atoi(e) == 0);
 }
 
+static bool wide_filter_enabled(const mhip_params* P) {
+    const char* fe = getenv("MECAT_SEED_FILTER");      // the same knob: 0 disables every relevance filter
+    const int gate = 2 * P->min_kmer_match;
+    return gate >= 4 && gate < 6 && !(fe && atoi(fe) == 0);
+}
+
 static bool fused_enabled(const mhip_params* P) {
     const char* fe = getenv("MECAT_SEED_FUSED");       // debug knob: 0 sends every strand through the kernel chain
     return filter_enabled(P) && !(fe && atoi(fe) == 0);
@@ -1805,7 +1940,7 @@ static bool fused_enabled(const mhip_params* P) {
 // so larger batches are what fills the chip.
 static int next_batch_end(const mhip_index* idx, const mhip_volume* reads, const ReadSel sel, int rb, int re, const mhip_params* P) {
     const double hits_per_lookup = (double)idx->num_kmers / (double)NKMER + 2.0;
-    double budget = filter_enabled(P) ? 3.2e9 : 400e6;   // ~25 GB of batch arrays either way (1.6e9: 5 ms more per config-2 pass, tail of the one-wave-per-read kernel)
+    double budget = filter_enabled(P) ? 3.2e9 : wide_filter_enabled(P) ? 1.6e9 : 400e6;   // ~25 GB of batch arrays either way (1.6e9: 5 ms more per config-2 pass, tail of the one-wave-per-read kernel)
     if (const char* e = getenv("MECAT_SEED_BATCH_HITS")) budget = std::max(1e6, atof(e));   // tuning knob
     double acc = 0;
     int r = rb;

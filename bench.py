@@ -8,6 +8,7 @@ Workload (BASELINE.json configs[1]): 100 000 synthetic PacBio-st
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...      (one rank per GPU, RCCL)
+    python bench.py --gpus N ...            (no launcher: the script re-executes itself under torch.distributed.run with N ranks)
 
 N > 1 (strong scaling, total work fixed): the library's own multi-GPU calls, as in the mecat2pw driver — every rank rebuilds
 the index itself (recompute beats moving up to 6 GB of positions over a 153 GB/s xGMI link), the reads are dealt out in
@@ -214,6 +215,16 @@ def main():
     ap.add_argument("--stats", default="", help="write per-kernel stats JSON here (rank 0)")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` without a launcher around it (no WORLD_SIZE in the environment): start N ranks of this script, one per
+    # GPU, through torch.distributed.run on the loop-back address, and become that launcher (the run must not
+    # quietly fall back to one GPU).  Under a launcher (WORLD_SIZE set) the ranks must be exactly --gpus.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        port = os.environ.get("MASTER_PORT", str(29500 + os.getpid() % 2000))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+        log("[bench] --gpus %d without a launcher: exec %s" % (args.gpus, " ".join(cmd)))
+        os.execv(sys.executable, cmd)
+
     import torch
     import torch.distributed as dist
     from mecat_amd import hip as M
@@ -227,13 +238,18 @@ def main():
     backend = os.environ.get("MECAT_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank %= max(1, torch.cuda.device_count())
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d (or without a launcher: "
+                         "the script starts its own ranks)" % (args.gpus, world, args.gpus))
+    if world > 1 and backend == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: %d ranks but %d visible GPUs (one rank per GPU; MECAT_BENCH_BACKEND=gloo folds ranks onto the GPUs "
+                         "that exist, as a test hook only)" % (world, torch.cuda.device_count()))
     if world > 1:
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 

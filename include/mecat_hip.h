@@ -95,6 +95,8 @@ int  mhip_ctx_reserve_index(mhip_ctx* ctx, int64_t bases);
    from device memory to the host on the context's stream that returns when the bytes have arrived */
 int  mhip_ctx_buffer(mhip_ctx* ctx, const char* name, size_t bytes, void** d_ptr);
 int  mhip_download(mhip_ctx* ctx, void* host_dst, const void* d_src, size_t bytes);
+/* free / total device memory as the driver sees it now (callers size the tables they keep resident from it) */
+int  mhip_ctx_mem_info(mhip_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
 void mhip_params_default(mhip_params* p, int tech);           /* pw_options.cpp:30-50 + pw_impl.cpp:843-851 */
 
 /* per-kernel timing with HIP events on the context's stream (for bench.py's roofline block).
@@ -253,7 +255,10 @@ int mhip_cns_align_candidates_dev(mhip_ctx* ctx, const mhip_volume* ref, const m
  * function subtracts the reference's 0.02.  Output (malloc'ed, release with mhip_cns_free): one record per accepted alignment
  * in the order the reference would add them, template by template, and the gap-normalised aligned strings
  * (normalize_gaps(.., push = true), reads_correction_aux.cpp:3-81) that meap_add_one_aln / CnsAlns::add_aln consume:
- * strings + str_offset = qaln (aln_size chars + NUL), then saln (aln_size chars + NUL). */
+ * strings + str_offset = qaln (aln_size chars + NUL), then saln (aln_size chars + NUL).
+ * Ties: candidates equal in (score, qid, qext) keep the order the reference's own std::sort gives them when cands[] arrives in the
+ * reference's order (the partition file's); any other input order may accept tied records in another order.  Every record's
+ * qsize / ssize must equal the volume's read lengths (refused otherwise). */
 typedef struct { int32_t qdir, qid, qext, qsize, qoff, qend, sdir, sid, sext, ssize, soff, send, score; } mhip_ext_candidate;
 typedef struct {
     int32_t template_index;      /* index into tmpl_begin */

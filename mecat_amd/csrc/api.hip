@@ -139,6 +139,15 @@ int mhip_download(mhip_ctx* c, void* host_dst, const void* d_src, size_t bytes) 
     return 0;
 }
 
+int mhip_ctx_mem_info(mhip_ctx* c, size_t* free_bytes, size_t* total_bytes) {
+    HIPCHK(hipSetDevice(c->device));
+    size_t f = 0, t = 0;
+    HIPCHK(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return 0;
+}
+
 int mhip_ctx_sync(mhip_ctx* c) {
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));

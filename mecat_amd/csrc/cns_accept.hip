@@ -114,12 +114,22 @@ int mhip_cns_accept_templates(mhip_ctx* c, const mhip_volume* vol, const uint8_t
     parallel_for(num_templates, num_threads, [&](int64_t t) {
         mhip_ext_candidate* b = cands + tmpl_begin[t];
         mhip_ext_candidate* e = cands + tmpl_begin[t + 1];
+        // std::sort, not stable_sort: the reference sorts the same array (file order of the partition) with the same comparator and
+        // the same libstdc++ introsort (mecat_correction.cpp:409 / :472), so records that tie on (score, qid, qext) come out in the
+        // reference's order exactly when the input order is the reference's — which is what the caller hands over
         std::sort(b, e, CmpByScore());
-        for (mhip_ext_candidate* p = b; p < e; ++p)
+        for (mhip_ext_candidate* p = b; p < e; ++p) {
             if (p->sdir != 0 || p->qid < start_id || p->qid >= start_id + nreads || p->sid < start_id || p->sid >= start_id + nreads ||
-                p->sid != b->sid)
+                p->sid != b->sid) {
                 bad = 1;
+                continue;
+            }
+            // the record's read lengths are the volume's: the replay indexes the coverage array and the reads with them (the
+            // reference has a fixed MAX_SEQ_SIZE array there; a record that disagrees with the volume is refused, not trusted)
+            if (p->qsize != vol->h_offs[(size_t)(p->qid - start_id)].size || p->ssize != vol->h_offs[(size_t)(p->sid - start_id)].size) bad = 2;
+        }
     });
+    if (bad.load() == 2) { mhip_set_error("cns accept: a candidate's qsize / ssize differs from the read lengths of the volume"); return -1; }
     if (bad.load()) { mhip_set_error("cns accept: a candidate is outside the volume, has sdir != 0 or sits in another template's range"); return -1; }
 
     // 2. the first <= 200 candidates of every template, as alignment jobs
@@ -167,7 +177,7 @@ int mhip_cns_accept_templates(mhip_ctx* c, const mhip_volume* vol, const uint8_t
     parallel_for(num_templates, num_threads, [&](int64_t t) {
         const int64_t b = tmpl_begin[t], n = tmpl_begin[t + 1] - b;
         if (n == 0) return;
-        const int ssize = cands[b].ssize;
+        const int ssize = vol->h_offs[(size_t)(cands[b].sid - start_id)].size;      // (== every candidate's ssize: checked above)
         std::vector<uint8_t> cov((size_t)std::max(ssize, 1), 0);
         std::set<int> used;
         int num_added = 0, num_ext = 0;

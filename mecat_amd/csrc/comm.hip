@@ -287,6 +287,40 @@ int allgatherv(mhip_comm* cm, const void* d_send, void* d_recv, const std::vecto
     return 0;
 }
 
+// Failure is made collective before every payload exchange: each rank contributes one status word (0 = its local work of this
+// step succeeded), and a step any rank failed fails on EVERY rank with the same return code — instead of one rank returning early
+// while its peers sit in ncclAllGather / ncclSend / ncclRecv waiting for it.  `local_err` != 0 keeps the rank's own
+// error text; the others name the rank that failed.
+int agree(mhip_comm* cm, int local_err, const char* what) {
+    mhip_ctx* c = cm->ctx;
+    const int P = cm->nranks;
+    if (P == 1) return local_err ? -1 : 0;
+    int32_t* d;
+    if (c->scratch("xg_status", sizeof(int32_t) * (size_t)(P + 1), (void**)&d)) {
+        // no room for P + 1 words: this rank cannot even report; the peers' watchdogs (driver) or the transport's timeout end the step
+        return -1;
+    }
+    const int32_t mine = local_err ? 1 : 0;
+    if (hipMemcpyAsync(d + P, &mine, sizeof(mine), hipMemcpyHostToDevice, c->stream) != hipSuccess) return -1;
+    std::vector<size_t> bytes((size_t)P, sizeof(int32_t)), displ((size_t)P);
+    for (int r = 0; r < P; ++r) displ[(size_t)r] = sizeof(int32_t) * (size_t)r;
+    std::string own = local_err ? mhip_last_error() : "";
+    if (allgatherv(cm, d + P, d, bytes, displ)) return -1;
+    std::vector<int32_t> st((size_t)P);
+    if (hipMemcpyAsync(st.data(), d, sizeof(int32_t) * (size_t)P, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) {
+        mhip_set_error("%s: status exchange failed", what);
+        return -1;
+    }
+    for (int r = 0; r < P; ++r)
+        if (st[(size_t)r]) {
+            if (local_err) mhip_set_error("%s", own.c_str());
+            else mhip_set_error("%s: rank %d failed its part of the step; every rank stops", what, r);
+            return -1;
+        }
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -441,15 +475,18 @@ int mhip_allgather_candidates(mhip_comm* cm, const void* d_cands, const void* d_
     cm->sh = sh;
     cm->maxc = maxc;
     cm->n_pad = n_pad;
-    int32_t *d_pad, *d_cnt_all;
-    uint32_t* d_pref;
-    long long* d_tot;      // [P] totals, [P] displacements
-    int* d_rid0;
-    if (c->scratch("xg_cntpad", sizeof(int32_t) * (size_t)n_pad, (void**)&d_pad)) return -1;
-    if (c->scratch("xg_cntall", sizeof(int32_t) * (size_t)n_pad * P, (void**)&d_cnt_all)) return -1;
-    if (c->scratch("xg_pref", sizeof(uint32_t) * (size_t)n_pad * P, (void**)&d_pref)) return -1;
-    if (c->scratch("xg_tot", sizeof(long long) * 2 * (size_t)P, (void**)&d_tot)) return -1;
-    if (c->scratch("xg_rid0", sizeof(int) * (size_t)P, (void**)&d_rid0)) return -1;
+    int32_t *d_pad = nullptr, *d_cnt_all = nullptr;
+    uint32_t* d_pref = nullptr;
+    long long* d_tot = nullptr;      // [P] totals, [P] displacements
+    int* d_rid0 = nullptr;
+    {
+        const int lerr = c->scratch("xg_cntpad", sizeof(int32_t) * (size_t)n_pad, (void**)&d_pad) ||
+                         c->scratch("xg_cntall", sizeof(int32_t) * (size_t)n_pad * P, (void**)&d_cnt_all) ||
+                         c->scratch("xg_pref", sizeof(uint32_t) * (size_t)n_pad * P, (void**)&d_pref) ||
+                         c->scratch("xg_tot", sizeof(long long) * 2 * (size_t)P, (void**)&d_tot) ||
+                         c->scratch("xg_rid0", sizeof(int) * (size_t)P, (void**)&d_rid0);
+        if (agree(cm, lerr, "mhip_allgather_candidates (count buffers)")) return -1;
+    }
     HIPCHK(hipMemsetAsync(d_pad, 0, sizeof(int32_t) * (size_t)n_pad, c->stream));
     if (n_local) HIPCHK(hipMemcpyAsync(d_pad, d_counts, sizeof(int32_t) * (size_t)n_local, hipMemcpyDeviceToDevice, c->stream));
     // 1. counts
@@ -470,9 +507,15 @@ int mhip_allgather_candidates(mhip_comm* cm, const void* d_cands, const void* d_
     HIPCHK(hipMemcpyAsync(d_tot + P, displ_rec.data(), sizeof(long long) * (size_t)P, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(d_rid0, rid0s.data(), sizeof(int) * (size_t)P, hipMemcpyHostToDevice, c->stream));
     // 2. payload: only the occupied records
-    mhip_candidate *d_pack, *d_dense;
-    if (c->scratch("xg_pack", sizeof(mhip_candidate) * (size_t)std::max<long long>(tot[(size_t)me], 1), (void**)&d_pack)) return -1;
-    if (c->scratch("xg_dense", sizeof(mhip_candidate) * (size_t)std::max<long long>(total, 1), (void**)&d_dense)) return -1;
+    // (every rank holds the same totals[]: size limits are checked on all of them, so that all ranks fail alike)
+    for (int r = 0; r < P; ++r)
+        if (tot[(size_t)r] > 0x7fffffffLL) { mhip_set_error("rank %d holds %lld candidates of this slab (limit 2^31 - 1): use smaller slabs", r, tot[(size_t)r]); return -1; }
+    mhip_candidate *d_pack = nullptr, *d_dense = nullptr;
+    {
+        const int lerr = c->scratch("xg_pack", sizeof(mhip_candidate) * (size_t)std::max<long long>(tot[(size_t)me], 1), (void**)&d_pack) ||
+                         c->scratch("xg_dense", sizeof(mhip_candidate) * (size_t)std::max<long long>(total, 1), (void**)&d_dense);
+        if (agree(cm, lerr, "mhip_allgather_candidates (payload buffers)")) return -1;
+    }
     if (n_local) {
         const size_t nt = (size_t)n_local * (size_t)maxc;
         LAUNCH(c, "xg_pack", xg_pack, (unsigned)((nt + 255) / 256), 256, 0, (const mhip_candidate*)d_cands, (const int32_t*)d_counts,
@@ -510,12 +553,15 @@ int mhip_seed_reads_sharded(mhip_comm* cm, const mhip_index* idx, const mhip_vol
     if (n == 0) return 0;
     const Shard sh{rid_begin, rid_end, chunk, cell_shift, cm->nranks};
     const int n_local = sh.local_count(cm->rank);
-    if (c->scratch("xg_local", sizeof(mhip_candidate) * (size_t)std::max(n_local, 1) * (size_t)P->maxc, (void**)&cm->d_local)) return -1;
-    if (c->scratch("xg_localcnt", sizeof(int32_t) * (size_t)std::max(n_local, 1), (void**)&cm->d_local_cnt)) return -1;
-    if (c->scratch("xg_all", sizeof(mhip_candidate) * (size_t)n * (size_t)P->maxc, (void**)&cm->d_all)) return -1;
-    if (c->scratch("xg_allcnt", sizeof(int32_t) * (size_t)n, (void**)&cm->d_all_cnt)) return -1;
-    if (n_local && mhip_seed_reads_chunked_dev(c, idx, ref, reads, sh.rid0(cm->rank), chunk, cm->nranks, n_local, P, cm->d_local, cm->d_local_cnt))
-        return -1;
+    {
+        int lerr = c->scratch("xg_local", sizeof(mhip_candidate) * (size_t)std::max(n_local, 1) * (size_t)P->maxc, (void**)&cm->d_local) ||
+                   c->scratch("xg_localcnt", sizeof(int32_t) * (size_t)std::max(n_local, 1), (void**)&cm->d_local_cnt) ||
+                   c->scratch("xg_all", sizeof(mhip_candidate) * (size_t)n * (size_t)P->maxc, (void**)&cm->d_all) ||
+                   c->scratch("xg_allcnt", sizeof(int32_t) * (size_t)n, (void**)&cm->d_all_cnt);
+        if (!lerr && n_local) lerr = mhip_seed_reads_chunked_dev(c, idx, ref, reads, sh.rid0(cm->rank), chunk, cm->nranks, n_local, P, cm->d_local, cm->d_local_cnt);
+        if (!lerr && hipStreamSynchronize(c->stream) != hipSuccess) { mhip_set_error("seeding of this rank's reads failed on the device"); lerr = 1; }
+        if (agree(cm, lerr, "mhip_seed_reads_sharded")) return -1;      // a rank whose seeding failed takes every rank out before the exchange
+    }
     if (mhip_allgather_candidates(cm, cm->d_local, cm->d_local_cnt, rid_begin, rid_end, chunk, cell_shift, P->maxc, cm->d_all, cm->d_all_cnt)) return -1;
     if (out_counts) HIPCHK(hipMemcpyAsync(out_counts, cm->d_all_cnt, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
     if (out) HIPCHK(hipMemcpyAsync(out, cm->d_all, sizeof(mhip_candidate) * (size_t)n * (size_t)P->maxc, hipMemcpyDeviceToHost, c->stream));
@@ -534,20 +580,22 @@ int mhip_align_sharded(mhip_comm* cm, const mhip_volume* ref, const mhip_volume*
     if (n <= 0 || cm->totals.empty()) return 0;
     const int n_local = sh.local_count(me), maxc = cm->maxc, n_pad = cm->n_pad;
     const long long mine = cm->totals[(size_t)me], total = cm->n_jobs_total;
-    mhip_aln_job* d_jobs;
-    mhip_aln_result *d_res, *d_dense;
-    if (c->scratch("xg_jobs", sizeof(mhip_aln_job) * (size_t)std::max<long long>(mine, 1), (void**)&d_jobs)) return -1;
-    if (c->scratch("xg_res", sizeof(mhip_aln_result) * (size_t)std::max<long long>(mine, 1), (void**)&d_res)) return -1;
-    if (c->scratch("xg_resdense", sizeof(mhip_aln_result) * (size_t)std::max<long long>(total, 1), (void**)&d_dense)) return -1;
-    if (c->scratch("xg_resall", sizeof(mhip_aln_result) * (size_t)std::max<long long>(total, 1), (void**)&cm->d_all_res)) return -1;
-    if (mine > 0x7fffffffLL) { mhip_set_error("too many alignment jobs in one slab"); return -1; }
-    if (mine) {
-        const size_t nt = (size_t)n_local * (size_t)maxc;
-        LAUNCH(c, "xg_make_jobs", xg_make_jobs, (unsigned)((nt + 255) / 256), 256, 0, (const mhip_candidate*)cm->d_local, (const int32_t*)cm->d_local_cnt,
-               (const uint32_t*)(cm->d_pref + (size_t)me * n_pad), n_local, maxc, sh.rid0(me), sh.chunk, P, ref->start_read_id, d_jobs);
-        const int rc = tech == 1 ? mhip_xalign_candidates_dev(c, ref, reads, d_jobs, (int)mine, min_align_size, d_res)
-                                 : mhip_align_candidates_dev(c, ref, reads, d_jobs, (int)mine, min_align_size, d_res);
-        if (rc) return -1;
+    mhip_aln_job* d_jobs = nullptr;
+    mhip_aln_result *d_res = nullptr, *d_dense = nullptr;
+    {
+        int lerr = c->scratch("xg_jobs", sizeof(mhip_aln_job) * (size_t)std::max<long long>(mine, 1), (void**)&d_jobs) ||
+                   c->scratch("xg_res", sizeof(mhip_aln_result) * (size_t)std::max<long long>(mine, 1), (void**)&d_res) ||
+                   c->scratch("xg_resdense", sizeof(mhip_aln_result) * (size_t)std::max<long long>(total, 1), (void**)&d_dense) ||
+                   c->scratch("xg_resall", sizeof(mhip_aln_result) * (size_t)std::max<long long>(total, 1), (void**)&cm->d_all_res);
+        if (!lerr && mine) {      // (mine <= 2^31 - 1: checked on every rank's total in mhip_allgather_candidates)
+            const size_t nt = (size_t)n_local * (size_t)maxc;
+            LAUNCH(c, "xg_make_jobs", xg_make_jobs, (unsigned)((nt + 255) / 256), 256, 0, (const mhip_candidate*)cm->d_local, (const int32_t*)cm->d_local_cnt,
+                   (const uint32_t*)(cm->d_pref + (size_t)me * n_pad), n_local, maxc, sh.rid0(me), sh.chunk, P, ref->start_read_id, d_jobs);
+            lerr = tech == 1 ? mhip_xalign_candidates_dev(c, ref, reads, d_jobs, (int)mine, min_align_size, d_res)
+                             : mhip_align_candidates_dev(c, ref, reads, d_jobs, (int)mine, min_align_size, d_res);
+            if (!lerr && hipStreamSynchronize(c->stream) != hipSuccess) { mhip_set_error("extension of this rank's candidates failed on the device"); lerr = 1; }
+        }
+        if (agree(cm, lerr, "mhip_align_sharded")) return -1;
     }
     std::vector<size_t> bytes((size_t)P), displ((size_t)P);
     std::vector<long long> displ_rec((size_t)P);

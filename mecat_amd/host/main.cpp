@@ -366,14 +366,30 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
         // One process: the candidate lists of the whole cell are made in one go and stay in HBM; a slab is then job assembly and
         // extension on the device plus the copies the text needs (a seeding call per slab cost 5 x 17 ms instead of 59 at config 2,
         // and the host-side job assembly kept the GPU waiting).  With a communicator the sharded calls below do all of this.
+        // The resident table is [reads][MAXC] records of 48 bytes: a volume of short reads at a large -n would not fit (2 M reads at
+        // -n 1024: 100 GB), so the cell is seeded in super-slabs — a whole number of slabs whose table stays inside a budget taken from
+        // the free device memory (a quarter of it, at most 32 GB; MECAT_HIP_CELL_MB overrides) — one super-slab = the whole cell whenever
+        // it fits (config 2: 0.48 GB).
         void *d_cell_cands = NULL, *d_cell_counts = NULL;
+        int cell_first = 0, cell_reads = 0, super_reads = rd->num_reads;
         if (!comm) {
-            StageClock sc(&st[0]);
-            MCHK(mhip_ctx_buffer(ctx, "cell_cands", sizeof(mhip_candidate) * (size_t)rd->num_reads * P.maxc, &d_cell_cands));
-            MCHK(mhip_ctx_buffer(ctx, "cell_counts", sizeof(int32_t) * (size_t)rd->num_reads, &d_cell_counts));
-            MCHK(mhip_seed_reads_dev(ctx, idx, dref, dreads, 0, rd->num_reads, &P, d_cell_cands, d_cell_counts));
-            MCHK(mhip_ctx_sync(ctx));
+            size_t free_b = 0, total_b = 0;
+            MCHK(mhip_ctx_mem_info(ctx, &free_b, &total_b));
+            size_t budget = std::min<size_t>(free_b / 4, (size_t)32 << 30);
+            if (const char* e = getenv("MECAT_HIP_CELL_MB")) budget = (size_t)std::max(1L, atol(e)) << 20;
+            const size_t per_read = sizeof(mhip_candidate) * (size_t)P.maxc + sizeof(int32_t);
+            const size_t fit = std::max<size_t>(1, budget / per_read / (size_t)slab) * (size_t)slab;
+            super_reads = (int)std::min<size_t>((size_t)std::max(rd->num_reads, 1), fit);
         }
+        auto seed_super = [&](int first) {
+            StageClock sc(&st[0]);
+            cell_first = first;
+            cell_reads = std::min(super_reads, rd->num_reads - first);
+            MCHK(mhip_ctx_buffer(ctx, "cell_cands", sizeof(mhip_candidate) * (size_t)std::min(super_reads, rd->num_reads) * P.maxc, &d_cell_cands));
+            MCHK(mhip_ctx_buffer(ctx, "cell_counts", sizeof(int32_t) * (size_t)std::min(super_reads, rd->num_reads), &d_cell_counts));
+            MCHK(mhip_seed_reads_dev(ctx, idx, dref, dreads, first, first + cell_reads, &P, d_cell_cands, d_cell_counts));
+            MCHK(mhip_ctx_sync(ctx));
+        };
         int sno = 0;
         for (int rb = 0; rb < rd->num_reads; rb += slab, ++sno) {
             const int re = std::min(rd->num_reads, rb + slab), nr = re - rb;
@@ -389,6 +405,8 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
             B.rb = rb;
             B.nr = nr;
             B.packed = !comm;
+            if (!comm && (sno == 0 || rb >= cell_first + cell_reads)) seed_super(rb);      // (slabs never straddle super-slabs)
+            const int cb = rb - cell_first;                                                // the slab inside the resident table
             if (writes) {
                 StageClock sc(&st[5]);
                 if (comm) cands.resize((size_t)nr * P.maxc);
@@ -401,13 +419,13 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
             } else {
                 StageClock sc(&st[4]);      // (copies: booked with the writing)
                 // the counts, and the occupied entries of the lists packed on the device (a list is ~22 of its 100 slots)
-                MCHK(mhip_download(ctx, counts.data(), (const int32_t*)d_cell_counts + rb, sizeof(int32_t) * (size_t)nr));
+                MCHK(mhip_download(ctx, counts.data(), (const int32_t*)d_cell_counts + cb, sizeof(int32_t) * (size_t)nr));
                 jfirst.assign((size_t)nr + 1, 0);
                 for (int r = 0; r < nr; ++r) jfirst[(size_t)r + 1] = jfirst[(size_t)r] + (size_t)counts[(size_t)r];
                 void* d_pack = NULL;
                 int64_t total = 0;
                 MCHK(mhip_ctx_buffer(ctx, "slab_pack", sizeof(mhip_candidate) * (size_t)nr * P.maxc, &d_pack));
-                MCHK(mhip_pack_candidates_dev(ctx, (const mhip_candidate*)d_cell_cands + (size_t)rb * P.maxc, (const int32_t*)d_cell_counts + rb, nr, P.maxc,
+                MCHK(mhip_pack_candidates_dev(ctx, (const mhip_candidate*)d_cell_cands + (size_t)cb * P.maxc, (const int32_t*)d_cell_counts + cb, nr, P.maxc,
                                               d_pack, &total));
                 if ((size_t)total != jfirst[(size_t)nr]) DIE("%lld packed candidates for %zu counted", (long long)total, jfirst[(size_t)nr]);
                 cands.resize((size_t)total);
@@ -425,7 +443,7 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
                 {
                     StageClock sc(&st[1]);
                     MCHK(mhip_ctx_buffer(ctx, "slab_jobs", sizeof(mhip_aln_job) * (size_t)nr * P.maxc, &d_jobs));
-                    MCHK(mhip_jobs_from_candidates_dev(ctx, (const mhip_candidate*)d_cell_cands + (size_t)rb * P.maxc, (const int32_t*)d_cell_counts + rb, nr,
+                    MCHK(mhip_jobs_from_candidates_dev(ctx, (const mhip_candidate*)d_cell_cands + (size_t)cb * P.maxc, (const int32_t*)d_cell_counts + cb, nr,
                                                        P.maxc, rb, 1, ref.start_read_id, 0, 1, d_jobs, &nj));
                     if ((size_t)nj != jfirst[(size_t)nr]) DIE("%d jobs for %zu candidates", nj, jfirst[(size_t)nr]);
                 }
@@ -548,6 +566,9 @@ static std::string run_token() {
     std::string t = "p" + std::to_string((long)getppid());
     if (const char* e = getenv("TORCHELASTIC_RUN_ID")) t += std::string("_") + e;
     if (const char* e = getenv("MASTER_PORT")) t += std::string("_") + e;
+    // an elastic restart by the same launcher keeps all of the above: the restart count tells the attempts apart, so that a rank of
+    // attempt k + 1 never accepts the split marker (communicator id, rows to do) attempt k left behind
+    if (const char* e = getenv("TORCHELASTIC_RESTART_COUNT")) t += std::string("_r") + e;
     for (char& ch : t)
         if (!isalnum((unsigned char)ch) && ch != '_' && ch != '-') ch = '_';
     return t;
@@ -568,6 +589,51 @@ static bool from_hex(const std::string& s, uint8_t* p, size_t n) {
         p[i] = (uint8_t)(a * 16 + b);
     }
     return true;
+}
+
+// r_<i> appended to (first: replacing) the output file, copied inside the kernel.  false = not an ordinary file (or the copy could
+// not be made this way): the caller falls back to the reference's `cat`.
+static bool merge_copy(const std::string& fin, const char* output, bool first) {
+    struct stat so;
+    const int have = lstat(output, &so);
+    if (have == 0 && !S_ISREG(so.st_mode)) return false;
+    if (have != 0 && errno != ENOENT) return false;
+    if (have == 0 && first && unlink(output) != 0) return false;
+    if (have == 0 && !first && so.st_nlink > 1) return false;
+    const int in = open(fin.c_str(), O_RDONLY);
+    if (in < 0) return false;
+    const int out = open(output, O_WRONLY | O_CREAT | (first ? O_EXCL : 0), 0666);
+    if (out < 0) { close(in); return false; }
+    struct stat si;
+    bool ok = fstat(in, &si) == 0 && lseek(out, 0, SEEK_END) >= 0;
+    off_t left = ok ? si.st_size : 0;
+    const off_t at0 = ok ? lseek(out, 0, SEEK_CUR) : 0;
+    bool plain = false;
+    while (ok && left > 0) {
+        const ssize_t n = plain ? -1 : copy_file_range(in, NULL, out, NULL, (size_t)std::min<off_t>(left, (off_t)1 << 30), 0);
+        if (n > 0) { left -= n; continue; }
+        if (n == 0) break;
+        // no copy_file_range between these two files (EXDEV, EINVAL, ENOSYS ...): plain read / write from where it stopped
+        plain = true;
+        static char buf[1 << 20];
+        const ssize_t r = read(in, buf, sizeof(buf));
+        if (r < 0) { ok = false; break; }
+        if (r == 0) break;
+        for (ssize_t w = 0; w < r;) {
+            const ssize_t k = write(out, buf + w, (size_t)(r - w));
+            if (k <= 0) { ok = false; break; }
+            w += k;
+        }
+        left -= r;
+    }
+    ok = ok && left == 0;
+    close(in);
+    if (close(out) != 0) ok = false;
+    if (!ok) {
+        if (first) unlink(output);
+        else if (truncate(output, at0) != 0) DIE("write error on '%s'", output);
+    }
+    return ok;
 }
 
 int main(int argc, char* argv[]) {
@@ -622,20 +688,45 @@ int main(int argc, char* argv[]) {
     });
     struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } gpu_setup_joiner{gpu_setup};
 
-    // heartbeat + failure marker of the ranks above 0
+    // heartbeat + failure marker of every rank of a multi-process run, and a watchdog on the peers: a rank that sees another
+    // rank's failure marker (or, once that rank's heartbeat has been seen, no beat for a minute) leaves its own marker and exits —
+    // also when its main thread sits inside an RCCL collective the dead rank will never join (cells mode had no timeout)
     std::atomic<bool> beat_stop{false};
     std::thread beat;
-    if (world > 1 && rank > 0) {
+    if (world > 1) {
         snprintf(g_fail_marker, sizeof(g_fail_marker), "%s", rf.failed(rank).c_str());
         unlink(g_fail_marker);
         signal(SIGSEGV, [](int) { leave_fail_marker(); _exit(139); });
         signal(SIGTERM, [](int) { leave_fail_marker(); _exit(143); });
         const std::string alive = rf.alive(rank);
-        beat = std::thread([&beat_stop, alive]() {
+        std::vector<std::string> peer_failed, peer_alive;
+        for (int r = 0; r < world; ++r)
+            if (r != rank) { peer_failed.push_back(rf.failed(r)); peer_alive.push_back(rf.alive(r)); }
+        const bool watch = !getenv("MECAT_HIP_NO_WATCHDOG");
+        beat = std::thread([&beat_stop, alive, peer_failed, peer_alive, watch, rank]() {
+            std::vector<char> seen(peer_alive.size(), 0);
             while (!beat_stop.load()) {
                 const int fd = open(alive.c_str(), O_CREAT | O_WRONLY | O_TRUNC, 0644);
                 if (fd >= 0) { (void)!write(fd, "1\n", 2); close(fd); }
-                for (int i = 0; i < 20 && !beat_stop.load(); ++i) usleep(100 * 1000);
+                for (int i = 0; i < 20 && !beat_stop.load(); ++i) {
+                    usleep(100 * 1000);
+                    if (!watch || i % 5) continue;
+                    for (size_t k = 0; k < peer_failed.size(); ++k) {
+                        struct stat sb;
+                        bool dead = access(peer_failed[k].c_str(), F_OK) == 0;
+                        const char* why = "left a failure marker";
+                        if (!dead && stat(peer_alive[k].c_str(), &sb) == 0) {
+                            seen[k] = 1;
+                            if (now_s() - (double)sb.st_mtime > 60.0) { dead = true; why = "stopped responding"; }
+                        }
+                        if (dead && !beat_stop.load()) {
+                            fprintf(stderr, "[mecat2pw rank %d] a peer %s (%s): stopping\n", rank, why, peer_failed[k].c_str());
+                            leave_fail_marker();
+                            unlink(alive.c_str());
+                            _exit(1);
+                        }
+                    }
+                }
             }
             unlink(alive.c_str());
         });
@@ -673,10 +764,10 @@ int main(int argc, char* argv[]) {
         const double wait_limit = env_int("MECAT_HIP_WAIT_S", NULL, 6 * 3600);
         for (;;) {
             FILE* m = fopen(marker.c_str(), "r");
-            char tok[256] = "", hex[2 * MHIP_COMM_ID_BYTES + 8] = "";
+            char tok[256] = "", hex[2 * MHIP_COMM_ID_BYTES + 8] = "";      // 264 bytes: %263s below
             double t0 = 0;
             int nv = 0, cl = 0;
-            const bool ok = m && fscanf(m, "%255s %lf %d %d %300s", tok, &t0, &nv, &cl, hex) == 5;
+            const bool ok = m && fscanf(m, "%255s %lf %d %d %263s", tok, &t0, &nv, &cl, hex) == 5;
             if (ok && rf.token == tok && (explicit_token || t0 > t_start - 120.0) && from_hex(hex, comm_id, sizeof(comm_id))) {
                 int v;
                 while (fscanf(m, "%d", &v) == 1) todo.push_back(v);
@@ -779,17 +870,16 @@ int main(int argc, char* argv[]) {
             if (now - w0 > merge_wait) DIE("gave up waiting for volume %d of rank %d after %.0f s", i, owner, merge_wait);
             usleep(50 * 1000);
         }
-        // One volume, and the output is (going to be) an ordinary file on the same file system: the output becomes a second name
-        // of r_0 instead of a copy of it — the same bytes without moving them (0.05 s at config 2).  Everything else is the
-        // reference's `cat` through the shell (an existing output that is not a regular file — a FIFO, /dev/stdout — is written
-        // through, as the shell's `>` does).  MECAT_HIP_MERGE=cat always copies.
-        if (num_vols == 1 && !(getenv("MECAT_HIP_MERGE") && !strcmp(getenv("MECAT_HIP_MERGE"), "cat"))) {
+        // The reference runs `cat r_<i> > output` / `>> output` through the shell (pw.cpp:34-46).  Same bytes here, copied inside the
+        // kernel (copy_file_range: a reflink where the file system has one) when the output is, or is going to be, an ordinary file; an
+        // existing output that is not a regular file (a FIFO, /dev/stdout) is written through by the shell as before.  The output never
+        // shares an inode with r_<i> (a hard link would let a later `cat r_0 > output` of a resumed reference run truncate
+        // both), and an old output is never written through: it is removed first, so a name that is a second link to some other file
+        // cannot damage that file.  MECAT_HIP_MERGE=cat keeps the shell.
+        if (!(getenv("MECAT_HIP_MERGE") && !strcmp(getenv("MECAT_HIP_MERGE"), "cat")) && merge_copy(fin, opt.output, i == 0)) continue;
+        if (i == 0) {
             struct stat so;
-            const int have = lstat(opt.output, &so);
-            if ((have != 0 && errno == ENOENT) || (have == 0 && S_ISREG(so.st_mode))) {      // (an old output may itself be a second name of an older r_0: never written through)
-                if (have == 0) unlink(opt.output);
-                if (link(fin.c_str(), opt.output) == 0) continue;
-            }
+            if (lstat(opt.output, &so) == 0 && S_ISREG(so.st_mode) && so.st_nlink > 1) unlink(opt.output);
         }
         const std::string cmd = std::string("cat ") + fin + (i == 0 ? " >" : " >> ") + opt.output;
         if (system(cmd.c_str()) != 0) DIE("'%s' failed", cmd.c_str());

@@ -22,7 +22,7 @@ def main():
     tag = sys.argv[1]
     import bench
     meta = {"kernel_source_digest": bench.src_digest(), "command": "python bench.py --steps 1 --warmup 1 --no-cpu --no-extras --no-e2e",
-            "tool": "rocprofv3 --kernel-trace --stats / --pmc (separate passes), tests/profile_bench.sh"}
+            "tool": "rocprofv3 --kernel-trace --stats / --pmc (separate passes), tools/dev/profile_bench.sh"}
     asm = sys.argv[2] if len(sys.argv) > 2 else "/tmp/align_%s.s" % tag
     if not os.path.exists(asm):
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),

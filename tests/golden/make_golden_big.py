@@ -8,6 +8,9 @@ files); the read sets are re-generated from their seeds by mecat_amd/bin/synth_r
     python tests/golden/make_golden_big.py config3            # 3 volumes, 6 grid cells, -j 0: about an hour
     python tests/golden/make_golden_big.py config3_ecoli      # same reads x length on a 4.6 Mb genome (1300x): row 2 only
     python tests/golden/make_golden_big.py config5            # 19 volumes, -x 1: -j 0 rows 17 and 18, -j 1 row 18 (resume protocol)
+    python tests/golden/make_golden_big.py config3_j1         # config 3, `-j 1 -g 1`, grid row 1 = cells (1,1) and (1,2): dw extension
+                                                              # across two real volumes (adds config3.m4_rows; rows 0 and 2 planted)
+    python tests/golden/make_golden_big.py config5_row0       # config 5, `-j 0 -x 1`, grid row 0 = 19 cells (adds config5.rows["0"])
 
 Rows that are not pinned are skipped with the reference's own resume protocol: an existing wrk/r_<i> means "volume i has been
 finished" (mecat2pw/pw.cpp:65-81), so empty r_<i> files are planted for them before the run.
@@ -103,10 +106,67 @@ def cell_filter(vols, j):
     return "$1 >= %d && $1 < %d" % (lo, hi)          # .can field 1 = query read id
 
 
+def aligned_bases(path):
+    return int(subprocess.run(["awk", "-F\t", "{s += $7 - $6} END {printf \"%.0f\", s}", path], stdout=subprocess.PIPE, text=True,
+                              check=True).stdout)
+
+
+def extra(big, name):
+    """pins added to an existing entry of big.json (the entry's volumes must equal the ones this run splits)"""
+    base = "config3" if name == "config3_j1" else "config5"
+    n, L, e, G, seed, ont = SETS[base]
+    fa = gen(base)
+    m = big[base]
+    assert os.path.getsize(fa) == m["fasta_bytes"]
+    d = os.path.join(WORK, base)
+    os.makedirs(d, exist_ok=True)
+    nv = len(m["volumes"])
+    if name == "config3_j1":
+        out = os.path.join(d, "c3.m4")
+        wrk = os.path.join(d, "w1")
+        secs = run_ref(fa, out, wrk, ["-j", "1", "-g", "1"], skip_rows=(0, 2))
+        vols = volumes(wrk)
+        assert [v["sha256"] for v in vols] == [v["sha256"] for v in m["volumes"]]
+        r = os.path.join(wrk, "r_1")
+        row = {"seconds": secs, "threads": int(THREADS)}
+        row["lines"], row["sorted_sha256"] = sorted_sha(r)
+        row["aligned_bases"] = aligned_bases(r)
+        row["cells"] = {}
+        for j in (1, 2):                              # .m4 field 2 = query read id (field 1 is the subject, SURVEY.md A14)
+            lo = vols[j]["start_read_id"]
+            c = {}
+            c["lines"], c["sorted_sha256"] = sorted_sha(r, "$2 >= %d && $2 < %d" % (lo, lo + vols[j]["num_reads"]))
+            row["cells"]["1,%d" % j] = c
+        m.setdefault("m4_rows", {})["1"] = row
+    else:
+        out = os.path.join(d, "c5r0.can")
+        wrk = os.path.join(d, "w2")
+        secs = run_ref(fa, out, wrk, ["-j", "0", "-x", "1"], skip_rows=range(1, nv))
+        vols = volumes(wrk)
+        assert [(v["num_reads"], v["num_bases"], v["start_read_id"]) for v in vols] == \
+               [(v["num_reads"], v["num_bases"], v["start_read_id"]) for v in m["volumes"]]
+        r = os.path.join(wrk, "r_0")
+        row = {"seconds": secs, "threads": int(THREADS)}
+        row["lines"], row["sorted_sha256"] = sorted_sha(r)
+        row["cells"] = {}
+        for j in range(nv):
+            c = {}
+            c["lines"], c["sorted_sha256"] = sorted_sha(r, cell_filter(vols, j))
+            row["cells"]["0,%d" % j] = c
+        assert [v["sha256"] for v in vols] == [v["sha256"] for v in m["volumes"]]
+        m["rows"]["0"] = row
+    json.dump(big, open(OUT, "w"), indent=1, sort_keys=True)
+    print(name, json.dumps(row)[:600], file=sys.stderr)
+
+
 def main():
     which = sys.argv[1:] or ["config2"]
     big = json.load(open(OUT)) if os.path.exists(OUT) else {}
     for name in which:
+        if name in ("config3_j1", "config5_row0"):
+            extra(big, name)
+            big = json.load(open(OUT))
+            continue
         n, L, e, G, seed, ont = SETS[name]
         fa = gen(name)
         m = {"gen": dict(nreads=n, L=L, err=e, genome=G, seed=seed, ont=ont), "fasta_bytes": os.path.getsize(fa),

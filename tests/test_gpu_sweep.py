@@ -1,6 +1,6 @@
 """Randomized candidate parity: the device path (seed_strand and the kernel chain mixed strand by strand, bucket cuts, early drop of
 higher-id subjects) against the CPU oracle on seeded random read sets of varying size, read length, error, coverage, technology
-and MAXC, every third one with ragged read lengths (down to a single base).  tests/scratch/parity_sweep.py is the long version
+and MAXC, every third one with ragged read lengths (down to a single base).  tools/dev/parity_sweep.py is the long version
 (125 sets run clean when this was written)."""
 import numpy as np
 import pytest

@@ -1,14 +1,14 @@
 """Throughput of the mecat2cns re-aligner on config-2-style candidates, next to the unmodified
 reference (oracle/_ref/libref_cns.so, one thread) on a sample of the same jobs.  Not part of bench.py's metric.
-    python tests/bench_cns.py [nreads]"""
+    python tools/dev/bench_cns.py [nreads]"""
 import os
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))      # tests/helpers.py
 import torch  # noqa: F401,E402  (before the HIP library, see conftest.py)
 import helpers as H  # noqa: E402
 from mecat_amd import hip as M, workload as W  # noqa: E402

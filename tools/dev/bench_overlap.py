@@ -1,5 +1,5 @@
 """Dev experiment (not a test): how well do seeding (latency/HBM bound) and dw extension (VALU bound) overlap when run
-from two contexts on two streams?  python tests/bench_overlap.py [dw_waves ...]"""
+from two contexts on two streams?  python tools/dev/bench_overlap.py [dw_waves ...]"""
 import os
 import sys
 import threading
@@ -8,7 +8,8 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))      # tests/helpers.py
 import mecat_amd.hip as M            # noqa: E402
 from mecat_amd import workload as W  # noqa: E402
 

@@ -1,5 +1,5 @@
 """Dev experiment (not a test): do two seeding calls on disjoint read ranges overlap when issued from two contexts / streams?
-python tests/bench_seed_split.py"""
+python tools/dev/bench_seed_split.py"""
 import os
 import sys
 import threading
@@ -7,7 +7,8 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))      # tests/helpers.py
 import mecat_amd.hip as M            # noqa: E402
 from mecat_amd import workload as W  # noqa: E402
 

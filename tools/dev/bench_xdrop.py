@@ -1,5 +1,7 @@
 import sys, time, numpy as np
-sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))      # tests/helpers.py
 import torch
 from mecat_amd import hip as M, workload as W
 codes, lens = W.synth_reads(5000, 10000, 0.12, 1_700_000, 7, 1)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# dev helper (GPU box): config-2 sized FASTA through the CLI with MECAT_TRACE timers.   bash tests/e2e_config2.sh [task] [reads]
+# dev helper (GPU box): config-2 sized FASTA through the CLI with MECAT_TRACE timers.   bash tools/dev/e2e_config2.sh [task] [reads]
 T=${1:-1}; N=${2:-100000}
 D=/tmp/e2e_c2; rm -rf $D; mkdir -p $D
 mecat_amd/bin/synth_reads $D/reads.fa $N 15000 0.15 50000000 1 > /dev/null 2>&1

@@ -1,6 +1,6 @@
 #!/bin/bash
 # dev helper (GPU box): nanopore mode end to end, ours vs the unmodified reference on the same FASTA.
-#   bash tests/e2e_nanopore.sh <reads> <len> <genome> <out.txt>
+#   bash tools/dev/e2e_nanopore.sh <reads> <len> <genome> <out.txt>
 set -u
 N=${1:-40000}; L=${2:-10000}; G=${3:-13000000}; OUT=${4:-gpurun_out/e2e_nanopore.txt}
 D=/tmp/e2e_ont; rm -rf $D; mkdir -p $D

@@ -1,5 +1,5 @@
 #!/bin/bash
-# dev helper: SQ counters for the X-drop kernels of tests/bench_xdrop.py (run on the GPU box)
+# dev helper: SQ counters for the X-drop kernels of tools/dev/bench_xdrop.py (run on the GPU box)
 cd /tmp && export TMPDIR=/tmp
 i=0
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_INSTS_VMEM_WR SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_SMEM"; do

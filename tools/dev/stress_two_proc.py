@@ -1,6 +1,7 @@
 """Dev helper: hammer the two-process mode of the driver (both ranks on GPU 0) and print what a failing rank said."""
 import json, os, subprocess, sys, tempfile, time
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))      # tests/helpers.py
 import helpers as H
 BIN = os.path.join(H.ROOT, "mecat_amd", "bin", "mecat2pw")
 G = json.load(open(os.path.join(H.GOLDEN, "golden.json")))

@@ -62,3 +62,10 @@ ref:
 clean:
 	rm -rf build $(LIBDIR) $(BINDIR)
 	$(MAKE) -C oracle clean
+
+# development variant of the library with dw_extend2's section clocks and row statistics compiled in (tools/dev/dw_breakdown.sh)
+dwstats: $(LIBDIR)/libmecat_hip_dwstats.so
+$(LIBDIR)/libmecat_hip_dwstats.so: $(HIP_SRCS) $(HIP_HDRS)
+	@mkdir -p build/dwstats $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -DMECAT_DW_STATS -x hip -c $(CSRC)/align.hip -o build/dwstats/align.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC build/dwstats/align.o $(filter-out build/align.o,$(HIP_OBJS)) -o $@

@@ -32,6 +32,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 
@@ -489,7 +490,19 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
     const uint32_t rbase = (uint32_t)(uintptr_t)(lds_u16_t*)&rings[(threadIdx.x >> 6) * 2 + hh][0];
     unsigned int cells = 0, nblocks = 0, nhand = 0;
 #ifdef MECAT_DW_STATS
+    // development build only (tools/dev/dw_breakdown.sh -> profiles/rNN_dw_row_breakdown.md): where the wave's time and rows go.
+    // Clocks are s_memrealtime ticks (100 MHz), summed per section over the wave's life; counts are per dual row.
     unsigned long long nrows = 0, nidle = 0, nwide = 0;
+    unsigned long long tk_rows = 0, tk_setup = 0, tk_ended = 0, tk_trace = 0, tk_acct = 0, n_outer = 0, n_setup = 0, n_ended = 0, n_pass3 = 0;
+    unsigned long long nh[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // unit rows by band width: <= 8, 16, 24, 32, 48, 64, 96, more
+    unsigned long long q16[6] = {0, 0, 0, 0, 0, 0};           // unit rows by ceil(nslot / 16): 1, 2, 3, 4, 5-6, more
+    unsigned long long snake2 = 0;                            // snake steps beyond the first (per pass)
+    const unsigned long long tk_start = wall_clock64();
+#define DWS_T(var) const unsigned long long var = wall_clock64()
+#define DWS_ADD(acc, a, b) acc += (b) - (a)
+#else
+#define DWS_T(var)
+#define DWS_ADD(acc, a, b)
 #endif
 
     // per-half unit state (uniform inside a half)
@@ -510,6 +523,11 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
     int dlim = 0;               // rows run while d < dlim: max_d of the block, 0 once an end was reached / without a block
 
     while (true) {
+#ifdef MECAT_DW_STATS
+        n_outer += 1;
+        n_setup += BALLOT(setup) ? 1u : 0u;
+#endif
+        DWS_T(t_a);
         if (BALLOT(setup)) {
             // ---- 1. a half without a unit pulls the next one
             if (setup && need_unit) {
@@ -563,6 +581,8 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
         }
         if (!BALLOT(!exhausted)) break;
         const int q_len = qblk, t_len = tblk, k_offset = max_d;
+        DWS_T(t_b);
+        DWS_ADD(tk_setup, t_a, t_b);
 
         // ---- 3. one row per half (Align, diff_gapalign.cpp:107-219); the halves' row counters are independent.  Only the
         // running maximum of x + y is tracked here; a block that ends without reaching an end of either sequence (0.06 %
@@ -574,7 +594,8 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
         int NJ = 1;
         // band update (:172-179) of the row at ring position rlin; m0 / mp = x + y of the lane's diagonal in the last / previous
         // pass (NJ <= 2), otherwise recomputed from the ring
-        auto band_update = [&](const int NJ, const int m0, const int mp) __attribute__((always_inline)) {
+        auto band_update = [&](const int NJ, const int m0, const int mp, auto both_tag) __attribute__((always_inline)) {
+            constexpr bool BOTH = decltype(both_tag)::value;      // both halves are in a block: no per-half guard on the band state
             // qualifying lanes first .. last of the half.  The mask of a half that is in a block is never empty: the lane that holds
             // the row maximum qualifies, and the row maximum is the running maximum (x + y grows by at least one per row along
             // the best path, which the band never prunes).
@@ -613,7 +634,7 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                 }
                 first = half_min(lo); last = half_max(hi);
             }
-            if (inblock) {
+            if (BOTH || inblock) {
                 // new band [min_k + 2 first - 1, min_k + 2 last + 1] = last - first + 2 diagonals; the previous-row entry of diagonal
                 // (new min_k) - 1 sits at ring position rlin + first - 1
                 pbase = rlin + 2u * (unsigned)(first - 1);
@@ -622,11 +643,15 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
             }
         };
         int last_m0 = 0, last_mp = 0;
+        // The loop exists twice: with both halves in a block (98.6 % of the dual rows: inmask is all ones for as long as the loop
+        // runs) the band update writes its three per-half values without the `inblock` guard (three v_cndmask, 12 issue cycles of
+        // the ~236 of a one-pass dual row).
+        auto row_loop = [&](auto both_tag) __attribute__((always_inline)) {
         while (true) {
             // :118 "max_k - min_k <= band_size"; the two conditions as masks (a ballot of their conjunction makes the compiler
             // turn the mask into a 0/1 vector and compare it again)
             const unsigned long long rmask = BALLOT(d < dlim) & BALLOT(nslot <= band_tol + 1);
-            if (rmask != inmask) break;
+            if (rmask != inmask) return;
 #ifdef MECAT_DW_STATS
             nrows += 1;
             nidle += (rmask == ~0ull) ? 0u : 1u;
@@ -639,6 +664,14 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
             NJ = (max(ns_a, ns_b) + 31) >> 5;
 #ifdef MECAT_DW_STATS
             nwide += NJ > 1 ? 1u : 0u;
+            n_pass3 += NJ > 2 ? 1u : 0u;
+            for (int hq = 0; hq < 2; ++hq) {
+                if (!((rmask >> (hq << 5)) & 1ull)) continue;      // the half is not rowing
+                const int ns = hq ? ns_b : ns_a;
+                nh[ns <= 8 ? 0 : ns <= 16 ? 1 : ns <= 24 ? 2 : ns <= 32 ? 3 : ns <= 48 ? 4 : ns <= 64 ? 5 : ns <= 96 ? 6 : 7] += 1;
+                const int p16 = (ns + 15) >> 4;
+                q16[p16 <= 4 ? p16 - 1 : p16 <= 6 ? 4 : 5] += 1;
+            }
 #endif
             // one or two passes of 32 diagonals per half cover 99 % of the rows: with the pass count a constant the pass loop and
             // the previous-pass bookkeeping fold away
@@ -657,9 +690,18 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                     // 0 <= y <= t_len and x <= q_len on every live diagonal (a diagonal at an end stops the block); idle lanes sit
                     // at (q_len, 0), where lim == 0
                     x = act ? x : q_len;
-                    int y = act ? x - k : 0;
+                    // (idle lanes: lim <= 0 whatever y is, so they never move forward and never ask for another step; their window
+                    // loads may fall outside the staged block or outside the LDS allocation, where reads return 0: nothing of an
+                    // idle lane is kept — the store, the end mask and m0 below are all guarded by `act`)
+                    int y = x - k;
                     int lim, nn;
+#ifdef MECAT_DW_STATS
+                    snake2 -= 1;
+#endif
                     do {
+#ifdef MECAT_DW_STATS
+                        snake2 += 1;
+#endif
                         lim = min(q_len - x, t_len - y);
                         // 0..15 equal bases, or >= 16 (0x7fffffff) when the whole window matches.  A lane with exactly 16 bases left
                         // that all match asks for one more step, which then moves nothing.
@@ -686,20 +728,28 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
             };
             if (NJ == 1) {
                 row_passes(1);
-                if (ended) break;
-                band_update(1, last_m0, last_mp);
+                if (ended) return;
+                band_update(1, last_m0, last_mp, both_tag);
             } else if (NJ == 2) {
                 row_passes(2);
-                if (ended) break;
-                band_update(2, last_m0, last_mp);
+                if (ended) return;
+                band_update(2, last_m0, last_mp, both_tag);
             } else {
                 row_passes(NJ);
-                if (ended) break;
-                band_update(NJ, last_m0, last_mp);
+                if (ended) return;
+                band_update(NJ, last_m0, last_mp, both_tag);
             }
             d += 1;
             __builtin_amdgcn_wave_barrier();
         }
+        };
+        if (inmask == ~0ull) row_loop(std::true_type{});
+        else row_loop(std::false_type{});
+        DWS_T(t_c);
+        DWS_ADD(tk_rows, t_b, t_c);
+#ifdef MECAT_DW_STATS
+        n_ended += ended ? 1u : 0u;
+#endif
         if (ended) {
             // Once per block, outside the row loop (inside it, the state written here costs register copies on every row): the
             // lowest diagonal that reached an end (:168-169), from the row just stored; then the rest of that row for the
@@ -717,11 +767,13 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                 aligned = 1; end_k = (hkey >> 10) - k_offset; end_x = hkey & 1023; end_d = d;
                 dlim = 0;
             }
-            band_update(max(NJ, 3), 0, 0);   // (the general form: from the ring)
+            band_update(max(NJ, 3), 0, 0, std::false_type{});   // (the general form: from the ring)
             d += 1;
             __builtin_amdgcn_wave_barrier();
         }
         row_ok = d < dlim && nslot <= band_tol + 1;
+        DWS_T(t_d);
+        DWS_ADD(tk_ended, t_c, t_d);
 
         const bool fin = inblock && !row_ok;
 
@@ -768,6 +820,8 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
             }
         }
         const int trim_ok = has_aln && found && (aln_size - acnt >= 2);
+        DWS_T(t_e);
+        DWS_ADD(tk_trace, t_d, t_e);
 
         // ---- 5. block accounting (dw_in_one_direction, diff_gapalign.cpp:259-290); a block this kernel cannot finish (0.07 %: the
         // tail needs a row that left the ring, or no end was reached) hands the unit over to dw_extend, which redoes that block
@@ -808,6 +862,8 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
             setup = true;
             dlim = 0;           // a half without a block must never look like it is rowing (its rows may have ended on the band limit)
         }
+        DWS_T(t_f);
+        DWS_ADD(tk_acct, t_e, t_f);
     }
     unsigned long long c64 = cells, b64 = nblocks, h64 = nhand;
     for (int off = 32; off > 0; off >>= 1) { b64 += __shfl_xor(b64, off); c64 += __shfl_xor(c64, off); h64 += __shfl_xor(h64, off); }
@@ -819,6 +875,20 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
         atomicAdd(&counters[9], nrows);          // dual rows
         atomicAdd(&counters[10], nidle);         // dual rows with one idle half
         atomicAdd(&counters[11], nwide);         // dual rows with more than 32 diagonals in a half
+        atomicAdd(&counters[16], wall_clock64() - tk_start);      // wave life, ticks
+        atomicAdd(&counters[17], tk_setup);
+        atomicAdd(&counters[18], tk_rows);
+        atomicAdd(&counters[19], tk_ended);
+        atomicAdd(&counters[20], tk_trace);
+        atomicAdd(&counters[21], tk_acct);
+        atomicAdd(&counters[22], n_outer);
+        atomicAdd(&counters[23], n_setup);
+        atomicAdd(&counters[24], n_ended);
+        atomicAdd(&counters[25], n_pass3);
+        atomicAdd(&counters[26], 1ull);                           // waves
+        atomicAdd(&counters[27], snake2);
+        for (int i = 0; i < 8; ++i) atomicAdd(&counters[32 + i], nh[i]);
+        for (int i = 0; i < 6; ++i) atomicAdd(&counters[40 + i], q16[i]);
 #endif
     }
 }

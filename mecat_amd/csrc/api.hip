@@ -62,8 +62,8 @@ int mhip_ctx_create(int device, void* stream, mhip_ctx** out) {
         c->own_stream = true;
     }
     // 8 public counters (mecat_hip.h) + 8 debug slots
-    if (hipMalloc((void**)&c->d_counters, 16 * sizeof(int64_t)) != hipSuccess) { delete c; mhip_set_error("hipMalloc counters failed"); return -1; }
-    (void)hipMemsetAsync(c->d_counters, 0, 16 * sizeof(int64_t), c->stream);
+    if (hipMalloc((void**)&c->d_counters, 64 * sizeof(int64_t)) != hipSuccess) { delete c; mhip_set_error("hipMalloc counters failed"); return -1; }
+    (void)hipMemsetAsync(c->d_counters, 0, 64 * sizeof(int64_t), c->stream);
     *out = c;
     return 0;
 }
@@ -163,13 +163,13 @@ int mhip_ctx_set_profiling(mhip_ctx* c, int on) {
 int mhip_ctx_reset_stats(mhip_ctx* c) {
     if (c->drain_events()) return -1;
     c->stats.clear();
-    HIPCHK(hipMemsetAsync(c->d_counters, 0, 16 * sizeof(int64_t), c->stream));
+    HIPCHK(hipMemsetAsync(c->d_counters, 0, 64 * sizeof(int64_t), c->stream));
     return 0;
 }
 
 // debug slots 8..15 (8: dw blocks re-run with spilled rows)
 int mhip_debug_counter(mhip_ctx* c, int slot, int64_t* out) {
-    if (slot < 0 || slot >= 16) return -1;
+    if (slot < 0 || slot >= 64) return -1;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpyAsync(out, c->d_counters + slot, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));

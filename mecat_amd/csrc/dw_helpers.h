@@ -91,7 +91,12 @@ __device__ __forceinline__ int match16(const uint32_t* Q, int x, const uint32_t*
 // little-endian staged blocks (view_word_le; no pad word: base i lives in word i >> 4)
 __device__ __forceinline__ int match16_le(const uint32_t* Q, int x, const uint32_t* T, int y) {
     const int wq = x >> 4, wt = y >> 4;
-    const uint32_t d = __builtin_amdgcn_alignbit(Q[wq + 1], Q[wq], (uint32_t)(x + x)) ^ __builtin_amdgcn_alignbit(T[wt + 1], T[wt], (uint32_t)(y + y));
+    // the shift operands 2x and 2y as v_add_u32 x, x (written out: the optimizer turns x + x into a shift left, and on this chip a
+    // shift left occupies the SIMD for 4 cycles where the plain 32-bit add takes 2 — DESIGN.md §3.3, valu_peak)
+    uint32_t sx, sy;
+    asm("v_add_u32 %0, %1, %1" : "=v"(sx) : "v"(x));
+    asm("v_add_u32 %0, %1, %1" : "=v"(sy) : "v"(y));
+    const uint32_t d = __builtin_amdgcn_alignbit(Q[wq + 1], Q[wq], sx) ^ __builtin_amdgcn_alignbit(T[wt + 1], T[wt], sy);
     uint32_t tz;                                        // v_ffbl_b32 of 0 is -1: 16 equal bases read as 0x7fffffff
     asm("v_ffbl_b32 %0, %1" : "=v"(tz) : "v"(d));
     return (int)(tz >> 1);

@@ -8,7 +8,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "libmecat_hip.so")
+    # MECAT_HIP_LIB: a development build of the same library (e.g. the -DMECAT_DW_STATS variant, tools/dev/dw_breakdown.sh)
+    return os.environ.get("MECAT_HIP_LIB") or os.path.join(_HERE, "lib", "libmecat_hip.so")
 
 
 class MhipError(RuntimeError):

@@ -22,6 +22,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "index_part.h"
 
 #define IDX_BLOCK 256
 #define SCAN_ITEMS 16
@@ -872,6 +873,39 @@ static int index_add_slots(mhip_ctx* c, mhip_index* idx) {
     return 0;
 }
 
+// the whole table through the stable two-level partition (index_part.hip): level-1 bins [0, 512)
+static int index_build_whole(mhip_ctx* c, const mhip_volume* v, mhip_index* idx) {
+    IxpSlice sl;
+    sl.d_starts = idx->d_starts;
+    sl.user = idx;
+    const bool with_recs = idx->max_bucket <= 255;
+    if (with_recs) {
+        const int segs = (idx->num_bases + 2000 - 1) / 2000;
+        idx->cut_step = ((segs + 7) / 8) * 2000;
+        sl.cut_step = idx->cut_step;
+    }
+    struct Ctx { mhip_ctx* c; mhip_index* idx; bool with_recs; } cx{c, idx, with_recs};
+    sl.user = &cx;
+    sl.alloc = [](IxpSlice* s, size_t kept) -> int {
+        Ctx* x = (Ctx*)s->user;
+        mhip_index* I = x->idx;
+        if (dev_alloc_recycled(x->c->device, sizeof(int32_t) * (kept + 64), (void**)&I->d_offsets, &I->cap_offsets)) return -1;
+        if (dev_alloc_recycled(x->c->device, sizeof(uint16_t) * (kept + 64), (void**)&I->d_slots, &I->cap_slots)) return -1;
+        if (x->with_recs && dev_alloc_recycled(x->c->device, sizeof(uint4) * (size_t)NKMER, (void**)&I->d_recs, &I->cap_recs) != 0) I->d_recs = nullptr;
+        s->d_offsets = I->d_offsets;
+        s->d_slots = I->d_slots;
+        s->d_recs = I->d_recs;
+        return 0;
+    };
+    if (index_build_partitioned(c, v, idx->max_bucket, 0, IXP_NB1, &sl)) return -1;
+    idx->num_kmers = sl.num_kept;
+    if (sl.num_kept == 0 && !idx->d_offsets) {      // empty volume: starts[] is all zero, nothing else exists
+        HIPCHK(hipMemsetAsync(idx->d_starts, 0, sizeof(uint32_t) * ((size_t)NKMER + 1), c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
 extern "C" {
 
 int mhip_index_build(mhip_ctx* c, const mhip_volume* v, mhip_index** out) { return mhip_index_build_ex(c, v, MAX_BUCKET, out); }
@@ -899,10 +933,15 @@ int mhip_index_build_ex(mhip_ctx* c, const mhip_volume* v, int max_bucket, mhip_
     }
     {
         const char* e = getenv("MECAT_IDX_BUILD");       // debug knob: 1 = direct atomic walks, default = binned build
-        if (!(e && atoi(e) == 1)) {
-            if (getenv("MECAT_TRACE")) fprintf(stderr, "[idx trace] pre-alloc      %.2f ms\n", now_ms() - tb0);
+        if (e && atoi(e) == 2) {           // debug knob: round 2's build (three 64-way passes of 8-byte entries + per-bucket sorts)
             if (index_build_binned(c, v, idx)) { mhip_index_free(idx); return -1; }
             if (index_add_slots(c, idx)) { mhip_index_free(idx); return -1; }
+            *out = idx;
+            return 0;
+        }
+        if (!(e && atoi(e) == 1)) {
+            if (getenv("MECAT_TRACE")) fprintf(stderr, "[idx trace] pre-alloc      %.2f ms\n", now_ms() - tb0);
+            if (index_build_whole(c, v, idx)) { mhip_index_free(idx); return -1; }
             *out = idx;
             return 0;
         }

@@ -14,5 +14,6 @@ for it in range(2):
         idx = M.Index(ctx, vol); idx.free()
     except Exception as e:
         print("build failed (expected in the timing experiment):", str(e)[:80])
+tot = sum(ms for k, (c, ms) in ctx.kernel_stats().items() if k.startswith("idx") or k.startswith("ix_")); print("index kernels total %.2f ms" % tot)
 for k, (c, ms) in sorted(ctx.kernel_stats().items(), key=lambda kv: -kv[1][1]):
-    if k.startswith("idx"): print("  %-16s %3d launches %8.2f ms" % (k, c, ms))
+    if k.startswith("idx") or k.startswith("ix_"): print("  %-16s %3d launches %8.2f ms" % (k, c, ms))

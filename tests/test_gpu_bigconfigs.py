@@ -4,7 +4,8 @@ C ABI -> text output), against hashes of the UNMODIFIED reference's output on th
 
   config 2   100 000 x 15 kb @ 15 %, one volume:    `-j 0` and `-j 1 -g 1`, sorted-output SHA-256, line counts, aligned bases
   config 3   500 000 x 12 kb @ 15 %, three volumes: `-j 0`, every grid row r_<i> and every grid cell (i, j) hashed separately
-             (real 2.14 Gbase volume limit, int32 coordinates up to the limit, no test knob)
+             (real 2.14 Gbase volume limit, int32 coordinates up to the limit, no test knob); `-j 1 -g 1` grid row 1 = cells (1, 1)
+             and (1, 2): dw extension across two real volumes
   config 5   2 000 000 x 20 kb ONT-style, 19 volumes, `-x 1`: `-j 0` grid rows 17 and 18 and `-j 1 -g 1` (X-drop extension) row 18
              against the reference (the rows before them are planted as finished through the reference's own resume protocol,
              as the golden run did);
@@ -137,6 +138,35 @@ def test_config3_three_volume_grid_equals_reference(workdir, name):
             assert _sorted_sha(r, "$1 >= %d && $1 < %d" % (lo, hi)) == (c["lines"], c["sorted_sha256"]), "cell " + cell
     if "can_sorted_sha256" in g:
         assert _sorted_sha(out) == (g["can_lines"], g["can_sorted_sha256"])
+
+
+def test_config3_extension_across_two_real_volumes(workdir):
+    """`-j 1 -g 1` on grid row 1 of config 3 = cells (1, 1) and (1, 2): dw extension of candidates whose query reads live in another
+    2.14 Gbase volume than their subject reads (local ids, int32 volume coordinates up to the limit, no test knob), against the
+    unmodified reference's r_1 (rows 0 and 2 planted as finished on both sides: pw.cpp:65-81)."""
+    g = _golden("config3")
+    if "m4_rows" not in g:
+        pytest.skip("no -j 1 pin for config 3 in tests/golden/big.json")
+    fa = _gen(workdir, g)
+    wrk = os.path.join(workdir, "w1")
+    os.makedirs(wrk)
+    pinned = sorted(int(i) for i in g["m4_rows"])
+    for i in range(len(g["volumes"])):
+        if i not in pinned:
+            open(os.path.join(wrk, "r_%d" % i), "w").close()
+    _run(["-j", "1", "-g", "1"], fa, os.path.join(workdir, "o.m4"), wrk)
+    os.unlink(fa)
+    vols = _volumes(wrk)
+    for i in pinned:
+        row = g["m4_rows"][str(i)]
+        r = os.path.join(wrk, "r_%d" % i)
+        assert _sorted_sha(r) == (row["lines"], row["sorted_sha256"]), "row %d" % i
+        ab = int(subprocess.run(["awk", "-F\t", "{s += $7 - $6} END {printf \"%.0f\", s}", r], stdout=subprocess.PIPE, text=True, check=True).stdout)
+        assert ab == row["aligned_bases"]
+        for cell, c in row["cells"].items():
+            j = int(cell.split(",")[1])          # .m4 field 2 = the query read (field 1 is the subject, SURVEY.md A14)
+            lo, hi = vols[j]["start_read_id"], vols[j]["start_read_id"] + vols[j]["num_reads"]
+            assert _sorted_sha(r, "$2 >= %d && $2 < %d" % (lo, hi)) == (c["lines"], c["sorted_sha256"]), "cell " + cell
 
 
 def test_config5_nanopore_19_volume_grid(workdir):

@@ -10,11 +10,12 @@ Workload (BASELINE.json configs[1]): 100 000 synthetic PacBio-st
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...      (one rank per GPU, RCCL)
     python bench.py --gpus N ...            (no launcher: the script re-executes itself under torch.distributed.run with N ranks)
 
-N > 1 (strong scaling, total work fixed): the library's own multi-GPU calls, as in the mecat2pw driver — every rank rebuilds
-the index itself (recompute beats moving up to 6 GB of positions over a 153 GB/s xGMI link), the reads are dealt out in
-chunks of 500 (chunk c -> rank c mod N), each rank seeds and extends its own, and the candidate lists and extension results
-are all-gathered count-then-payload over RCCL (mhip_seed_reads_sharded / mhip_align_sharded), so every rank holds the
-complete candidate table and overlap set.
+N > 1 (strong scaling, total work fixed): the library's own multi-GPU calls, as in the mecat2pw driver — from four ranks on the
+index is built in k-mer key-range shards and all-gathered (mhip_index_build_sharded; with two or three ranks every rank rebuilds
+it: 4.7 GB of positions over one or two xGMI links cost more than the 23 ms rebuild), the reads are dealt out in chunks of 500
+(chunk c -> rank c mod N), each rank seeds and extends its own, and the candidate lists and extension results are all-gathered
+count-then-payload over RCCL (mhip_seed_reads_sharded / mhip_align_sharded), so every rank holds the complete candidate table
+and overlap set.
 
 Prints ONE JSON line on rank 0 (see the task contract): value = candidate overlaps/sec of the whole job, plus
 aligned Gbase/sec, a `roofline` block for the dominant kernel and a `cpu_baseline` block (the unmodified reference
@@ -297,6 +298,11 @@ def main():
         d_jobs = torch.empty((n * maxc + maxc, 5), dtype=torch.int32, device=dev)
         d_res = torch.empty((d_jobs.shape[0], 8), dtype=torch.int32, device=dev)
 
+    # the index of the cell's reference volume: from four ranks on built by the ranks together (key-range shards + all-gather,
+    # mhip_index_build_sharded), below that rebuilt on every rank; MECAT_HIP_INDEX_SHARD=0 / 1 overrides, as in the driver
+    shard_index = comm is not None and world >= 4
+    if os.environ.get("MECAT_HIP_INDEX_SHARD") is not None:
+        shard_index = comm is not None and os.environ["MECAT_HIP_INDEX_SHARD"] not in ("", "0")
     keep = {}
     released = False
 
@@ -304,7 +310,7 @@ def main():
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         h0 = time.perf_counter()
         ev[0].record(stream)
-        idx = M.Index(ctx, vol)
+        idx = comm.index_build_sharded(vol) if shard_index else M.Index(ctx, vol)
         ev[1].record(stream)
         keep["num_kmers"] = idx.num_kmers
         njobs = 0
@@ -363,7 +369,7 @@ def main():
             aligned_bases = int(((r[:, 2] - r[:, 1]).to(torch.int64) * ok).sum().item())
     else:
         exch = {"bytes_received_per_step": comm.bytes_received() / max(1, args.steps + args.warmup)}
-        idx = M.Index(ctx, vol)
+        idx = comm.index_build_sharded(vol) if shard_index else M.Index(ctx, vol)
         _, h_cnt = comm.seed_reads_sharded(idx, vol, vol, 0, n, params, chunk=CH, cell_shift=0, host=True)
         ncand = int(h_cnt.sum())
         aln_ok = aligned_bases = 0
@@ -471,7 +477,8 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": "%s: %d reads x %d bp @ %.0f%% error, genome %d, seed %d, k=13, all-vs-all, -j 1 (index+seed+dw)"
                                    % (args.workload, n, L, err * 100, G, seed), "reads": n, "bases": int(num_bases),
-                       "parallelism": "1 GPU" if world == 1 else "grid cell sharded: chunks of %d reads, chunk c -> rank c mod %d; RCCL count-then-payload all-gather" % (CH, world)},
+                       "parallelism": "1 GPU" if world == 1 else "grid cell sharded: chunks of %d reads, chunk c -> rank c mod %d; RCCL count-then-payload all-gather; index %s"
+                                      % (CH, world, "built in k-mer key-range shards + all-gather" if shard_index else "rebuilt on every rank")},
             "candidates": ncand, "overlaps_ok": aln_ok, "aligned_gbase_per_s": aligned_bases / 1e9 / (ms_step / 1e3),
             "overlaps_per_s": aln_ok / (ms_step / 1e3),
             "phase_ms": {"index": float(phase[0]), "seed": float(phase[1]), "align": float(phase[2])},

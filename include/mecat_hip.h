@@ -127,6 +127,10 @@ void mhip_index_free(mhip_index* idx);                       /* waits for the de
 int64_t mhip_index_num_kmers(const mhip_index* idx);
 /* parity/debug: counts[4^13] (kept occurrences) and/or offsets[num_kmers]; either may be NULL */
 int  mhip_index_download(mhip_ctx* ctx, const mhip_index* idx, int32_t* counts, int32_t* offsets);
+/* test hook: the two side arrays the seeding stage reads — slots[num_kmers] ((position / 2000) mod 2^15) and the 16-byte bucket
+ * records recs[4^13][4] (start, occurrences below seven position cuts at multiples of *cut_step, occurrences); returns 1 when the
+ * table has no records (bucket cap above 255, or not built yet) */
+int  mhip_index_download_aux(mhip_ctx* ctx, const mhip_index* idx, uint16_t* slots, uint32_t* recs, int* cut_step);
 
 /* candidates of reads [rid_begin, rid_end) of `reads` against (`ref`, `idx`): for read r the list is written to
    out[(r - rid_begin) * maxc ...] in the reference's list order (score descending, stable), out_counts[r - rid_begin]
@@ -221,6 +225,11 @@ int  mhip_align_sharded(mhip_comm* comm, const mhip_volume* ref, const mhip_volu
                         mhip_aln_result* out, int64_t* num_jobs);
 /* device views of the tables the last two calls left on this rank (complete on every rank) */
 int  mhip_sharded_tables(mhip_comm* comm, void** d_cands, void** d_counts, void** d_results, int64_t* num_jobs);
+/* mhip_index_build by all ranks of the communicator together (replaces create_ref_index, common/lookup_table.cpp:63-160, in a
+ * multi-GPU cell): the 4^13 key space is cut into P contiguous ranges of equal occupancy, each rank builds the buckets of its range,
+ * positions and table slices are all-gathered (counts first, then payload), and every rank returns the complete table — equal, array
+ * for array, to the one mhip_index_build makes.  Collective: every rank of `comm` calls it with the same volume. */
+int  mhip_index_build_sharded(mhip_comm* comm, const mhip_volume* v, mhip_index** out);
 
 /* ---- mecat2cns re-aligner: ns_banded_sw::GetAlignment of src/mecat2cns/dw.cpp:482-553, which
  * mecat2cns calls for up to 200 candidates per template read (mecat_correction.cpp:286, 347, 431, 494) -------------------

@@ -311,7 +311,7 @@ const uint4* index_ensure_cuts(mhip_ctx* c, const mhip_index* cidx) {
     return p;
 }
 
-static int index_add_slots(mhip_ctx* c, mhip_index* idx) {
+int index_add_slots(mhip_ctx* c, mhip_index* idx) {
     if (idx->num_kmers <= 0 || idx->d_slots) return 0;      // the binned build writes the slots with the positions
     if (dev_alloc_recycled(c->device, sizeof(uint16_t) * ((size_t)idx->num_kmers + 64), (void**)&idx->d_slots, &idx->cap_slots)) return -1;
     LAUNCH(c, "idx_slots", idx_slots, (unsigned)((idx->num_kmers + 1023) / 1024), 256, 0, (const int32_t*)idx->d_offsets, idx->num_kmers,
@@ -430,6 +430,15 @@ void mhip_index_free(mhip_index* idx) {
 }
 
 int64_t mhip_index_num_kmers(const mhip_index* idx) { return idx->num_kmers; }
+
+int mhip_index_download_aux(mhip_ctx* c, const mhip_index* idx, uint16_t* slots, uint32_t* recs, int* cut_step) {
+    HIPCHK(hipSetDevice(c->device));
+    if (cut_step) *cut_step = idx->d_recs ? idx->cut_step : 0;
+    if (slots && idx->num_kmers && idx->d_slots) HIPCHK(hipMemcpyAsync(slots, idx->d_slots, sizeof(uint16_t) * (size_t)idx->num_kmers, hipMemcpyDeviceToHost, c->stream));
+    if (recs && idx->d_recs) HIPCHK(hipMemcpyAsync(recs, idx->d_recs, sizeof(uint4) * (size_t)NKMER, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return (recs && !idx->d_recs) ? 1 : 0;
+}
 
 int mhip_index_download(mhip_ctx* c, const mhip_index* idx, int32_t* counts, int32_t* offsets) {
     HIPCHK(hipSetDevice(c->device));

@@ -28,3 +28,6 @@ struct IxpSlice {
 };
 
 int index_build_partitioned(mhip_ctx* c, const mhip_volume* v, int max_bucket, int bin_lo, int bin_hi, IxpSlice* out);
+
+// index.hip: slots[] of a finished table ((position / 2000) mod 2^15 of every kept position), and a bare table handle for comm.hip
+int index_add_slots(mhip_ctx* c, mhip_index* idx);

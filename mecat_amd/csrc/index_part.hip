@@ -610,8 +610,9 @@ int index_build_partitioned(mhip_ctx* c, const mhip_volume* v, int max_bucket, i
     const int ngroup = (ntile + G1 - 1) / G1;
     out->num_kept = 0;
     out->bin_total.assign((size_t)NB1 + 1, 0u);
-    if (ntile == 0 || v->num_reads == 0) {
+    if (ntile == 0 || v->num_reads == 0) {      // nothing to index: an all-empty slice (no position arrays are allocated)
         if (out->d_starts) HIPCHK(hipMemsetAsync(out->d_starts, 0, sizeof(uint32_t) * (((size_t)nb << (26 - IXP_L1_BITS)) + 1), c->stream));
+        if (out->d_recs && nb > 0) HIPCHK(hipMemsetAsync(out->d_recs, 0, sizeof(uint4) * ((size_t)nb << (26 - IXP_L1_BITS)), c->stream));
         return 0;
     }
     uint32_t *d_hist1, *d_grp, *d_binbase, *d_base1T;

@@ -234,6 +234,17 @@ class Index:
                                        offs.ctypes.data if want_offsets else None))
         return counts, offs
 
+    def download_aux(self):
+        """(slots uint16[num_kmers], recs uint32[4^13, 4] or None, cut_step): the side arrays of the seeding stage (test hook)"""
+        slots = np.empty(self.num_kmers, dtype=np.uint16)
+        recs = np.empty((1 << 26, 4), dtype=np.uint32)
+        cs = C.c_int()
+        lib().mhip_index_download_aux.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        rc = lib().mhip_index_download_aux(self.ctx.h, self.h, slots.ctypes.data, recs.ctypes.data, C.byref(cs))
+        if rc < 0:
+            raise MhipError(lib().mhip_last_error().decode())
+        return slots, (recs if rc == 0 else None), cs.value
+
     def free(self):
         if self.h:
             lib().mhip_index_free(self.h)
@@ -369,6 +380,15 @@ class Comm:
 
     def bytes_received(self):
         return int(lib().mhip_comm_bytes_received(self.h))
+
+    def index_build_sharded(self, vol):
+        """mhip_index_build_sharded: the volume's table built by all ranks together; every rank gets the complete table"""
+        idx = Index.__new__(Index)
+        idx.h = C.c_void_p()
+        idx.ctx = self.ctx
+        lib().mhip_index_build_sharded.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+        _chk(lib().mhip_index_build_sharded(self.h, vol.h, C.byref(idx.h)))
+        return idx
 
     def seed_reads_sharded(self, idx, ref, reads, rid_begin, rid_end, params, chunk=SHARD_CHUNK, cell_shift=0, host=True):
         """-> (cands [n, maxc] structured, counts [n]) on the host when host=True, else None (tables stay on the device)"""

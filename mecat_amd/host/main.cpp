@@ -189,7 +189,14 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
     mhip_index* idx = NULL;
     {
         ScopedTimer t("create_ref_index");
-        MCHK(mhip_index_build(ctx, dref, &idx));
+        // cells mode: from four ranks on the ranks build the table together, each the buckets of its own k-mer key range, and gather
+        // positions and table slices (mhip_index_build_sharded) — a replicated rebuild is the part of a sharded cell that does not
+        // shrink with the number of GPUs; with two or three ranks the 4.7 GB of positions over one or two xGMI links cost more than
+        // the rebuild.  MECAT_HIP_INDEX_SHARD=0 / 1 overrides.
+        bool shard_index = comm && mhip_comm_nranks(comm) >= 4;
+        if (const char* e = getenv("MECAT_HIP_INDEX_SHARD")) shard_index = comm && atoi(e) != 0;
+        if (shard_index) MCHK(mhip_index_build_sharded(comm, dref, &idx));
+        else MCHK(mhip_index_build(ctx, dref, &idx));
     }
     printf("number of kmers: %lld\n", (long long)mhip_index_num_kmers(idx));
 

@@ -131,13 +131,15 @@ def test_cli_two_processes_share_the_grid_rows(tmp_path, task):
     assert sorted(f for f in os.listdir(wrk) if f.startswith("r_")) == ["r_0", "r_1", "r_2"]
 
 
-@pytest.mark.parametrize("task,nproc,vols", [("0", 2, 1), ("1", 2, 1), ("1", 3, 3), ("0", 2, 3)])
-def test_cli_processes_share_the_grid_cells(tmp_path, task, nproc, vols):
+@pytest.mark.parametrize("task,nproc,vols,ishard", [("0", 2, 1, "1"), ("1", 2, 1, "0"), ("1", 3, 3, "1"), ("0", 2, 3, "0")])
+def test_cli_processes_share_the_grid_cells(tmp_path, task, nproc, vols, ishard):
     """multi-GPU mode of the driver, cell sharding: every rank works on every (reference volume, query volume)
     cell — the query reads dealt out in chunks, chunk c of query volume j to rank (c + j) mod P — the candidate lists and
     extension results are all-gathered (mhip_seed_reads_sharded / mhip_align_sharded) and rank 0 writes r_<i>.  Here the ranks
     share GPU 0 and exchange through the host-file transport (RCCL refuses two ranks on one device); a one-volume input, which
-    the row sharding cannot split, is spread over all ranks.  The output must be byte-identical to the single-process run."""
+    the row sharding cannot split, is spread over all ranks.  ishard = "1": the ranks also build each reference volume's look-up table
+    together (mhip_index_build_sharded: key-range shards + all-gather; the driver's default from four ranks on).  The output must be
+    byte-identical to the single-process run."""
     import uuid
     fa = _fasta(tmp_path, "config1" if vols == 1 else "tiny")
     env = dict(os.environ)
@@ -154,7 +156,7 @@ def test_cli_processes_share_the_grid_cells(tmp_path, task, nproc, vols):
     for rank in reversed(range(nproc)):          # rank 0 last: the others have to wait for its split
         e = dict(env, MECAT_HIP_WORLD=str(nproc), MECAT_HIP_RANK=str(rank), MECAT_HIP_DEVICE="0", MECAT_HIP_SHARD="cells",
                  MECAT_HIP_COMM="file", MECAT_HIP_RUN_ID=run, MECAT_HIP_SHARD_CHUNK="100" if vols > 1 else "500",
-                 MECAT_HIP_COMM_TIMEOUT_S="60", MECAT_HIP_WAIT_S="120")
+                 MECAT_HIP_COMM_TIMEOUT_S="60", MECAT_HIP_WAIT_S="120", MECAT_HIP_INDEX_SHARD=ishard)
         procs.append(subprocess.Popen([BIN, "-d", fa, "-o", many, "-w", wrk, "-t", "4"] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                                       text=True, env=e))
     for p in procs:
@@ -283,3 +285,27 @@ def test_cli_candidate_partition_files(tmp_path):
     r = subprocess.run(cmd4, capture_output=True, text=True, env=env4)          # resumed: the text path
     assert r.returncode == 0 and "has been finished" in r.stderr, r.stderr[-2000:]
     assert parts(out4) == d4
+
+
+def test_cli_cells_mode_stops_when_a_peer_fails(tmp_path):
+    """cells mode: a rank that dies (here: killed) leaves a failure marker (or a heartbeat that goes stale); the surviving rank must
+    stop with a message instead of waiting in the exchange for ever (watchdog of the heartbeat thread)"""
+    import signal
+    import time
+    import uuid
+    fa = _fasta(tmp_path, "config1")
+    wrk = str(tmp_path / "w")
+    run = uuid.uuid4().hex[:10]
+    env = dict(os.environ, MECAT_HIP_WORLD="2", MECAT_HIP_DEVICE="0", MECAT_HIP_SHARD="cells", MECAT_HIP_COMM="file", MECAT_HIP_RUN_ID=run,
+               MECAT_HIP_COMM_TIMEOUT_S="300", MECAT_HIP_WAIT_S="300")
+    # rank 1 is started and killed while it waits for rank 0's split: its SIGTERM handler leaves the failure marker
+    p1 = subprocess.Popen([BIN, "-j", "1", "-d", fa, "-o", str(tmp_path / "o"), "-w", wrk, "-t", "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          text=True, env=dict(env, MECAT_HIP_RANK="1"))
+    time.sleep(1.5)
+    p1.send_signal(signal.SIGTERM)
+    p1.communicate(timeout=60)
+    t0 = time.time()
+    r0 = subprocess.run([BIN, "-j", "1", "-d", fa, "-o", str(tmp_path / "o"), "-w", wrk, "-t", "2"], capture_output=True, text=True,
+                        env=dict(env, MECAT_HIP_RANK="0"), timeout=200)
+    assert r0.returncode != 0 and "a peer" in r0.stderr, r0.stderr[-1500:]
+    assert time.time() - t0 < 120

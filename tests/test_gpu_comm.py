@@ -93,6 +93,43 @@ def test_sharded_seeding_and_extension_equal_single_gpu(data, nranks, chunk, rb,
         assert nbytes < (48 + 32) * total + 4 * (re - rb + nranks * chunk) * 2 + 4096, (nbytes, total)
 
 
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_sharded_index_build_equals_single_build(data, nranks):
+    """mhip_index_build_sharded: every rank builds the buckets of its own k-mer key range, positions and table slices are gathered,
+    and every rank must hold the table mhip_index_build makes — bucket boundaries, positions, segment slots and bucket records, array
+    for array (host-file transport on one GPU)"""
+    M, vol, idx = data["M"], data["vol"], data["idx"]
+    want_c, want_o = idx.download()
+    want_s, want_r, want_cs = idx.download_aux()
+    assert want_r is not None
+    d = tempfile.mkdtemp(prefix="mecat_comm_")
+    run = uuid.uuid4().hex[:8]
+
+    def rank_body(r):
+        ctx = M.Context(0)
+        cm = M.Comm(ctx, nranks, r, hostfile_dir=d, run_id=run)
+        cm.barrier()
+        ix = cm.index_build_sharded(vol)
+        got = ix.download() + ix.download_aux() + (ix.num_kmers, cm.bytes_received())
+        # ... and it seeds like the single build
+        cands, cnt = M.seed_reads(ctx, ix, vol, vol, 0, 300, data["p"])
+        ix.free()
+        cm.barrier()
+        cm.close()
+        ctx.close()
+        return got + (cands, cnt)
+
+    for r, (c, o, s, rec, cs, nk, nbytes, cands, cnt) in enumerate(_run_ranks(nranks, rank_body)):
+        assert nk == idx.num_kmers, r
+        assert np.array_equal(c, want_c) and np.array_equal(o, want_o), r
+        assert np.array_equal(s, want_s) and cs == want_cs and np.array_equal(rec, want_r), r
+        assert np.array_equal(cnt, data["cnt"][:300]), r
+        mask = np.arange(data["p"].maxc)[None, :] < cnt[:, None]
+        assert np.array_equal(cands[mask], data["cands"][:300][mask]), r
+        # a rank receives the other ranks' positions and table slices, not the table it built itself
+        assert nbytes < 4 * idx.num_kmers + (4 + 16) * (1 << 26) + 4096, (nbytes, idx.num_kmers)
+
+
 def test_rccl_loads_and_moves_bytes_on_this_device(data):
     """the RCCL transport itself cannot run two ranks on one GPU; this checks what can be checked here: librccl is found,
     every symbol the library uses resolves, a communicator comes up on the context's device and both transport forms

@@ -129,6 +129,48 @@ def cpu_baseline_config1():
     return out
 
 
+def cns_cpu_baseline(codes, lens, rec, tb, ids, templates=100):
+    """BASELINE config 4's CPU side, same run: the UNMODIFIED consensus_one_read_can_pacbio (oracle/_ref/libref_cns_accept.so = mecat2cns
+    compiled from the reference's sources) on the first `templates` templates of the very records the GPU leg was given — one thread, as a
+    mecat2cns worker runs it (the reference parallelises over templates: multiply by its thread count)."""
+    from mecat_amd import workload as W
+    so = os.path.join(ROOT, "oracle", "_ref", "libref_cns_accept.so")
+    if not os.path.exists(so):
+        return None
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    d = tempfile.mkdtemp(prefix="mecat_cns_", dir=base)
+    try:
+        fa = os.path.join(d, "reads.fa")
+        W.write_fasta(fa, codes, lens)
+        A = C.CDLL(so)
+        A.refa_load_reads.argtypes = [C.c_char_p]
+        A.refa_consensus_can.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_long, C.POINTER(C.c_long)]
+        t0 = time.time()
+        if A.refa_load_reads(fa.encode()) != len(lens):
+            return {"error": "refa_load_reads"}
+        t_load = time.time() - t0
+        K = min(templates, len(ids))
+        sbuf = np.zeros(64_000_000, dtype=np.int8)
+        meta = np.zeros((128, 4), dtype=np.int32)
+        naln = nacc = 0
+        t0 = time.time()
+        for t in range(K):
+            b, e = int(tb[t]), int(tb[t + 1])
+            cand = np.ascontiguousarray(rec[b:e]).copy()
+            used = C.c_long()
+            k = A.refa_consensus_can(0, cand.ctypes.data, e - b, int(ids[t]), 2000, 0.9, meta.ctypes.data, sbuf.ctypes.data, len(sbuf), C.byref(used))
+            if k < 0:
+                return {"error": "refa_consensus_can"}
+            naln += min(e - b, 200)
+            nacc += k
+        dt = time.time() - t0
+        return {"kind": "reference", "cores": 1, "templates": K, "candidates_offered": naln, "accepted": nacc, "seconds": dt,
+                "templates_per_s": K / dt, "load_reads_s": t_load,
+                "sample": "first %d templates of the GPU leg's records, consensus_one_read_can_pacbio up to the consensus table, one thread" % K}
+    finally:
+        subprocess.run(["rm", "-rf", d])
+
+
 def e2e_cli(workload, codes, lens, threads):
     """SURVEY.md §8d's second denominator: wall clock of the drop-in binary (FASTA split, H2D/D2H, kernels, text output), -j 0 and
     -j 1 -g 1, on the same workload.  The FASTA sits in /dev/shm (or the temp dir) so that no disk speed enters."""
@@ -258,7 +300,7 @@ def main():
     t0 = time.time()
     codes, lens = W.synth_reads(n, L, err, G, seed, ont)
     pac, offs, num_bases = W.pack_volume(codes, lens)
-    if rank != 0 or world > 1 or args.no_e2e:
+    if rank != 0 or world > 1 or (args.no_e2e and (args.no_cpu or args.no_extras)):
         del codes
     if rank == 0:
         log("[bench] %s: %d reads, %d bases incl. pads, generated+packed in %.1fs" % (args.workload, n, num_bases, time.time() - t0))
@@ -450,21 +492,23 @@ def main():
                 try:
                     im = json.load(open(os.path.join(prof_dir, tag + "_instruction_mix.json"))).get(dname)
                     ach = im["valu_insts_per_launch"] / (avg_ms / 1e3) / 1e9
-                    f4 = im.get("valu_4cycle_fraction_static")          # share of 4-cycle-class instructions in the kernel's ISA
-                    vi.update({"achieved": ach, "peak": ceil["valu_dw_mix"], "frac": min(1.0, ach / ceil["valu_dw_mix"]),
-                               "salu_achieved": im["salu_insts_per_launch"] / (avg_ms / 1e3) / 1e9,
-                               "source": "profiles/%s_instruction_mix.json (SQ_INSTS_VALU / SQ_INSTS_SALU per launch, same sources)" % tag})
-                    vi["note"] = ("peak = VALU rate of valu_peak's mix_dw_rowbody (independent streams, this kernel's instruction mix, best over 1-8 "
-                                  "waves per SIMD); dw_extend2 runs 7 waves per SIMD (72 VGPRs, 21.5 KB LDS per 4 waves)")
+                    # Ceiling = the two measured issue rates of this device (valu_peak, live: independent streams of plain 32-bit adds = the
+                    # 2-cycle class, of v_alignbit = the 4-cycle class, best over 1-8 waves per SIMD), weighted harmonically by the share of
+                    # 4-cycle-class instructions in the kernel's d-row loops (tools/isa_mix.py --row-loops on hipcc's assembly; the loops are
+                    # 92 % of the kernel's time, profiles/r03_dw_row_breakdown.md).  Never clamped: a kernel above its "ceiling" means the
+                    # ceiling is wrong.  The mix stream's own rate (mix_dw_rowbody) is kept beside it for comparison.
+                    f4 = im.get("valu_4cycle_fraction_row_loops", im.get("valu_4cycle_fraction_static"))
+                    vi.update({"achieved": ach, "salu_achieved": im["salu_insts_per_launch"] / (avg_ms / 1e3) / 1e9,
+                               "source": "profiles/%s_instruction_mix.json (SQ_INSTS_VALU / SQ_INSTS_SALU per launch, same sources)" % tag,
+                               "mix_stream_rate": ceil["valu_dw_mix"]})
                     if f4 is not None:
-                        vi["valu_4cycle_fraction_static"] = f4
-                        # the guide's nominal issue rates (one wave64 VALU instruction per SIMD every 2 cycles for the simple class,
-                        # every 4 for the rest; 1024 SIMDs x 2.4 GHz), weighted by the kernel's static mix: the calibrated ceiling
-                        # above is what independent streams of that mix reach on this chip (the kernel, with scalar work co-issued,
-                        # runs past it), this one is what the data sheet allows
+                        peak = 1.0 / (f4 / ceil["valu_4cycle_class"] + (1.0 - f4) / ceil["valu_2cycle_class"])
                         nominal = 1.0 / (f4 / (1024 * 2.4 / 4) + (1.0 - f4) / (1024 * 2.4 / 2))
-                        vi["nominal_mix_ceiling"] = nominal
-                        vi["frac_of_nominal"] = ach / nominal
+                        vi.update({"peak": peak, "frac": ach / peak, "valu_4cycle_fraction_row_loops": f4,
+                                   "nominal_mix_ceiling": nominal, "frac_of_nominal": ach / nominal})
+                        vi["note"] = ("peak = 1 / (f4 / R4 + (1 - f4) / R2): R2, R4 = issue rates of the 2-cycle and 4-cycle VALU classes measured live by "
+                                      "valu_peak, f4 = share of 4-cycle-class instructions in dw_extend2's d-row loops; nominal = the same with the "
+                                      "data-sheet rates (1024 SIMDs x 2.4 GHz / 2 and / 4); 7 waves per SIMD (72 VGPRs, 21.5 KB LDS per 4 waves)")
                 except (OSError, ValueError, KeyError, TypeError):
                     pass
             roof["valu_issue"] = vi
@@ -522,7 +566,8 @@ def main():
                 ec = W.ext_candidates_from_table(h_cands, h_cnt, lens)
                 rec, tb, ids = W.cns_templates(ec, n)
                 T = min(len(ids), 4000)
-                rec_s = np.ascontiguousarray(rec[: tb[T]])
+                rec_orig = np.ascontiguousarray(rec[: tb[T]]).copy()      # (the call sorts its records in place; the reference leg below wants them as loaded)
+                rec_s = rec_orig.copy()
                 pac_h, _, _ = W.pack_volume(W.synth_reads(n, L, err, G, seed, ont)[0], lens)
                 c0 = time.perf_counter()
                 acc, strs, nja = M.cns_accept_templates(ctx, vol, pac_h, rec_s, tb[: T + 1], ont, 2000 if not ont else 500, 0.9 if not ont else 0.4,
@@ -532,9 +577,29 @@ def main():
                 line["cns_accept"] = {"templates": T, "alignments": int(nja), "accepted": int(len(acc)), "seconds": dtc,
                                       "templates_per_s": T / dtc, "alignments_per_s": nja / dtc, "template_gbase_per_s": tbases / 1e9 / dtc,
                                       "aligned_string_bytes": len(strs),
-                                      "note": "sort + <= 200 re-alignments per template on the GPU + accept replay + normalised strings on %d host threads; "
-                                              "the reference does the same per template on one core at ~1.3 k alignments/s (profiles/r01_cns_bench.txt); "
-                                              "the consensus table / POA after it stay with mecat2cns" % min(64, os.cpu_count() or 1)}
+                                      "note": "BASELINE config 4 up to the consensus table: sort + <= 200 re-alignments per template on the GPU + accept replay + "
+                                              "normalised strings on %d host threads; the consensus table / POA after it stay with mecat2cns" % min(64, os.cpu_count() or 1)}
+                # parity: the first templates against what the UNMODIFIED consensus_one_read_can_pacbio accepted on the same records
+                # (tests/golden/cns_config2.npz, written by tests/golden/make_golden_cns_config2.py in the build container)
+                try:
+                    import hashlib
+                    g4 = np.load(os.path.join(ROOT, "tests", "golden", "cns_config2.npz"))
+                    Tg = int(g4["par"][1])
+                    if args.workload == "config2" and Tg <= T and np.array_equal(g4["ids"], ids[:Tg]) and np.array_equal(g4["tmpl_begin"], tb[: Tg + 1]):
+                        sel = acc[acc["template_index"] < Tg]
+                        ok = np.array_equal(np.bincount(sel["template_index"], minlength=Tg), g4["nacc"]) and \
+                            np.array_equal(np.stack([sel["soff"], sel["send"], sel["aln_size"]], axis=1), g4["meta"])
+                        first = np.concatenate([[0], np.cumsum(g4["nacc"])])
+                        for t in range(Tg):
+                            if not ok or g4["nacc"][t] == 0:
+                                continue
+                            a = sel[first[t]: first[t + 1]]
+                            lo, hi = int(a["str_offset"][0]), int(a["str_offset"][-1]) + 2 * (int(a["aln_size"][-1]) + 1)
+                            ok = ok and hashlib.sha256(strs[lo:hi]).hexdigest() == str(g4["sha"][t])
+                        line["cns_accept"]["parity_vs_reference"] = {"templates": Tg, "accepted": int(g4["nacc"].sum()), "identical": bool(ok)}
+                except Exception as e:      # noqa: BLE001
+                    line["cns_accept"]["parity_vs_reference"] = {"error": repr(e)[:200]}
+                keep["cns"] = (rec_orig, tb.copy(), ids.copy())
                 del h_cands, ec, rec, rec_s, acc, strs, pac_h
             except Exception as e:      # noqa: BLE001
                 log("[bench] cns_accept skipped: %r" % (e,))
@@ -589,8 +654,27 @@ def main():
                     line["cpu_baseline_config1"] = c1
             except Exception as e:  # noqa: BLE001
                 line["cpu_baseline_config1"] = {"error": repr(e)[:300]}
+            if "cns" in keep and "cns_accept" in line:
+                try:
+                    cb = cns_cpu_baseline(codes, lens, *keep["cns"])
+                    if cb:
+                        line["cns_accept"]["cpu_baseline"] = cb
+                        if "templates_per_s" in cb:
+                            line["cns_accept"]["speedup_vs_one_reference_thread"] = line["cns_accept"]["templates_per_s"] / cb["templates_per_s"]
+                except Exception as e:  # noqa: BLE001
+                    line["cns_accept"]["cpu_baseline"] = {"error": repr(e)[:200]}
             try:
                 line["cpu_baseline"] = cpu_baseline(args.workload, os.cpu_count() or 1)
+                try:      # context: the unmodified reference on the FULL workload, timed in the build container (tests/golden/big.json)
+                    big = json.load(open(os.path.join(ROOT, "tests", "golden", "big.json"))).get(args.workload)
+                    if big and "j0_seconds" in big:
+                        line["cpu_baseline"]["full_size_reference"] = {
+                            "threads": big.get("reference_threads"), "host": "build container (8 cores), not this host",
+                            "j0_seconds": big["j0_seconds"], "candidates_per_s": big["can_lines"] / big["j0_seconds"],
+                            "j1_seconds": big.get("j1_seconds"), "overlaps_per_s": big["m4_g1_lines"] / big["j1_seconds"] if big.get("j1_seconds") else None,
+                            "source": "tests/golden/big.json (make_golden_big.py: whole mecat2pw runs incl. split and output)"}
+                except Exception:  # noqa: BLE001
+                    pass
             except Exception as e:  # the GPU number must survive a CPU-leg problem
                 line["cpu_baseline"] = {"value": None, "unit": "candidates/s", "cores": os.cpu_count(), "kind": "reference",
                                         "sample": "failed: %r" % (e,)}

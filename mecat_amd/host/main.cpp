@@ -146,7 +146,8 @@ static void run_threads(int nt, F f) {
 
 // comm == NULL: this process computes the whole grid row.  Otherwise every rank of the communicator runs this function for the
 // same row: the reads of a slab are dealt out in chunks (chunk c of query volume j -> rank (c + j) mod P), each rank seeds and
-// extends its own, the lists are all-gathered (mhip_seed_reads_sharded / mhip_align_sharded), and rank 0 (out != NULL) writes.
+// extends its own, the lists are all-gathered (mhip_seed_reads_sharded / mhip_align_sharded), and every rank formats and writes the
+// lines of its own reads into its part of r_<i> (out = that part).
 static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, const std::vector<std::string>& vn, FILE* out, PartitionWriter* pw,
                                double part_ratio, mhip_comm* comm, int shard_chunk) {
     mhip_params P;
@@ -239,6 +240,12 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
             PinnedBuf<mhip_aln_result>& res = B.res;
             std::vector<size_t>& jfirst = B.jfirst;
             const int rb = B.rb, nr = B.nr;
+            // cells mode: every rank holds the slab's complete tables (the all-gather of the candidate lists and results) and formats
+            // and writes the reads of its OWN chunks — chunk c of query volume vid belongs to rank (c + vid) mod P — into its own part
+            // of r_<i>; rank 0 strings the parts together (main).  The line order of r_<i> is then "by rank" instead of "by read": the
+            // multiset of lines is the contract, the reference's own order depends on its thread timing.
+            const int c_rank = comm ? mhip_comm_rank(comm) : 0, c_world = comm ? mhip_comm_nranks(comm) : 1;
+            auto mine = [&](int r) { return c_world == 1 || ((rb + r) / shard_chunk + vid) % c_world == c_rank; };
             std::vector<std::string> text((size_t)nt);
             auto range_of = [&](int t, int* lo, int* hi) { *lo = (int)((long long)nr * t / nt); *hi = (int)((long long)nr * (t + 1) / nt); };
             if (opt.task == TASK_SEED) {
@@ -251,6 +258,7 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
                     std::string& o = text[(size_t)t];
                     char line[160];
                     for (int r = lo; r < hi; ++r) {
+                        if (!mine(r)) continue;
                         const int qsize = rd->offs[(size_t)(rb + r)].size, qid = rb + r + rd->start_read_id;
                         const size_t c0 = B.packed ? jfirst[(size_t)r] : (size_t)r * P.maxc;
                         for (int k = 0; k < counts[(size_t)r]; ++k) {
@@ -282,6 +290,7 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
                 std::vector<int> valid;
                 char line[320];
                 for (int r = lo; r < hi; ++r) {
+                    if (!mine(r)) continue;
                     const int qsize = rd->offs[(size_t)(rb + r)].size, qid = rb + r + rd->start_read_id;
                     size_t ji = jfirst[(size_t)r];
                     const size_t c0 = B.packed ? jfirst[(size_t)r] : (size_t)r * P.maxc;
@@ -557,7 +566,8 @@ static double now_s() {
 //   cells  (#volumes <  P)  every rank works on every cell: the query reads of a cell are dealt out in chunks of 500
 //          (MECAT_HIP_SHARD_CHUNK; chunk c of query volume j -> rank (c + j) mod P), each rank builds the index of
 //          the row's reference volume itself, and the candidate lists / extension results are all-gathered over RCCL
-//          (mhip_seed_reads_sharded, mhip_align_sharded); rank 0 writes r_<i>.  A one-volume input (config 2) uses every GPU.
+//          (mhip_seed_reads_sharded, mhip_align_sharded); every rank formats and writes the lines of its own reads (r_<i>.part<rank>),
+//          rank 0 strings the parts together into r_<i>.  A one-volume input (config 2) uses every GPU.
 // A run is identified by a token (MECAT_HIP_RUN_ID, else the launcher's TORCHELASTIC_RUN_ID + the parent pid, which every rank
 // of one launch shares): rank 0 puts it into the split marker, the other ranks accept no other marker.  Ranks above 0 keep a
 // heartbeat file fresh and leave a failure marker when they abort; rank 0 stops waiting for a row whose owner has died.
@@ -833,18 +843,27 @@ int main(int argc, char* argv[]) {
             continue;
         }
         if (!cells && i % world != rank) continue;               // rows: dealt out cyclically
-        const bool writes = !cells || rank == 0;
+        // rows: the owner of row i writes r_<i>.  cells: every rank writes the lines of its own reads to r_<i>.part<rank>, and once all
+        // parts are closed rank 0 strings them together into r_<i>.working -> r_<i> (the resume protocol sees only complete rows)
         const std::string fin = results_name(opt.wrk_dir, i, false), wrk = results_name(opt.wrk_dir, i, true);
-        FILE* out = NULL;
-        if (writes) {
-            out = fopen(wrk.c_str(), "w");
-            if (!out) DIE("failed to open file '%s' with mode 'ios::out'", wrk.c_str());
-        }
+        const std::string mine = cells ? fin + ".part" + std::to_string(rank) : wrk;
+        FILE* out = fopen(mine.c_str(), "w");
+        if (!out) DIE("failed to open file '%s' with mode 'ios::out'", mine.c_str());
         process_one_volume(opt, ctx, i, vn, out, pw, part_ratio, comm, shard_chunk);
-        if (writes) {
-            if (fclose(out) != 0) DIE("write error!");
-            if (rename(wrk.c_str(), fin.c_str()) != 0) DIE("cannot rename %s", wrk.c_str());
+        if (fclose(out) != 0) DIE("write error!");
+        if (cells) {
+            MCHK(mhip_comm_barrier(comm));
+            if (rank == 0) {
+                TraceTimer tt("parts -> r_<i>");
+                for (int r = 0; r < world; ++r) {
+                    const std::string part = fin + ".part" + std::to_string(r);
+                    if (!merge_copy(part, wrk.c_str(), r == 0)) DIE("cannot append '%s' to '%s'", part.c_str(), wrk.c_str());
+                    unlink(part.c_str());
+                }
+            }
         }
+        if (!cells || rank == 0)
+            if (rename(wrk.c_str(), fin.c_str()) != 0) DIE("cannot rename %s", wrk.c_str());
     }
     if (comm) {
         MCHK(mhip_comm_barrier(comm));

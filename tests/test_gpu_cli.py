@@ -135,11 +135,11 @@ def test_cli_two_processes_share_the_grid_rows(tmp_path, task):
 def test_cli_processes_share_the_grid_cells(tmp_path, task, nproc, vols, ishard):
     """multi-GPU mode of the driver, cell sharding: every rank works on every (reference volume, query volume)
     cell — the query reads dealt out in chunks, chunk c of query volume j to rank (c + j) mod P — the candidate lists and
-    extension results are all-gathered (mhip_seed_reads_sharded / mhip_align_sharded) and rank 0 writes r_<i>.  Here the ranks
-    share GPU 0 and exchange through the host-file transport (RCCL refuses two ranks on one device); a one-volume input, which
-    the row sharding cannot split, is spread over all ranks.  ishard = "1": the ranks also build each reference volume's look-up table
-    together (mhip_index_build_sharded: key-range shards + all-gather; the driver's default from four ranks on).  The output must be
-    byte-identical to the single-process run."""
+    extension results are all-gathered (mhip_seed_reads_sharded / mhip_align_sharded), every rank formats and writes the lines of
+    its own reads and rank 0 strings the parts together into r_<i>.  Here the ranks share GPU 0 and exchange through the host-file
+    transport (RCCL refuses two ranks on one device); a one-volume input, which the row sharding cannot split, is spread over all
+    ranks.  ishard = "1": the ranks also build each reference volume's look-up table together (mhip_index_build_sharded: key-range
+    shards + all-gather; the driver's default from four ranks on).  The output must be the single-process run's as a multiset of lines."""
     import uuid
     fa = _fasta(tmp_path, "config1" if vols == 1 else "tiny")
     env = dict(os.environ)
@@ -162,9 +162,11 @@ def test_cli_processes_share_the_grid_cells(tmp_path, task, nproc, vols, ishard)
     for p in procs:
         out, err = p.communicate(timeout=300)
         assert p.returncode == 0, err[-2000:]
-    assert open(many).read() == open(one).read()
+    # every rank writes the lines of its own reads and rank 0 strings the parts together: the multiset of lines is the contract
+    # (the reference's own line order depends on its thread timing)
+    assert sorted(open(many).read().splitlines()) == sorted(open(one).read().splitlines())
     assert len(open(many).read().splitlines()) > (5000 if vols == 1 else 300)
-    assert sorted(f for f in os.listdir(wrk) if f.startswith("r_")) == ["r_%d" % i for i in range(vols)]
+    assert sorted(f for f in os.listdir(wrk) if f.startswith("r_")) == ["r_%d" % i for i in range(vols)]      # no part files left behind
 
 
 def test_cli_dead_rank_does_not_hang_rank_0(tmp_path):

@@ -10,8 +10,12 @@ Classes follow the issue costs measured by mecat_amd/bin/valu_peak on gfx950 (pr
 Also reports `vcc_rereads`: v_cndmask reads of VCC beyond the first after each write of VCC (the slow pattern: a chain of
 selects on one compare through VCC issues 2-4x slower than through an SGPR pair).
 
-    python tools/isa_mix.py build/align.s dw_extend2 [--loops]
-"""
+    python tools/isa_mix.py build/align.s dw_extend2 [--ops] [--row-loops]
+
+--row-loops: only the basic blocks of dw_extend2's d-row loops — the depth-2 loops (LLVM's loop annotations in the assembly) that
+contain the half-wave row maximum (v_permlane16_swap), with the snake loops nested in them; set-up, tail traceback and accounting
+code are left out (the share of 4-cycle-class instructions that prices the kernel must come from the loop it spends
+its time in)."""
 import re
 import sys
 from collections import Counter
@@ -59,11 +63,55 @@ def kernel_lines(path, name):
     return out
 
 
+def row_loop_lines(lines):
+    """lines of the blocks that belong to a depth-2 loop containing v_permlane16_swap (and to the loops nested inside it)"""
+    blocks = []
+    for ln in lines:
+        m = re.match(r"^\.L(BB\d+_\d+):", ln)
+        if m or re.match(r"^; %bb\.\d+:", ln) or not blocks:
+            blocks.append({"label": m.group(1) if m else None, "lines": []})
+        blocks[-1]["lines"].append(ln)
+    parent, depth_of = {}, {}
+    for b in blocks:
+        head = "\n".join(b["lines"][:16])
+        mh = re.search(r"=>\s*This (?:Inner )?Loop Header: Depth=(\d+)", head)
+        mi = re.search(r"in Loop: Header=(BB\d+_\d+) Depth=(\d+)", b["lines"][0])
+        if mh and b["label"]:
+            b["inner"] = b["label"]
+            depth_of[b["label"]] = int(mh.group(1))
+            ps = [(int(d), h) for h, d in re.findall(r"Parent Loop (BB\d+_\d+) Depth=(\d+)", head)]
+            parent[b["label"]] = max(ps)[1] if ps else None
+        elif mi:
+            b["inner"] = mi.group(1)
+        else:
+            b["inner"] = None
+
+    def chain(h):
+        out = []
+        while h:
+            out.append(h)
+            h = parent.get(h)
+        return out
+    has_swap = set()
+    for b in blocks:
+        if b["inner"] and any("v_permlane16_swap" in ln for ln in b["lines"]):
+            has_swap.update(chain(b["inner"]))
+    rows = {h for h in has_swap if depth_of.get(h) == 2}
+    keep = []
+    for b in blocks:
+        if b["inner"] and any(h in rows for h in chain(b["inner"])):
+            keep += b["lines"]
+    return keep, sorted(rows)
+
+
 def main():
     path, name = sys.argv[1], sys.argv[2]
     lines = kernel_lines(path, name)
     if not lines:
         sys.exit("kernel %s not found in %s" % (name, path))
+    if "--row-loops" in sys.argv:
+        lines, rows = row_loop_lines(lines)
+        print("row loops (depth 2, with the half-wave maximum): %s" % " ".join(rows))
     mix, ops = Counter(), Counter()
     vcc_reads_since_write, vcc_rereads = 0, 0
     for ln in lines:

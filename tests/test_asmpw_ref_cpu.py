@@ -91,3 +91,82 @@ def test_reference_reproduces_the_index_golden():
     order = np.argsort(pw, kind="stable")
     assert np.array_equal(pw[order], g["ids"]) and np.array_equal(cnt[order], g["counts"])
     assert np.array_equal(np.concatenate([pos[i] - 1 for i in order]), g["positions"])
+
+
+# ---- the candidate stage of pairwise_mapping (mecat2asmpw.c:580-718): the restatement (oracle/asmpw_oracle.c) against the unmodified file
+def _block_text(codes, starts, lens, b, e):
+    import numpy as np
+    parts, st, off = [], [], 0
+    for rid in range(b, e + 1):
+        s = codes[starts[rid - 1]: starts[rid]]
+        st.append(off)
+        parts.append(bytes(b"ACGT"[c] for c in s) + b"\0")
+        off += len(s) + 1
+    return b"".join(parts), np.array(st, dtype=np.int32), lens[b - 1: e].astype(np.int32)
+
+
+def _expected_calls(text, cand, fwd, rev):
+    """the two `align` calls the reference makes for a candidate when the first block of either extension reports no alignment
+    (mecat2asmpw.c:741-749, :800-809): slices of the block text and of the query strand, min(num, 500) long (num > 600: 500)"""
+    q = fwd if cand.chain == b"F" else rev
+    out = []
+    n1 = 500 if cand.num1 > 600 else cand.num1
+    a, b = cand.loc1 + 13 - 2, cand.loc2 + 13 - 1                    # seq_pr1 / seq_pr2, walked backwards
+    out.append((bytes(text[a - i] for i in range(n1)), bytes(q[b - i] for i in range(n1)), int(0.10 * n1)))
+    n2 = 500 if cand.num2 > 600 else cand.num2
+    a, b = cand.loc1 - 1, cand.loc2
+    out.append((bytes(text[a: a + n2]), bytes(q[b: b + n2]), int(0.10 * n2)))
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(H.ROOT, "oracle", "_ref", "libref_asmpw_cand.so")), reason="the reference harness is built in the build container only")
+@pytest.mark.parametrize("start", [1, 2])
+def test_candidate_stage_equals_reference(start):
+    """Every candidate of every query read of the golden set — subject position, query position, strand, num1, num2, in list order —
+    as the UNMODIFIED pairwise_mapping selects them (observed through its `align` calls, ref_harness_asmpw_cand.c) and as
+    oracle/asmpw_oracle.c restates them.  start = the indexed block (-S); the queries are the reads of that block and of the later ones."""
+    import ctypes as C
+    import numpy as np
+    sys.path.insert(0, H.GOLDEN)
+    import make_golden_asmpw as G
+    codes, lens = H.synth_reads(G.GEN["nreads"], G.GEN["L"], G.GEN["err"], G.GEN["genome"], G.GEN["seed"], G.GEN["ont"])
+    starts = np.concatenate([[0], np.cumsum(lens.astype(np.int64))])
+    b, e = G.BLOCKS[start - 1]
+    text, st, ln = _block_text(codes, starts, lens, b, e)
+    R = C.CDLL(os.path.join(H.ROOT, "oracle", "_ref", "libref_asmpw_cand.so"))
+    R.refasmc_setup.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    R.refasmc_candidates.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_long, C.POINTER(C.c_long)]
+    tbuf = C.create_string_buffer(text, len(text))
+    R.refasmc_setup(tbuf, len(text), st.ctypes.data, ln.ctypes.data, e - b + 1, b)
+
+    class Cand(C.Structure):
+        _fields_ = [(n, C.c_int) for n in ("loc1", "loc2", "left1", "left2", "right1", "right2", "score", "num1", "num2", "readno", "readstart")] + [("chain", C.c_char)]
+    O = C.CDLL(os.path.join(H.ROOT, "oracle", "liboracle.so"))
+    O.asm_block_new.restype = C.c_void_p
+    O.asm_block_new.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_int, C.c_int]
+    O.asm_candidates.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p]
+    O.asm_block_free.argtypes = [C.c_void_p]
+    B = O.asm_block_new(tbuf, len(text), st.ctypes.data, e - b + 1, b)
+    rec = np.zeros(8_000_000, dtype=np.uint8)
+    out = (Cand * 100)()
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    total = 0
+    for rid in range(b, G.GEN["nreads"] + 1):
+        fwd = bytes(b"ACGT"[c] for c in codes[starts[rid - 1]: starts[rid]])
+        rev = fwd[::-1].translate(comp)
+        used = C.c_long()
+        ncalls = R.refasmc_candidates(C.create_string_buffer(fwd), rid, rec.ctypes.data, len(rec), C.byref(used))
+        assert ncalls >= 0 and ncalls % 2 == 0
+        n = O.asm_candidates(B, fwd, len(fwd), rid, out)
+        assert 2 * n == ncalls, (rid, n, ncalls)
+        raw, at = rec[: used.value].tobytes(), 0
+        for i in range(n):
+            for want_q, want_t, band in _expected_calls(text, out[i], fwd, rev):
+                ql, tl, bd = np.frombuffer(raw[at: at + 12], dtype=np.int32)
+                got_q, got_t = raw[at + 12: at + 12 + ql], raw[at + 12 + ql: at + 12 + ql + tl]
+                at += 12 + ql + tl
+                # (the reference passes the subject slice as `query_seq` and the query read's slice as `target_seq`)
+                assert (got_q, got_t, bd) == (want_q, want_t, band), (rid, i)
+        total += n
+    O.asm_block_free(B)
+    assert total > 2000      # (7 000+ candidates with block 1 indexed, 2 400+ with block 2)

@@ -60,6 +60,9 @@ typedef struct {
     asm_seg* db;        /* [n / ZV + 5] (+ slack behind for the sweeps' reads past the last segment) */
     int* index_list;
     short* index_score;
+    int fresh;          /* asm_block_fresh(): every read starts from an all-zero segment array (see there) */
+    int* dirty;         /* segments touched by the current read */
+    int ndirty;
 } asm_block;
 
 static int base_code(char c) {      /* atcttrans :299-305 (the digit order only names the buckets: any bijection gives the same buckets) */
@@ -75,6 +78,7 @@ static int base_code(char c) {      /* atcttrans :299-305 (the digit order only 
 void asm_block_free(asm_block* B) {
     if (!B) return;
     free(B->lloc); free(B->readno); free(B->counts); free(B->first); free(B->pos); free(B->db); free(B->index_list); free(B->index_score);
+    free(B->dirty);
     free(B);
 }
 
@@ -119,9 +123,18 @@ asm_block* asm_block_new(const char* text, int n, const int* starts, int nreads,
         for (i = 0; i < nseg + 8; ++i) B->db[i].index = -1;
         B->index_list = (int*)malloc((size_t)nseg * sizeof(int));
         B->index_score = (short*)malloc((size_t)nseg * sizeof(short));
+        B->dirty = (int*)malloc((size_t)nseg * 2 * sizeof(int));
     }
     return B;
 }
+
+/* The reference resets only `score` and `index` of the segments a strand touched (:717): the stored seeds, `seednum` and whatever a
+ * worker thread's earlier reads left in a segment stay, and the sweeps' reads past the 60 stored entries can land on them — so its
+ * candidates depend, in principle, on which reads the same thread mapped before.  With on != 0 every READ starts from an all-zero
+ * segment array (the forward strand's leftovers are still there for the reverse strand, as in the reference, where the two strands
+ * always follow each other on one thread): the deterministic definition the device path implements.  The golden sets give the same
+ * candidates either way (tests/test_asmpw_ref_cpu.py). */
+void asm_block_fresh(asm_block* B, int on) { B->fresh = on; }
 
 static int find_read(const int* a, int key, int n) {             /* binary :283-297, statement for statement (its quirks decide results) */
     int left = 0, right = n - 1, mid = (left + right) / 2;
@@ -254,7 +267,11 @@ static void strand(asm_block* B, const char* s, int len, int read_name, char cha
             if (*ncand < AMAXC) ++*ncand;
         }
     }
-    for (i = 0; i < touched; ++i) { db[B->index_list[i]].score = 0; db[B->index_list[i]].index = -1; }      /* :717 */
+    for (i = 0; i < touched; ++i) {                                /* :717 */
+        db[B->index_list[i]].score = 0;
+        db[B->index_list[i]].index = -1;
+        if (B->fresh) B->dirty[B->ndirty++] = B->index_list[i];
+    }
 }
 
 /* candidates of one query read (upper-case text) in list order; out[AMAXC].  Returns their number. */
@@ -269,5 +286,7 @@ int asm_candidates(asm_block* B, const char* query, int qlen, int read_name, asm
     rc[qlen] = 0;
     strand(B, rc, qlen, read_name, 'R', out, &n);
     free(rc);
+    for (i = 0; i < B->ndirty; ++i) { memset(&B->db[B->dirty[i]], 0, sizeof(asm_seg)); B->db[B->dirty[i]].index = -1; }
+    B->ndirty = 0;
     return n;
 }

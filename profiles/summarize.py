@@ -16,8 +16,8 @@ import sys
 
 
 def short(name):
-    n = name.split("(")[0]
-    return n.replace("void ", "")[:60]
+    n = name.replace("void ", "").replace("(anonymous namespace)::", "")
+    return n.split("(")[0].split("<")[0][:60]
 
 
 def main():

@@ -120,11 +120,14 @@ def _expected_calls(text, cand, fwd, rev):
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(H.ROOT, "oracle", "_ref", "libref_asmpw_cand.so")), reason="the reference harness is built in the build container only")
-@pytest.mark.parametrize("start", [1, 2])
-def test_candidate_stage_equals_reference(start):
+@pytest.mark.parametrize("start,fresh", [(1, 0), (2, 0), (1, 1), (2, 1)])
+def test_candidate_stage_equals_reference(start, fresh):
     """Every candidate of every query read of the golden set — subject position, query position, strand, num1, num2, in list order —
     as the UNMODIFIED pairwise_mapping selects them (observed through its `align` calls, ref_harness_asmpw_cand.c) and as
-    oracle/asmpw_oracle.c restates them.  start = the indexed block (-S); the queries are the reads of that block and of the later ones."""
+    oracle/asmpw_oracle.c restates them.  start = the indexed block (-S); the queries are the reads of that block and of the later ones.
+    fresh = 1: the restatement starts every read from an all-zero segment array (asm_block_fresh: the deterministic definition the
+    device path implements) — the reference, whose worker threads keep the stale seeds of their earlier reads, selects the same
+    candidates on these sets."""
     import ctypes as C
     import numpy as np
     sys.path.insert(0, H.GOLDEN)
@@ -147,10 +150,12 @@ def test_candidate_stage_equals_reference(start):
     O.asm_candidates.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p]
     O.asm_block_free.argtypes = [C.c_void_p]
     B = O.asm_block_new(tbuf, len(text), st.ctypes.data, e - b + 1, b)
+    O.asm_block_fresh.argtypes = [C.c_void_p, C.c_int]
+    O.asm_block_fresh(B, fresh)
     rec = np.zeros(8_000_000, dtype=np.uint8)
     out = (Cand * 100)()
     comp = bytes.maketrans(b"ACGT", b"TGCA")
-    total = 0
+    total = reordered = 0
     for rid in range(b, G.GEN["nreads"] + 1):
         fwd = bytes(b"ACGT"[c] for c in codes[starts[rid - 1]: starts[rid]])
         rev = fwd[::-1].translate(comp)
@@ -160,13 +165,22 @@ def test_candidate_stage_equals_reference(start):
         n = O.asm_candidates(B, fwd, len(fwd), rid, out)
         assert 2 * n == ncalls, (rid, n, ncalls)
         raw, at = rec[: used.value].tobytes(), 0
+        got, want = [], []
         for i in range(n):
-            for want_q, want_t, band in _expected_calls(text, out[i], fwd, rev):
+            pair = []
+            for _ in range(2):
                 ql, tl, bd = np.frombuffer(raw[at: at + 12], dtype=np.int32)
-                got_q, got_t = raw[at + 12: at + 12 + ql], raw[at + 12 + ql: at + 12 + ql + tl]
-                at += 12 + ql + tl
                 # (the reference passes the subject slice as `query_seq` and the query read's slice as `target_seq`)
-                assert (got_q, got_t, bd) == (want_q, want_t, band), (rid, i)
+                pair.append((raw[at + 12: at + 12 + ql], raw[at + 12 + ql: at + 12 + ql + tl], int(bd)))
+                at += 12 + ql + tl
+            got.append(tuple(pair))
+            want.append(tuple(_expected_calls(text, out[i], fwd, rev)))
+        if fresh:      # the stale seeds of earlier reads can move a candidate's score by a few votes, i.e. change the list ORDER: same candidates
+            assert sorted(got) == sorted(want), rid
+            reordered += got != want
+        else:
+            assert got == want, rid
         total += n
     O.asm_block_free(B)
     assert total > 2000      # (7 000+ candidates with block 1 indexed, 2 400+ with block 2)
+    assert reordered <= 3    # (reads whose list order differs between the reference's thread history and a fresh start: 0 and 1 on these sets)

@@ -225,6 +225,18 @@ int  mhip_align_sharded(mhip_comm* comm, const mhip_volume* ref, const mhip_volu
                         mhip_aln_result* out, int64_t* num_jobs);
 /* device views of the tables the last two calls left on this rank (complete on every rank) */
 int  mhip_sharded_tables(mhip_comm* comm, void** d_cands, void** d_counts, void** d_results, int64_t* num_jobs);
+/* ---- mecat2canu's overlapper for corrected reads (mecat2asmpw / mecat2trimpw), candidate stage ----
+ * Replaces the part of pairwise_mapping in front of its extension loop (mecat2canu/src/mecat2asmpw/mecat2asmpw.c:580-718): seeding of
+ * both strands of query reads [rid_begin, rid_end) of `reads` against one block of reads (`block`: the tool's STRMEM as a volume — one
+ * pad base after every read is the tool's one NUL after every read, so offsets agree; start_read_id = the block's first read number)
+ * whose table was built with mhip_index_build_ex(ctx, block, 256, ..) (creat_ref_index + sumvalue_x: cap 256), and candidate
+ * selection.  out[(rid - rid_begin) * 100 .. ] = the read's candidates in list order (canidate_save, :55-58; positions 1-based as in
+ * the tool, chain 0 = 'F', 1 = 'R'), out_counts[] their number (<= 100).  Every read starts from an all-zero segment array (the
+ * tool's worker threads keep stale seeds of the reads they mapped before, which can move a score by a few votes: INTEGRATION.md). */
+typedef struct { int32_t loc1, loc2, left1, left2, right1, right2, score, num1, num2, readno, readstart, chain; } mhip_asm_candidate;
+int  mhip_asm_seed_reads(mhip_ctx* ctx, const mhip_index* idx, const mhip_volume* block, const mhip_volume* reads, int rid_begin,
+                         int rid_end, mhip_asm_candidate* out, int32_t* out_counts);
+
 /* mhip_index_build by all ranks of the communicator together (replaces create_ref_index, common/lookup_table.cpp:63-160, in a
  * multi-GPU cell): the 4^13 key space is cut into P contiguous ranges of equal occupancy, each rank builds the buckets of its range,
  * positions and table slices are all-gathered (counts first, then payload), and every rank returns the complete table — equal, array

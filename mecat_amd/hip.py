@@ -251,6 +251,20 @@ class Index:
             self.h = C.c_void_p()
 
 
+ASM_CAND_DTYPE = np.dtype([(n, np.int32) for n in ("loc1", "loc2", "left1", "left2", "right1", "right2", "score", "num1", "num2", "readno",
+                                                    "readstart", "chain")])
+
+
+def asm_seed_reads(ctx, idx, block, reads, rid_begin, rid_end):
+    """mhip_asm_seed_reads: the candidate stage of mecat2asmpw's pairwise_mapping -> (cands [n, 100] ASM_CAND_DTYPE, counts int32[n])"""
+    n = rid_end - rid_begin
+    out = np.zeros((n, 100), dtype=ASM_CAND_DTYPE)
+    cnt = np.zeros(n, dtype=np.int32)
+    lib().mhip_asm_seed_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    _chk(lib().mhip_asm_seed_reads(ctx.h, idx.h, block.h, reads.h, rid_begin, rid_end, out.ctypes.data, cnt.ctypes.data))
+    return out, cnt
+
+
 def seed_reads(ctx, idx, ref, reads, rid_begin, rid_end, params):
     """-> (cands structured array [n, maxc], counts int32[n]) on the host"""
     n = rid_end - rid_begin

@@ -35,3 +35,66 @@ def test_index_with_cap_256_equals_the_reference_table():
     with pytest.raises(M.MhipError):
         M.Index(ctx, vol, max_bucket=257)
     idx.free(); idx128.free(); vol.free(); ctx.close()
+
+
+@pytest.mark.parametrize("start", [1, 2])
+def test_candidate_stage_equals_the_restatement(start):
+    """mhip_asm_seed_reads (asm_seed.hip) against oracle/asmpw_oracle.c in its fresh-per-read mode — which tests/test_asmpw_ref_cpu.py
+    pins to the UNMODIFIED pairwise_mapping of mecat2asmpw.c (same candidates; the reference's thread history can move a score by a few
+    votes) — on the golden set of corrected reads laid out as canu's two overlap blocks: every field of every candidate, in list order.
+    start = the indexed block (-S); queries = the reads of that block and of the later ones, as the tool maps them."""
+    import ctypes as C
+    import sys
+    import mecat_amd.hip as M
+    from mecat_amd import workload as W
+    sys.path.insert(0, H.GOLDEN)
+    import make_golden_asmpw as G
+    codes, lens = H.synth_reads(G.GEN["nreads"], G.GEN["L"], G.GEN["err"], G.GEN["genome"], G.GEN["seed"], G.GEN["ont"])
+    starts = np.concatenate([[0], np.cumsum(lens.astype(np.int64))])
+    b, e = G.BLOCKS[start - 1]
+    # the device side: block and query reads as volumes (read numbers from 1, as canu numbers them)
+    ctx = M.Context(0)
+    bpac, boffs, bnb = W.pack_volume(codes[starts[b - 1]: starts[e]], lens[b - 1: e])
+    block = M.Volume(ctx, bpac, boffs, bnb, b)
+    idx = M.Index(ctx, block, max_bucket=256)
+    qpac, qoffs, qnb = W.pack_volume(codes[starts[b - 1]:], lens[b - 1:])
+    reads = M.Volume(ctx, qpac, qoffs, qnb, b)
+    nq = G.GEN["nreads"] - b + 1
+    got, cnt = M.asm_seed_reads(ctx, idx, block, reads, 0, nq)
+    # the restatement
+    parts, st, off = [], [], 0
+    for rid in range(b, e + 1):
+        s = codes[starts[rid - 1]: starts[rid]]
+        st.append(off)
+        parts.append(bytes(b"ACGT"[c] for c in s) + b"\0")
+        off += len(s) + 1
+    text = b"".join(parts)
+    st = np.array(st, dtype=np.int32)
+    assert np.array_equal(st, np.asarray(boffs).reshape(-1, 2)[:, 0])      # one pad base after a read == the tool's one NUL: same offsets
+
+    class Cand(C.Structure):
+        _fields_ = [(n, C.c_int) for n in ("loc1", "loc2", "left1", "left2", "right1", "right2", "score", "num1", "num2", "readno", "readstart")] + [("chain", C.c_char)]
+    O = C.CDLL(os.path.join(H.ROOT, "oracle", "liboracle.so"))
+    O.asm_block_new.restype = C.c_void_p
+    O.asm_block_new.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_int, C.c_int]
+    O.asm_candidates.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p]
+    O.asm_block_fresh.argtypes = [C.c_void_p, C.c_int]
+    O.asm_block_free.argtypes = [C.c_void_p]
+    tbuf = C.create_string_buffer(text, len(text))
+    B = O.asm_block_new(tbuf, len(text), st.ctypes.data, e - b + 1, b)
+    O.asm_block_fresh(B, 1)
+    out = (Cand * 100)()
+    total = 0
+    names = ("loc1", "loc2", "left1", "left2", "right1", "right2", "score", "num1", "num2", "readno", "readstart")
+    for q in range(nq):
+        rid = b + q
+        fwd = bytes(b"ACGT"[c] for c in codes[starts[rid - 1]: starts[rid]])
+        n = O.asm_candidates(B, fwd, len(fwd), rid, out)
+        assert cnt[q] == n, (rid, cnt[q], n)
+        for i in range(n):
+            want = tuple(getattr(out[i], f) for f in names) + (0 if out[i].chain == b"F" else 1,)
+            assert tuple(int(got[q, i][f]) for f in names + ("chain",)) == want, (rid, i)
+        total += n
+    O.asm_block_free(B)
+    assert total > 2000
+    idx.free(); block.free(); reads.free(); ctx.close()

@@ -132,7 +132,9 @@ def cpu_baseline_config1():
 def cns_cpu_baseline(codes, lens, rec, tb, ids, templates=100):
     """BASELINE config 4's CPU side, same run: the UNMODIFIED consensus_one_read_can_pacbio (oracle/_ref/libref_cns_accept.so = mecat2cns
     compiled from the reference's sources) on the first `templates` templates of the very records the GPU leg was given — one thread, as a
-    mecat2cns worker runs it (the reference parallelises over templates: multiply by its thread count)."""
+    mecat2cns worker runs it (the reference parallelises over templates: multiply by its thread count).  Runs in a child process with
+    OMP_NUM_THREADS=1: the reference is built with -D_GLIBCXX_PARALLEL as its own Makefile does, and on a many-core host every std::sort
+    inside a worker would otherwise start a thread team."""
     from mecat_amd import workload as W
     so = os.path.join(ROOT, "oracle", "_ref", "libref_cns_accept.so")
     if not os.path.exists(so):
@@ -142,33 +144,46 @@ def cns_cpu_baseline(codes, lens, rec, tb, ids, templates=100):
     try:
         fa = os.path.join(d, "reads.fa")
         W.write_fasta(fa, codes, lens)
-        A = C.CDLL(so)
-        A.refa_load_reads.argtypes = [C.c_char_p]
-        A.refa_consensus_can.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_long, C.POINTER(C.c_long)]
-        t0 = time.time()
-        if A.refa_load_reads(fa.encode()) != len(lens):
-            return {"error": "refa_load_reads"}
-        t_load = time.time() - t0
         K = min(templates, len(ids))
-        sbuf = np.zeros(64_000_000, dtype=np.int8)
-        meta = np.zeros((128, 4), dtype=np.int32)
-        naln = nacc = 0
-        t0 = time.time()
-        for t in range(K):
-            b, e = int(tb[t]), int(tb[t + 1])
-            cand = np.ascontiguousarray(rec[b:e]).copy()
-            used = C.c_long()
-            k = A.refa_consensus_can(0, cand.ctypes.data, e - b, int(ids[t]), 2000, 0.9, meta.ctypes.data, sbuf.ctypes.data, len(sbuf), C.byref(used))
-            if k < 0:
-                return {"error": "refa_consensus_can"}
-            naln += min(e - b, 200)
-            nacc += k
-        dt = time.time() - t0
-        return {"kind": "reference", "cores": 1, "templates": K, "candidates_offered": naln, "accepted": nacc, "seconds": dt,
-                "templates_per_s": K / dt, "load_reads_s": t_load,
-                "sample": "first %d templates of the GPU leg's records, consensus_one_read_can_pacbio up to the consensus table, one thread" % K}
+        np.savez(os.path.join(d, "in.npz"), rec=np.ascontiguousarray(rec[: tb[K]]), tb=tb[: K + 1], ids=ids[:K], n=len(lens))
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--cns-cpu-leg", d], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                           env=dict(os.environ, OMP_NUM_THREADS="1"), timeout=600)
+        if p.returncode != 0:
+            return {"error": p.stderr[-300:]}
+        out = json.loads(p.stdout.strip().splitlines()[-1])
+        out["sample"] = "first %d templates of the GPU leg's records, consensus_one_read_can_pacbio up to the consensus table, one thread" % K
+        return out
     finally:
         subprocess.run(["rm", "-rf", d])
+
+
+def cns_cpu_leg(d):
+    """child process of cns_cpu_baseline"""
+    A = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_cns_accept.so"))
+    A.refa_load_reads.argtypes = [C.c_char_p]
+    A.refa_consensus_can.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_long, C.POINTER(C.c_long)]
+    g = np.load(os.path.join(d, "in.npz"))
+    rec, tb, ids = g["rec"], g["tb"], g["ids"]
+    t0 = time.time()
+    if A.refa_load_reads(os.path.join(d, "reads.fa").encode()) != int(g["n"]):
+        raise SystemExit("refa_load_reads")
+    t_load = time.time() - t0
+    sbuf = np.zeros(64_000_000, dtype=np.int8)
+    meta = np.zeros((128, 4), dtype=np.int32)
+    naln = nacc = 0
+    t0 = time.time()
+    for t in range(len(ids)):
+        b, e = int(tb[t]), int(tb[t + 1])
+        cand = np.ascontiguousarray(rec[b:e]).copy()
+        used = C.c_long()
+        k = A.refa_consensus_can(0, cand.ctypes.data, e - b, int(ids[t]), 2000, 0.9, meta.ctypes.data, sbuf.ctypes.data, len(sbuf), C.byref(used))
+        if k < 0:
+            raise SystemExit("refa_consensus_can")
+        naln += min(e - b, 200)
+        nacc += k
+    dt = time.time() - t0
+    print(json.dumps({"kind": "reference", "cores": 1, "templates": len(ids), "candidates_offered": naln, "accepted": nacc, "seconds": dt,
+                      "templates_per_s": len(ids) / dt, "load_reads_s": t_load}))
 
 
 def e2e_cli(workload, codes, lens, threads):
@@ -691,4 +706,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) == 3 and sys.argv[1] == "--cns-cpu-leg":
+        cns_cpu_leg(sys.argv[2])
+    else:
+        main()

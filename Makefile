@@ -29,7 +29,7 @@ $(LIBDIR)/libmecat_hip.so: $(HIP_OBJS)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(HIP_OBJS) -o $@
 
-host: $(BINDIR)/mecat2pw $(BINDIR)/mecat2cns_partition $(BINDIR)/valu_peak $(BINDIR)/gather_peak
+host: $(BINDIR)/mecat2pw $(BINDIR)/mecat2cns_partition $(BINDIR)/valu_peak $(BINDIR)/gather_peak $(BINDIR)/mecat2asmpw
 # issue-rate calibration for bench.py's dw roofline (measures, computes nothing of the path)
 $(BINDIR)/valu_peak: mecat_amd/tools/valu_peak.hip
 	@mkdir -p $(BINDIR)
@@ -41,6 +41,12 @@ $(BINDIR)/gather_peak: mecat_amd/tools/gather_peak.hip
 $(BINDIR)/mecat2pw: $(HOST_SRCS) $(wildcard mecat_amd/host/*.h) include/mecat_hip.h $(LIBDIR)/libmecat_hip.so
 	@mkdir -p $(BINDIR)
 	$(CXX) -O2 -std=c++17 -pthread -Wall -Iinclude $(HOST_SRCS) -L$(LIBDIR) -lmecat_hip -Wl,-rpath,'$$ORIGIN/../lib' -o $@
+
+# mecat2canu's overlappers for corrected reads: one program under the four names the canu job scripts start
+$(BINDIR)/mecat2asmpw: mecat_amd/asmpw/asmpw_main.cpp include/mecat_hip.h $(LIBDIR)/libmecat_hip.so
+	@mkdir -p $(BINDIR)
+	$(CXX) -O2 -std=c++17 -pthread -Wall -Iinclude mecat_amd/asmpw/asmpw_main.cpp -L$(LIBDIR) -lmecat_hip -Wl,-rpath,'$$ORIGIN/../lib' -o $@
+	for n in mecat2trimpw mecat2asmpw50 mecat2trimpw50; do cp -f $@ $(BINDIR)/$$n; done
 
 $(BINDIR)/mecat2cns_partition: mecat_amd/tools/partition_main.cpp mecat_amd/host/partition.cpp mecat_amd/host/partition.h
 	@mkdir -p $(BINDIR)

@@ -236,6 +236,21 @@ int  mhip_sharded_tables(mhip_comm* comm, void** d_cands, void** d_counts, void*
 typedef struct { int32_t loc1, loc2, left1, left2, right1, right2, score, num1, num2, readno, readstart, chain; } mhip_asm_candidate;
 int  mhip_asm_seed_reads(mhip_ctx* ctx, const mhip_index* idx, const mhip_volume* block, const mhip_volume* reads, int rid_begin,
                          int rid_end, mhip_asm_candidate* out, int32_t* out_counts);
+int  mhip_asm_seed_reads_ex(mhip_ctx* ctx, const mhip_index* idx, const mhip_volume* block, const mhip_volume* reads, int rid_begin,
+                            int rid_end, int gate /*10: mecat2asmpw, 8: mecat2trimpw*/, int maxc /*100; 50: the *50 variants*/,
+                            mhip_asm_candidate* out /*[n][100]*/, int32_t* out_counts);
+/* The tool's extension loop (mecat2asmpw.c:723-841: blocks of 500 bases while more than 600 remain, O(ND) `align` at error rate 0.10,
+ * a block's tail cut in front of its last run of four matches) for a batch of (candidate, both directions) jobs.  A job names the two
+ * reads (xid in `block`, yid in `reads`), the strand of the mapped read, and per direction the start positions (local to the read /
+ * to the mapped strand) and the bases available: from a candidate c of query read r, with x0 = c.loc1 - 1 - c.readstart,
+ *   left   lx = x0 + 12, ly = c.loc2 + 12, lnx = c.left1, lny = c.left2      (backwards from the LAST base of the seed 13-mer)
+ *   right  rx = x0,      ry = c.loc2,      rnx = c.right1, rny = c.right2    (forwards from its first base)
+ * dirs[2 i + d] = {columns, x bases, y bases, y-only columns, x-only columns, 0} of direction d (0 left, 1 right);
+ * ops[(2 i + d) * dir_cols_cap / 16 ...] the columns, 2 bits each, in extension order: 0 = both bases (always equal: O(ND) paths have
+ * no mismatch columns), 1 = y base only, 2 = x base only. */
+typedef struct { int32_t xid, yid, chain, lx, ly, lnx, lny, rx, ry, rnx, rny, pad; } mhip_asm_job;
+int  mhip_asm_extend(mhip_ctx* ctx, const mhip_volume* block, const mhip_volume* reads, const mhip_asm_job* jobs, int n, int dir_cols_cap,
+                     int32_t* dirs /*[2 n][6]*/, uint32_t* ops /*[2 n][dir_cols_cap / 16]*/);
 
 /* mhip_index_build by all ranks of the communicator together (replaces create_ref_index, common/lookup_table.cpp:63-160, in a
  * multi-GPU cell): the 4^13 key space is cut into P contiguous ranges of equal occupancy, each rank builds the buckets of its range,

@@ -1,0 +1,331 @@
+// mecat2asmpw / mecat2trimpw (and their *50 variants) of mecat2canu on the MI355X path: a drop-in for
+// /root/reference/mecat2canu/src/mecat2asmpw/{mecat2asmpw,mecat2trimpw,mecat2asmpw50,mecat2trimpw50}.c behind their own command line
+//     <tool> -P<blocks dir> -T<threads> -S<start block> -E<last block>
+// as canu's overlap jobs start them (mecat2canu/src/pipelines/canu/Overlapmecat2asmpw.pm:483-503): reads <dir>/ovlprep (one line
+// per block: "-allreads -allbases -b <first read> -e <last read>") and <dir>/%06d.fasta (a header line and ONE sequence line per
+// read), indexes block S, maps the reads of blocks S .. E against it and writes <dir>/<S>_<t>.r for t in [0, T) — the files the job
+// script then concatenates.  Which of the four tools this is follows from the name it is started under:
+//     ...trimpw...   seeding gate > 8 instead of > 10 (:644), jscore = mismatches / (4 * columns) instead of (2 cols - mism) * 120 / cols (:942-943)
+//     ...50          at most 50 candidates per read instead of 100 (:23)
+// On the device (C ABI, include/mecat_hip.h): the look-up table with bucket cap 256 (mhip_index_build_ex), seeding + candidate
+// selection (mhip_asm_seed_reads_ex, asm_seed.hip), the O(ND) extension of every candidate in both directions (mhip_asm_extend,
+// cns_align.hip).  On the host, per candidate and on -T threads: what the tool does with the two aligned string pairs afterwards —
+// string_check's gap shuffling of the left pair (:199-281), the overlap of the two directions on the seed 13-mer, coordinates, the
+// 450-base test, jscore and the 12-field line (:843-948).  Line order inside the .r files is by read here and by thread timing in the
+// tool: the consumer (mecat2asmpwConvert) reads lines one by one.
+// Not supported: bases other than A, C, G, T (the tool skips k-mers with an N and aligns N as a character; 2-bit volumes cannot hold
+// it) — such input is refused with a message.
+#include <errno.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "mecat_hip.h"
+
+#define DIE(...)                                  \
+    do {                                          \
+        fprintf(stderr, "[mecat2asmpw] ");        \
+        fprintf(stderr, __VA_ARGS__);             \
+        fprintf(stderr, "\n");                    \
+        exit(1);                                  \
+    } while (0)
+#define MCHK(call)                                                    \
+    do {                                                              \
+        if ((call) != 0) DIE("%s failed: %s", #call, mhip_last_error()); \
+    } while (0)
+
+static const int SEED = 13;
+
+struct Reads {                       // one fasta block: 2-bit volume (one pad base after every read) + its host copy
+    std::vector<uint8_t> pac;
+    std::vector<mhip_offset_t> offs;
+    int num_bases = 0, first_no = 0;
+    int base(int r, int i) const {
+        const int64_t idx = (int64_t)offs[(size_t)r].offset + i;
+        return (pac[(size_t)(idx >> 2)] >> ((~idx & 3) << 1)) & 3;
+    }
+};
+
+// load_read / load_fastq (:388-409, :982-1010): ">header" line, one sequence line; lower case is upper-cased
+static void load_block(const std::string& path, int first_no, Reads* R) {
+    FILE* f = fopen(path.c_str(), "r");
+    if (!f) DIE("cannot open '%s': %s", path.c_str(), strerror(errno));
+    R->first_no = first_no;
+    R->offs.clear();
+    std::vector<uint8_t> codes;
+    char* line = NULL;
+    size_t cap = 0;
+    ssize_t n;
+    int64_t at = 0;
+    bool want_seq = false;
+    while ((n = getline(&line, &cap, f)) > 0) {
+        while (n > 0 && (line[n - 1] == '\n' || line[n - 1] == '\r')) --n;
+        if (!want_seq) {
+            if (n == 0) continue;
+            if (line[0] != '>') DIE("%s: a header line was expected", path.c_str());
+            want_seq = true;
+            continue;
+        }
+        mhip_offset_t o;
+        o.offset = (int)at;
+        o.size = (int)n;
+        for (ssize_t i = 0; i < n; ++i) {
+            int c;
+            switch (line[i]) {
+            case 'A': case 'a': c = 0; break;
+            case 'C': case 'c': c = 1; break;
+            case 'G': case 'g': c = 2; break;
+            case 'T': case 't': c = 3; break;
+            default: DIE("%s: base '%c' in read %d: only A, C, G, T are supported on this path", path.c_str(), line[i], first_no + (int)R->offs.size()); c = 0;
+            }
+            codes.push_back((uint8_t)c);
+        }
+        codes.push_back(0);                      // the pad base = the tool's NUL behind every read
+        at += n + 1;
+        if (at > 2140000000LL) DIE("%s: more than 2.14 G bases in one block", path.c_str());
+        R->offs.push_back(o);
+        want_seq = false;
+    }
+    free(line);
+    fclose(f);
+    R->num_bases = (int)at;
+    R->pac.assign(((size_t)at + 3) / 4, 0);
+    for (int64_t i = 0; i < at; ++i) R->pac[(size_t)(i >> 2)] |= (uint8_t)(codes[(size_t)i] << ((~i & 3) << 1));
+}
+
+// string_check (:199-281): gaps of the left pair are moved over runs that also match one column further on.  a / b = the aligned
+// pair in extension order, s1 / s2 = the same two sequences without gaps.  S(i) may be one past the end (the C string's NUL).
+static void shuffle_gaps(const std::string& s1, const std::string& s2, std::string& a, std::string& b) {
+    const int len1 = (int)s1.size() - 1, len2 = (int)s2.size() - 1;
+    const char* S1 = s1.c_str();
+    const char* S2 = s2.c_str();
+    int loc1 = 0, loc2 = 0;
+    for (int p = (int)a.size() - 1; p > -1; --p) {
+        auto move_run = [&](int k, int o1, int o2) {
+            int s = 0, j = p;
+            while (s < k && j >= 0) { if (a[(size_t)j] != '-') { a[(size_t)j] = '-'; ++s; } --j; }
+            s = 0; j = p;
+            while (s < k && j >= 0) { if (b[(size_t)j] != '-') { b[(size_t)j] = '-'; ++s; } --j; }
+            for (s = 0, j = p; s < k && j >= 0; --j, ++s) { a[(size_t)j] = S1[o1 - s]; b[(size_t)j] = S2[o2 - s]; }
+        };
+        if (a[(size_t)p] != '-') ++loc1;
+        else if (loc1 <= len1 && loc2 <= len2 && S1[len1 - loc1] == S2[len2 - loc2]) {
+            int k = 1;
+            while (loc1 + k <= len1 && loc2 + k <= len2 && S1[len1 - loc1 - k] == S2[len2 - loc2 - k]) ++k;
+            move_run(k, len1 - loc1, len2 - loc2);
+            if (a[(size_t)p] != '-') ++loc1;
+        }
+        if (b[(size_t)p] != '-') ++loc2;
+        else if (a[(size_t)p] != '-' && (loc1 - 1 <= len1 && loc2 <= len2 && S1[len1 - loc1 + 1] == S2[len2 - loc2])) {
+            int k = 1;
+            while (loc1 + k - 1 <= len1 && loc2 + k <= len2 && S1[len1 - loc1 + 1 - k] == S2[len2 - loc2 - k]) ++k;
+            move_run(k, len1 - loc1 + 1, len2 - loc2);
+            if (b[(size_t)p] != '-') ++loc2;
+        } else if (a[(size_t)p] == '-' && (loc1 - 1 <= len1 && loc2 <= len2 && S1[len1 - loc1] == S2[len2 - loc2])) {
+            int k = 1;
+            while (loc1 + k <= len1 && loc2 + k <= len2 && S1[len1 - loc1 - k] == S2[len2 - loc2 - k]) ++k;
+            move_run(k, len1 - loc1, len2 - loc2);
+            if (b[(size_t)p] != '-') ++loc2;
+        }
+    }
+}
+
+struct Tool { int gate = 10, maxc = 100; bool trim = false; };
+
+int main(int argc, char** argv) {
+    std::string dir;
+    int threads = -1, start = -1, last = -1;
+    for (int i = 1; i < argc; ++i) {             // param_read (:1012-1056): -P<dir> -T<n> -S<n> -E<n>, value glued to the letter
+        if (argv[i][0] != '-' || !argv[i][1]) { fprintf(stderr, "usage: %s -P<blocks dir> -T<threads> -S<start block> -E<last block>\n", argv[0]); return 1; }
+        const char* v = argv[i] + 2;
+        switch (argv[i][1]) {
+        case 'P': dir = v; break;
+        case 'T': threads = atoi(v); break;
+        case 'S': start = atoi(v); break;
+        case 'E': last = atoi(v); break;
+        default: break;
+        }
+    }
+    if (dir.empty() || threads < 1 || start < 1 || last < start) {
+        fprintf(stderr, "usage: %s -P<blocks dir> -T<threads> -S<start block> -E<last block>\n", argv[0]);
+        return 1;
+    }
+    Tool tool;
+    {
+        const char* b = strrchr(argv[0], '/');
+        const std::string name = b ? b + 1 : argv[0];
+        if (const char* e = getenv("MECAT_ASMPW_TOOL")) { if (strstr(e, "trim")) tool.trim = true; if (strstr(e, "50")) tool.maxc = 50; }
+        else { if (name.find("trim") != std::string::npos) tool.trim = true; if (name.find("50") != std::string::npos) tool.maxc = 50; }
+        if (tool.trim) tool.gate = 8;
+    }
+    // ovlprep (:1086-1094): " %s %s %s %d %s %d"
+    std::vector<int> first_read, last_read;
+    {
+        const std::string p = dir + "/ovlprep";
+        FILE* f = fopen(p.c_str(), "r");
+        if (!f) DIE("cannot open '%s': %s", p.c_str(), strerror(errno));
+        char a[300], b2[300], c2[300], d2[300];
+        int k, e;
+        while ((int)first_read.size() < last && fscanf(f, " %299s %299s %299s %d %299s %d", a, b2, c2, &k, d2, &e) == 6) { first_read.push_back(k); last_read.push_back(e); }
+        fclose(f);
+        if ((int)first_read.size() < last) DIE("%s names %zu blocks, -E is %d", p.c_str(), first_read.size(), last);
+    }
+    auto block_path = [&](int id) { char t[32]; snprintf(t, sizeof(t), "/%06d.fasta", id); return dir + t; };
+
+    mhip_ctx* ctx = NULL;
+    const int device = getenv("MECAT_HIP_DEVICE") ? atoi(getenv("MECAT_HIP_DEVICE")) : 0;
+    MCHK(mhip_ctx_create(device, NULL, &ctx));
+    Reads blk;
+    load_block(block_path(start), first_read[(size_t)start - 1], &blk);
+    mhip_volume* dblk = NULL;
+    MCHK(mhip_volume_upload(ctx, blk.pac.data(), blk.offs.data(), (int)blk.offs.size(), blk.num_bases, blk.first_no, &dblk));
+    mhip_index* idx = NULL;
+    MCHK(mhip_index_build_ex(ctx, dblk, 256, &idx));
+
+    std::vector<FILE*> out((size_t)threads);
+    for (int t = 0; t < threads; ++t) {
+        const std::string p = dir + "/" + std::to_string(start) + "_" + std::to_string(t) + ".r";
+        out[(size_t)t] = fopen(p.c_str(), "w");
+        if (!out[(size_t)t]) DIE("cannot write '%s': %s", p.c_str(), strerror(errno));
+    }
+    int next_file = 0;
+
+    for (int bi = start; bi <= last; ++bi) {
+        Reads qs_own;
+        const Reads* qs = &blk;
+        mhip_volume* dq = dblk;
+        if (bi != start) {
+            load_block(block_path(bi), first_read[(size_t)bi - 1], &qs_own);
+            qs = &qs_own;
+            MCHK(mhip_volume_upload(ctx, qs->pac.data(), qs->offs.data(), (int)qs->offs.size(), qs->num_bases, qs->first_no, &dq));
+        }
+        const int nq = (int)qs->offs.size();
+        int maxlen = 16;
+        for (const mhip_offset_t& o : blk.offs) maxlen = std::max(maxlen, o.size);
+        for (const mhip_offset_t& o : qs->offs) maxlen = std::max(maxlen, o.size);
+        const int cap = ((maxlen * 2 + 64 + 15) / 16) * 16;          // columns of one direction <= bases of both reads on that side
+        const size_t dir_words = (size_t)cap / 16;
+        const int slab = std::max(1, getenv("MECAT_ASMPW_SLAB") ? atoi(getenv("MECAT_ASMPW_SLAB")) : 1000);
+        std::vector<mhip_asm_candidate> cands((size_t)slab * 100);
+        std::vector<int32_t> counts((size_t)slab);
+        for (int rb = 0; rb < nq; rb += slab) {
+            const int re = std::min(nq, rb + slab), nr = re - rb;
+            MCHK(mhip_asm_seed_reads_ex(ctx, idx, dblk, dq, rb, re, tool.gate, tool.maxc, cands.data(), counts.data()));
+            std::vector<size_t> first((size_t)nr + 1, 0);
+            for (int r = 0; r < nr; ++r) first[(size_t)r + 1] = first[(size_t)r] + (size_t)counts[(size_t)r];
+            const size_t nj = first[(size_t)nr];
+            if (nj == 0) continue;
+            std::vector<mhip_asm_job> jobs(nj);
+            for (int r = 0; r < nr; ++r)
+                for (int k = 0; k < counts[(size_t)r]; ++k) {
+                    const mhip_asm_candidate& c = cands[(size_t)r * 100 + k];
+                    mhip_asm_job j;
+                    const int x0 = c.loc1 - 1 - c.readstart;        // the seed 13-mer's first base inside the subject read
+                    j.xid = c.readno; j.yid = rb + r; j.chain = c.chain;
+                    j.lx = x0 + SEED - 1; j.ly = c.loc2 + SEED - 1; j.lnx = c.left1; j.lny = c.left2;       // :736
+                    j.rx = x0; j.ry = c.loc2; j.rnx = c.right1; j.rny = c.right2;                            // :793
+                    j.pad = 0;
+                    jobs[first[(size_t)r] + (size_t)k] = j;
+                }
+            std::vector<int32_t> dirs(nj * 2 * 6);
+            std::vector<uint32_t> ops(nj * 2 * dir_words);
+            MCHK(mhip_asm_extend(ctx, dblk, dq, jobs.data(), (int)nj, cap, dirs.data(), ops.data()));
+
+            // ---- per candidate: the tool's string work and its output line (:843-948)
+            std::vector<std::string> text((size_t)threads);
+            std::atomic<int> next_read{0};
+            auto worker = [&](int t) {
+                std::string& o = text[(size_t)t];
+                std::string L1, L2, R1, R2, g1, g2, O1, O2;
+                char line[256];
+                for (;;) {
+                    const int r = next_read.fetch_add(1);
+                    if (r >= nr) break;
+                    const int qrid = rb + r, read_len = qs->offs[(size_t)qrid].size, read_name = qs->first_no + qrid;
+                    for (int k = 0; k < counts[(size_t)r]; ++k) {
+                        const size_t ji = first[(size_t)r] + (size_t)k;
+                        const mhip_asm_candidate& c = cands[(size_t)r * 100 + k];
+                        const mhip_asm_job& jb = jobs[ji];
+                        auto ybase = [&](int pos) {                 // base at position pos of the mapped strand
+                            return jb.chain ? 3 - qs->base(qrid, read_len - 1 - pos) : qs->base(qrid, pos);
+                        };
+                        auto build = [&](int d, std::string& s1, std::string& s2) {
+                            const int cols = dirs[(ji * 2 + (size_t)d) * 6];
+                            const uint32_t* w = ops.data() + (ji * 2 + (size_t)d) * dir_words;
+                            s1.resize((size_t)cols); s2.resize((size_t)cols);
+                            int x = d ? jb.rx : jb.lx, y = d ? jb.ry : jb.ly;
+                            const int step = d ? 1 : -1;
+                            for (int m = 0; m < cols; ++m) {
+                                const int op = (int)((w[m >> 4] >> ((m & 15) << 1)) & 3u);
+                                char a = '-', b = '-';
+                                if (op != 1) { a = "ACGT"[blk.base(jb.xid, x)]; x += step; }
+                                if (op != 2) { b = "ACGT"[ybase(y)]; y += step; }
+                                s1[(size_t)m] = a; s2[(size_t)m] = b;
+                            }
+                        };
+                        build(0, L1, L2);
+                        build(1, R1, R2);
+                        g1.clear(); g2.clear();
+                        for (size_t m = 0; m < L1.size(); ++m) { if (L1[m] != '-') g1 += L1[m]; if (L2[m] != '-') g2 += L2[m]; }
+                        shuffle_gaps(g1, g2, L1, L2);
+                        const int u_k = (int)L1.size();
+                        O1.assign(L1.rbegin(), L1.rend());
+                        O2.assign(L2.rbegin(), L2.rend());
+                        int nl1 = 0, nl2 = 0;
+                        for (int m = 0; m < u_k; ++m) { nl1 += L1[(size_t)m] != '-'; nl2 += L2[(size_t)m] != '-'; }
+                        int left_loc1, left_loc, right_loc1, right_loc;
+                        if (u_k == SEED - 1) { left_loc1 = c.loc1 + SEED - nl1 - 1; left_loc = c.loc2 + SEED - nl2; }
+                        else if (u_k > 0) { left_loc1 = c.loc1 + SEED - nl1; left_loc = c.loc2 + SEED - nl2 + 1; }
+                        else { left_loc1 = c.loc1; left_loc = c.loc2 + 1; }
+                        const int s_k = (int)R1.size();
+                        int nr1 = 0, nr2 = 0;
+                        for (int m = 0; m < s_k; ++m) { nr1 += R1[(size_t)m] != '-'; nr2 += R2[(size_t)m] != '-'; }
+                        if (s_k > 0) { right_loc1 = c.loc1 + nr1 - 1; right_loc = c.loc2 + nr2; }
+                        else { right_loc1 = c.loc1 + SEED - 1; right_loc = c.loc2 + SEED; }
+                        if (s_k >= SEED && u_k >= SEED) { O1.append(R1, SEED, std::string::npos); O2.append(R2, SEED, std::string::npos); }
+                        else if (u_k < SEED) { O1 = R1; O2 = R2; }
+                        left_loc1 -= c.readstart;
+                        right_loc1 -= c.readstart;
+                        if (!(right_loc1 - left_loc1 > 450)) continue;
+                        int mism = 0;
+                        const int cols = (int)O1.size();
+                        for (int m = 0; m < cols; ++m) mism += !(O1[(size_t)m] == O2[(size_t)m] && O2[(size_t)m] != '-');
+                        float jscore;
+                        if (!tool.trim) { jscore = (float)(2 * cols - mism); jscore = jscore * 30 * 4 / (cols); }
+                        else { jscore = (float)mism; jscore = jscore / (4 * cols); }
+                        const int sno = blk.first_no + c.readno, slen = blk.offs[(size_t)c.readno].size;
+                        int w;
+                        if (!jb.chain) w = snprintf(line, sizeof(line), "%d %d %.3f 100 0 %d %d %d 0 %d %d %d\n", sno, read_name, jscore, left_loc1 - 1, right_loc1, slen,
+                                                    left_loc - 1, right_loc, read_len);
+                        else w = snprintf(line, sizeof(line), "%d %d %.3f 100 0 %d %d %d 1 %d %d %d\n", sno, read_name, jscore, left_loc1 - 1, right_loc1, slen,
+                                          read_len - right_loc, read_len - left_loc + 1, read_len);
+                        o.append(line, (size_t)w);
+                    }
+                }
+            };
+            std::vector<std::thread> th;
+            for (int t = 1; t < threads; ++t) th.emplace_back(worker, t);
+            worker(0);
+            for (std::thread& x : th) x.join();
+            for (int t = 0; t < threads; ++t) {
+                FILE* f = out[(size_t)((next_file + t) % threads)];
+                if (!text[(size_t)t].empty() && fwrite(text[(size_t)t].data(), 1, text[(size_t)t].size(), f) != text[(size_t)t].size()) DIE("write error");
+            }
+            next_file = (next_file + 1) % threads;
+        }
+        if (dq != dblk) mhip_volume_free(dq);
+    }
+    for (FILE* f : out)
+        if (fclose(f) != 0) DIE("write error");
+    mhip_index_free(idx);
+    mhip_volume_free(dblk);
+    mhip_ctx_destroy(ctx);
+    return 0;
+}

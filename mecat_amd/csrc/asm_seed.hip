@@ -90,7 +90,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_seed(const uint32_t* __restrict
                                                      int bstart_id, const uint32_t* __restrict__ starts, const int32_t* __restrict__ offsets,
                                                      const uint32_t* __restrict__ qpac, const mhip_offset_t* __restrict__ qoffs, int qstart_id,
                                                      int rid_begin, int n, short* __restrict__ img_all, int* __restrict__ ilist_all,
-                                                     short* __restrict__ iscore_all, int* __restrict__ dirty_all, int nseg,
+                                                     short* __restrict__ iscore_all, int* __restrict__ dirty_all, int nseg, int gate, int maxc,
                                                      unsigned int* __restrict__ cursor, mhip_asm_candidate* __restrict__ out, int32_t* __restrict__ out_counts) {
     __shared__ AsmWaveLds lds[ASM_WAVES];
     AsmWaveLds& S = lds[threadIdx.x >> 6];
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_seed(const uint32_t* __restrict
             // ---- candidates (:643-716)
             for (int i = 0; i < touched; ++i) {
                 const int seg = ((volatile int*)ilist)[i];
-                if (!(iscore[i] > 10)) continue;
+                if (!(iscore[i] > gate)) continue;        // :644: > 10 (mecat2asmpw), > 8 (mecat2trimpw)
                 vshort* g = rec(seg);
                 const int score = g[A_SCORE];
                 if (score == 0) continue;
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_seed(const uint32_t* __restrict
                     const int mid = (lo + hi) / 2;
                     if (mid >= ncand || S.cand[mid].score < c.score) hi = mid - 1; else lo = mid + 1;
                 }
-                const int top = ncand < AMAXC ? ncand - 1 : ncand - 2;      // last entry that moves one place down
+                const int top = ncand < maxc ? ncand - 1 : ncand - 2;        // last entry that moves one place down
                 __builtin_amdgcn_wave_barrier();
                 // (entries hi + 1 .. top move to hi + 2 .. top + 1: every lane reads its entries first, then writes)
                 mhip_asm_candidate mv[2];
@@ -325,8 +325,8 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_seed(const uint32_t* __restrict
                     const int j = hi + 1 + lane + 64 * q;
                     if (has[q]) S.cand[j + 1] = mv[q];
                 }
-                if (lane == 0 && hi + 1 < AMAXC) S.cand[hi + 1] = c;
-                if (ncand < AMAXC) ++ncand;
+                if (lane == 0 && hi + 1 < maxc) S.cand[hi + 1] = c;
+                if (ncand < maxc) ++ncand;
                 __builtin_amdgcn_wave_barrier();
             }
             // ---- the strand's touched segments: score and index reset (:717); remembered for the clean-up behind the read
@@ -361,7 +361,13 @@ extern "C" {
 
 int mhip_asm_seed_reads(mhip_ctx* c, const mhip_index* idx, const mhip_volume* block, const mhip_volume* reads, int rid_begin, int rid_end,
                         mhip_asm_candidate* out, int32_t* out_counts) {
+    return mhip_asm_seed_reads_ex(c, idx, block, reads, rid_begin, rid_end, 10, AMAXC, out, out_counts);
+}
+
+int mhip_asm_seed_reads_ex(mhip_ctx* c, const mhip_index* idx, const mhip_volume* block, const mhip_volume* reads, int rid_begin, int rid_end,
+                           int gate, int maxc, mhip_asm_candidate* out, int32_t* out_counts) {
     HIPCHK(hipSetDevice(c->device));
+    if (maxc < 1 || maxc > AMAXC || gate < 0) { mhip_set_error("bad gate %d / list length %d (1..100)", gate, maxc); return -1; }
     if (rid_begin < 0 || rid_end > reads->num_reads || rid_begin > rid_end) { mhip_set_error("bad read range [%d,%d)", rid_begin, rid_end); return -1; }
     if (idx->max_bucket != 256) { mhip_set_error("mhip_asm_seed_reads needs an index built with bucket cap 256 (mhip_index_build_ex), not %d", idx->max_bucket); return -1; }
     if (idx->num_bases != block->num_bases) { mhip_set_error("the index was not built from this block"); return -1; }
@@ -394,7 +400,7 @@ int mhip_asm_seed_reads(mhip_ctx* c, const mhip_index* idx, const mhip_volume* b
     LAUNCH(c, "asm_init_records", asm_init_records, (unsigned)((nrec + 255) / 256), 256, 0, d_img, nrec);
     LAUNCH(c, "asm_seed", asm_seed, grid, ASM_BLOCK, 0, (const uint32_t*)block->d_pac, (const mhip_offset_t*)block->d_offs, block->num_reads,
            block->start_read_id, (const uint32_t*)idx->d_starts, (const int32_t*)idx->d_offsets, (const uint32_t*)reads->d_pac,
-           (const mhip_offset_t*)reads->d_offs, reads->start_read_id, rid_begin, n, d_img, d_ilist, d_iscore, d_dirty, nseg, d_cur, d_out, d_cnt);
+           (const mhip_offset_t*)reads->d_offs, reads->start_read_id, rid_begin, n, d_img, d_ilist, d_iscore, d_dirty, nseg, gate, maxc, d_cur, d_out, d_cnt);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out_counts, d_cnt, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(out, d_out, sizeof(mhip_asm_candidate) * (size_t)n * AMAXC, hipMemcpyDeviceToHost, c->stream));

@@ -76,9 +76,16 @@ __device__ __forceinline__ int cns_load_window(CnsLds& S, const uint16_t* grow, 
     return r - count + 1;
 }
 
+// ASM = false: mecat2cns (jobs = mhip_aln_job: one start point, both directions from it, the strand on the x sequence).
+// ASM = true: the extension of mecat2canu's mecat2asmpw / mecat2trimpw (mecat2canu/src/mecat2asmpw/mecat2asmpw.c:723-841), which is the
+// code dw.cpp was derived from — same blocks, same tail rule, same failure rules — with jobs = mhip_asm_job: each direction has its
+// own start point and sizes (the left extension starts on the LAST base of the seed 13-mer, the right one on its first: both contain
+// the seed), the x sequence is the subject read of the indexed block (always forward), the strand applies to the y sequence (the
+// mapped read), and the band is band_frac * block (0.10: `ErrorRate * s_k`, :749) where mecat2cns has 0.3.
+template <bool ASM>
 __global__ __launch_bounds__(CN_BLOCK, 6) void cns_extend(const uint32_t* __restrict__ rpac, const mhip_offset_t* __restrict__ roffs,
                                                        const uint32_t* __restrict__ qpac, const mhip_offset_t* __restrict__ qoffs,
-                                                       const mhip_aln_job* __restrict__ jobs, int n, double error_rate, int dir_cols_cap,
+                                                       const void* __restrict__ jobs_v, int n, double error_rate, double band_frac, int dir_cols_cap,
                                                        uint32_t* __restrict__ ops, CnsDir* __restrict__ dres, uint16_t* __restrict__ gscratch,
                                                        unsigned int* __restrict__ cursor, int* __restrict__ err_flag) {
     __shared__ CnsLds lds[CN_WAVES];
@@ -91,17 +98,31 @@ __global__ __launch_bounds__(CN_BLOCK, 6) void cns_extend(const uint32_t* __rest
         if (lane == 0) unit = atomicAdd(cursor, 1u);
         unit = __shfl(unit, 0);
         if (unit >= 2u * (unsigned)n) break;
-        const mhip_aln_job jb = jobs[unit >> 1];
         const int right = unit & 1;
-        const int qsize = qoffs[jb.qid_local].size, tsize = roffs[jb.sid_local].size;
         SeqView q, t;
-        q.pac = qpac; q.off = qoffs[jb.qid_local].offset; q.comp = jb.chain;
-        t.pac = rpac; t.off = roffs[jb.sid_local].offset; t.comp = 0;
-        const int qs0 = right ? jb.qstart : jb.qstart - 1, step = right ? 1 : -1;
-        if (jb.chain) { q.A = qsize - 1 - qs0; q.B = -step; } else { q.A = qs0; q.B = step; }
-        t.A = right ? jb.sstart : jb.sstart - 1; t.B = step;
-        const int query_size = right ? qsize - jb.qstart : jb.qstart;
-        const int target_size = right ? tsize - jb.sstart : jb.sstart;
+        q.pac = qpac; t.pac = rpac;
+        int query_size, target_size;
+        if (!ASM) {
+            const mhip_aln_job jb = ((const mhip_aln_job*)jobs_v)[unit >> 1];
+            const int qsize = qoffs[jb.qid_local].size, tsize = roffs[jb.sid_local].size;
+            q.off = qoffs[jb.qid_local].offset; q.comp = jb.chain;
+            t.off = roffs[jb.sid_local].offset; t.comp = 0;
+            const int qs0 = right ? jb.qstart : jb.qstart - 1, step = right ? 1 : -1;
+            if (jb.chain) { q.A = qsize - 1 - qs0; q.B = -step; } else { q.A = qs0; q.B = step; }
+            t.A = right ? jb.sstart : jb.sstart - 1; t.B = step;
+            query_size = right ? qsize - jb.qstart : jb.qstart;
+            target_size = right ? tsize - jb.sstart : jb.sstart;
+        } else {
+            const mhip_asm_job jb = ((const mhip_asm_job*)jobs_v)[unit >> 1];
+            const int tsize = roffs[jb.yid].size, step = right ? 1 : -1;
+            q.off = qoffs[jb.xid].offset; q.comp = 0;
+            t.off = roffs[jb.yid].offset; t.comp = jb.chain;
+            q.A = right ? jb.rx : jb.lx; q.B = step;
+            const int ys0 = right ? jb.ry : jb.ly;            // position on the mapped strand
+            if (jb.chain) { t.A = tsize - 1 - ys0; t.B = -step; } else { t.A = ys0; t.B = step; }
+            query_size = right ? jb.rnx : jb.lnx;
+            target_size = right ? jb.rny : jb.lny;
+        }
         uint32_t* uops = ops + (size_t)unit * dir_words;
 
         int extend1 = 0, extend2 = 0, cols = 0, n_ins = 0, n_del = 0;
@@ -112,7 +133,7 @@ __global__ __launch_bounds__(CN_BLOCK, 6) void cns_extend(const uint32_t* __rest
             if (extend_size > CN_SEG + 100) seg = CN_SEG;
             else { seg = extend_size; more = false; }
             if (seg <= 0) break;                         // Align "succeeds" on an empty block, then i == extend_size ends it (:356)
-            const int band_tol = (int)(0.3 * seg);
+            const int band_tol = (int)(band_frac * seg);
             const int max_d = (int)(2.0 * error_rate * (seg + seg));
             const int koff = max_d, band_size = band_tol * 2;
             __builtin_amdgcn_wave_barrier();
@@ -355,8 +376,8 @@ int mhip_cns_align_candidates_dev(mhip_ctx* c, const mhip_volume* ref, const mhi
     HIPCHK(hipMemsetAsync(d_cur, 0, 64, c->stream));
     const size_t dir_words = (size_t)dir_cols_cap / 16;
     HIPCHK(hipMemsetAsync(d_ops, 0, sizeof(uint32_t) * dir_words * 2 * (size_t)n, c->stream));
-    LAUNCH(c, "cns_extend", cns_extend, grid, CN_BLOCK, 0, (const uint32_t*)ref->d_pac, (const mhip_offset_t*)ref->d_offs,
-           (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs, (const mhip_aln_job*)d_jobs, n, error_rate, dir_cols_cap,
+    LAUNCH(c, "cns_extend", cns_extend<false>, grid, CN_BLOCK, 0, (const uint32_t*)ref->d_pac, (const mhip_offset_t*)ref->d_offs,
+           (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs, (const void*)d_jobs, n, error_rate, 0.3, dir_cols_cap,
            (uint32_t*)d_ops, d_dres, d_g, d_cur, d_err);
     LAUNCH(c, "cns_stitch", cns_stitch, (n + 255) / 256, 256, 0, (const mhip_aln_job*)d_jobs, (const CnsDir*)d_dres, (const uint32_t*)d_ops,
            dir_cols_cap, n, min_align_size, (mhip_cns_result*)d_results);
@@ -382,6 +403,56 @@ int mhip_cns_align_candidates(mhip_ctx* c, const mhip_volume* ref, const mhip_vo
     HIPCHK(hipMemcpyAsync(results, d_res, sizeof(mhip_cns_result) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
     if (ops) HIPCHK(hipMemcpyAsync(ops, d_ops, ops_bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+}  // extern "C"
+
+extern "C" {
+
+// The extension of mecat2asmpw / mecat2trimpw for a batch of candidates (mecat2canu/src/mecat2asmpw/mecat2asmpw.c:723-841): per job and
+// direction the columns of the alignment the tool strings together in left_store / right_store (2 bits each, in extension order: 0 both
+// bases, 1 y base only — a gap in the subject's row —, 2 x base only) and the bases of either sequence they cover.  x = reads of
+// `block`, y = reads of `reads`.  dirs[2 * i + d] = {cols, xbases, ybases, ins, del, 0} for direction d (0 left, 1 right) of job i,
+// ops[(2 * i + d) * dir_cols_cap / 16 ...] its columns.  What the tool does with them afterwards (string_check, the seed overlap of the
+// two directions, coordinates, jscore, the output line) is host work: mecat_amd/host/asmpw.cpp.
+int mhip_asm_extend(mhip_ctx* c, const mhip_volume* block, const mhip_volume* reads, const mhip_asm_job* jobs, int n, int dir_cols_cap,
+                    int32_t* dirs, uint32_t* ops) {
+    HIPCHK(hipSetDevice(c->device));
+    if (n <= 0) return 0;
+    if (dir_cols_cap < 16 || (dir_cols_cap & 15)) { mhip_set_error("dir_cols_cap must be a positive multiple of 16"); return -1; }
+    for (int i = 0; i < n; ++i)
+        if (jobs[i].xid < 0 || jobs[i].xid >= block->num_reads || jobs[i].yid < 0 || jobs[i].yid >= reads->num_reads) {
+            mhip_set_error("extension job %d: read index out of range", i);
+            return -1;
+        }
+    const int max_waves = c->num_cus * 24;
+    const int grid = std::min(max_waves / CN_WAVES, (2 * n + CN_WAVES - 1) / CN_WAVES);
+    CnsDir* d_dres;
+    uint16_t* d_g;
+    unsigned int* d_cur;
+    void *d_jobs, *d_ops;
+    const size_t dir_words = (size_t)dir_cols_cap / 16, ops_bytes = sizeof(uint32_t) * dir_words * 2 * (size_t)n;
+    if (c->scratch("cn_dres", sizeof(CnsDir) * 2 * (size_t)n, (void**)&d_dres)) return -1;
+    if (c->scratch("cn_rows", sizeof(uint16_t) * CN_GROW * (size_t)max_waves, (void**)&d_g)) return -1;
+    if (c->scratch("cn_cursor", 64, (void**)&d_cur)) return -1;
+    if (c->scratch("cn_asmjobs", sizeof(mhip_asm_job) * (size_t)n, &d_jobs)) return -1;
+    if (c->scratch("cn_ops", ops_bytes, &d_ops)) return -1;
+    int* d_err = (int*)(d_cur + 8);
+    HIPCHK(hipMemsetAsync(d_cur, 0, 64, c->stream));
+    HIPCHK(hipMemsetAsync(d_ops, 0, ops_bytes, c->stream));
+    HIPCHK(hipMemcpyAsync(d_jobs, jobs, sizeof(mhip_asm_job) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    // x = the block (the kernel's "reads" side), y = the mapped reads (its "ref" side); max_d = int(0.10 * (q + t)) = int(2 * 0.05 * ..)
+    LAUNCH(c, "asm_extend", cns_extend<true>, grid, CN_BLOCK, 0, (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs,
+           (const uint32_t*)block->d_pac, (const mhip_offset_t*)block->d_offs, (const void*)d_jobs, n, 0.05, 0.10, dir_cols_cap,
+           (uint32_t*)d_ops, d_dres, d_g, d_cur, d_err);
+    int err = 0;
+    HIPCHK(hipMemcpyAsync(&err, d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(dirs, d_dres, sizeof(CnsDir) * 2 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(ops, d_ops, ops_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipGetLastError());
+    if (err) { mhip_set_error("mecat2asmpw extension: a direction needed more than dir_cols_cap = %d columns", dir_cols_cap); return -1; }
     return 0;
 }
 

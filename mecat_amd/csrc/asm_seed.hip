@@ -13,7 +13,7 @@
 // one dense array per wave in HBM (block bases / 1000 + 5 records: 248 KB per million bases; 288 GB of HBM is what lets every
 // resident wave own one), and the sweeps index it as a flat array of shorts exactly like the reference's out-of-range indices do.
 // Every read starts from an all-zero array (the reference's worker threads keep the stale seeds of the reads they mapped before,
-// which can move a candidate's score by a few votes: oracle/asmpw_oracle.c, asm_block_fresh); the forward strand's leftovers stay for
+// which can move a candidate's score by a few votes: INTEGRATION.md, divergences); the forward strand's leftovers stay for
 // the reverse strand, as there.
 //
 // Mapping: one wave per query read, persistent, pulling reads from an atomic cursor.  Everything order dependent runs in the
@@ -25,7 +25,8 @@
 //   candidates     the touched segments one after the other (their state changes under the loop: self-hit scrub, neighbours zeroed
 //                  by the sweeps); find_location's vote with one list entry per lane and the per-entry `tempi` chain in registers,
 //                  the sweeps 64 entries per step, the top-100 list in LDS
-// Parity: tests/test_gpu_asmpw.py against oracle/asmpw_oracle.c (fresh mode; itself pinned to the unmodified pairwise_mapping).
+// Parity: tests/test_gpu_asmpw.py against the CPU restatement of the test-suite (fresh mode; itself pinned to the unmodified
+// pairwise_mapping), and the whole tool against the sorted output of the unmodified binaries.
 #include <stdlib.h>
 
 #include <algorithm>

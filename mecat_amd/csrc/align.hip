@@ -428,19 +428,20 @@ __global__ __launch_bounds__(AL_BLOCK) void dw_extend(const uint32_t* __restrict
 #define RROWS 32              // rows the tail traceback can go back (the ring itself holds ~40 average rows)
 #endif
 #define SEQ_WORDS2 48          // 736 bases + one 16-base window, 16 bases per word, no pad word
-// Per-half LDS, 2.7 KB incl. the ring below (21.5 KB per workgroup of four waves: seven workgroups per CU).  There is no V[] array: row d reads the
+// Per-half LDS, 2.5 KB incl. the ring below (20 KB per workgroup of four waves: eight workgroups per CU, 160 KB exactly).  There is no V[] array: row d reads the
 // furthest x of diagonals k - 1 and k + 1 of row d - 1 straight from that row's entries in the ring (they are always inside its
 // band), at pbase + tt and pbase + tt + 1 with pbase uniform per half.
 struct HalfLds {
     uint32_t Qp[SEQ_WORDS2];
     uint32_t Tp[SEQ_WORDS2];
-    int2 rrec[RROWS];           // per d-row: x = min_k (low 16 bits) | nslot << 16, y = linear ring position of the row, in BYTES
+    uint32_t rrec[RROWS];       // per d-row: min_k (low 16 bits) | nslot << 16
 };
 // The ring of d-rows of a half: u16 rows packed back to back, wrapping (the first two entries of a block are the zeros row 0 reads).
 // It is its own 2 KB-aligned LDS array so that the address of ring byte position p is `base | (p & 0x7fe)`: one v_and_or_b32.
 // Positions (lin, pbase, rlin) are kept in bytes.
 typedef __attribute__((address_space(3))) uint16_t lds_u16_t;
-__device__ __forceinline__ int ring_ld(uint32_t base, uint32_t pos) { return (int)*(lds_u16_t*)(uintptr_t)(base | (pos & (2 * RCAP - 2))); }
+typedef __attribute__((address_space(3))) int16_t lds_i16_t;
+__device__ __forceinline__ int ring_ld(uint32_t base, uint32_t pos) { return (int)*(lds_i16_t*)(uintptr_t)(base | (pos & (2 * RCAP - 2))); }
 __device__ __forceinline__ void ring_st(uint32_t base, uint32_t pos, int x) { *(lds_u16_t*)(uintptr_t)(base | (pos & (2 * RCAP - 2))) = (uint16_t)x; }
 
 // mask of the lanes where p holds, without the bool -> int -> compare round trip of __ballot
@@ -476,7 +477,7 @@ __device__ __forceinline__ unsigned int lowbits32(int n) {
 }
 
 #ifndef DW2_WAVES_PER_SIMD
-#define DW2_WAVES_PER_SIMD 7
+#define DW2_WAVES_PER_SIMD 8
 #endif
 __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const uint32_t* __restrict__ rpac, const mhip_offset_t* __restrict__ roffs,
                                                        const uint32_t* __restrict__ qpac, const mhip_offset_t* __restrict__ qoffs,
@@ -570,10 +571,12 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                 }
                 // The reference zero-fills V per block (:232-233); row d only reads diagonals written by row d - 1, except row 0,
                 // which reads V[k_offset - 1] and V[k_offset + 1]: the two zeros in front of row 0.
-                if (sl < 2) ring_st(rbase, 2u * sl, 0);
+                // Between two rows of the ring sits one entry of -1 (see the start point below); in front of row 0: -1, 0, -1 — row 0 reads
+                // the first two (x = max(-1 + 1, 0) = 0), row 1 reads the third as the entry "left of row 0".
+                if (sl < 3) ring_st(rbase, 2u * sl, sl == 1 ? 0 : -1);
                 best_m = -1; min_k = 0; nslot = 1;
                 aligned = 0; end_x = 0; end_k = 0; end_d = 0; d = 0;
-                lin = 4; pbase = 0; rlin = 0;
+                lin = 6; pbase = 0; rlin = 0;
                 dlim = max_d; inblock = true;
                 setup = false;
             }
@@ -643,26 +646,90 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
             }
         };
         int last_m0 = 0, last_mp = 0;
-        // The loop exists twice: with both halves in a block (98.6 % of the dual rows: inmask is all ones for as long as the loop
-        // runs) the band update writes its three per-half values without the `inblock` guard (three v_cndmask, 12 issue cycles of
-        // the ~236 of a one-pass dual row).
-        auto row_loop = [&](auto both_tag) __attribute__((always_inline)) {
-        while (true) {
-            // :118 "max_k - min_k <= band_size"; the two conditions as masks (a ballot of their conjunction makes the compiler
-            // turn the mask into a 0/1 vector and compare it again)
-            const unsigned long long rmask = BALLOT(d < dlim) & BALLOT(nslot <= band_tol + 1);
-            if (rmask != inmask) return;
+        // One d-row of both halves in NJ passes of 32 diagonals per half (NJ a constant for 1 and 2: the pass loop and the previous-pass
+        // bookkeeping fold away).  ns_a / ns_b: the two halves' slot counts on the scalar unit.  A row is followed in the ring by one
+        // entry of -1, which the first idle lane of the last pass writes: every lane of a pass stores (its x, or -1 when idle) at its
+        // own position — no exec juggling around the store, no store of its own for the -1 (unless a half fills its last pass to the
+        // last lane: the caller's business, see `full` below).  What idle lanes write beyond the -1 is overwritten by the rows that
+        // follow, except for up to 64 entries behind the last row of a block with NJ <= 2: the tail traceback's window is shortened
+        // by as much (rows with more passes guard their stores).  FAST: 1 <= slots <= 31 in both halves, one pass.
+        auto row_passes = [&](const int NJ, const int ns_a, const int ns_b, auto fast_tag) __attribute__((always_inline)) {
+            constexpr bool FAST = decltype(fast_tag)::value;
+            S.rrec[d & (RROWS - 1)] = __builtin_amdgcn_perm((unsigned)nslot, (unsigned)min_k, 0x05040100u);      // row record: min_k | slots << 16
+            int mmax = -0x40000000, m0 = -0x40000000, mp = -0x40000000;
+            unsigned long long e = 0;
+            int j = 0;
+            do {                                 // at least one pass (a pass over an empty band only moves idle lanes)
+                const int tt = sl + 32 * j;
+                // the active lanes of this pass: the low (slots - 32 j) bits of each half, made on the scalar unit from the two
+                // slot counts and used as the lane predicate as it is
+                unsigned long long amask;
+                if (FAST) {
+                    unsigned int ma, mb;
+                    asm("s_bfm_b32 %0, %1, 0" : "=s"(ma) : "s"(ns_a));
+                    asm("s_bfm_b32 %0, %1, 0" : "=s"(mb) : "s"(ns_b));
+                    amask = ((unsigned long long)mb << 32) | ma;
+                } else {
+                    amask = lowbits32(ns_a - 32 * j) | ((unsigned long long)lowbits32(ns_b - 32 * j) << 32);
+                }
+                const bool act = __builtin_amdgcn_inverse_ballot_w64(amask);
+                const int k = min_k + 2 * tt;
+                const unsigned int rp = pbase + 2u * (unsigned)tt;      // idle lanes read (and ignore) whatever the ring holds there
+                const int vl = ring_ld(rbase, rp), vr = ring_ld(rbase, rp + 2u);
+                // :138-142 `if (k == min_k || (k != max_k && V[k-1] < V[k+1])) x = V[k+1]; else x = V[k-1] + 1;` as max(vl + 1, vr):
+                // inside the band the two are the same thing (vl < vr <=> vr >= vl + 1).  At k == min_k the entry on the left is either
+                // the -1 between two rows (vl + 1 = 0 <= vr) or a diagonal of row d - 1 that the band update dropped while its right
+                // neighbour stayed: 2 vl - (k - 1) < best - tol <= 2 vr - (k + 1), i.e. vl + 1 < vr; mirrored at k == max_k (vr is -1, or
+                // a dropped diagonal with vr < vl + 1).  So the two edge tests fold into the same max — in the 16-bit forms of add and
+                // max, which issue at twice the rate of the 32-bit max (the result is >= 0 and comes back zero-extended).
+                int x;
+                {
+                    int v1;
+                    asm("v_add_u16 %0, 1, %1" : "=v"(v1) : "v"(vl));
+                    asm("v_max_i16 %0, %1, %2" : "=v"(x) : "v"(v1), "v"(vr));
+                }
+                // 0 <= y <= t_len and x <= q_len on every live diagonal (a diagonal at an end stops the block); idle lanes sit
+                // at (q_len, 0), where lim == 0
+                x = act ? x : q_len;
+                // (idle lanes: lim <= 0 whatever y is, so they never move forward and never ask for another step; their window
+                // loads may fall outside the staged block or outside the LDS allocation, where reads return 0: nothing of an
+                // idle lane is kept — the stored value, the end mask and m0 below are all guarded by `act`)
+                int y = x - k;
+                int lim, nn;
 #ifdef MECAT_DW_STATS
+                snake2 -= 1;
+#endif
+                do {
+#ifdef MECAT_DW_STATS
+                    snake2 += 1;
+#endif
+                    lim = min(q_len - x, t_len - y);
+                    // 0..15 equal bases, or >= 16 (0x7fffffff) when the whole window matches.  A lane with exactly 16 bases left
+                    // that all match asks for one more step, which then moves nothing.
+                    const int m = match16_le(S.Qp, x, S.Tp, y);
+                    asm("v_min3_i32 %0, %1, %2, 16" : "=v"(nn) : "v"(m), "v"(lim));
+                    x += nn; y += nn;
+                } while (BALLOT(nn == 16));
+                if (NJ <= 2 || tt <= nslot) ring_st(rbase, lin + 2u * (unsigned)tt, act ? x : -1);
+                // nothing left of the query or of the target on this diagonal
+                e |= BALLOT(lim == nn) & amask;
+                mp = m0;
+                m0 = act ? x + y : -0x40000000;     // also read by the band update (NJ <= 2); idle lanes never qualify
+                mmax = NJ == 1 ? m0 : max(mmax, m0);
+            } while (++j < NJ);
+            ended = e;
+            last_m0 = m0; last_mp = mp;
+            rlin = lin;
+            lin += 2u * (unsigned)nslot + 2u;
+            __builtin_amdgcn_wave_barrier();
+            // running maximum of x + y (:160-167) = the maximum of this row: the best diagonal k* of the row before qualifies for
+            // the band, so k* - 1 and k* + 1 are in this row and start at least one further along
+            best_m = half_max(mmax);
+        };
+#ifdef MECAT_DW_STATS
+        auto row_stats = [&](unsigned long long rmask, int ns_a, int ns_b, int NJ) {
             nrows += 1;
             nidle += (rmask == ~0ull) ? 0u : 1u;
-#endif
-            {                                // row record: band limits + linear ring position.  Every lane of the half stores the same
-                int2* rr = &S.rrec[d & (RROWS - 1)];      // two words to the same address (no exec juggling on the scalar unit)
-                rr->x = (int)__builtin_amdgcn_perm((unsigned)nslot, (unsigned)min_k, 0x05040100u); rr->y = (int)lin;
-            }
-            const int ns_a = __builtin_amdgcn_readlane(nslot, 0), ns_b = __builtin_amdgcn_readlane(nslot, 32);
-            NJ = (max(ns_a, ns_b) + 31) >> 5;
-#ifdef MECAT_DW_STATS
             nwide += NJ > 1 ? 1u : 0u;
             n_pass3 += NJ > 2 ? 1u : 0u;
             for (int hq = 0; hq < 2; ++hq) {
@@ -672,79 +739,77 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                 const int p16 = (ns + 15) >> 4;
                 q16[p16 <= 4 ? p16 - 1 : p16 <= 6 ? 4 : 5] += 1;
             }
-#endif
-            // one or two passes of 32 diagonals per half cover 99 % of the rows: with the pass count a constant the pass loop and
-            // the previous-pass bookkeeping fold away
-            auto row_passes = [&](const int NJ) __attribute__((always_inline)) {
-                int mmax = -0x40000000, m0 = -0x40000000, mp = -0x40000000;
-                unsigned long long e = 0;
-                int j = 0;
-                do {                                 // at least one pass (a pass over an empty band only moves idle lanes)
-                    const int tt = sl + 32 * j;
-                    const bool act = tt < nslot;
-                    const int k = min_k + 2 * tt;
-                    const unsigned int rp = pbase + 2u * (unsigned)tt;      // idle lanes read (and ignore) whatever the ring holds there
-                    const int vl = ring_ld(rbase, rp), vr = ring_ld(rbase, rp + 2u);
-                    // :138-142 (k == min_k, k != max_k), without short circuits: both neighbours are always loaded
-                    int x = ((tt == 0) | ((tt + 1 != nslot) & (vl < vr))) ? vr : vl + 1;
-                    // 0 <= y <= t_len and x <= q_len on every live diagonal (a diagonal at an end stops the block); idle lanes sit
-                    // at (q_len, 0), where lim == 0
-                    x = act ? x : q_len;
-                    // (idle lanes: lim <= 0 whatever y is, so they never move forward and never ask for another step; their window
-                    // loads may fall outside the staged block or outside the LDS allocation, where reads return 0: nothing of an
-                    // idle lane is kept — the store, the end mask and m0 below are all guarded by `act`)
-                    int y = x - k;
-                    int lim, nn;
-#ifdef MECAT_DW_STATS
-                    snake2 -= 1;
-#endif
-                    do {
-#ifdef MECAT_DW_STATS
-                        snake2 += 1;
-#endif
-                        lim = min(q_len - x, t_len - y);
-                        // 0..15 equal bases, or >= 16 (0x7fffffff) when the whole window matches.  A lane with exactly 16 bases left
-                        // that all match asks for one more step, which then moves nothing.
-                        const int m = match16_le(S.Qp, x, S.Tp, y);
-                        asm("v_min3_i32 %0, %1, %2, 16" : "=v"(nn) : "v"(m), "v"(lim));
-                        x += nn; y += nn;
-                    } while (BALLOT(nn == 16));
-                    if (act) ring_st(rbase, lin + 2u * (unsigned)tt, x);
-                    // nothing left of the query or of the target on this diagonal; the mask of the active lanes of this pass comes from
-                    // the two halves' slot counts on the scalar unit
-                    e |= BALLOT(lim == nn) & (lowbits32(ns_a - 32 * j) | ((unsigned long long)lowbits32(ns_b - 32 * j) << 32));
-                    mp = m0;
-                    m0 = act ? x + y : -0x40000000;     // also read by the band update (NJ <= 2); idle lanes never qualify
-                    mmax = NJ == 1 ? m0 : max(mmax, m0);
-                } while (++j < NJ);
-                ended = e;
-                last_m0 = m0; last_mp = mp;
-                rlin = lin;
-                lin += 2u * (unsigned)nslot;
-                __builtin_amdgcn_wave_barrier();
-                // running maximum of x + y (:160-167) = the maximum of this row: the best diagonal k* of the row before qualifies for
-                // the band, so k* - 1 and k* + 1 are in this row and start at least one further along
-                best_m = half_max(mmax);
-            };
-            if (NJ == 1) {
-                row_passes(1);
-                if (ended) return;
-                band_update(1, last_m0, last_mp, both_tag);
-            } else if (NJ == 2) {
-                row_passes(2);
-                if (ended) return;
-                band_update(2, last_m0, last_mp, both_tag);
-            } else {
-                row_passes(NJ);
-                if (ended) return;
-                band_update(NJ, last_m0, last_mp, both_tag);
-            }
-            d += 1;
-            __builtin_amdgcn_wave_barrier();
-        }
         };
-        if (inmask == ~0ull) row_loop(std::true_type{});
-        else row_loop(std::false_type{});
+#define DWS_ROW(rmask, a, b, nj) row_stats(rmask, a, b, nj)
+#else
+#define DWS_ROW(rmask, a, b, nj)
+#endif
+        int ns_a = __builtin_amdgcn_readlane(nslot, 0), ns_b = __builtin_amdgcn_readlane(nslot, 32);
+        if (inmask == ~0ull) {
+            // Both halves in a block (98.6 % of the dual rows; it stays that way for as long as the loop runs): the band update writes
+            // its per-half values without the `inblock` guard, and the loop control is scalar — the rows the two blocks may still run
+            // (d < dlim in both) as one count-down, the band-size limits (:118 "max_k - min_k <= band_size") of the two halves next to
+            // the slot counts, which are on the scalar unit anyway.  One-pass rows run in a loop of their own.
+            int rows_left = min(__builtin_amdgcn_readlane(dlim - d, 0), __builtin_amdgcn_readlane(dlim - d, 32));
+            const int lim_a = __builtin_amdgcn_readlane(band_tol, 0) + 1, lim_b = __builtin_amdgcn_readlane(band_tol, 32) + 1;
+            const int one_a = min(lim_a, 31), one_b = min(lim_b, 31);
+            while (true) {
+                while (rows_left > 0 && ns_a <= one_a && ns_b <= one_b) {
+                    DWS_ROW(~0ull, ns_a, ns_b, 1);
+                    rows_left -= 1;
+                    row_passes(1, ns_a, ns_b, std::true_type{});
+                    if (ended) break;
+                    band_update(1, last_m0, last_mp, std::true_type{});
+                    d += 1;
+                    __builtin_amdgcn_wave_barrier();
+                    ns_a = __builtin_amdgcn_readlane(nslot, 0); ns_b = __builtin_amdgcn_readlane(nslot, 32);
+                }
+                if (ended) { NJ = 1; break; }
+                if (rows_left <= 0 || ns_a > lim_a || ns_b > lim_b) break;
+                rows_left -= 1;
+                const int ns_max = max(ns_a, ns_b);
+                NJ = (ns_max + 31) >> 5;
+                const bool full = (ns_max & 31) == 0;       // a half fills its last pass: no idle lane for the -1 behind its row
+                DWS_ROW(~0ull, ns_a, ns_b, NJ);
+                if (NJ == 2) {
+                    row_passes(2, ns_a, ns_b, std::false_type{});
+                    if (full) ring_st(rbase, lin - 2u, -1);
+                    if (ended) break;
+                    band_update(2, last_m0, last_mp, std::true_type{});
+                } else if (NJ == 1) {
+                    row_passes(1, ns_a, ns_b, std::false_type{});
+                    if (full) ring_st(rbase, lin - 2u, -1);
+                    if (ended) break;
+                    band_update(1, last_m0, last_mp, std::true_type{});
+                } else {
+                    row_passes(NJ, ns_a, ns_b, std::false_type{});
+                    if (full) ring_st(rbase, lin - 2u, -1);
+                    if (ended) break;
+                    band_update(NJ, last_m0, last_mp, std::true_type{});
+                }
+                d += 1;
+                __builtin_amdgcn_wave_barrier();
+                ns_a = __builtin_amdgcn_readlane(nslot, 0); ns_b = __builtin_amdgcn_readlane(nslot, 32);
+            }
+        } else {
+            // one half is between blocks (or out of units) while the other one rows on: the general form of everything
+            while (true) {
+                // the two conditions as masks (a ballot of their conjunction makes the compiler turn the mask into a 0/1 vector and
+                // compare it again)
+                const unsigned long long rmask = BALLOT(d < dlim) & BALLOT(nslot <= band_tol + 1);
+                if (rmask != inmask) break;
+                const int ns_max = max(ns_a, ns_b);
+                NJ = (ns_max + 31) >> 5;
+                DWS_ROW(rmask, ns_a, ns_b, NJ);
+                row_passes(NJ, ns_a, ns_b, std::false_type{});
+                if ((ns_max & 31) == 0) ring_st(rbase, lin - 2u, -1);
+                if (ended) break;
+                band_update(NJ, last_m0, last_mp, std::false_type{});
+                d += 1;
+                __builtin_amdgcn_wave_barrier();
+                ns_a = __builtin_amdgcn_readlane(nslot, 0); ns_b = __builtin_amdgcn_readlane(nslot, 32);
+            }
+        }
         DWS_T(t_c);
         DWS_ADD(tk_rows, t_b, t_c);
 #ifdef MECAT_DW_STATS
@@ -785,16 +850,20 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
         int cd = end_d, ck = end_k, cx2 = end_x;
         int qcnt = 0, tcnt = 0, acnt = 0, found = 0;
         bool tracing = has_aln;
+        unsigned int clin = rlin;        // ring position of row cd (the row that reached the end is the row that ran last); rows are walked
+                                         // back over their records: row r - 1 starts (its slots + the -1 behind it) entries before row r
         while (BALLOT(tracing)) {
             if (tracing) {
                 int x1 = 0, pre_k = 0, takes_q = 0;
                 if (cd > 0) {
                     const int r = cd - 1;
-                    const int2 pr = S.rrec[r & (RROWS - 1)], cr = S.rrec[cd & (RROWS - 1)];
-                    const unsigned int plin = (unsigned int)pr.y;
-                    if (d - 1 - r >= RROWS || lin - plin > 2 * RCAP) { handover = true; tracing = false; }
+                    const int pr = (int)S.rrec[r & (RROWS - 1)], cr = (int)S.rrec[cd & (RROWS - 1)];
+                    const unsigned int plin = clin - 2u - 2u * (unsigned)(pr >> 16);
+                    // (128: what the idle lanes of the last row's passes may have written behind it, see row_passes)
+                    if (d - 1 - r >= RROWS || lin - plin > 2 * RCAP - 128) { handover = true; tracing = false; }
                     else {
-                        const int pmin = (int)(int16_t)pr.x, pmax = pmin + 2 * ((pr.x >> 16) - 1), cmin = (int)(int16_t)cr.x, cmax = cmin + 2 * ((cr.x >> 16) - 1);
+                        const int pmin = (int)(int16_t)pr, pmax = pmin + 2 * ((pr >> 16) - 1), cmin = (int)(int16_t)cr, cmax = cmin + 2 * ((cr >> 16) - 1);
+                        clin = plin;
                         const int kl = ck - 1, kr = ck + 1;
                         int vl = 0, vr = 0;
                         if (kl >= pmin && kl <= pmax) vl = ring_ld(rbase, plin + (unsigned)(kl - pmin));      // entry (kl - pmin) / 2, two bytes each
@@ -839,7 +908,7 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                 need_unit = true;
             } else {
                 nblocks += (sl == 0) ? 1u : 0u;
-                cells += (sl == 0) ? (lin - 4u) >> 1 : 0u;      // diagonals visited in this block
+                cells += (sl == 0) ? ((lin - 6u) >> 1) - (unsigned)d : 0u;      // diagonals visited in this block (d rows, one -1 behind each)
                 Rb += 1;
                 stop = !has_aln || !trim_ok;
                 if (!stop) {
@@ -1016,7 +1085,7 @@ int mhip_align_candidates_dev(mhip_ctx* c, const mhip_volume* ref, const mhip_vo
                (unsigned long long*)c->d_counters, (const DwHandover*)nullptr, (const unsigned int*)nullptr);
     } else {
         if (c->scratch("al_hand", sizeof(DwHandover) * 2 * (size_t)n, (void**)&d_hand)) return -1;
-        int waves2 = DW2_WAVES_PER_SIMD * 4;                  // LDS 21.5 KB per four waves, 72 VGPRs
+        int waves2 = DW2_WAVES_PER_SIMD * 4;                  // LDS 20 KB per four waves, 64 VGPRs
         if (const char* e = getenv("MECAT_DW_WAVES")) waves2 = std::max(4, std::min(32, atoi(e)));
         const int grid2 = std::min(c->num_cus * waves2 / AL_WAVES, (n + AL_WAVES - 1) / AL_WAVES);
         if (getenv("MECAT_TRACE")) {

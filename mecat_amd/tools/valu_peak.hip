@@ -152,6 +152,10 @@
                        "v_cmp_lt_u32 s[20:21], " n ", %12\n s_and_b64 s[24:25], s[20:21], %13\n v_cndmask_b32 " d ", " d ", %12, s[24:25]\n v_xor_b32 " d ", " d ", %12\n" \
                        "v_lshl_add_u32 " d ", " d ", 1, %12\n s_add_u32 %9, %9, 3\n v_sub_u32 " d ", " d ", %12\n v_max_i32 " d ", " d ", %12\n" \
                        "ds_read_b32 v30, %14\n v_ffbh_u32 " d ", " d "\n s_bcnt1_i32_b64 %10, %13\n v_add_u32 " d ", " d ", %12\n"
+#define I_LSHR_B64(d, n) "v_lshrrev_b64 v[28:29], " d ", v[30:31]\n"
+#define I_LSHR_B64_S(d, n) "v_lshrrev_b64 v[28:29], " d ", %13\n"
+#define I_DS_WRITE_B64(d, n) "ds_write_b64 %14, v[30:31]\n"
+#define I_BFM(s) "s_bfm_b64 s[20:21], " s ", 0\n"
 #define WAIT "s_waitcnt lgkmcnt(0)\n"
 
 #define KERNELS(X)                                                                                                      \
@@ -189,6 +193,8 @@
     X(mix_ds_read_3vadd, S8(I_MIX_DS_VALU) WAIT, 32) X(seq_v_cmp_vcc_3cndmask, S8(I_CMP_3CNDMASK), 32)                            \
     X(seq_v_cmp_sgpr_3cndmask, S8(I_CMP_3CNDMASK_SGPR), 32) X(seq_s_mov_vcc_cndmask, S8(I_SMOV_VCC_CNDMASK), 16)                 \
     X(mix_max_i16_add_u16, S8(I_MAX_I16_PAIR), 16) X(mix_3vadd_1vmax, S8(I_MIX_ADD_MAXI32), 32)                                   \
+    X(v_lshrrev_b64, S8(I_LSHR_B64), 8) X(v_lshrrev_b64_sgpr, S8(I_LSHR_B64_S), 8) X(ds_write_b64, S8(I_DS_WRITE_B64) WAIT, 8)          \
+    X(s_bfm_b64, SS8(I_BFM), 8)                                                                                                   \
     X(mix_dw_rowbody, S8(I_MIX_DW) WAIT, 128)
 
 #define X_DEF(NAME, BODY, N) DEF_KERNEL(NAME, BODY)

@@ -1,22 +1,18 @@
 #!/bin/bash
-# dev helper (GPU box): SQ counters of dw_extend2 for one bench pass
-R=$(pwd); O=$R/gpurun_out
+# dev helper (GPU box): one rocprofv3 --pmc pass of the hot path, per-launch sums of the given counters for dw_extend2
+# usage: bash tools/dev/pmc_dw.sh "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY"
+SET=${1:-"SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY"}
+R=$(pwd); O=$R/gpurun_out/pmc_dw
+rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 1 --warmup 0 --no-cpu --no-extras --no-e2e"
-rm -rf /tmp/pmc_dw*
-i=0
-for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES" "SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_ACTIVE_INST_SCA" "SQ_INSTS SQ_INSTS_BRANCH SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS" "SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU2 SQ_INSTS_VALU_INT32 SQ_IFETCH"; do
-  i=$((i+1))
-  timeout 300 rocprofv3 --pmc $set --output-format csv -d /tmp/pmc_dw$i -- $CMD > /tmp/pmc_dw$i.log 2>&1
-done
-python3 - <<'PY'
-import csv, glob, collections
-tot = collections.defaultdict(lambda: collections.defaultdict(float))
-for f in glob.glob("/tmp/pmc_dw*/**/*counter_collection.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0]
-        if k.startswith("dw_extend"):
-            tot[k][r["Counter_Name"]] += float(r["Counter_Value"])
-for k, d in tot.items():
-    print(k, {n: "%.3e" % v for n, v in sorted(d.items())})
-PY
+timeout 300 rocprofv3 --pmc $SET --output-format csv -d $O -- python $R/bench.py --steps 1 --warmup 0 --no-cpu --no-extras --no-e2e > $O/log 2>&1
+python - <<P
+import glob, pandas as pd
+f = glob.glob("$O/**/*counter_collection.csv", recursive=True)
+d = pd.concat(pd.read_csv(x) for x in f)
+d = d[d["Kernel_Name"].str.contains("dw_extend2")]
+n = d["Dispatch_Id"].nunique()
+print("launches", n)
+print((d.groupby("Counter_Name")["Counter_Value"].sum() / n).to_string())
+P
+find $O -name "*.db" -delete 2>/dev/null

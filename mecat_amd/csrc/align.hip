@@ -455,8 +455,9 @@ __device__ __forceinline__ void ring_st(uint32_t base, uint32_t pos, int x) { *(
 template <int CTRL> __device__ __forceinline__ int dpp_max_step(int v) {
     return max(v, __builtin_amdgcn_update_dpp((int)0x80000000, v, CTRL, 0xf, 0xf, false));
 }
-__device__ __forceinline__ int half_max(int v) {
-    v = dpp_max_step<0xB1>(v);           // quad_perm:[1,0,3,2]
+__device__ __forceinline__ int half_max(int v0) {
+    int v;                               // quad_perm:[1,0,3,2], into a register of its own: the caller keeps v0 (no copy in front of the chain)
+    asm("s_nop 1\n\tv_max_i32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(v) : "v"(v0));
     v = dpp_max_step<0x4E>(v);           // quad_perm:[2,3,0,1]
     v = dpp_max_step<0x141>(v);          // row_half_mirror
     v = dpp_max_step<0x140>(v);          // row_mirror: every lane of a 16-lane row holds the row's maximum
@@ -474,6 +475,21 @@ __device__ __forceinline__ unsigned int lowbits32(int n) {
     int c;
     asm("s_min_i32 %1, %2, 32\n\ts_max_i32 %1, %1, 0\n\ts_bfm_b64 %0, %1, 0" : "=s"(r), "=&s"(c) : "s"(n) : "scc");
     return (unsigned int)r;
+}
+
+// n bits set from bit `off` up (s_bfm_b64; 0 <= n <= 32, off 0 or 32: a half's lane mask already in its half of the wave's mask)
+template <int OFF> __device__ __forceinline__ unsigned long long bits_at(int n) {
+    unsigned long long r;
+    asm("s_bfm_b64 %0, %1, %2" : "=s"(r) : "s"(n), "n"(OFF));
+    return r;
+}
+
+// the same for any n: min(max(n, 0), 32) bits (the clamp written out on the scalar unit, like lowbits32)
+template <int OFF> __device__ __forceinline__ unsigned long long clamped_bits_at(int n) {
+    unsigned long long r;
+    int c;
+    asm("s_min_i32 %1, %2, 32\n\ts_max_i32 %1, %1, 0\n\ts_bfm_b64 %0, %1, %3" : "=s"(r), "=&s"(c) : "s"(n), "n"(OFF) : "scc");
+    return r;
 }
 
 #ifndef DW2_WAVES_PER_SIMD
@@ -597,7 +613,9 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
         int NJ = 1;
         // band update (:172-179) of the row at ring position rlin; m0 / mp = x + y of the lane's diagonal in the last / previous
         // pass (NJ <= 2), otherwise recomputed from the ring
-        auto band_update = [&](const int NJ, const int m0, const int mp, auto both_tag) __attribute__((always_inline)) {
+        // sa / sb: the new slot counts of the two halves for the scalar unit — with both halves in a block and NJ <= 2 straight from
+        // the ballots (scalar find-first / find-last), otherwise read back from the vector state
+        auto band_update = [&](const int NJ, const int m0, const int mp, auto both_tag, int& sa, int& sb) __attribute__((always_inline)) {
             constexpr bool BOTH = decltype(both_tag)::value;      // both halves are in a block: no per-half guard on the band state
             // qualifying lanes first .. last of the half.  The mask of a half that is in a block is never empty: the lane that holds
             // the row maximum qualifies, and the row maximum is the running maximum (x + y grows by at least one per row along
@@ -612,6 +630,11 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                 asm("v_ffbl_b32 %0, %1" : "=v"(first) : "v"(m32));
                 asm("v_ffbh_u32 %0, %1" : "=v"(lz) : "v"(m32));
                 last = 31 - lz;
+                if (BOTH) {
+                    const unsigned int wa = (unsigned int)q0, wb = (unsigned int)(q0 >> 32);
+                    sa = 33 - (__builtin_ctz(wa) + __builtin_clz(wa));
+                    sb = 33 - (__builtin_ctz(wb) + __builtin_clz(wb));
+                }
             } else if (NJ == 2) {
                 // up to 64 diagonals per half: two ballots, the half's 2 x 32 qualification bits.  Branch-free: v_ffbl / v_ffbh return
                 // -1 for an empty word, which `| 32` leaves at 0xffffffff (first: unsigned min) and `^ 31` turns into -32 (last:
@@ -626,6 +649,11 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                 asm("v_ffbh_u32 %0, %1" : "=v"(lh) : "v"(hi32));
                 first = (int)min(fl, fh | 32u);
                 last = max((int)(ll ^ 31u), (int)((lh ^ 31u) | 32u));
+                if (BOTH) {
+                    const unsigned long long wa = (q0 & 0xffffffffull) | (q1 << 32), wb = (q0 >> 32) | (q1 & 0xffffffff00000000ull);
+                    sa = 65 - (__builtin_ctzll(wa) + __builtin_clzll(wa));
+                    sb = 65 - (__builtin_ctzll(wb) + __builtin_clzll(wb));
+                }
             } else {
                 int lo = 0x7fffffff, hi = -0x7fffffff;
                 for (int j = 0; j < NJ; ++j) {
@@ -644,18 +672,23 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                 nslot = last - first + 2;
                 min_k = min_k + 2 * first - 1;
             }
+            if (!(BOTH && NJ <= 2)) { sa = __builtin_amdgcn_readlane(nslot, 0); sb = __builtin_amdgcn_readlane(nslot, 32); }
         };
         int last_m0 = 0, last_mp = 0;
+        unsigned int row_bytes = 0;
         // One d-row of both halves in NJ passes of 32 diagonals per half (NJ a constant for 1 and 2: the pass loop and the previous-pass
         // bookkeeping fold away).  ns_a / ns_b: the two halves' slot counts on the scalar unit.  A row is followed in the ring by one
         // entry of -1, which the first idle lane of the last pass writes: every lane of a pass stores (its x, or -1 when idle) at its
         // own position — no exec juggling around the store, no store of its own for the -1 (unless a half fills its last pass to the
         // last lane: the caller's business, see `full` below).  What idle lanes write beyond the -1 is overwritten by the rows that
         // follow, except for up to 64 entries behind the last row of a block with NJ <= 2: the tail traceback's window is shortened
-        // by as much (rows with more passes guard their stores).  FAST: 1 <= slots <= 31 in both halves, one pass.
+        // by as much (rows with more passes guard their stores).  FAST 1: 1 <= slots <= 31 in both halves, one pass; FAST 2: 1 <= slots
+        // <= 63, two passes; FAST 0: anything.
         auto row_passes = [&](const int NJ, const int ns_a, const int ns_b, auto fast_tag) __attribute__((always_inline)) {
-            constexpr bool FAST = decltype(fast_tag)::value;
+            constexpr int FAST = decltype(fast_tag)::value;
+
             S.rrec[d & (RROWS - 1)] = __builtin_amdgcn_perm((unsigned)nslot, (unsigned)min_k, 0x05040100u);      // row record: min_k | slots << 16
+            row_bytes = 2u * (unsigned)nslot + 2u;
             int mmax = -0x40000000, m0 = -0x40000000, mp = -0x40000000;
             unsigned long long e = 0;
             int j = 0;
@@ -664,13 +697,16 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                 // the active lanes of this pass: the low (slots - 32 j) bits of each half, made on the scalar unit from the two
                 // slot counts and used as the lane predicate as it is
                 unsigned long long amask;
-                if (FAST) {
+                if (FAST == 2) {
+                    amask = j == 0 ? (bits_at<0>(min(ns_a, 32)) | bits_at<32>(min(ns_b, 32)))
+                                   : (bits_at<0>(max(ns_a, 32) - 32) | bits_at<32>(max(ns_b, 32) - 32));
+                } else if (FAST == 1) {
                     unsigned int ma, mb;
                     asm("s_bfm_b32 %0, %1, 0" : "=s"(ma) : "s"(ns_a));
                     asm("s_bfm_b32 %0, %1, 0" : "=s"(mb) : "s"(ns_b));
                     amask = ((unsigned long long)mb << 32) | ma;
                 } else {
-                    amask = lowbits32(ns_a - 32 * j) | ((unsigned long long)lowbits32(ns_b - 32 * j) << 32);
+                    amask = clamped_bits_at<0>(ns_a - 32 * j) | clamped_bits_at<32>(ns_b - 32 * j);
                 }
                 const bool act = __builtin_amdgcn_inverse_ballot_w64(amask);
                 const int k = min_k + 2 * tt;
@@ -719,8 +755,7 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
             } while (++j < NJ);
             ended = e;
             last_m0 = m0; last_mp = mp;
-            rlin = lin;
-            lin += 2u * (unsigned)nslot + 2u;
+            rlin = lin;                          // (the caller moves lin behind the row and its -1: lin += row_bytes)
             __builtin_amdgcn_wave_barrier();
             // running maximum of x + y (:160-167) = the maximum of this row: the best diagonal k* of the row before qualifies for
             // the band, so k* - 1 and k* + 1 are in this row and start at least one further along
@@ -753,43 +788,50 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
             int rows_left = min(__builtin_amdgcn_readlane(dlim - d, 0), __builtin_amdgcn_readlane(dlim - d, 32));
             const int lim_a = __builtin_amdgcn_readlane(band_tol, 0) + 1, lim_b = __builtin_amdgcn_readlane(band_tol, 32) + 1;
             const int one_a = min(lim_a, 31), one_b = min(lim_b, 31);
+            const int two_a = min(lim_a, 63), two_b = min(lim_b, 63);
+            typedef std::integral_constant<int, 0> fast0;
+            typedef std::integral_constant<int, 1> fast1;
+            typedef std::integral_constant<int, 2> fast2;
             while (true) {
-                while (rows_left > 0 && ns_a <= one_a && ns_b <= one_b) {
+                // one-pass rows (rows left, and both slot counts within their limits: one sign test)
+                while (((rows_left - 1) | (one_a - ns_a) | (one_b - ns_b)) >= 0) {
                     DWS_ROW(~0ull, ns_a, ns_b, 1);
                     rows_left -= 1;
-                    row_passes(1, ns_a, ns_b, std::true_type{});
+                    row_passes(1, ns_a, ns_b, fast1{});
+                    band_update(1, last_m0, last_mp, std::true_type{}, ns_a, ns_b);
+                    lin += row_bytes;
                     if (ended) break;
-                    band_update(1, last_m0, last_mp, std::true_type{});
                     d += 1;
                     __builtin_amdgcn_wave_barrier();
-                    ns_a = __builtin_amdgcn_readlane(nslot, 0); ns_b = __builtin_amdgcn_readlane(nslot, 32);
                 }
-                if (ended) { NJ = 1; break; }
+                if (ended) break;
+                // two-pass rows: a half has 32 .. 63 slots
+                while ((((rows_left - 1) | (two_a - ns_a) | (two_b - ns_b)) >= 0) && max(ns_a, ns_b) >= 32) {
+                    DWS_ROW(~0ull, ns_a, ns_b, 2);
+                    NJ = 2;
+                    rows_left -= 1;
+                    row_passes(2, ns_a, ns_b, fast2{});
+                    band_update(2, last_m0, last_mp, std::true_type{}, ns_a, ns_b);
+                    lin += row_bytes;
+                    if (ended) break;
+                    d += 1;
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (ended) break;
                 if (rows_left <= 0 || ns_a > lim_a || ns_b > lim_b) break;
-                rows_left -= 1;
                 const int ns_max = max(ns_a, ns_b);
+                if (ns_max < 64) continue;                   // back to the two loops above
+                // a half with 64 slots or more (0.01 % of the rows): the general form
+                rows_left -= 1;
                 NJ = (ns_max + 31) >> 5;
-                const bool full = (ns_max & 31) == 0;       // a half fills its last pass: no idle lane for the -1 behind its row
                 DWS_ROW(~0ull, ns_a, ns_b, NJ);
-                if (NJ == 2) {
-                    row_passes(2, ns_a, ns_b, std::false_type{});
-                    if (full) ring_st(rbase, lin - 2u, -1);
-                    if (ended) break;
-                    band_update(2, last_m0, last_mp, std::true_type{});
-                } else if (NJ == 1) {
-                    row_passes(1, ns_a, ns_b, std::false_type{});
-                    if (full) ring_st(rbase, lin - 2u, -1);
-                    if (ended) break;
-                    band_update(1, last_m0, last_mp, std::true_type{});
-                } else {
-                    row_passes(NJ, ns_a, ns_b, std::false_type{});
-                    if (full) ring_st(rbase, lin - 2u, -1);
-                    if (ended) break;
-                    band_update(NJ, last_m0, last_mp, std::true_type{});
-                }
+                row_passes(NJ, ns_a, ns_b, fast0{});
+                lin += row_bytes;
+                if ((ns_max & 31) == 0) ring_st(rbase, lin - 2u, -1);      // a half fills its last pass: no idle lane for the -1 behind its row
+                band_update(NJ, last_m0, last_mp, std::true_type{}, ns_a, ns_b);
+                if (ended) break;
                 d += 1;
                 __builtin_amdgcn_wave_barrier();
-                ns_a = __builtin_amdgcn_readlane(nslot, 0); ns_b = __builtin_amdgcn_readlane(nslot, 32);
             }
         } else {
             // one half is between blocks (or out of units) while the other one rows on: the general form of everything
@@ -801,13 +843,13 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                 const int ns_max = max(ns_a, ns_b);
                 NJ = (ns_max + 31) >> 5;
                 DWS_ROW(rmask, ns_a, ns_b, NJ);
-                row_passes(NJ, ns_a, ns_b, std::false_type{});
+                row_passes(NJ, ns_a, ns_b, std::integral_constant<int, 0>{});
+                lin += row_bytes;
                 if ((ns_max & 31) == 0) ring_st(rbase, lin - 2u, -1);
+                band_update(NJ, last_m0, last_mp, std::false_type{}, ns_a, ns_b);
                 if (ended) break;
-                band_update(NJ, last_m0, last_mp, std::false_type{});
                 d += 1;
                 __builtin_amdgcn_wave_barrier();
-                ns_a = __builtin_amdgcn_readlane(nslot, 0); ns_b = __builtin_amdgcn_readlane(nslot, 32);
             }
         }
         DWS_T(t_c);
@@ -817,12 +859,14 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
 #endif
         if (ended) {
             // Once per block, outside the row loop (inside it, the state written here costs register copies on every row): the
-            // lowest diagonal that reached an end (:168-169), from the row just stored; then the rest of that row for the
-            // other half.
+            // lowest diagonal that reached an end (:168-169), from the row just stored.  The band of that row comes from its record:
+            // the band update for the row after it has been done already (the other half goes on with it).
+            const int rec = (int)S.rrec[d & (RROWS - 1)];
+            const int emin = (int)(int16_t)rec, en = rec >> 16;
             int hkey = 0x7fffffff;
-            for (int jj = 0; jj < NJ; ++jj) {
-                const int tt = sl + 32 * jj, k = min_k + 2 * tt, kk = k + k_offset;
-                if (tt < nslot) {
+            for (int tt = sl; BALLOT(tt < en); tt += 32) {
+                const int k = emin + 2 * tt, kk = k + k_offset;
+                if (tt < en) {
                     const int x = ring_ld(rbase, rlin + 2u * (unsigned)tt);
                     if (x >= q_len || x - k >= t_len) hkey = min(hkey, (kk << 10) | x);
                 }
@@ -832,7 +876,6 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                 aligned = 1; end_k = (hkey >> 10) - k_offset; end_x = hkey & 1023; end_d = d;
                 dlim = 0;
             }
-            band_update(max(NJ, 3), 0, 0, std::false_type{});   // (the general form: from the ring)
             d += 1;
             __builtin_amdgcn_wave_barrier();
         }

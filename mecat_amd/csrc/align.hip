@@ -641,18 +641,27 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                 // signed max; x ^ 31 == 31 - x for x in 0..31)
                 const int thr = best_m - band_tol;
                 const unsigned long long q0 = BALLOT(mp >= thr), q1 = BALLOT(m0 >= thr);
-                const unsigned int lo32 = (unsigned int)(q0 >> (hh << 5)), hi32 = (unsigned int)(q1 >> (hh << 5));
-                unsigned int fl, fh, ll, lh;
-                asm("v_ffbl_b32 %0, %1" : "=v"(fl) : "v"(lo32));
-                asm("v_ffbl_b32 %0, %1" : "=v"(fh) : "v"(hi32));
-                asm("v_ffbh_u32 %0, %1" : "=v"(ll) : "v"(lo32));
-                asm("v_ffbh_u32 %0, %1" : "=v"(lh) : "v"(hi32));
-                first = (int)min(fl, fh | 32u);
-                last = max((int)(ll ^ 31u), (int)((lh ^ 31u) | 32u));
                 if (BOTH) {
+                    // first / last qualifying diagonal of each half on the scalar unit (its 64 bits: the half's word of both ballots),
+                    // handed to the lanes as one packed value per half: two moves and a select instead of two 64-bit shifts, four
+                    // find-first / find-last and their merge
                     const unsigned long long wa = (q0 & 0xffffffffull) | (q1 << 32), wb = (q0 >> 32) | (q1 & 0xffffffff00000000ull);
-                    sa = 65 - (__builtin_ctzll(wa) + __builtin_clzll(wa));
-                    sb = 65 - (__builtin_ctzll(wb) + __builtin_clzll(wb));
+                    const int fa = __builtin_ctzll(wa), fb = __builtin_ctzll(wb);
+                    const int la = 63 - __builtin_clzll(wa), lb = 63 - __builtin_clzll(wb);
+                    sa = la - fa + 2;
+                    sb = lb - fb + 2;
+                    const int pk = hh ? (fb | (lb << 8)) : (fa | (la << 8));
+                    first = pk & 0xff;
+                    last = pk >> 8;
+                } else {
+                    const unsigned int lo32 = (unsigned int)(q0 >> (hh << 5)), hi32 = (unsigned int)(q1 >> (hh << 5));
+                    unsigned int fl, fh, ll, lh;
+                    asm("v_ffbl_b32 %0, %1" : "=v"(fl) : "v"(lo32));
+                    asm("v_ffbl_b32 %0, %1" : "=v"(fh) : "v"(hi32));
+                    asm("v_ffbh_u32 %0, %1" : "=v"(ll) : "v"(lo32));
+                    asm("v_ffbh_u32 %0, %1" : "=v"(lh) : "v"(hi32));
+                    first = (int)min(fl, fh | 32u);
+                    last = max((int)(ll ^ 31u), (int)((lh ^ 31u) | 32u));
                 }
             } else {
                 int lo = 0x7fffffff, hi = -0x7fffffff;

@@ -424,9 +424,6 @@ __global__ __launch_bounds__(AL_BLOCK) void dw_extend(const uint32_t* __restrict
 #ifndef RCAP
 #define RCAP 1024
 #endif
-#ifndef RROWS
-#define RROWS 32              // rows the tail traceback can go back (the ring itself holds ~40 average rows)
-#endif
 #define SEQ_WORDS2 48          // 736 bases + one 16-base window, 16 bases per word, no pad word
 // Per-half LDS, 2.5 KB incl. the ring below (20 KB per workgroup of four waves: eight workgroups per CU, 160 KB exactly).  There is no V[] array: row d reads the
 // furthest x of diagonals k - 1 and k + 1 of row d - 1 straight from that row's entries in the ring (they are always inside its
@@ -434,7 +431,6 @@ __global__ __launch_bounds__(AL_BLOCK) void dw_extend(const uint32_t* __restrict
 struct HalfLds {
     uint32_t Qp[SEQ_WORDS2];
     uint32_t Tp[SEQ_WORDS2];
-    uint32_t rrec[RROWS];       // per d-row: min_k (low 16 bits) | nslot << 16
 };
 // The ring of d-rows of a half: u16 rows packed back to back, wrapping (the first two entries of a block are the zeros row 0 reads).
 // It is its own 2 KB-aligned LDS array so that the address of ring byte position p is `base | (p & 0x7fe)`: one v_and_or_b32.
@@ -533,10 +529,14 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
     int Rq = 0, Rt = 0, Rm = 0, Rc = 0, Rb = 0;
     // per-half block state
     int qblk = 0, tblk = 0, last_block = 0, band_tol = 0, max_d = 0;
-    int best_m = -1, min_k = 0, nslot = 0, aligned = 0, end_x = 0, end_k = 0, end_d = 0, d = 0;      // band = nslot diagonals from min_k; d = rows done
-    unsigned int lin = 0;       // ring position behind the last row (bytes, like the next two)
-    unsigned int pbase = 0;     // ring position of the previous row's entry for diagonal (this row's min_k) - 1
-    unsigned int rlin = 0;      // ring position of the row that ran last
+    // band = nslot diagonals from min_k; d = rows done.  The three values every lane adds its own 2 * sl to on every row are kept with
+    // it added (`_l`: per lane): the row code then uses them as they are, and the band update moves all lanes by the same amount.
+    int best_m = -1, mk_l = 0, nslot = 0, aligned = 0, end_x = 0, end_k = 0, end_d = 0, end_mk = 0, end_ns = 0, d = 0;
+    int sepv = -1;              // what idle lanes store behind the row: ~(slots of the row | left cut of the row before << 8), see row_passes
+    int cut = 0;                // diagonals the last band update dropped on the left (`first`)
+    unsigned int lin_l = 0;     // ring position behind the last row (bytes, like the next two) + 2 sl
+    unsigned int pb_l = 0;      // ring position of the previous row's entry for diagonal (this row's min_k) - 1, + 2 sl
+    unsigned int rlin_l = 0;    // ring position of the row that ran last, + 2 sl
     int dlim = 0;               // rows run while d < dlim: max_d of the block, 0 once an end was reached / without a block
 
     while (true) {
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                 unsigned int u = 0;
                 if (sl == 0) u = atomicAdd(cursor, 1u);
                 u = __shfl(u, hh << 5);
-                if (u >= 2u * (unsigned)n) { exhausted = true; setup = false; min_k = 0; nslot = 0; dlim = 0; }      // never rowing
+                if (u >= 2u * (unsigned)n) { exhausted = true; setup = false; mk_l = 2 * sl; nslot = 0; dlim = 0; }      // never rowing
                 else {
                     unit = u;
                     const mhip_aln_job jb = jobs[u >> 1];
@@ -590,9 +590,9 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                 // Between two rows of the ring sits one entry of -1 (see the start point below); in front of row 0: -1, 0, -1 — row 0 reads
                 // the first two (x = max(-1 + 1, 0) = 0), row 1 reads the third as the entry "left of row 0".
                 if (sl < 3) ring_st(rbase, 2u * sl, sl == 1 ? 0 : -1);
-                best_m = -1; min_k = 0; nslot = 1;
+                best_m = -1; mk_l = 2 * sl; nslot = 1; sepv = ~1; cut = 0;
                 aligned = 0; end_x = 0; end_k = 0; end_d = 0; d = 0;
-                lin = 6; pbase = 0; rlin = 0;
+                lin_l = 6u + 2u * sl; pb_l = 2u * sl; rlin_l = 2u * sl;
                 dlim = max_d; inblock = true;
                 setup = false;
             }
@@ -668,8 +668,8 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                 for (int j = 0; j < NJ; ++j) {
                     const int tt = sl + 32 * j;
                     const bool act = inblock && tt < nslot;
-                    const int k = min_k + 2 * tt;
-                    const int u = act ? 2 * ring_ld(rbase, rlin + 2u * (unsigned)tt) - k : -0x40000000;
+                    const int k = mk_l + 64 * j;
+                    const int u = act ? 2 * ring_ld(rbase, rlin_l + 64u * (unsigned)j) - k : -0x40000000;
                     if (act && u >= best_m - band_tol) { lo = min(lo, tt); hi = max(hi, tt); }
                 }
                 first = half_min(lo); last = half_max(hi);
@@ -677,9 +677,16 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
             if (BOTH || inblock) {
                 // new band [min_k + 2 first - 1, min_k + 2 last + 1] = last - first + 2 diagonals; the previous-row entry of diagonal
                 // (new min_k) - 1 sits at ring position rlin + first - 1
-                pbase = rlin + 2u * (unsigned)(first - 1);
+                pb_l = rlin_l + 2u * (unsigned)(first - 1);
                 nslot = last - first + 2;
-                min_k = min_k + 2 * first - 1;
+                mk_l = mk_l + 2 * first - 1;
+                cut = first;
+                // what the idle lanes of the next row store behind it: its slot count and this cut (7 bits, saturating: the tail
+                // traceback hands a block over when it meets 127), as a negative 16-bit number — which is all the start point needs
+                // of the entry between two rows
+                int c7;
+                asm("v_min_u16 %0, 0x7f, %1" : "=v"(c7) : "v"(first));
+                sepv = ~(nslot | (c7 << 8));
             }
             if (!(BOTH && NJ <= 2)) { sa = __builtin_amdgcn_readlane(nslot, 0); sb = __builtin_amdgcn_readlane(nslot, 32); }
         };
@@ -696,7 +703,6 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
         auto row_passes = [&](const int NJ, const int ns_a, const int ns_b, auto fast_tag) __attribute__((always_inline)) {
             constexpr int FAST = decltype(fast_tag)::value;
 
-            S.rrec[d & (RROWS - 1)] = __builtin_amdgcn_perm((unsigned)nslot, (unsigned)min_k, 0x05040100u);      // row record: min_k | slots << 16
             row_bytes = 2u * (unsigned)nslot + 2u;
             int mmax = -0x40000000, m0 = -0x40000000, mp = -0x40000000;
             unsigned long long e = 0;
@@ -718,8 +724,8 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                     amask = clamped_bits_at<0>(ns_a - 32 * j) | clamped_bits_at<32>(ns_b - 32 * j);
                 }
                 const bool act = __builtin_amdgcn_inverse_ballot_w64(amask);
-                const int k = min_k + 2 * tt;
-                const unsigned int rp = pbase + 2u * (unsigned)tt;      // idle lanes read (and ignore) whatever the ring holds there
+                const int k = mk_l + 64 * j;
+                const unsigned int rp = pb_l + 64u * (unsigned)j;       // idle lanes read (and ignore) whatever the ring holds there
                 const int vl = ring_ld(rbase, rp), vr = ring_ld(rbase, rp + 2u);
                 // :138-142 `if (k == min_k || (k != max_k && V[k-1] < V[k+1])) x = V[k+1]; else x = V[k-1] + 1;` as max(vl + 1, vr):
                 // inside the band the two are the same thing (vl < vr <=> vr >= vl + 1).  At k == min_k the entry on the left is either
@@ -755,7 +761,7 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                     asm("v_min3_i32 %0, %1, %2, 16" : "=v"(nn) : "v"(m), "v"(lim));
                     x += nn; y += nn;
                 } while (BALLOT(nn == 16));
-                if (NJ <= 2 || tt <= nslot) ring_st(rbase, lin + 2u * (unsigned)tt, act ? x : -1);
+                if (NJ <= 2 || tt <= nslot) ring_st(rbase, lin_l + 64u * (unsigned)j, act ? x : sepv);
                 // nothing left of the query or of the target on this diagonal
                 e |= BALLOT(lim == nn) & amask;
                 mp = m0;
@@ -764,7 +770,7 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
             } while (++j < NJ);
             ended = e;
             last_m0 = m0; last_mp = mp;
-            rlin = lin;                          // (the caller moves lin behind the row and its -1: lin += row_bytes)
+            rlin_l = lin_l;                      // (the caller moves lin_l behind the row and the entry behind it: lin_l += row_bytes)
             __builtin_amdgcn_wave_barrier();
             // running maximum of x + y (:160-167) = the maximum of this row: the best diagonal k* of the row before qualifies for
             // the band, so k* - 1 and k* + 1 are in this row and start at least one further along
@@ -808,7 +814,7 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                     rows_left -= 1;
                     row_passes(1, ns_a, ns_b, fast1{});
                     band_update(1, last_m0, last_mp, std::true_type{}, ns_a, ns_b);
-                    lin += row_bytes;
+                    lin_l += row_bytes;
                     if (ended) break;
                     d += 1;
                     __builtin_amdgcn_wave_barrier();
@@ -821,7 +827,7 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                     rows_left -= 1;
                     row_passes(2, ns_a, ns_b, fast2{});
                     band_update(2, last_m0, last_mp, std::true_type{}, ns_a, ns_b);
-                    lin += row_bytes;
+                    lin_l += row_bytes;
                     if (ended) break;
                     d += 1;
                     __builtin_amdgcn_wave_barrier();
@@ -835,8 +841,8 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                 NJ = (ns_max + 31) >> 5;
                 DWS_ROW(~0ull, ns_a, ns_b, NJ);
                 row_passes(NJ, ns_a, ns_b, fast0{});
-                lin += row_bytes;
-                if ((ns_max & 31) == 0) ring_st(rbase, lin - 2u, -1);      // a half fills its last pass: no idle lane for the -1 behind its row
+                lin_l += row_bytes;
+                if ((ns_max & 31) == 0) ring_st(rbase, lin_l - 2u * sl - 2u, sepv);      // a half fills its last pass: no idle lane for the entry behind its row
                 band_update(NJ, last_m0, last_mp, std::true_type{}, ns_a, ns_b);
                 if (ended) break;
                 d += 1;
@@ -853,8 +859,8 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                 NJ = (ns_max + 31) >> 5;
                 DWS_ROW(rmask, ns_a, ns_b, NJ);
                 row_passes(NJ, ns_a, ns_b, std::integral_constant<int, 0>{});
-                lin += row_bytes;
-                if ((ns_max & 31) == 0) ring_st(rbase, lin - 2u, -1);
+                lin_l += row_bytes;
+                if ((ns_max & 31) == 0) ring_st(rbase, lin_l - 2u * sl - 2u, sepv);
                 band_update(NJ, last_m0, last_mp, std::false_type{}, ns_a, ns_b);
                 if (ended) break;
                 d += 1;
@@ -868,21 +874,22 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
 #endif
         if (ended) {
             // Once per block, outside the row loop (inside it, the state written here costs register copies on every row): the
-            // lowest diagonal that reached an end (:168-169), from the row just stored.  The band of that row comes from its record:
-            // the band update for the row after it has been done already (the other half goes on with it).
-            const int rec = (int)S.rrec[d & (RROWS - 1)];
-            const int emin = (int)(int16_t)rec, en = rec >> 16;
+            // lowest diagonal that reached an end (:168-169), from the row just stored.  The band update for the row after it has been
+            // done already (the other half goes on with it): the band of the end row is what that update started from — its slots
+            // from the row's length in the ring, its first diagonal from the cut.
+            const int en = (int)((lin_l - rlin_l) >> 1) - 1, emk_l = mk_l - 2 * cut + 1;
             int hkey = 0x7fffffff;
-            for (int tt = sl; BALLOT(tt < en); tt += 32) {
-                const int k = emin + 2 * tt, kk = k + k_offset;
-                if (tt < en) {
-                    const int x = ring_ld(rbase, rlin + 2u * (unsigned)tt);
+            for (int j = 0; BALLOT(sl + 32 * j < en); ++j) {
+                const int k = emk_l + 64 * j, kk = k + k_offset;
+                if (sl + 32 * j < en) {
+                    const int x = ring_ld(rbase, rlin_l + 64u * (unsigned)j);
                     if (x >= q_len || x - k >= t_len) hkey = min(hkey, (kk << 10) | x);
                 }
             }
             hkey = half_min(hkey);
             if (inblock && hkey != 0x7fffffff) {
                 aligned = 1; end_k = (hkey >> 10) - k_offset; end_x = hkey & 1023; end_d = d;
+                end_mk = emk_l - 2 * sl; end_ns = en;
                 dlim = 0;
             }
             d += 1;
@@ -902,26 +909,30 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
         int cd = end_d, ck = end_k, cx2 = end_x;
         int qcnt = 0, tcnt = 0, acnt = 0, found = 0;
         bool tracing = has_aln;
-        unsigned int clin = rlin;        // ring position of row cd (the row that reached the end is the row that ran last); rows are walked
-                                         // back over their records: row r - 1 starts (its slots + the -1 behind it) entries before row r
+        // Rows are walked back over the entries between them: behind row r sits ~(slots of r | left cut of row r - 1 << 8).  clin / cmin /
+        // cns: ring position, first diagonal and slots of row cd (the row that reached the end is the row that ran last).
+        const unsigned int lin_u = lin_l - 2u * sl;
+        unsigned int clin = rlin_l - 2u * sl;
+        int cmin = end_mk, cns = end_ns;
         while (BALLOT(tracing)) {
             if (tracing) {
                 int x1 = 0, pre_k = 0, takes_q = 0;
                 if (cd > 0) {
-                    const int r = cd - 1;
-                    const int pr = (int)S.rrec[r & (RROWS - 1)], cr = (int)S.rrec[cd & (RROWS - 1)];
-                    const unsigned int plin = clin - 2u - 2u * (unsigned)(pr >> 16);
-                    // (128: what the idle lanes of the last row's passes may have written behind it, see row_passes)
-                    if (d - 1 - r >= RROWS || lin - plin > 2 * RCAP - 128) { handover = true; tracing = false; }
+                    const int sc = ~ring_ld(rbase, clin + 2u * (unsigned)cns), sp = ~ring_ld(rbase, clin - 2u);
+                    const int pcut = (sc >> 8) & 127, pns = sp & 255;
+                    const unsigned int plin = clin - 2u - 2u * (unsigned)pns;
+                    // (128: what the idle lanes of the last row's passes may have written behind it, see row_passes; a cut of 127 or
+                    // more is not recorded)
+                    if (pcut == 127 || lin_u - plin > 2 * RCAP - 128) { handover = true; tracing = false; }
                     else {
-                        const int pmin = (int)(int16_t)pr, pmax = pmin + 2 * ((pr >> 16) - 1), cmin = (int)(int16_t)cr, cmax = cmin + 2 * ((cr >> 16) - 1);
-                        clin = plin;
+                        const int pmin = cmin - 2 * pcut + 1, pmax = pmin + 2 * (pns - 1), cmax = cmin + 2 * (cns - 1);
                         const int kl = ck - 1, kr = ck + 1;
                         int vl = 0, vr = 0;
                         if (kl >= pmin && kl <= pmax) vl = ring_ld(rbase, plin + (unsigned)(kl - pmin));      // entry (kl - pmin) / 2, two bytes each
                         if (kr >= pmin && kr <= pmax) vr = ring_ld(rbase, plin + (unsigned)(kr - pmin));
                         if (ck == cmin || (ck != cmax && vl < vr)) { x1 = vr; pre_k = kr; takes_q = 0; }
                         else { x1 = vl + 1; pre_k = kl; takes_q = 1; }
+                        clin = plin; cmin = pmin; cns = pns;
                     }
                 }
                 if (tracing) {
@@ -960,7 +971,7 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                 need_unit = true;
             } else {
                 nblocks += (sl == 0) ? 1u : 0u;
-                cells += (sl == 0) ? ((lin - 6u) >> 1) - (unsigned)d : 0u;      // diagonals visited in this block (d rows, one -1 behind each)
+                cells += (sl == 0) ? ((lin_l - 6u) >> 1) - (unsigned)d : 0u;      // diagonals visited in this block (d rows, one -1 behind each)
                 Rb += 1;
                 stop = !has_aln || !trim_ok;
                 if (!stop) {

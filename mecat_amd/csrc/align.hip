@@ -698,7 +698,7 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
         // own position — no exec juggling around the store, no store of its own for the -1 (unless a half fills its last pass to the
         // last lane: the caller's business, see `full` below).  What idle lanes write beyond the -1 is overwritten by the rows that
         // follow, except for up to 64 entries behind the last row of a block with NJ <= 2: the tail traceback's window is shortened
-        // by as much (rows with more passes guard their stores).  FAST 1: 1 <= slots <= 31 in both halves, one pass; FAST 2: 1 <= slots
+        // by as much (rows with more passes guard their stores).  FAST 1: 1 <= slots <= 32 in both halves, one pass; FAST 2: 1 <= slots
         // <= 63, two passes; FAST 0: anything.
         auto row_passes = [&](const int NJ, const int ns_a, const int ns_b, auto fast_tag) __attribute__((always_inline)) {
             constexpr int FAST = decltype(fast_tag)::value;
@@ -716,10 +716,7 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                     amask = j == 0 ? (bits_at<0>(min(ns_a, 32)) | bits_at<32>(min(ns_b, 32)))
                                    : (bits_at<0>(max(ns_a, 32) - 32) | bits_at<32>(max(ns_b, 32) - 32));
                 } else if (FAST == 1) {
-                    unsigned int ma, mb;
-                    asm("s_bfm_b32 %0, %1, 0" : "=s"(ma) : "s"(ns_a));
-                    asm("s_bfm_b32 %0, %1, 0" : "=s"(mb) : "s"(ns_b));
-                    amask = ((unsigned long long)mb << 32) | ma;
+                    amask = bits_at<0>(ns_a) | bits_at<32>(ns_b);
                 } else {
                     amask = clamped_bits_at<0>(ns_a - 32 * j) | clamped_bits_at<32>(ns_b - 32 * j);
                 }
@@ -802,7 +799,7 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
             // the slot counts, which are on the scalar unit anyway.  One-pass rows run in a loop of their own.
             int rows_left = min(__builtin_amdgcn_readlane(dlim - d, 0), __builtin_amdgcn_readlane(dlim - d, 32));
             const int lim_a = __builtin_amdgcn_readlane(band_tol, 0) + 1, lim_b = __builtin_amdgcn_readlane(band_tol, 32) + 1;
-            const int one_a = min(lim_a, 31), one_b = min(lim_b, 31);
+            const int one_a = min(lim_a, 32), one_b = min(lim_b, 32);
             const int two_a = min(lim_a, 63), two_b = min(lim_b, 63);
             typedef std::integral_constant<int, 0> fast0;
             typedef std::integral_constant<int, 1> fast1;
@@ -812,16 +809,18 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                 while (((rows_left - 1) | (one_a - ns_a) | (one_b - ns_b)) >= 0) {
                     DWS_ROW(~0ull, ns_a, ns_b, 1);
                     rows_left -= 1;
-                    row_passes(1, ns_a, ns_b, fast1{});
-                    band_update(1, last_m0, last_mp, std::true_type{}, ns_a, ns_b);
+                    const bool full = ((ns_a | ns_b) & 32) != 0;       // a half has all of its 32 lanes on diagonals: nobody stores the entry
+                    row_passes(1, ns_a, ns_b, fast1{});                //   behind its row (the other half's idle lane rewrites its own)
                     lin_l += row_bytes;
+                    if (full) ring_st(rbase, lin_l - 2u * sl - 2u, sepv);
+                    band_update(1, last_m0, last_mp, std::true_type{}, ns_a, ns_b);
                     if (ended) break;
                     d += 1;
                     __builtin_amdgcn_wave_barrier();
                 }
                 if (ended) break;
-                // two-pass rows: a half has 32 .. 63 slots
-                while ((((rows_left - 1) | (two_a - ns_a) | (two_b - ns_b)) >= 0) && max(ns_a, ns_b) >= 32) {
+                // two-pass rows: a half has 33 .. 63 slots
+                while ((((rows_left - 1) | (two_a - ns_a) | (two_b - ns_b)) >= 0) && max(ns_a, ns_b) > 32) {
                     DWS_ROW(~0ull, ns_a, ns_b, 2);
                     NJ = 2;
                     rows_left -= 1;

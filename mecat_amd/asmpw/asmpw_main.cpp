@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <string>
 #include <thread>
 #include <vector>
@@ -55,49 +56,63 @@ struct Reads {                       // one fasta block: 2-bit volume (one pad b
 
 // load_read / load_fastq (:388-409, :982-1010): ">header" line, one sequence line; lower case is upper-cased
 static void load_block(const std::string& path, int first_no, Reads* R) {
-    FILE* f = fopen(path.c_str(), "r");
+    FILE* f = fopen(path.c_str(), "rb");
     if (!f) DIE("cannot open '%s': %s", path.c_str(), strerror(errno));
+    std::vector<char> buf;
+    {
+        if (fseek(f, 0, SEEK_END) != 0) DIE("cannot read '%s'", path.c_str());
+        const long sz = ftell(f);
+        rewind(f);
+        buf.resize((size_t)std::max(0L, sz));
+        if (sz > 0 && fread(buf.data(), 1, (size_t)sz, f) != (size_t)sz) DIE("cannot read '%s'", path.c_str());
+        fclose(f);
+    }
+    static int8_t code[256];
+    static bool code_ready = false;
+    if (!code_ready) {
+        memset(code, -1, sizeof(code));
+        code[(int)'A'] = code[(int)'a'] = 0; code[(int)'C'] = code[(int)'c'] = 1; code[(int)'G'] = code[(int)'g'] = 2; code[(int)'T'] = code[(int)'t'] = 3;
+        code_ready = true;
+    }
     R->first_no = first_no;
     R->offs.clear();
-    std::vector<uint8_t> codes;
-    char* line = NULL;
-    size_t cap = 0;
-    ssize_t n;
+    R->pac.assign(buf.size() / 4 + 16, 0);       // (never more bases + pads than bytes in the file)
     int64_t at = 0;
     bool want_seq = false;
-    while ((n = getline(&line, &cap, f)) > 0) {
-        while (n > 0 && (line[n - 1] == '\n' || line[n - 1] == '\r')) --n;
+    const char* p = buf.data();
+    const char* const end = p + buf.size();
+    while (p < end) {
+        const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+        const char* le = nl ? nl : end;
+        const char* next = nl ? nl + 1 : end;
+        while (le > p && le[-1] == '\r') --le;
+        const int64_t n = le - p;
         if (!want_seq) {
-            if (n == 0) continue;
-            if (line[0] != '>') DIE("%s: a header line was expected", path.c_str());
-            want_seq = true;
+            if (n > 0) {
+                if (p[0] != '>') DIE("%s: a header line was expected", path.c_str());
+                want_seq = true;
+            }
+            p = next;
             continue;
         }
+        if (at + n + 1 > 2140000000LL) DIE("%s: more than 2.14 G bases in one block", path.c_str());
         mhip_offset_t o;
         o.offset = (int)at;
         o.size = (int)n;
-        for (ssize_t i = 0; i < n; ++i) {
-            int c;
-            switch (line[i]) {
-            case 'A': case 'a': c = 0; break;
-            case 'C': case 'c': c = 1; break;
-            case 'G': case 'g': c = 2; break;
-            case 'T': case 't': c = 3; break;
-            default: DIE("%s: base '%c' in read %d: only A, C, G, T are supported on this path", path.c_str(), line[i], first_no + (int)R->offs.size()); c = 0;
-            }
-            codes.push_back((uint8_t)c);
+        uint8_t* pac = R->pac.data();
+        for (int64_t i = 0; i < n; ++i) {
+            const int c = code[(unsigned char)p[i]];
+            if (c < 0) DIE("%s: base '%c' in read %d: only A, C, G, T are supported on this path", path.c_str(), p[i], first_no + (int)R->offs.size());
+            const int64_t idx = at + i;
+            pac[idx >> 2] |= (uint8_t)(c << ((~idx & 3) << 1));
         }
-        codes.push_back(0);                      // the pad base = the tool's NUL behind every read
-        at += n + 1;
-        if (at > 2140000000LL) DIE("%s: more than 2.14 G bases in one block", path.c_str());
+        at += n + 1;                             // the pad base (code 0) = the tool's NUL behind every read
         R->offs.push_back(o);
         want_seq = false;
+        p = next;
     }
-    free(line);
-    fclose(f);
     R->num_bases = (int)at;
-    R->pac.assign(((size_t)at + 3) / 4, 0);
-    for (int64_t i = 0; i < at; ++i) R->pac[(size_t)(i >> 2)] |= (uint8_t)(codes[(size_t)i] << ((~i & 3) << 1));
+    R->pac.resize(((size_t)at + 3) / 4);
 }
 
 // string_check (:199-281): gaps of the left pair are moved over runs that also match one column further on.  a / b = the aligned
@@ -179,15 +194,25 @@ int main(int argc, char** argv) {
     }
     auto block_path = [&](int id) { char t[32]; snprintf(t, sizeof(t), "/%06d.fasta", id); return dir + t; };
 
+    // MECAT_ASMPW_TIMES=1: where the wall time went, on stderr at the end
+    const bool times = getenv("MECAT_ASMPW_TIMES") != NULL;
+    double t_load = 0, t_index = 0, t_seed = 0, t_jobs = 0, t_extend = 0, t_host = 0, t_flush = 0;
+    size_t n_jobs = 0;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
     mhip_ctx* ctx = NULL;
     const int device = getenv("MECAT_HIP_DEVICE") ? atoi(getenv("MECAT_HIP_DEVICE")) : 0;
     MCHK(mhip_ctx_create(device, NULL, &ctx));
+    const double t_ctx = now() - t_begin;
     Reads blk;
+    double t0 = now();
     load_block(block_path(start), first_read[(size_t)start - 1], &blk);
+    t_load += now() - t0; t0 = now();
     mhip_volume* dblk = NULL;
     MCHK(mhip_volume_upload(ctx, blk.pac.data(), blk.offs.data(), (int)blk.offs.size(), blk.num_bases, blk.first_no, &dblk));
     mhip_index* idx = NULL;
     MCHK(mhip_index_build_ex(ctx, dblk, 256, &idx));
+    t_index += now() - t0;
 
     std::vector<FILE*> out((size_t)threads);
     for (int t = 0; t < threads; ++t) {
@@ -202,9 +227,11 @@ int main(int argc, char** argv) {
         const Reads* qs = &blk;
         mhip_volume* dq = dblk;
         if (bi != start) {
+            t0 = now();
             load_block(block_path(bi), first_read[(size_t)bi - 1], &qs_own);
             qs = &qs_own;
             MCHK(mhip_volume_upload(ctx, qs->pac.data(), qs->offs.data(), (int)qs->offs.size(), qs->num_bases, qs->first_no, &dq));
+            t_load += now() - t0;
         }
         const int nq = (int)qs->offs.size();
         int maxlen = 16;
@@ -212,53 +239,51 @@ int main(int argc, char** argv) {
         for (const mhip_offset_t& o : qs->offs) maxlen = std::max(maxlen, o.size);
         const int cap = ((maxlen * 2 + 64 + 15) / 16) * 16;          // columns of one direction <= bases of both reads on that side
         const size_t dir_words = (size_t)cap / 16;
-        const int slab = std::max(1, getenv("MECAT_ASMPW_SLAB") ? atoi(getenv("MECAT_ASMPW_SLAB")) : 1000);
+        // Candidates are found for `slab` query reads per launch (one wave per read; 2 048 by default: more resident waves thrash on their record arrays); their extensions
+        // run in chunks of at most `chunk` candidates (the edit scripts of a chunk are what the host buffers hold), and the string work
+        // of a chunk runs on the -T threads while the device extends the next one.
+        const int slab = std::max(1, getenv("MECAT_ASMPW_SLAB") ? atoi(getenv("MECAT_ASMPW_SLAB")) : 2048);
+        const size_t chunk_bytes = (size_t)std::max(1, getenv("MECAT_ASMPW_CHUNK_MB") ? atoi(getenv("MECAT_ASMPW_CHUNK_MB")) : 128) << 20;
+        const size_t chunk = std::max<size_t>(64, chunk_bytes / (2 * dir_words * sizeof(uint32_t)));
         std::vector<mhip_asm_candidate> cands((size_t)slab * 100);
         std::vector<int32_t> counts((size_t)slab);
-        for (int rb = 0; rb < nq; rb += slab) {
-            const int re = std::min(nq, rb + slab), nr = re - rb;
-            MCHK(mhip_asm_seed_reads_ex(ctx, idx, dblk, dq, rb, re, tool.gate, tool.maxc, cands.data(), counts.data()));
-            std::vector<size_t> first((size_t)nr + 1, 0);
-            for (int r = 0; r < nr; ++r) first[(size_t)r + 1] = first[(size_t)r] + (size_t)counts[(size_t)r];
-            const size_t nj = first[(size_t)nr];
-            if (nj == 0) continue;
-            std::vector<mhip_asm_job> jobs(nj);
-            for (int r = 0; r < nr; ++r)
-                for (int k = 0; k < counts[(size_t)r]; ++k) {
-                    const mhip_asm_candidate& c = cands[(size_t)r * 100 + k];
-                    mhip_asm_job j;
-                    const int x0 = c.loc1 - 1 - c.readstart;        // the seed 13-mer's first base inside the subject read
-                    j.xid = c.readno; j.yid = rb + r; j.chain = c.chain;
-                    j.lx = x0 + SEED - 1; j.ly = c.loc2 + SEED - 1; j.lnx = c.left1; j.lny = c.left2;       // :736
-                    j.rx = x0; j.ry = c.loc2; j.rnx = c.right1; j.rny = c.right2;                            // :793
-                    j.pad = 0;
-                    jobs[first[(size_t)r] + (size_t)k] = j;
-                }
-            std::vector<int32_t> dirs(nj * 2 * 6);
-            std::vector<uint32_t> ops(nj * 2 * dir_words);
-            MCHK(mhip_asm_extend(ctx, dblk, dq, jobs.data(), (int)nj, cap, dirs.data(), ops.data()));
-
-            // ---- per candidate: the tool's string work and its output line (:843-948)
+        struct Chunk {                                   // one extension call and what the host stage needs of it
+            std::vector<mhip_asm_job> jobs;
+            std::vector<mhip_asm_candidate> cand;
+            std::vector<int> qrid;                       // query read (index in its block) of every job
+            int32_t* dirs = NULL;
+            uint32_t* ops = NULL;
+            std::thread post;
+        } ck[2];
+        for (Chunk& c : ck) {
+            c.dirs = (int32_t*)malloc(chunk * 2 * 6 * sizeof(int32_t));
+            c.ops = (uint32_t*)malloc(chunk * 2 * dir_words * sizeof(uint32_t));
+            if (!c.dirs || !c.ops) DIE("out of memory (MECAT_ASMPW_CHUNK_MB)");
+        }
+        int cur = 0;
+        // ---- per candidate: the tool's string work and its output line (:843-948)
+        auto host_stage = [&](Chunk* C) {
+            const double th0 = now();
+            const size_t nj = C->jobs.size();
             std::vector<std::string> text((size_t)threads);
-            std::atomic<int> next_read{0};
+            std::atomic<size_t> next_job{0};
             auto worker = [&](int t) {
                 std::string& o = text[(size_t)t];
                 std::string L1, L2, R1, R2, g1, g2, O1, O2;
                 char line[256];
                 for (;;) {
-                    const int r = next_read.fetch_add(1);
-                    if (r >= nr) break;
-                    const int qrid = rb + r, read_len = qs->offs[(size_t)qrid].size, read_name = qs->first_no + qrid;
-                    for (int k = 0; k < counts[(size_t)r]; ++k) {
-                        const size_t ji = first[(size_t)r] + (size_t)k;
-                        const mhip_asm_candidate& c = cands[(size_t)r * 100 + k];
-                        const mhip_asm_job& jb = jobs[ji];
+                    const size_t j0 = next_job.fetch_add(64);
+                    if (j0 >= nj) break;
+                    for (size_t ji = j0; ji < std::min(nj, j0 + 64); ++ji) {
+                        const int qrid = C->qrid[ji], read_len = qs->offs[(size_t)qrid].size, read_name = qs->first_no + qrid;
+                        const mhip_asm_candidate& c = C->cand[ji];
+                        const mhip_asm_job& jb = C->jobs[ji];
                         auto ybase = [&](int pos) {                 // base at position pos of the mapped strand
                             return jb.chain ? 3 - qs->base(qrid, read_len - 1 - pos) : qs->base(qrid, pos);
                         };
                         auto build = [&](int d, std::string& s1, std::string& s2) {
-                            const int cols = dirs[(ji * 2 + (size_t)d) * 6];
-                            const uint32_t* w = ops.data() + (ji * 2 + (size_t)d) * dir_words;
+                            const int cols = C->dirs[(ji * 2 + (size_t)d) * 6];
+                            const uint32_t* w = C->ops + (ji * 2 + (size_t)d) * dir_words;
                             s1.resize((size_t)cols); s2.resize((size_t)cols);
                             int x = d ? jb.rx : jb.lx, y = d ? jb.ry : jb.ly;
                             const int step = d ? 1 : -1;
@@ -319,6 +344,51 @@ int main(int argc, char** argv) {
                 if (!text[(size_t)t].empty() && fwrite(text[(size_t)t].data(), 1, text[(size_t)t].size(), f) != text[(size_t)t].size()) DIE("write error");
             }
             next_file = (next_file + 1) % threads;
+            t_host += now() - th0;
+        };
+        auto flush = [&](Chunk* C) {                     // extend the chunk's candidates, then hand it to the host stage
+            if (C->jobs.empty()) return;
+            const double tf0 = now();
+            MCHK(mhip_asm_extend(ctx, dblk, dq, C->jobs.data(), (int)C->jobs.size(), cap, C->dirs, C->ops));
+            t_extend += now() - tf0;
+            n_jobs += C->jobs.size();
+            Chunk* prev = &ck[cur ^ 1];
+            if (prev->post.joinable()) prev->post.join();          // the host stages run one after the other (they share the output files)
+            C->post = std::thread(host_stage, C);
+            cur ^= 1;
+            Chunk* nxt = &ck[cur];
+            if (nxt->post.joinable()) nxt->post.join();
+            nxt->jobs.clear(); nxt->cand.clear(); nxt->qrid.clear();
+            t_flush += now() - tf0;
+        };
+        for (int rb = 0; rb < nq; rb += slab) {
+            const int re = std::min(nq, rb + slab), nr = re - rb;
+            t0 = now();
+            MCHK(mhip_asm_seed_reads_ex(ctx, idx, dblk, dq, rb, re, tool.gate, tool.maxc, cands.data(), counts.data()));
+            t_seed += now() - t0;
+            const double tj0 = now(), tfl0 = t_flush;
+            for (int r = 0; r < nr; ++r)
+                for (int k = 0; k < counts[(size_t)r]; ++k) {
+                    Chunk* C = &ck[cur];
+                    const mhip_asm_candidate& c = cands[(size_t)r * 100 + k];
+                    mhip_asm_job j;
+                    const int x0 = c.loc1 - 1 - c.readstart;        // the seed 13-mer's first base inside the subject read
+                    j.xid = c.readno; j.yid = rb + r; j.chain = c.chain;
+                    j.lx = x0 + SEED - 1; j.ly = c.loc2 + SEED - 1; j.lnx = c.left1; j.lny = c.left2;       // :736
+                    j.rx = x0; j.ry = c.loc2; j.rnx = c.right1; j.rny = c.right2;                            // :793
+                    j.pad = 0;
+                    C->jobs.push_back(j);
+                    C->cand.push_back(c);
+                    C->qrid.push_back(rb + r);
+                    if (C->jobs.size() >= chunk) flush(C);
+                }
+            t_jobs += (now() - tj0) - (t_flush - tfl0);
+        }
+        flush(&ck[cur]);
+        for (Chunk& c : ck) {
+            if (c.post.joinable()) c.post.join();
+            free(c.dirs);
+            free(c.ops);
         }
         if (dq != dblk) mhip_volume_free(dq);
     }
@@ -327,5 +397,9 @@ int main(int argc, char** argv) {
     mhip_index_free(idx);
     mhip_volume_free(dblk);
     mhip_ctx_destroy(ctx);
+    if (times)
+        fprintf(stderr, "[mecat2asmpw] %.2f s: context %.2f, blocks read + packed + uploaded %.2f, table %.2f, candidates %.2f, jobs %.2f, extension %.2f (%zu candidates), "
+                        "strings + lines on %d threads %.2f (beside the device's next chunk; the device stage waited %.2f for them)\n", now() - t_begin, t_ctx, t_load, t_index, t_seed,
+                t_jobs, t_extend, n_jobs, threads, t_host, t_flush - t_extend);
     return 0;
 }

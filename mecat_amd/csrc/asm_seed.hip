@@ -379,7 +379,12 @@ int mhip_asm_seed_reads_ex(mhip_ctx* c, const mhip_index* idx, const mhip_volume
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
     const size_t per_wave = (size_t)(nseg + 8) * AREC * sizeof(short) + (size_t)nseg * (sizeof(int) + sizeof(short) + 2 * sizeof(int));
-    size_t waves = std::min<size_t>((size_t)c->num_cus * 16, std::max<size_t>(1, (free_b / 2) / per_wave));
+    // (measured on 80 Mbase blocks, 20 MB of records per wave: 24 GB and 48 GB of records are equally fast, 12 GB 45 % slower; with 48 GB
+    // one run in three took four times as long, with 80 GB every run — the random record updates then miss every level of address
+    // translation.  MECAT_ASM_RECORDS_GB overrides the 24.)
+    const char* gb = getenv("MECAT_ASM_RECORDS_GB");
+    const size_t budget = std::min<size_t>(free_b / 2, (size_t)(gb && atoi(gb) > 0 ? atoi(gb) : 24) << 30);
+    size_t waves = std::min<size_t>((size_t)c->num_cus * 16, std::max<size_t>(1, budget / per_wave));
     waves = std::min<size_t>(waves, (size_t)n);
     const unsigned grid = (unsigned)((waves + ASM_WAVES - 1) / ASM_WAVES);
     waves = (size_t)grid * ASM_WAVES;

@@ -178,8 +178,10 @@ def test_config5_nanopore_19_volume_grid(workdir):
     os.makedirs(wrk)
     pinned = sorted(int(i) for i in g["rows"])
     if not full:
-        for i in range(pinned[0]):
-            open(os.path.join(wrk, "r_%d" % i), "w").close()
+        # rows that are not pinned are skipped through the resume protocol (an existing r_<i> = "volume i is finished")
+        for i in range(len(g["volumes"])):
+            if i not in pinned:
+                open(os.path.join(wrk, "r_%d" % i), "w").close()
     secs = _run(["-j", "0", "-x", "1"], fa, out, wrk, threads=64)
     if "m4_row18" in g:
         # X-drop extension at this scale: grid row 18 = cell (18, 18) with `-j 1 -x 1 -g 1`, the rows before it planted as finished
@@ -199,6 +201,10 @@ def test_config5_nanopore_19_volume_grid(workdir):
         assert _sha_file(vols[i]["path"]) == g["volumes"][i]["sha256"]
         row = g["rows"][str(i)]
         assert _sorted_sha(os.path.join(wrk, "r_%d" % i)) == (row["lines"], row["sorted_sha256"]), "row %d" % i
+        for cell, c in row.get("cells", {}).items():      # .can field 1 = the query read (field 2 is the subject, of volume i)
+            j = int(cell.split(",")[1])
+            lo, hi = vols[j]["start_read_id"], vols[j]["start_read_id"] + vols[j]["num_reads"]
+            assert _sorted_sha(os.path.join(wrk, "r_%d" % i), "$1 >= %d && $1 < %d" % (lo, hi)) == (c["lines"], c["sorted_sha256"]), "cell " + cell
     if full:
         # size-independent properties over all 190 cells: subject < query, coordinates inside the reads, sdir == 0 (mecat2cns
         # asserts it, mecat_correction.cpp:423), every row file holds subjects of its own volume only, at most MAXC lines per

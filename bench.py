@@ -662,6 +662,29 @@ def main():
                 line["e2e"] = e2e_cli(args.workload, codes, lens, min(32, os.cpu_count() or 1))
             except Exception as e:  # noqa: BLE001
                 line["e2e"] = {"error": repr(e)[:300]}
+        # not part of the metric: mecat2canu's overlapper for corrected reads as the drop-in tool, end to end through its
+        # own command line on 20 000 synthetic corrected reads (161 Mbases, 2 blocks as canu lays them out); the unmodified tool on the same
+        # files, same machine, belongs to the CPU leg below
+        if world == 1 and not args.no_extras and args.workload == "config2":
+            try:
+                import shutil
+                import tempfile
+                ad = tempfile.mkdtemp(prefix="bench_asm_")
+                blocks, abases = W.asm_blocks_layout(ad, 20000, 8000, 5_000_000, 2, 77)
+                T = min(64, os.cpu_count() or 1)
+                alines, asecs, aerr = W.asm_tool_run(os.path.join(ROOT, "mecat_amd", "bin", "mecat2asmpw"), ad, T, 1, 2, env=dict(os.environ, MECAT_ASMPW_TIMES="1"))
+                line["asm_overlap"] = {"tool": "mecat2asmpw -T%d -S1 -E2" % T, "reads": 20000, "bases": abases, "overlaps": len(alines), "seconds": asecs,
+                                       "mbases_per_s": abases / 1e6 / asecs, "stages": [ln for ln in aerr.splitlines() if ln.startswith("[mecat2asmpw]")][-1:]}
+                if not args.no_cpu:
+                    ref = os.path.join(ROOT, "oracle", "_ref", "mecat2asmpw")
+                    if os.path.exists(ref):
+                        rlines, rsecs, _ = W.asm_tool_run(ref, ad, T, 1, 2)
+                        line["asm_overlap"]["cpu_baseline"] = {"kind": "reference", "threads": T, "seconds": rsecs, "identical_output": rlines == alines,
+                                                               "sample": "the unmodified tool (oracle/_ref/mecat2asmpw) on the same files, same host"}
+                        line["asm_overlap"]["speedup_vs_reference_threads"] = rsecs / asecs
+                shutil.rmtree(ad, ignore_errors=True)
+            except Exception as e:  # noqa: BLE001
+                line["asm_overlap"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_cpu:
             try:
                 c1 = cpu_baseline_config1()

@@ -134,3 +134,40 @@ def cns_templates(ec, num_reads, min_cov=4, min_size=5000):
     sel = np.concatenate([np.arange(first[t], first[t + 1]) for t in ids]) if len(ids) else np.zeros(0, np.int64)
     tb = np.concatenate([[0], np.cumsum(n_t[ids])]).astype(np.int64)
     return np.ascontiguousarray(rec[sel]), tb, ids
+
+
+def asm_blocks_layout(d, nreads, L, genome, nblocks, seed, err=0.02):
+    """corrected reads (2 % error) laid out as canu hands them to mecat2asmpw / mecat2trimpw (Overlapmecat2asmpw.pm:483-503): <d>/ovlprep
+    with one "-allreads -allbases -b <first> -e <last>" line per block and <d>/%06d.fasta, reads numbered from 1.
+    -> (blocks [(first, last)], total bases)"""
+    codes, lens = synth_reads(nreads, L, err, genome, seed, 0)
+    starts = np.concatenate([[0], np.cumsum(lens.astype(np.int64))])
+    per = (nreads + nblocks - 1) // nblocks
+    blocks = [(k * per + 1, min(nreads, (k + 1) * per)) for k in range(nblocks)]
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    with open(os.path.join(d, "ovlprep"), "w") as f:
+        for b, e in blocks:
+            f.write("-allreads -allbases -b %d -e %d\n" % (b, e))
+    for k, (b, e) in enumerate(blocks):
+        with open(os.path.join(d, "%06d.fasta" % (k + 1)), "wb") as f:
+            for rid in range(b, e + 1):
+                f.write(b">%d\n" % rid + lut[codes[starts[rid - 1]: starts[rid]]].tobytes() + b"\n")
+    return blocks, int(lens.sum())
+
+
+def asm_tool_run(exe, d, threads, start, nblocks, env=None, timeout=1800):
+    """one run of an overlapper through its own command line -> (sorted output lines, seconds, stderr)"""
+    import time
+    t0 = time.time()
+    r = subprocess.run([exe, "-P" + d, "-T%d" % threads, "-S%d" % start, "-E%d" % nblocks], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True,
+                       env=env, timeout=timeout)
+    secs = time.time() - t0
+    if r.returncode != 0:
+        raise RuntimeError("%s failed: %s" % (exe, r.stderr[-500:]))
+    lines = []
+    for t in range(threads):
+        p = os.path.join(d, "%d_%d.r" % (start, t))
+        lines += open(p).read().splitlines()
+        os.unlink(p)
+    lines.sort()
+    return lines, secs, r.stderr

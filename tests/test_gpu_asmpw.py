@@ -131,3 +131,23 @@ def test_drop_in_tool_equals_the_reference_output(tmp_path, tool, start):
         assert not bad, bad[:3]
     assert len(lines) == m["lines"]
     assert hashlib.sha256(("\n".join(lines) + "\n").encode()).hexdigest() == m["sha256"]
+
+
+@pytest.mark.parametrize("tool,start", [("mecat2asmpw", 1), ("mecat2trimpw", 2)])
+def test_drop_in_tool_equals_the_reference_run_on_this_machine(tmp_path, tool, start):
+    """Beyond the golden set: 4 000 corrected reads (32 Mbases, 32x of a 1 Mb genome) in two blocks, the UNMODIFIED tool (oracle/_ref/<tool>,
+    built in the container from /root/reference/mecat2canu/src/mecat2asmpw by oracle/Makefile; the binary travels with the repo) and the
+    drop-in run one after the other on this machine: sorted outputs equal line by line (~118 000 / ~40 000 lines)."""
+    from mecat_amd import workload as W
+    ref = os.path.join(H.ROOT, "oracle", "_ref", tool)
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref/%s is not built (make -C oracle ref, in the container)" % tool)
+    d = str(tmp_path)
+    blocks, bases = W.asm_blocks_layout(d, 4000, 8000, 1_000_000, 2, 77)
+    want, ref_s, _ = W.asm_tool_run(ref, d, 32, start, 2)
+    got, dev_s, _ = W.asm_tool_run(os.path.join(H.ROOT, "mecat_amd", "bin", tool), d, 32, start, 2)
+    assert len(want) > 30000
+    assert len(got) == len(want)
+    bad = [(a, b) for a, b in zip(got, want) if a != b]
+    assert not bad, bad[:3]
+    print("%s -S%d: %d lines, reference %.1f s on 32 threads, device tool %.1f s" % (tool, start, len(want), ref_s, dev_s))

@@ -523,7 +523,7 @@ def main():
                                    "nominal_mix_ceiling": nominal, "frac_of_nominal": ach / nominal})
                         vi["note"] = ("peak = 1 / (f4 / R4 + (1 - f4) / R2): R2, R4 = issue rates of the 2-cycle and 4-cycle VALU classes measured live by "
                                       "valu_peak, f4 = share of 4-cycle-class instructions in dw_extend2's d-row loops; nominal = the same with the "
-                                      "data-sheet rates (1024 SIMDs x 2.4 GHz / 2 and / 4); 7 waves per SIMD (72 VGPRs, 21.5 KB LDS per 4 waves)")
+                                      "data-sheet rates (1024 SIMDs x 2.4 GHz / 2 and / 4); 8 waves per SIMD (64 VGPRs, 19 KB LDS per 4 waves)")
                 except (OSError, ValueError, KeyError, TypeError):
                     pass
             roof["valu_issue"] = vi

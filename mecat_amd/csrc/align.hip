@@ -650,9 +650,11 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                     const int la = 63 - __builtin_clzll(wa), lb = 63 - __builtin_clzll(wb);
                     sa = la - fa + 2;
                     sb = lb - fb + 2;
-                    const int pk = hh ? (fb | (lb << 8)) : (fa | (la << 8));
+                    int pka = fa | (sa << 8), pkb = fb | (sb << 8);          // (first, new slot count: last = first + slots - 2)
+                    asm("" : "+s"(pka), "+s"(pkb));                          // (kept packed: the compiler would select the four values one by one)
+                    const int pk = hh ? pkb : pka;
                     first = pk & 0xff;
-                    last = pk >> 8;
+                    last = first + (pk >> 8) - 2;
                 } else {
                     const unsigned int lo32 = (unsigned int)(q0 >> (hh << 5)), hi32 = (unsigned int)(q1 >> (hh << 5));
                     unsigned int fl, fh, ll, lh;

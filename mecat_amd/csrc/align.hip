@@ -411,28 +411,31 @@ __global__ __launch_bounds__(AL_BLOCK) void dw_extend(const uint32_t* __restrict
 // ------------------------------------------------------------------------------------------------------------------
 // dw_extend2 — two (candidate, direction) units per wave, one per 32-lane half.  (-DMECAT_DW_STATS: per-row debug counters.)
 //
-// The adaptive band keeps ~25 diagonals alive on average (config 2: 6.0e9 rows, 1.5e11 cells), so a whole wave per
+// The adaptive band keeps ~26 diagonals alive on average (config 2: 6.0e9 rows, 1.5e11 cells), so a whole wave per
 // unit leaves 60 % of the lanes idle and the kernel is VALU-issue bound.  Here each half-wave runs its own unit with its
 // own block and row counter: one pass over the row code advances both halves by one d-row of their respective blocks; a
 // half whose rows ended does its tail traceback, accounting and next block setup (or pulls a new unit) while the other
 // half is masked off, and rejoins the row code at its row 0.  Everything that is a
-// scalar in the one-unit kernel (band limits, best point, block sizes ...) is a per-half-uniform VGPR value here;
-// per-half row maxima use a 5-step DPP chain (quad swaps, half/row mirrors, row_bcast:15) + two readlanes, first-index
-// decisions use the two 32-bit halves of a ballot.  d-rows live in a 1024-entry circular buffer per half (rows are
-// packed back to back, wrapping: the average row is 25 entries, so ~40 rows stay traceable); the rare block whose tail
-// traceback needs an overwritten row is re-run by the one-unit code path with rows spilled to global scratch.
+// scalar in the one-unit kernel (band limits, best point, block sizes ...) is a per-half-uniform VGPR value here (the band's
+// first diagonal and the two ring positions with the lane's own offset already added); what steers the row loops — rows left, slot
+// counts, lane masks of a pass — lives on the scalar unit.  Per-half row maxima: four mirrored DPP steps + v_permlane16_swap;
+// first / last qualifying diagonal of the band update from the two 32-bit halves of a ballot.  d-rows live in a 1024-entry
+// circular buffer per half, packed back to back with one entry between two rows that is the row record (see row_passes): ~37 rows
+// stay traceable; the rare block whose tail traceback needs an overwritten row, or that never reached an end of either sequence,
+// is handed over to the one-unit kernel (dw_extend), which keeps every row.
 #ifndef RCAP
 #define RCAP 1024
 #endif
 #define SEQ_WORDS2 48          // 736 bases + one 16-base window, 16 bases per word, no pad word
-// Per-half LDS, 2.5 KB incl. the ring below (20 KB per workgroup of four waves: eight workgroups per CU, 160 KB exactly).  There is no V[] array: row d reads the
-// furthest x of diagonals k - 1 and k + 1 of row d - 1 straight from that row's entries in the ring (they are always inside its
-// band), at pbase + tt and pbase + tt + 1 with pbase uniform per half.
+// Per-half LDS, 2.4 KB incl. the ring below (19 KB per workgroup of four waves: eight workgroups per CU).  There is no V[] array: row d
+// reads the furthest x of diagonals k - 1 and k + 1 of row d - 1 straight from that row's entries in the ring, at pbase + tt and
+// pbase + tt + 1 (inside the band they are entries of that row; at its two edges the entry between rows or a dropped diagonal: see
+// the start point in row_passes).
 struct HalfLds {
     uint32_t Qp[SEQ_WORDS2];
     uint32_t Tp[SEQ_WORDS2];
 };
-// The ring of d-rows of a half: u16 rows packed back to back, wrapping (the first two entries of a block are the zeros row 0 reads).
+// The ring of d-rows of a half: 16-bit rows packed back to back, wrapping (in front of row 0: -1, 0, -1, see the block set-up).
 // It is its own 2 KB-aligned LDS array so that the address of ring byte position p is `base | (p & 0x7fe)`: one v_and_or_b32.
 // Positions (lin, pbase, rlin) are kept in bytes.
 typedef __attribute__((address_space(3))) uint16_t lds_u16_t;
@@ -447,7 +450,7 @@ __device__ __forceinline__ void ring_st(uint32_t base, uint32_t pos, int x) { *(
 // maximum in every lane; v_permlane16_swap (gfx950) then exchanges rows 1 <-> 0 and 3 <-> 2 between two copies.
 // Written with the DPP builtin (old = the identity of max, so the DPP combiner fuses mov_dpp + max into one v_max_i32_dpp) rather
 // than as one asm block: the compiler then fills the two wait states each step needs with independent instructions of the row
-// (row record, masks) instead of s_nops.
+// instead of s_nops (the first step is asm, three-address: its input stays live for the band update without a copy).
 template <int CTRL> __device__ __forceinline__ int dpp_max_step(int v) {
     return max(v, __builtin_amdgcn_update_dpp((int)0x80000000, v, CTRL, 0xf, 0xf, false));
 }

@@ -26,6 +26,7 @@ import ctypes as C
 import json
 import os
 import re
+import shutil
 import subprocess
 import sys
 import tempfile
@@ -667,8 +668,6 @@ def main():
         # files, same machine, belongs to the CPU leg below
         if world == 1 and not args.no_extras and args.workload == "config2":
             try:
-                import shutil
-                import tempfile
                 ad = tempfile.mkdtemp(prefix="bench_asm_")
                 blocks, abases = W.asm_blocks_layout(ad, 20000, 8000, 5_000_000, 2, 77)
                 T = min(64, os.cpu_count() or 1)

@@ -184,3 +184,20 @@ def test_cli_blank_line_rules_of_the_reference_reader(tmp_path):
                 assert rr.returncode != 0, name
             else:
                 assert open(os.path.join(rw, "vol0"), "rb").read() == open(os.path.join(wrk, "vol0"), "rb").read(), name
+
+
+def test_bench_has_no_function_local_import_of_a_module_level_name():
+    """a function-local `import x` makes x local to the whole function: a use before that statement (another branch of main()) then fails
+    with UnboundLocalError — which is how the N > 1 path of bench.py broke once"""
+    import ast
+    t = ast.parse(open(os.path.join(H.ROOT, "bench.py")).read())
+    top = set()
+    for n in t.body:
+        if isinstance(n, (ast.Import, ast.ImportFrom)):
+            top.update(a.asname or a.name.split(".")[0] for a in n.names)
+    for f in (n for n in t.body if isinstance(n, ast.FunctionDef)):
+        local = set()
+        for n in ast.walk(f):
+            if isinstance(n, (ast.Import, ast.ImportFrom)):
+                local.update(a.asname or a.name.split(".")[0] for a in n.names)
+        assert not (local & top), (f.name, sorted(local & top))

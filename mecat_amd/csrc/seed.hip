@@ -1845,6 +1845,15 @@ static int seed_batch(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref
 #ifdef FS_PROF
         for (int i = 0; i < 12; ++i) fprintf(stderr, "FS_PROF phase %d: F %.1f R %.1f us per strand\n", i, (double)ctl.prof[i] / 50.0 / ns, (double)ctl.prof[i + 16] / 50.0 / ns);
 #endif
+        if (getenv("MECAT_SEED_STATS")) {       // development (tools/dev/seed_stats.py): per-strand sizes of the strand pipeline
+            std::vector<uint32_t> h[5];
+            const uint32_t* src[5] = {A.strand_hits_all, F.strand_hits, F.nseg, F.nrec, F.ngated};
+            for (int i = 0; i < 5; ++i) { h[i].resize((size_t)ns); HIPCHK(hipMemcpy(h[i].data(), src[i], sizeof(uint32_t) * (size_t)ns, hipMemcpyDeviceToHost)); }
+            std::vector<int32_t> fu((size_t)ns);
+            HIPCHK(hipMemcpy(fu.data(), A.fused, sizeof(int32_t) * (size_t)ns, hipMemcpyDeviceToHost));
+            for (int s = 0; s < ns; ++s)
+                if (fu[(size_t)s]) fprintf(stderr, "SEEDSTAT %d %u %u %u %u %u\n", s & 1, h[0][(size_t)s], h[1][(size_t)s], h[2][(size_t)s], h[3][(size_t)s], h[4][(size_t)s]);
+        }
     }
 
     // ---- the kernel chain for every other strand

@@ -59,7 +59,8 @@ def _run_ranks(nranks, fn):
     return out
 
 
-@pytest.mark.parametrize("nranks,chunk,rb,re,shift", [(2, 500, 0, None, 0), (3, 64, 0, None, 1), (2, 64, 640, 2500, 5), (3, 500, 500, None, 2)])
+@pytest.mark.parametrize("nranks,chunk,rb,re,shift", [(2, 500, 0, None, 0), (3, 64, 0, None, 1), (2, 64, 640, 2500, 5), (3, 500, 500, None, 2),
+                                                        (4, 64, 0, None, 3), (8, 500, 0, None, 0), (8, 64, 128, 2600, 7)])
 def test_sharded_seeding_and_extension_equal_single_gpu(data, nranks, chunk, rb, re, shift):
     M, vol, idx, p = data["M"], data["vol"], data["idx"], data["p"]
     re = data["n"] if re is None else re
@@ -93,7 +94,7 @@ def test_sharded_seeding_and_extension_equal_single_gpu(data, nranks, chunk, rb,
         assert nbytes < (48 + 32) * total + 4 * (re - rb + nranks * chunk) * 2 + 4096, (nbytes, total)
 
 
-@pytest.mark.parametrize("nranks", [2, 3])
+@pytest.mark.parametrize("nranks", [2, 3, 4, 8])      # (bench.py and the driver shard the index from four ranks on)
 def test_sharded_index_build_equals_single_build(data, nranks):
     """mhip_index_build_sharded: every rank builds the buckets of its own k-mer key range, positions and table slices are gathered,
     and every rank must hold the table mhip_index_build makes — bucket boundaries, positions, segment slots and bucket records, array

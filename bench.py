@@ -671,7 +671,9 @@ def main():
                 ad = tempfile.mkdtemp(prefix="bench_asm_")
                 blocks, abases = W.asm_blocks_layout(ad, 20000, 8000, 5_000_000, 2, 77)
                 T = min(64, os.cpu_count() or 1)
-                # (best of two runs: the first process on a device that has just taken back tens of GB from this one can spend seconds in hipMalloc)
+                # (best of two runs after a pause: a process started on a device that has just taken back tens of GB from this one and from
+                # the e2e runs can spend seconds in hipMalloc while the driver reclaims the pages)
+                time.sleep(5.0)
                 runs = [W.asm_tool_run(os.path.join(ROOT, "mecat_amd", "bin", "mecat2asmpw"), ad, T, 1, 2, env=dict(os.environ, MECAT_ASMPW_TIMES="1")) for _ in range(2)]
                 alines, asecs, aerr = min(runs, key=lambda r: r[1])
                 line["asm_overlap"] = {"tool": "mecat2asmpw -T%d -S1 -E2" % T, "reads": 20000, "bases": abases, "overlaps": len(alines), "seconds": asecs,

@@ -203,6 +203,13 @@ int64_t mhip_comm_bytes_received(const mhip_comm* comm);      /* payload + count
  * them `rank` owns and the first one; local index i is read first + (i / chunk) * chunk * nranks + i % chunk */
 int  mhip_shard_local_count(int rid_begin, int rid_end, int chunk, int cell_shift, int rank, int nranks);
 int  mhip_shard_first_read(int rid_begin, int rid_end, int chunk, int cell_shift, int rank, int nranks);
+/* rows mode (#volumes >= ranks: a grid row per GPU, no data moves): the static deal of the rows still to do.  Row i of the upper
+ * triangular volume grid holds the cells (i, i) .. (i, num_vols - 1) (mecat2pw/pw.cpp:65-81, pw_impl.cpp:859-879), so a row costs
+ * num_vols - i cell visits (+ one index build, priced at a quarter of a cell); rows are taken heaviest first and each goes to the rank
+ * with the least work so far (ties: the lowest rank) — 19 rows over 8 ranks: heaviest rank 26 cells against a mean of 23.75, where the
+ * cyclic deal i mod P gave 33.  Every rank derives the same deal from the split marker alone.  owner[i] = the rank of row i, -1 for a
+ * row that is not in todo[].  Returns the heaviest rank's cell count, -1 on bad arguments. */
+int  mhip_shard_deal_rows(int num_vols, const int* todo, int ntodo, int nranks, int* owner /*[num_vols]*/);
 /* mhip_seed_reads_dev for the local reads of such a shard (first = mhip_shard_first_read, n = mhip_shard_local_count) */
 int  mhip_seed_reads_chunked_dev(mhip_ctx* ctx, const mhip_index* idx, const mhip_volume* ref, const mhip_volume* reads, int first,
                                  int chunk, int nranks, int n, const mhip_params* p, void* d_out, void* d_out_counts);

@@ -22,6 +22,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -458,6 +459,31 @@ int mhip_shard_first_read(int rid_begin, int rid_end, int chunk, int cell_shift,
     if (chunk < 1 || nranks < 1 || rid_begin % chunk != 0) return -1;
     const Shard s{rid_begin, rid_end, chunk, cell_shift, nranks};
     return s.rid0(rank);
+}
+
+// rows mode: longest-processing-time deal of the grid rows still to do (mecat_hip.h)
+int mhip_shard_deal_rows(int num_vols, const int* todo, int ntodo, int nranks, int* owner) {
+    if (num_vols < 0 || ntodo < 0 || nranks < 1 || (ntodo && !todo) || (num_vols && !owner)) return -1;
+    for (int i = 0; i < num_vols; ++i) owner[i] = -1;
+    std::vector<int> rows;
+    for (int k = 0; k < ntodo; ++k) {
+        if (todo[k] < 0 || todo[k] >= num_vols || owner[todo[k]] == -2) return -1;
+        owner[todo[k]] = -2;
+        rows.push_back(todo[k]);
+    }
+    std::sort(rows.begin(), rows.end());                  // ascending row = descending cost
+    std::vector<long> load((size_t)nranks, 0), cells((size_t)nranks, 0);
+    for (int i : rows) {
+        int best = 0;
+        for (int r = 1; r < nranks; ++r)
+            if (load[(size_t)r] < load[(size_t)best]) best = r;
+        owner[i] = best;
+        load[(size_t)best] += 4L * (num_vols - i) + 1;   // cells of the row + a quarter cell for its index build
+        cells[(size_t)best] += num_vols - i;
+    }
+    long mx = 0;
+    for (long v : cells) mx = std::max(mx, v);
+    return (int)mx;
 }
 
 // d_cands[n_local][maxc], d_counts[n_local]: this rank's reads of the shard (local index i = read rid0 + (i / chunk) * chunk * P + i % chunk).

@@ -111,6 +111,7 @@ def lib():
     L.mhip_comm_bytes_received.argtypes = [vp]
     L.mhip_shard_local_count.argtypes = [i32, i32, i32, i32, i32, i32]
     L.mhip_shard_first_read.argtypes = [i32, i32, i32, i32, i32, i32]
+    L.mhip_shard_deal_rows.argtypes = [i32, vp, i32, i32, vp]
     L.mhip_seed_reads_chunked_dev.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, C.POINTER(Params), vp, vp]
     L.mhip_allgather_candidates.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
     L.mhip_seed_reads_sharded.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, C.POINTER(Params), vp, vp]
@@ -124,6 +125,16 @@ def lib():
     assert L.mhip_abi_version() == 1
     _lib = L
     return L
+
+
+def deal_rows(num_vols, todo, nranks):
+    """rows mode's static deal (mhip_shard_deal_rows) -> (owner[num_vols], heaviest rank's cells)"""
+    todo = np.ascontiguousarray(todo, dtype=np.int32)
+    owner = np.zeros(max(1, num_vols), dtype=np.int32)
+    mx = lib().mhip_shard_deal_rows(num_vols, todo.ctypes.data, len(todo), nranks, owner.ctypes.data)
+    if mx < 0:
+        raise MhipError("mhip_shard_deal_rows: bad arguments")
+    return owner[:num_vols], mx
 
 
 def _chk(rc):

@@ -561,8 +561,9 @@ static double now_s() {
 // `python -m torch.distributed.run --no-python --nproc-per-node 8 mecat2pw ...`) or MECAT_HIP_WORLD / MECAT_HIP_RANK.  Rank 0
 // splits the input, merges the r_<i> files and writes the output; hand-offs between the processes are files in wrk_dir, like
 // the resume protocol itself.  Two ways to share the volume x volume grid (MECAT_HIP_SHARD=rows|cells overrides the choice):
-//   rows   (#volumes >= P)  grid row i -> rank i mod P, each row computed by one GPU exactly as in a single-GPU run (one index
-//          build per row, no data moves between the processes);
+//   rows   (#volumes >= P)  the grid rows still to do are dealt out by cost (row i = num_vols - i cells, heaviest first to the least
+//          loaded rank: mhip_shard_deal_rows), each row computed by one GPU exactly as in a single-GPU run (one index build per row, no
+//          data moves between the processes);
 //   cells  (#volumes <  P)  every rank works on every cell: the query reads of a cell are dealt out in chunks of 500
 //          (MECAT_HIP_SHARD_CHUNK; chunk c of query volume j -> rank (c + j) mod P), each rank builds the index of
 //          the row's reference volume itself, and the candidate lists / extension results are all-gathered over RCCL
@@ -720,8 +721,14 @@ int main(int argc, char* argv[]) {
         for (int r = 0; r < world; ++r)
             if (r != rank) { peer_failed.push_back(rf.failed(r)); peer_alive.push_back(rf.alive(r)); }
         const bool watch = !getenv("MECAT_HIP_NO_WATCHDOG");
-        beat = std::thread([&beat_stop, alive, peer_failed, peer_alive, watch, rank]() {
+        // Markers and heartbeats are only believed when they are younger than this process (a token can be reused — a fixed
+        // MECAT_HIP_RUN_ID, ranks started by hand from one shell — and a failed attempt leaves every rank's failure marker and possibly a
+        // stale heartbeat behind; a rank of the next attempt must not take those for its peers' state before they have started and
+        // cleared them).  The 60 s silence rule applies to a peer only once a heartbeat of THIS attempt has been seen from it.
+        const double t_mine = t_start - 1.0;                     // st_mtime has one-second granularity on some file systems
+        beat = std::thread([&beat_stop, alive, peer_failed, peer_alive, watch, rank, t_mine]() {
             std::vector<char> seen(peer_alive.size(), 0);
+            auto mtime_of = [](const struct stat& sb) { return (double)sb.st_mtim.tv_sec + 1e-9 * (double)sb.st_mtim.tv_nsec; };
             while (!beat_stop.load()) {
                 const int fd = open(alive.c_str(), O_CREAT | O_WRONLY | O_TRUNC, 0644);
                 if (fd >= 0) { (void)!write(fd, "1\n", 2); close(fd); }
@@ -730,11 +737,11 @@ int main(int argc, char* argv[]) {
                     if (!watch || i % 5) continue;
                     for (size_t k = 0; k < peer_failed.size(); ++k) {
                         struct stat sb;
-                        bool dead = access(peer_failed[k].c_str(), F_OK) == 0;
+                        bool dead = stat(peer_failed[k].c_str(), &sb) == 0 && mtime_of(sb) >= t_mine;
                         const char* why = "left a failure marker";
                         if (!dead && stat(peer_alive[k].c_str(), &sb) == 0) {
-                            seen[k] = 1;
-                            if (now_s() - (double)sb.st_mtime > 60.0) { dead = true; why = "stopped responding"; }
+                            if (mtime_of(sb) >= t_mine) seen[k] = 1;
+                            if (seen[k] && now_s() - mtime_of(sb) > 60.0) { dead = true; why = "stopped responding"; }
                         }
                         if (dead && !beat_stop.load()) {
                             fprintf(stderr, "[mecat2pw rank %d] a peer %s (%s): stopping\n", rank, why, peer_failed[k].c_str());
@@ -835,6 +842,18 @@ int main(int argc, char* argv[]) {
         if (part_batch <= 0) DIE("MECAT_HIP_PARTITION: batch size must be positive");
     }
     part_ratio = part_ratio - 0.02;                               // reads_correction_m4.cpp:79
+    // rows mode: the static, cost-aware deal of the rows still to do (mhip_shard_deal_rows: row i costs num_vols - i cells; every rank
+    // derives it from the split marker's list alone)
+    std::vector<int> row_owner((size_t)num_vols, 0);
+    if (world > 1 && !cells) {
+        const int heaviest = mhip_shard_deal_rows(num_vols, todo.data(), (int)todo.size(), world, row_owner.data());
+        if (heaviest < 0) DIE("cannot deal %d rows to %d ranks", (int)todo.size(), world);
+        if (rank == 0 && getenv("MECAT_TRACE")) {
+            long total = 0;
+            for (int i : todo) total += num_vols - i;
+            fprintf(stderr, "[trace] rows dealt: heaviest rank %d cells of %ld (mean %.2f)\n", heaviest, total, (double)total / world);
+        }
+    }
     PartitionWriter* pw = (part_batch > 0 && world == 1) ? new PartitionWriter(opt.output, part_batch, part_min) : NULL;
     if (pw && (int)todo.size() != num_vols) { pw->abandon(); delete pw; pw = NULL; }      // finished rows' records are only on disk
     for (int i = 0; i < num_vols; ++i) {
@@ -842,7 +861,7 @@ int main(int argc, char* argv[]) {
             if (rank == 0) fprintf(stderr, "[%s, %u] volume %d has been finished\n\n", __func__, __LINE__, i);
             continue;
         }
-        if (!cells && i % world != rank) continue;               // rows: dealt out cyclically
+        if (!cells && world > 1 && row_owner[(size_t)i] != rank) continue;      // rows: dealt out by cost
         // rows: the owner of row i writes r_<i>.  cells: every rank writes the lines of its own reads to r_<i>.part<rank>, and once all
         // parts are closed rank 0 strings them together into r_<i>.working -> r_<i> (the resume protocol sees only complete rows)
         const std::string fin = results_name(opt.wrk_dir, i, false), wrk = results_name(opt.wrk_dir, i, true);
@@ -882,11 +901,11 @@ int main(int argc, char* argv[]) {
     const double merge_wait = env_int("MECAT_HIP_WAIT_S", NULL, 6 * 3600);
     for (int i = 0; i < num_vols; ++i) {
         const std::string fin = results_name(opt.wrk_dir, i, false);
-        const int owner = i % world;
+        const int owner = world > 1 && !cells && row_owner[(size_t)i] >= 0 ? row_owner[(size_t)i] : 0;
         const double w0 = now_s();
         while (world > 1 && !cells && access(fin.c_str(), F_OK) != 0) {
-            if (access(rf.failed(owner).c_str(), F_OK) == 0) DIE("rank %d failed before it finished volume %d", owner, i);
             struct stat sb;
+            if (stat(rf.failed(owner).c_str(), &sb) == 0 && (double)sb.st_mtime >= t_start - 1.0) DIE("rank %d failed before it finished volume %d", owner, i);
             const double now = now_s();
             if (stat(rf.alive(owner).c_str(), &sb) == 0) {
                 if (now - (double)sb.st_mtime > 60.0) DIE("rank %d stopped responding (volume %d unfinished)", owner, i);

@@ -90,3 +90,30 @@ def test_two_rank_shard_exchange_equals_single_process(tmp_path):
         assert o["received"] < 48 * MAXC * len(outs[peer]["rids"]) / 3
     assert torch.equal(outs[0]["cands"], outs[1]["cands"]) and torch.equal(outs[0]["res"], outs[1]["res"])
     assert total > 50
+
+
+def test_rows_mode_deal_is_balanced_and_deterministic():
+    """rows mode (#volumes >= ranks): grid row i holds num_vols - i cells (pw.cpp:65-81, pw_impl.cpp:859-879); the cost-aware static
+    deal keeps the heaviest rank within 10 % of the mean at config 5's 19 rows over 8 ranks (the cyclic deal i mod P: 33 of a mean
+    23.75 cells, i.e. at most 5.76x on 8 GPUs), deals every todo row exactly once, and ignores finished rows."""
+    from mecat_amd import hip as M
+    owner, heaviest = M.deal_rows(19, np.arange(19), 8)
+    cells = np.bincount(owner, weights=19 - np.arange(19), minlength=8)
+    assert heaviest == cells.max() == 26 and cells.sum() == 190
+    assert cells.max() <= 1.1 * cells.mean()
+    cyc = np.bincount(np.arange(19) % 8, weights=19 - np.arange(19), minlength=8)
+    assert cyc.max() == 33
+    # a resume: only some rows left; the others are -1 and the rest is balanced over the ranks again
+    todo = [3, 4, 9, 10, 11, 17, 18]
+    owner2, h2 = M.deal_rows(19, todo, 4)
+    assert sorted(np.nonzero(owner2 >= 0)[0].tolist()) == todo and (owner2[[0, 1, 2, 5]] == -1).all()
+    c2 = np.bincount(owner2[todo], weights=19 - np.array(todo), minlength=4)
+    assert h2 == c2.max() == 17                       # 16 | 15 | 10 + 2 + 1 | 9 + 8 (a perfect split of 61 cells would be 16)
+    # sweep: never worse than the cyclic deal, every rank count
+    for nv in (2, 5, 8, 19, 40):
+        for P in (2, 3, 4, 8):
+            o, h = M.deal_rows(nv, np.arange(nv), P)
+            w = nv - np.arange(nv)
+            assert h == np.bincount(o, weights=w, minlength=P).max() <= np.bincount(np.arange(nv) % P, weights=w, minlength=P).max()
+    # bad arguments
+    assert M.lib().mhip_shard_deal_rows(3, np.array([0, 0], np.int32).ctypes.data, 2, 2, np.zeros(3, np.int32).ctypes.data) == -1

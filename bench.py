@@ -284,10 +284,15 @@ def main():
         log("[bench] --gpus %d without a launcher: exec %s" % (args.gpus, " ".join(cmd)))
         os.execv(sys.executable, cmd)
 
+    from mecat_amd import workload as W
+    if args.workload in W.GRIDS:        # multi-volume workloads (config 3, a grid cell of config 5): bench_grid.py, same contract line
+        import bench_grid
+        bench_grid.run(args)
+        return
+
     import torch
     import torch.distributed as dist
     from mecat_amd import hip as M
-    from mecat_amd import workload as W
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -480,7 +485,7 @@ def main():
         roof["kernel_source_digest"] = digest
         pmc_ok = False
         try:
-            sfile = sorted(f for f in os.listdir(prof_dir) if f.endswith("_pmc_source.json"))[-1]
+            sfile = sorted(f for f in os.listdir(prof_dir) if re.match(r"r\d+_pmc_source\.json$", f))[-1]
             meta = json.load(open(os.path.join(prof_dir, sfile)))
             pmc_ok = meta.get("kernel_source_digest") == digest
             if not pmc_ok:

@@ -48,6 +48,7 @@ struct XBlockOut {
     int l0q, l0t, l0m;          // type of the last column of the whole block string
     int l1q, l1t, l1m;          // type of the column just before the trimmed tail
     int overflow;
+    int cells, rows;            // work counters: DP cells visited (window widths summed over the rows), rows
 };
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -115,6 +116,7 @@ __device__ void xdrop_block_w(XwLds<HFN>& S, const XView& q, int qidx, int M, co
     auto stHF = [&](int b, int h, int f) { S.HF[slot(b)] = make_int2(h, f); };
     o.ae = o.be = 0; o.n = o.nmatch = 0; o.qcnt = o.tcnt = o.acnt = o.mtail = 0; o.trim_ok = 0; o.overflow = 0;
     o.l0q = o.l0t = o.l0m = o.l1q = o.l1t = o.l1m = 0;
+    o.cells = o.rows = 0;
     if (M <= 0 || N <= 0) return;
     const int lane = lane_id();
     const int X = 30;
@@ -130,6 +132,8 @@ __device__ void xdrop_block_w(XwLds<HFN>& S, const XView& q, int qidx, int M, co
     for (int a = 1; a <= M; ++a) {
         const int AC = S.Qb[a - 1];
         const int f0 = first_b, n0 = b_size;
+        o.cells += n0 - f0;
+        o.rows = a;
         uint8_t* srow = st + (size_t)a * STRIDE;
         int runP = XW_NEG, bb = best, rowarg = -1, firstkept = -1, lastkept = -1, lastkeptH = 0;
         int prevHp = 0;
@@ -372,7 +376,7 @@ __global__ __launch_bounds__(XW_BLOCK) void xd_extend_w(const uint32_t* __restri
     XwLds<HFN>& S = lds[threadIdx.x >> 6];
     const int lane = lane_id();
     uint8_t* st = scratch + (size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (WIDE ? XW_WIDE_BYTES : XW_STATE_BYTES);
-    unsigned long long nblocks = 0;
+    unsigned long long nblocks = 0, ncells = 0, nrows = 0;
     while (true) {
         unsigned int unit = 0;
         if (lane == 0) unit = atomicAdd(cursor, 1u);
@@ -410,9 +414,15 @@ __global__ __launch_bounds__(XW_BLOCK) void xd_extend_w(const uint32_t* __restri
             if (!WIDE || !force_wide) xdrop_block_w<false, HFN>(S, q, qidx, qblk, t, tidx, tblk, st, o);
             ++nblocks;
             R.blocks += 1;
+            ncells += (unsigned)o.cells;
+            nrows += (unsigned)o.rows;
             if (o.overflow) {
                 if (!WIDE) { handed_over = true; R.blocks -= 1; break; }      // the block is counted again when it is redone
-                if constexpr (WIDE) xdrop_block_w<true, HFN>(S, q, qidx, qblk, t, tidx, tblk, st, o);      // only the blocks that need it
+                if constexpr (WIDE) {      // only the blocks that need it
+                    xdrop_block_w<true, HFN>(S, q, qidx, qblk, t, tidx, tblk, st, o);
+                    ncells += (unsigned)o.cells;
+                    nrows += (unsigned)o.rows;
+                }
             }
             const int full_map = (qblk - o.ae <= 20 || tblk - o.be <= 20);
             if (!full_map || last_block) {
@@ -439,7 +449,11 @@ __global__ __launch_bounds__(XW_BLOCK) void xd_extend_w(const uint32_t* __restri
             }
         }
     }
-    if (lane == 0) atomicAdd(&counters[3], nblocks);
+    if (lane == 0) {
+        atomicAdd(&counters[3], nblocks);
+        atomicAdd(&counters[4], ncells);      // DP cells (the slot dw's d-path cells use)
+        atomicAdd(&counters[9], nrows);
+    }
 }
 
 // XdropAligner::go tail (xdrop_gapalign.cpp:396-438): the left half is emitted without its last column

@@ -110,6 +110,56 @@ int64_t synth_pack_volume(const uint8_t* codes, const int32_t* lens, int64_t nre
     return curr;
 }
 
+/* the same for reads [first, first + nreads) of the set (read i has its own RNG stream, so any range of a set can be made alone:
+   the first two volumes of config 5 without the other seventeen).  `g` = the genome from synth_genome, or NULL to make it here. */
+int64_t synth_reads_range(const uint8_t* g_in, int64_t G, int64_t first, int64_t nreads, int L, double e, int ont, uint64_t seed,
+                          uint8_t* bases, int64_t bases_cap, int32_t* lens) {
+    double pdel, psub, pins; synth_rates(e, ont, &pdel, &psub, &pins);
+    uint8_t* g = (uint8_t*)g_in;
+    if (!g) {
+        g = (uint8_t*)malloc((size_t)G);
+        if (!g) return -1;
+        synth_genome(g, G, seed);
+    }
+    int cap = (int)(L * 1.25) + 64;
+    if (bases_cap < nreads * (int64_t)cap) { if (!g_in) free(g); return -2; }
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t i = 0; i < nreads; ++i)
+        lens[i] = synth_one_read(g, G, first + i, L, pdel, psub, pins, seed, bases + i * cap, cap);
+    int64_t tot = 0;
+    for (int64_t i = 0; i < nreads; ++i) {
+        if (tot != i * cap) memmove(bases + tot, bases + i * cap, (size_t)lens[i]);
+        tot += lens[i];
+    }
+    if (!g_in) free(g);
+    return tot;
+}
+
+/* synth_pack_volume on all cores: offsets first, then every read packs its own bases — whole bytes with plain stores, the bytes it
+   shares with its neighbours (head and tail) with atomic ORs.  Same bytes as synth_pack_volume. */
+int64_t synth_pack_volume_mt(const uint8_t* codes, const int32_t* lens, int64_t nreads, uint8_t* pac, int32_t* offs) {
+    int64_t* src0 = (int64_t*)malloc((size_t)(nreads + 1) * 8);
+    if (!src0) return -1;
+    int64_t curr = 0, src = 0;
+    for (int64_t i = 0; i < nreads; ++i) {
+        offs[2 * i] = (int32_t)curr; offs[2 * i + 1] = lens[i];
+        src0[i] = src;
+        src += lens[i];
+        curr += lens[i] + 1;
+    }
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t i = 0; i < nreads; ++i) {
+        const uint8_t* c = codes + src0[i];
+        int64_t p = offs[2 * i];
+        const int64_t end = p + lens[i];
+        for (; p < end && (p & 3); ++p, ++c) __atomic_fetch_or(&pac[p >> 2], (uint8_t)((*c & 3) << ((~p & 3) << 1)), __ATOMIC_RELAXED);
+        for (; p + 4 <= end; p += 4, c += 4) pac[p >> 2] = (uint8_t)(((c[0] & 3) << 6) | ((c[1] & 3) << 4) | ((c[2] & 3) << 2) | (c[3] & 3));
+        for (; p < end; ++p, ++c) __atomic_fetch_or(&pac[p >> 2], (uint8_t)((*c & 3) << ((~p & 3) << 1)), __ATOMIC_RELAXED);
+    }
+    free(src0);
+    return curr;
+}
+
 int synth_write_fasta(const char* path, const uint8_t* bases, const int32_t* lens, int64_t nreads) {
     FILE* f = fopen(path, "w");
     if (!f) return -1;

@@ -13,6 +13,20 @@ _ROOT = os.path.dirname(_HERE)
 CONFIGS = {
     "config1": (1000, 10000, 0.15, 500_000, 1, 0),
     "config2": (100_000, 15000, 0.15, 50_000_000, 2, 0),
+    "config3": (500_000, 12000, 0.15, 200_000_000, 3, 0),            # three volumes (2.14 + 2.14 + 2.04 Gbase)
+    "config5": (2_000_000, 20000, 0.12, 1_300_000_000, 5, 1),        # nineteen volumes, ONT-style, -x 1
+    "tinyset": (3000, 3000, 0.15, 300_000, 11, 0),                   # test input of the grid runner (three volumes at a 3.5 Mbase cut)
+    "tinyset_ont": (3000, 3000, 0.12, 300_000, 12, 1),
+}
+MCS = 2_140_000_000      # bases per volume, pads included (common/split_database.h:6)
+
+# multi-volume bench workloads: name -> (read set, volumes needed, grid cells (i, j) = (reference volume, query volume) in the driver's
+# loop order, mecat2pw/pw_impl.cpp:859-879: one index build per row i, then the cells j = i ..)
+GRIDS = {
+    "config3": ("config3", 3, [(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)], MCS),
+    "config5_cell": ("config5", 2, [(0, 1)], MCS),                   # one off-diagonal cell of config 5's 19 x 19 grid: volumes 0 and 1
+    "grid_tiny": ("tinyset", 3, [(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)], 3_500_000),          # tests only
+    "grid_tiny_ont": ("tinyset_ont", 3, [(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)], 3_500_000),
 }
 
 _lib = None
@@ -31,6 +45,12 @@ def synth_lib():
         L.synth_pack_volume.restype = C.c_int64
         L.synth_pack_volume.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.synth_write_fasta.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int64]
+        L.synth_genome.argtypes = [C.c_void_p, C.c_int64, C.c_uint64]
+        L.synth_reads_range.restype = C.c_int64
+        L.synth_reads_range.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_double, C.c_int, C.c_uint64, C.c_void_p, C.c_int64,
+                                        C.c_void_p]
+        L.synth_pack_volume_mt.restype = C.c_int64
+        L.synth_pack_volume_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -59,6 +79,62 @@ def pack_volume(codes, lens):
     nb = lib.synth_pack_volume(codes.ctypes.data, lens.ctypes.data, n, pac.ctypes.data, offs.ctypes.data)
     assert nb == total
     return pac, offs, total
+
+
+def synth_volumes(name, num_vols, keep_codes=False, mcs=MCS):
+    """the first num_vols volumes of a read set, cut as the reference's splitter cuts them (a read that would take the volume beyond MCS
+    opens the next one, split_database.cpp:240) -> list of dicts {pac, offs, num_bases, start_read_id, lens[, codes]}.  Reads are made in
+    batches (every read has its own RNG stream), so the first two volumes of config 5 cost 4.3 Gbase of generation, not 40."""
+    n, L, err, G, seed, ont = CONFIGS[name]
+    lib = synth_lib()
+    g = np.empty(G, dtype=np.uint8)
+    lib.synth_genome(g.ctypes.data, G, seed)
+    cap = int(L * 1.25) + 64
+    B = 32768
+    buf = np.empty(B * cap, dtype=np.uint8)
+    vols, cur_codes, cur_lens, cur_bases, first, start_id = [], [], [], 0, 0, 0
+
+    def close():
+        nonlocal cur_codes, cur_lens, cur_bases, start_id
+        lens = np.concatenate(cur_lens) if cur_lens else np.zeros(0, np.int32)
+        codes = np.concatenate(cur_codes) if cur_codes else np.zeros(0, np.uint8)
+        total = int(lens.astype(np.int64).sum()) + len(lens)
+        pac = np.zeros((total + 3) // 4, dtype=np.uint8)
+        offs = np.zeros((len(lens), 2), dtype=np.int32)
+        nb = lib.synth_pack_volume_mt(codes.ctypes.data, lens.ctypes.data, len(lens), pac.ctypes.data, offs.ctypes.data)
+        assert nb == total == cur_bases
+        v = {"pac": pac, "offs": offs, "num_bases": total, "start_read_id": start_id, "lens": lens}
+        if keep_codes:
+            v["codes"] = codes
+        vols.append(v)
+        start_id += len(lens)
+        cur_codes, cur_lens, cur_bases = [], [], 0
+
+    while first < n and len(vols) < num_vols:
+        nb_ = min(B, n - first)
+        lens = np.empty(nb_, dtype=np.int32)
+        tot = lib.synth_reads_range(g.ctypes.data, G, first, nb_, L, err, ont, seed, buf.ctypes.data, len(buf), lens.ctypes.data)
+        if tot < 0:
+            raise RuntimeError("synth_reads_range failed: %d" % tot)
+        ends = np.cumsum(lens.astype(np.int64) + 1)
+        lo, src = 0, 0
+        while lo < nb_ and len(vols) < num_vols:
+            # reads lo .. hi - 1 still fit the open volume: curr + rsize + 1 <= MCS
+            room = mcs - cur_bases + (ends[lo - 1] if lo else 0)
+            hi = int(np.searchsorted(ends, room, side="right"))
+            if hi > lo:
+                nbytes = int(lens[lo:hi].astype(np.int64).sum())
+                cur_codes.append(buf[src: src + nbytes].copy())
+                cur_lens.append(lens[lo:hi].copy())
+                cur_bases += nbytes + (hi - lo)
+                src += nbytes
+                lo = hi
+            if lo < nb_:
+                close()
+        first += nb_
+    if len(vols) < num_vols and cur_lens:
+        close()
+    return vols
 
 
 def write_fasta(path, codes, lens):

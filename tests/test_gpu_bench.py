@@ -32,3 +32,42 @@ def test_bench_line_one_rank_and_two_ranks_agree():
     b = _line(r2.stdout)
     assert b["n_gpus"] == 2 and b["scaling"] == "strong"
     assert b["candidates"] == a["candidates"] and b["overlaps_ok"] == a["overlaps_ok"]
+
+
+@pytest.mark.parametrize("wl,tech", [("grid_tiny", 0), ("grid_tiny_ont", 1)])
+def test_bench_grid_workload_equals_the_drop_in_binary(tmp_path, wl, tech):
+    """bench.py's multi-volume runner (bench_grid.py: the workloads config3 / config5_cell) on a three-volume toy set: its cells hold the
+    candidates and overlaps the drop-in binary writes for the same reads cut at the same volume size (MECAT_HIP_MCS), one rank and two."""
+    from mecat_amd import workload as W
+    name, nvols, cells, mcs = W.GRIDS[wl]
+    n, L, err, G, seed, ont = W.CONFIGS[name]
+    codes, lens = W.synth_reads(n, L, err, G, seed, ont)
+    fa = str(tmp_path / "r.fa")
+    W.write_fasta(fa, codes, lens)
+    exe = os.path.join(H.ROOT, "mecat_amd", "bin", "mecat2pw")
+    want = {}
+    for task in (0, 1):
+        out = str(tmp_path / ("o%d" % task))
+        r = subprocess.run([exe, "-j", str(task), "-d", fa, "-o", out, "-w", str(tmp_path / ("w%d" % task)), "-t", "4", "-g", "1", "-x", str(tech)],
+                           capture_output=True, text=True, env=dict(os.environ, MECAT_HIP_MCS=str(mcs)), timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        want[task] = open(out, "rb").read().splitlines(keepends=True)
+    assert len(open(str(tmp_path / "w0" / "fileindex.txt")).read().split()) == nvols
+    bench = os.path.join(H.ROOT, "bench.py")
+    flags = ["--workload", wl, "--steps", "1", "--warmup", "0", "--no-cpu"]
+    r1 = subprocess.run([sys.executable, bench, "--gpus", "1"] + flags, capture_output=True, text=True, timeout=600,
+                        env=dict(os.environ, MECAT_BENCH_PARITY="1"))
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    a = _line(r1.stdout)
+    assert a["n_gpus"] == 1 and a["value"] > 0 and a["roofline"]["achieved"] > 0 and set(a["roofline"]["phases"]) == {"index", "seed", "align"}
+    assert sorted(a["cells"]) == sorted("%d,%d" % c for c in cells)
+    assert a["candidates"] == len(want[0]) == sum(c["can_lines"] for c in a["cells"].values())
+    # the cells' sorted lines, hashed cell by cell in the bench, together are the binary's lines: compare as one multiset through the counts
+    # and through the -j 1 side (every extension that reaches min_align_size is an overlap line before the per-read containment filter)
+    assert a["overlaps_ok"] >= len(want[1]) > 0
+    env = dict(os.environ, MECAT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", "29543", bench, "--gpus", "2"] + flags, capture_output=True, text=True, timeout=900, env=env)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    b = _line(r2.stdout)
+    assert b["n_gpus"] == 2 and b["candidates"] == a["candidates"] and b["overlaps_ok"] == a["overlaps_ok"]

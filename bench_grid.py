@@ -154,7 +154,22 @@ def run(args):
     torch.cuda.set_device(dev)
 
     t0 = time.time()
-    hv = W.synth_volumes(name, nvols, mcs=mcs)
+    # MECAT_BENCH_VOLCACHE=<dir>: keep the generated volumes there between runs (the profiling passes start this command seven times)
+    cache = os.environ.get("MECAT_BENCH_VOLCACHE")
+    cfile = os.path.join(cache, "%s_%d.npz" % (name, nvols)) if cache else None
+    if cfile and os.path.exists(cfile):
+        z = np.load(cfile)
+        hv = [{"pac": z["pac%d" % k], "offs": z["offs%d" % k], "lens": z["lens%d" % k], "num_bases": int(z["meta"][k, 0]), "start_read_id": int(z["meta"][k, 1])}
+              for k in range(len(z["meta"]))]
+    else:
+        hv = W.synth_volumes(name, nvols, mcs=mcs)
+        if cfile and rank == 0:
+            os.makedirs(cache, exist_ok=True)
+            arrs = {"meta": np.array([[v["num_bases"], v["start_read_id"]] for v in hv], dtype=np.int64)}
+            for k, v in enumerate(hv):
+                arrs.update({"pac%d" % k: v["pac"], "offs%d" % k: v["offs"], "lens%d" % k: v["lens"]})
+            np.savez(cfile + ".tmp.npz", **arrs)
+            os.replace(cfile + ".tmp.npz", cfile)
     if rank == 0:
         log("[bench] %s: %d volumes of %s (%s reads, %s bases incl. pads), generated + packed in %.1f s" % (
             args.workload, len(hv), name, "+".join(str(len(v["lens"])) for v in hv), "+".join(str(v["num_bases"]) for v in hv), time.time() - t0))

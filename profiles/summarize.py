@@ -22,13 +22,16 @@ def short(name):
 
 def main():
     tag, kdir, fdir, wdir, passes = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5])
-    here = os.path.dirname(os.path.abspath(__file__))
+    here = os.environ.get("PROFILES_OUT") or os.path.dirname(os.path.abspath(__file__))
+    os.makedirs(here, exist_ok=True)
+    cmd = os.environ.get("PROFILE_CMD", "python bench.py --steps 1 --warmup 1 --no-cpu --no-extras --no-e2e")
+    label = os.environ.get("PROFILE_LABEL", "config 2")
     # the run may hold several traced processes (bench.py calls the valu_peak calibration binary): keep the one with the hot path
     def pick(pattern):
         c = [f for f in glob.glob(os.path.join(kdir, "**", pattern), recursive=True)]
         c.sort(key=lambda f: -os.path.getsize(f))
         for f in c:
-            if pattern.endswith("agent_info.csv") or "dw_extend" in open(f).read():
+            if pattern.endswith("agent_info.csv") or "dw_extend" in open(f).read() or "xd_extend" in open(f).read():
                 return f
         return c[0] if c else None
     for f in ("kernel_stats", "agent_info"):
@@ -55,7 +58,7 @@ def main():
     traffic = {}
     with open(os.path.join(here, "%s_hbm_counters.md" % tag), "w") as f:
         f.write("# %s - HBM traffic counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)\n\n" % tag)
-        f.write("Command: `python bench.py --steps 1 --warmup 1 --no-cpu --no-extras --no-e2e` (config 2), i.e. %d passes of the hot path per run.\n" % passes)
+        f.write("Command: `%s` (%s), i.e. %d passes of the hot path per run.\n" % (cmd, label, passes))
         f.write("Counter unit is KiB; bytes = value x 1024.  MI355X_MICROARCH.md (HBM): FETCH_SIZE reports half the bytes of a\n"
                 "16 B/lane coalesced streaming read and is uncalibrated for other widths; none of these kernels issues 16 B/lane\n"
                 "streams (4-8 B/lane gathers and scatters), so the values are reported uncorrected.  Infinity-Cache hits count.\n\n")

@@ -15,7 +15,9 @@ import sys
 
 def main():
     tag, passes, dirs = sys.argv[1], int(sys.argv[2]), sys.argv[3:]
-    here = os.path.dirname(os.path.abspath(__file__))
+    here = os.environ.get("PROFILES_OUT") or os.path.dirname(os.path.abspath(__file__))
+    os.makedirs(here, exist_ok=True)
+    label = os.environ.get("PROFILE_LABEL", "config 2")
     tot = collections.defaultdict(lambda: collections.defaultdict(float))
     launches = collections.defaultdict(lambda: collections.defaultdict(int))
     for d in dirs:
@@ -31,7 +33,7 @@ def main():
              "SQ_LDS_IDX_ACTIVE", "SQ_ACTIVE_INST_VALU2", "SQ_ACTIVE_INST_SCA", "SQ_INSTS_BRANCH"]
     out = {}
     with open(os.path.join(here, "%s_instruction_mix.md" % tag), "w") as f:
-        f.write("# %s - SQ instruction counters per launch (rocprofv3 --pmc, %d hot-path passes per run, config 2)\n\n" % (tag, passes))
+        f.write("# %s - SQ instruction counters per launch (rocprofv3 --pmc, %d hot-path passes per run, %s)\n\n" % (tag, passes, label))
         f.write("Wave-level instruction counts; SQ_ACTIVE_* / SQ_WAVE_CYCLES / SQ_WAIT_* are in quad-cycles (MI355X_MICROARCH.md).\n"
                 "Issue ceilings are not nominal figures here: mecat_amd/bin/valu_peak measures them on the device (profiles/*_valu_peak.json:\n"
                 "a wave64 VALU instruction issues in 4 cycles per SIMD, in 2 only for the plain 32-bit add / sub / logic / mov / lshr class\n"

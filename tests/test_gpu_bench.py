@@ -62,8 +62,21 @@ def test_bench_grid_workload_equals_the_drop_in_binary(tmp_path, wl, tech):
     assert a["n_gpus"] == 1 and a["value"] > 0 and a["roofline"]["achieved"] > 0 and set(a["roofline"]["phases"]) == {"index", "seed", "align"}
     assert sorted(a["cells"]) == sorted("%d,%d" % c for c in cells)
     assert a["candidates"] == len(want[0]) == sum(c["can_lines"] for c in a["cells"].values())
-    # the cells' sorted lines, hashed cell by cell in the bench, together are the binary's lines: compare as one multiset through the counts
-    # and through the -j 1 side (every extension that reaches min_align_size is an overlap line before the per-read containment filter)
+    # cell by cell: the binary's lines whose query / subject ids fall into the cell's volumes, sorted and hashed as the bench hashes its own
+    import bisect
+    import hashlib
+    starts = [v["start_read_id"] for v in a["config"]["volumes"]]
+    per = {}
+    for ln in want[0]:
+        f = ln.split(b"\t")
+        key = "%d,%d" % (bisect.bisect_right(starts, int(f[1])) - 1, bisect.bisect_right(starts, int(f[0])) - 1)
+        per.setdefault(key, []).append(ln)
+    for key, c in a["cells"].items():
+        h = hashlib.sha256()
+        for ln in sorted(per.get(key, [])):
+            h.update(ln)
+        assert (c["can_lines"], c["can_sorted_sha256"]) == (len(per.get(key, [])), h.hexdigest()), key
+    # the -j 1 side: every extension that reaches min_align_size is an overlap line before the per-read containment filter
     assert a["overlaps_ok"] >= len(want[1]) > 0
     env = dict(os.environ, MECAT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",

@@ -410,10 +410,11 @@ def run(args):
         log("[bench] kernel ms/step: " + ", ".join("%s=%.2f" % (k, v) for k, v in line["kernel_ms_per_step"].items()))
         if args.stats:
             json.dump({"kernels": {k: {"launches": v[0], "total_ms": v[1]} for k, v in kstats.items()}, "line": line}, open(args.stats, "w"), indent=1)
-        for v in vols:
-            v.free()
-        ctx.close()
-        vols = []
+        if world == 1:              # the CPU leg below needs no device: give the memory back first
+            for v in vols:
+                v.free()
+            ctx.close()
+            vols = []
         if world == 1 and not args.no_cpu:
             try:
                 line["cpu_baseline"] = cpu_baseline_grid(args.workload, os.cpu_count() or 1)
@@ -432,12 +433,14 @@ def run(args):
             except Exception as e:  # noqa: BLE001
                 line["cpu_baseline"] = {"value": None, "unit": "candidates/s", "cores": os.cpu_count(), "kind": "reference", "sample": "failed: %r" % (e,)}
         print(json.dumps(line), flush=True)
-    for v in vols:
-        v.free()
+    released = rank == 0 and world == 1
+    if not released:
+        for v in vols:
+            v.free()
     if comm is not None:
         comm.barrier()
         comm.close()
-    if vols:
+    if not released:
         ctx.close()
     if world > 1:
         dist.destroy_process_group()

@@ -173,7 +173,11 @@ __device__ void xdrop_block_w(XwLds<HFN>& S, const XView& q, int qidx, int M, co
             // kept: (H, F') with F' = max(F - 1, H - 1) = H - 1 (H >= F); dropped between kept cells: H = MIN, F stays; a leading
             // dropped cell only moves first_b.  One predicated store.
             if (kept || (in && (lower || firstkept >= 0))) stHF(b, kept ? Hc : X_MIN_SCORE, kept ? Hc - 1 : Fp);
+#if !defined(XD_EXP) || XD_EXP == 3
             srow[b - f0] = (uint8_t)(script | (mt ? XS_MATCH : 0));          // lanes past the window write bytes nobody reads
+#else
+            if (script == 0x7777) srow[b - f0] = 1;
+#endif
             // carries
             runP = max(runP, __builtin_amdgcn_readlane(incl, 63));
             if (ex && rowarg < 0) rowarg = c0 + j1;
@@ -194,7 +198,9 @@ __device__ void xdrop_block_w(XwLds<HFN>& S, const XView& q, int qidx, int M, co
         if (firstkept < 0) { first_b = n0; break; }
         first_b = firstkept;
         // the row's first column (after the passes: their idle lanes may have written over these two bytes)
+#if !defined(XD_EXP) || XD_EXP != 2
         if (lane == 0) { if (WIDE) S.rstart[a] = (int16_t)f0; else *(uint16_t*)(srow + XW_STRIDE - 2) = (uint16_t)f0; }
+#endif
         // The window ends after the last kept cell; if that is the row's last cell, the row gap keeps it open while it stays
         // within X of the best (:139-147; H >= E at a kept cell), and a closing (MIN, MIN) cell follows unless the block ends.
         // (b_size is N + 1 in a block with N <= X, where row 0 ran off the end: nothing is appended then.)
@@ -207,13 +213,18 @@ __device__ void xdrop_block_w(XwLds<HFN>& S, const XView& q, int qidx, int M, co
             const int bnew = bsz0 + lane;
             const bool tail = lane < cnt;
             if (lane < cnt + sent) stHF(bnew, tail ? e_end - lane : X_MIN_SCORE, tail ? e_end - lane - 1 : X_MIN_SCORE);
+#if !defined(XD_EXP) || XD_EXP != 2
             if (tail && bnew - f0 < STRIDE - 2) srow[bnew - f0] = XS_GAP_IN_A;
+#endif
             b_size = bsz0 + cnt + sent;
         }
         if (!WIDE && (b_size - first_b > XW_RING - 2 || b_size - f0 > XW_STRIDE - 2)) { o.overflow = 2; return; }
         __builtin_amdgcn_wave_barrier();
     }
     o.ae = ae; o.be = be;
+#if defined(XD_EXP)
+    if (!WIDE) { o.n = ae + be; o.nmatch = min(ae, be); return; }
+#endif
     // ---- traceback (:165-210) fused with script_to_aligned_string + trim_mismatch_end, as in the lane kernel
     __threadfence();
     __builtin_amdgcn_wave_barrier();

@@ -75,3 +75,10 @@ $(LIBDIR)/libmecat_hip_dwstats.so: $(HIP_SRCS) $(HIP_HDRS)
 	@mkdir -p build/dwstats $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -DMECAT_DW_STATS -x hip -c $(CSRC)/align.hip -o build/dwstats/align.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC build/dwstats/align.o $(filter-out build/align.o,$(HIP_OBJS)) -o $@
+
+# development variant with xd_extend_w's section clocks compiled in (tools/dev/xd_breakdown.py)
+xdstats: $(LIBDIR)/libmecat_hip_xdstats.so
+$(LIBDIR)/libmecat_hip_xdstats.so: $(HIP_SRCS) $(HIP_HDRS)
+	@mkdir -p build/xdstats $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -DMECAT_XD_STATS -x hip -c $(CSRC)/xalign.hip -o build/xdstats/xalign.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC build/xdstats/xalign.o $(filter-out build/xalign.o,$(HIP_OBJS)) -o $@

@@ -14,6 +14,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 
@@ -49,6 +50,9 @@ struct XBlockOut {
     int l1q, l1t, l1m;          // type of the column just before the trimmed tail
     int overflow;
     int cells, rows;            // work counters: DP cells visited (window widths summed over the rows), rows
+#ifdef MECAT_XD_STATS
+    unsigned long long tk_stage, tk_rows, tk_trace, n_rows2, n_win, n_steps, n_qfill;      // section clocks (s_memtime ticks) and event counts of the block
+#endif
 };
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -173,11 +177,7 @@ __device__ void xdrop_block_w(XwLds<HFN>& S, const XView& q, int qidx, int M, co
             // kept: (H, F') with F' = max(F - 1, H - 1) = H - 1 (H >= F); dropped between kept cells: H = MIN, F stays; a leading
             // dropped cell only moves first_b.  One predicated store.
             if (kept || (in && (lower || firstkept >= 0))) stHF(b, kept ? Hc : X_MIN_SCORE, kept ? Hc - 1 : Fp);
-#if !defined(XD_EXP) || XD_EXP == 3
             srow[b - f0] = (uint8_t)(script | (mt ? XS_MATCH : 0));          // lanes past the window write bytes nobody reads
-#else
-            if (script == 0x7777) srow[b - f0] = 1;
-#endif
             // carries
             runP = max(runP, __builtin_amdgcn_readlane(incl, 63));
             if (ex && rowarg < 0) rowarg = c0 + j1;
@@ -198,9 +198,7 @@ __device__ void xdrop_block_w(XwLds<HFN>& S, const XView& q, int qidx, int M, co
         if (firstkept < 0) { first_b = n0; break; }
         first_b = firstkept;
         // the row's first column (after the passes: their idle lanes may have written over these two bytes)
-#if !defined(XD_EXP) || XD_EXP != 2
         if (lane == 0) { if (WIDE) S.rstart[a] = (int16_t)f0; else *(uint16_t*)(srow + XW_STRIDE - 2) = (uint16_t)f0; }
-#endif
         // The window ends after the last kept cell; if that is the row's last cell, the row gap keeps it open while it stays
         // within X of the best (:139-147; H >= E at a kept cell), and a closing (MIN, MIN) cell follows unless the block ends.
         // (b_size is N + 1 in a block with N <= X, where row 0 ran off the end: nothing is appended then.)
@@ -213,18 +211,13 @@ __device__ void xdrop_block_w(XwLds<HFN>& S, const XView& q, int qidx, int M, co
             const int bnew = bsz0 + lane;
             const bool tail = lane < cnt;
             if (lane < cnt + sent) stHF(bnew, tail ? e_end - lane : X_MIN_SCORE, tail ? e_end - lane - 1 : X_MIN_SCORE);
-#if !defined(XD_EXP) || XD_EXP != 2
             if (tail && bnew - f0 < STRIDE - 2) srow[bnew - f0] = XS_GAP_IN_A;
-#endif
             b_size = bsz0 + cnt + sent;
         }
         if (!WIDE && (b_size - first_b > XW_RING - 2 || b_size - f0 > XW_STRIDE - 2)) { o.overflow = 2; return; }
         __builtin_amdgcn_wave_barrier();
     }
     o.ae = ae; o.be = be;
-#if defined(XD_EXP)
-    if (!WIDE) { o.n = ae + be; o.nmatch = min(ae, be); return; }
-#endif
     // ---- traceback (:165-210) fused with script_to_aligned_string + trim_mismatch_end, as in the lane kernel
     __threadfence();
     __builtin_amdgcn_wave_barrier();
@@ -375,6 +368,325 @@ __device__ void xdrop_block_w(XwLds<HFN>& S, const XView& q, int qidx, int M, co
     o.trim_ok = found && (n - o.acnt >= 2);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// xdrop_block_ring — the ring instantiation of round 4: same row formulation, organised around what the counters said bounds it
+// (profiles/r04a_config5_cell_*: both issue ports at ~40 %, 41 % of the wave time waiting on LDS round trips, three stores per
+// row and 907 GB of scratch traffic per 0.75 s launch):
+//   * the gap tail behind the window (:139-147) is not a second phase: the lanes behind the window run the same cell code with
+//     (H', F') = (MIN, MIN) and no diagonal, their row-gap value is exactly the tail's e_end - l, and "kept" is the tail's own
+//     condition (still within X of the best, b < N) — so a row is its passes and a few scalar instructions;
+//   * every lane stores its (H, F) and its script byte, no predicated stores: slots of cells outside the next window are never read
+//     (the ring holds 128 cells, a row at most 126); the closing (MIN, MIN) cell is one uniform store after the passes;
+//   * a row's first column lives in LDS (rs[]), not in bytes 126-127 of its script row: one store per pass is all that leaves the CU,
+//     and the script rows are packed: the first 64 cells of row a at byte 64 a of the scratch, cells 64.. of the rows that have them
+//     (one in ten) in a second array behind it — the scratch traffic was what capped the kernel (waves 16 -> 28: flat), now two rows
+//     share a cache line and a window of 24 rows is 1.5 KB (+ 1.5 KB only when one of its rows has a second chunk);
+//   * the score of a dropped cell's row gap (H of the nearest kept cell to the left - 1) is a scalar for every lane behind the last
+//     or in front of the first kept cell; only a row with a hole between kept cells takes the per-lane look-up;
+//   * the query bases of 64 rows sit in a register (one v_readlane per row instead of an LDS round trip).
+#define XR_WIN 3072                      // traceback window: 24 script rows
+struct XrLds {
+    int2 HF[XW_RING];
+    uint8_t Tb[X_MAXN + 72 + 64];        // Tb[b] = target base b - 1 (idle and tail lanes read up to 128 cells behind the window)
+    uint16_t rs[X_MAXN + 4];             // first column of every row's script bytes
+    uint32_t win[XR_WIN / 4];            // rows [wlo, wlo + 24): first chunks (64 B each), then second chunks
+    uint32_t two[(X_MAXN + 2 + 31) / 32 + 1];   // rows that wrote a second chunk
+};
+
+__device__ void xdrop_block_ring(XrLds& S, const XView& q, int qidx, int M, const XView& t, int tidx, int N, uint8_t* __restrict__ st, XBlockOut& o) {
+    o.ae = o.be = 0; o.n = o.nmatch = 0; o.qcnt = o.tcnt = o.acnt = o.mtail = 0; o.trim_ok = 0; o.overflow = 0;
+    o.l0q = o.l0t = o.l0m = o.l1q = o.l1t = o.l1m = 0;
+    o.cells = o.rows = 0;
+#ifdef MECAT_XD_STATS
+    o.tk_stage = o.tk_rows = o.tk_trace = o.n_rows2 = o.n_win = o.n_steps = o.n_qfill = 0;
+#endif
+    if (M <= 0 || N <= 0) return;
+    const int lane = lane_id();
+    const int X = 30;
+#ifdef MECAT_XD_STATS
+    unsigned long long tk0 = __builtin_amdgcn_s_memtime();
+#define XD_TICK(field) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); o.field += _t - tk0; tk0 = _t; } while (0)
+#define XD_COUNT(field) (++o.field)
+#else
+#define XD_TICK(field) do { } while (0)
+#define XD_COUNT(field) do { } while (0)
+#endif
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < N; i += 64) S.Tb[i + 1] = (uint8_t)xv_at(t, tidx + i);
+    const int n_init = min(N, X);
+    uint8_t* __restrict__ st2 = st + (size_t)(X_MAXN + 2) * 64;      // second chunks
+    if (lane <= n_init) { S.HF[lane] = make_int2(-lane, -lane - 1); if (lane) st[lane] = XS_GAP_IN_A; }
+    if (lane < (int)(sizeof(S.two) / 4)) S.two[lane] = 0;
+    if (lane == 0) S.rs[0] = 0;
+    int b_size = n_init + 1, best = 0, first_b = 0, ae = 0, be = 0;
+    int qreg = 0, cellacc = 0;
+    const bool special = N <= X;                         // row 0 ran off the end of the target: b_size = N + 1, every row through the general code
+    bool stop = false;
+    __builtin_amdgcn_wave_barrier();
+    XD_TICK(tk_stage);
+    for (int a0 = 1; a0 <= M && !stop; a0 += 64) {
+      // the query bases of the next 64 rows in a register: one v_readlane per row
+      qreg = (a0 - 1 + lane < M) ? xv_at(q, qidx + a0 - 1 + lane) : 0;
+      XD_COUNT(n_qfill);
+      const int aend = min(a0 + 63, M);
+      for (int a = a0; a <= aend; ++a) {
+        const int AC = __builtin_amdgcn_readlane(qreg, a - a0);
+        const int f0 = first_b, n0 = b_size;
+        uint8_t* srow = st + (size_t)a * 64;
+        // The common row — one pass, kept cells without a hole between them, gap tail inside the pass — with nothing but what it needs:
+        // no carries, no selects for the cases it excludes (checked on the kept mask before anything is stored; a row that fails
+        // the check is redone by the general code below).  The scalar port is what bounds this kernel (profiles/r04_xd_breakdown.md):
+        // masks are compared as masks (s_bfm), "none" is s_ff1's own -1, every lane behind or in front of the kept cells stores (MIN, MIN)
+        // — the closing cell is one of them, the others are never read — and the DP cells are counted per lane.
+        bool done = false;
+        if (__builtin_expect(n0 - f0 <= 64 && !special, 1)) {
+            const int b = f0 + lane;
+            const bool in0 = b < n0;
+            const bool live = b < N;                                     // (n0 <= N outside the special blocks)
+            int2 hf = S.HF[b & (XW_RING - 1)];
+            const int tb = S.Tb[b];
+            const int Hp = in0 ? hf.x : X_MIN_SCORE, Fp = in0 ? hf.y : X_MIN_SCORE;
+            const bool mt = AC == tb;
+            const int left = xw_shr1(Hp, 0);
+            const int diag = (in0 && lane != 0) ? left + (mt ? 1 : -1) : X_MIN_SCORE;
+            const int Mv = max(diag, Fp);
+            const int incl = xw_scan_max(Mv + b);
+            const int Ec = xw_shr1(incl, XW_NEG) - b;
+            const int Hc = max(Mv, Ec);
+            const unsigned long long livem = __builtin_amdgcn_ballot_w64(live);
+            const unsigned long long exm = __builtin_amdgcn_ballot_w64(Hc > best) & livem;
+            int j1;                                                       // first cell above the best so far; -1 (as unsigned: above every lane) if none
+            asm("s_ff1_i32_b64 %0, %1" : "=s"(j1) : "s"(exm));
+            const int thr = best - X + ((unsigned)lane > (unsigned)j1 ? 1 : 0);
+            const bool ge = Hc >= thr;
+            const unsigned long long km = __builtin_amdgcn_ballot_w64(ge) & livem;
+            int fkl;
+            asm("s_ff1_i32_b64 %0, %1" : "=s"(fkl) : "s"(km));
+            const int nk = __builtin_popcountll(km);
+            unsigned long long want;                                      // nk ones from bit fkl on (0 for nk = 64: such a row fails the test)
+            asm("s_bfm_b64 %0, %1, %2" : "=s"(want) : "s"(nk), "s"(fkl));
+            if (__builtin_expect(km != 0ull && km == want && (long long)km >= 0, 1)) {
+                const int lkl = fkl + nk - 1;
+                const bool kept = live && ge;
+                cellacc += in0 ? 1 : 0;
+                const int Hlk = __builtin_amdgcn_readlane(Hc, lkl);
+                const int et = lane > lkl ? Hlk - 1 : X_MIN_SCORE;
+                int script = diag < Fp ? XS_GAP_IN_B : XS_SUB;
+                if (Mv < (kept ? Ec : et)) script = XS_GAP_IN_A;
+                const bool xa = kept && Fp >= Hc, xb = kept && in0 && Ec >= Hc, xm = mt && in0;
+                script |= (xa ? XS_EXT_A : 0) | (xb ? XS_EXT_B : 0) | (xm ? XS_MATCH : 0);
+                S.HF[b & (XW_RING - 1)] = make_int2(kept ? Hc : X_MIN_SCORE, kept ? Hc - 1 : X_MIN_SCORE);
+                srow[lane] = (uint8_t)script;
+                S.rs[a] = (uint16_t)f0;                                  // (every lane, one address)
+                if (exm) { best += 1; ae = a; be = f0 + j1; }
+                first_b = f0 + fkl;
+                b_size = f0 + lkl + 1;
+                if (b_size < N) ++b_size;                                 // the closing cell: lane lkl + 1 wrote its (MIN, MIN)
+                done = true;
+            }
+        }
+        if (!done) {
+            const int nlim = max(n0, N);                 // cells that may be kept: the window, and behind it the gap tail while b < N
+            o.cells += n0 - f0;
+            int bb = best, rowarg = -1, fk = -1, lk = -1, lkH = 0;
+            int runP = XW_NEG, prevHp = 0, et_carry = X_MIN_SCORE;
+            auto pass = [&](auto first_tag, const int c0) __attribute__((always_inline)) {
+                constexpr bool FIRST = decltype(first_tag)::value;
+                const int b = c0 + lane;
+                const bool in0 = b < n0;
+                const bool live = b < nlim;
+                int2 hf = S.HF[b & (XW_RING - 1)];
+                const int tb = S.Tb[b];
+                const int Hp = in0 ? hf.x : X_MIN_SCORE, Fp = in0 ? hf.y : X_MIN_SCORE;
+                const bool mt = AC == tb;
+                const int left = xw_shr1(Hp, FIRST ? 0 : prevHp);
+                const bool dok = FIRST ? (in0 && lane != 0) : in0;            // no diagonal into the row's first cell, none into the gap tail
+                const int diag = dok ? left + (mt ? 1 : -1) : X_MIN_SCORE;
+                const int Mv = max(diag, Fp);
+                const int incl = xw_scan_max(Mv + b);                         // (lanes behind the window hold MIN + b: below every real cell)
+                int pex = xw_shr1(incl, XW_NEG);
+                if (!FIRST) pex = max(pex, runP);
+                const int Ec = pex - b;                                       // (the row's first cell: NEG - b, below MIN like the reference's MIN)
+                const int Hc = max(Mv, Ec);
+                const unsigned long long livem = __builtin_amdgcn_ballot_w64(live);
+                const unsigned long long in0m = __builtin_amdgcn_ballot_w64(in0);
+                // a row's scores exceed the best of the rows before by at most the match reward: all cells above bb hold bb + 1
+                const unsigned long long exm = __builtin_amdgcn_ballot_w64(Hc > bb) & livem;
+                const int j1 = exm ? __ffsll((long long)exm) - 1 : 64;
+                const int thr = bb - X + (lane > j1 ? 1 : 0);
+                const bool ge = Hc >= thr;
+                const unsigned long long km = __builtin_amdgcn_ballot_w64(ge) & livem;
+                const bool kept = live && ge;
+                const int fkl = km ? __ffsll((long long)km) - 1 : 64;
+                const int lkl = km ? 63 - __clzll((long long)km) : 64;       // 64: no kept cell in this pass
+                const int Hlk = __builtin_amdgcn_readlane(Hc, lkl & 63);
+                // the row gap a dropped cell compares with: H of the nearest kept cell to the left - 1 (MIN if none)
+                int et;
+                const unsigned long long holes = km ? (in0m & ~km & ((1ull << (lkl & 63)) - 1ull) & ~((2ull << (fkl & 63)) - 1ull)) : 0ull;
+                if (__builtin_expect(holes == 0ull, 1)) et = lane > lkl ? Hlk - 1 : et_carry;
+                else {
+                    const unsigned long long lower = km & ((1ull << lane) - 1ull);
+                    const int jsrc = lower ? 63 - __clzll((long long)lower) : 0;
+                    const int Hj = __shfl(Hc, jsrc);
+                    et = lower ? Hj - 1 : et_carry;
+                }
+                int script = diag < Fp ? XS_GAP_IN_B : XS_SUB;
+                if (Mv < (kept ? Ec : et)) script = XS_GAP_IN_A;
+                const bool xa = kept && Fp >= Hc, xb = kept && in0 && Ec >= Hc, xm = mt && in0;
+                script |= (xa ? XS_EXT_A : 0) | (xb ? XS_EXT_B : 0) | (xm ? XS_MATCH : 0);
+                S.HF[b & (XW_RING - 1)] = make_int2(kept ? Hc : X_MIN_SCORE, kept ? Hc - 1 : Fp);
+                (FIRST ? srow : st2 + (size_t)a * 64)[lane] = (uint8_t)script;
+                if (!FIRST) S.two[a >> 5] |= 1u << (a & 31);                 // (every lane, one address)
+                // carries
+                if (exm) { if (rowarg < 0) rowarg = c0 + j1; bb = bb + 1; }
+                if (km) {
+                    if (fk < 0) fk = c0 + fkl;
+                    lk = c0 + lkl;
+                    lkH = Hlk;
+                    et_carry = Hlk - 1;
+                }
+                if (FIRST) { runP = __builtin_amdgcn_readlane(incl, 63); prevHp = __builtin_amdgcn_readlane(Hp, 63); }
+            };
+            pass(std::integral_constant<bool, true>(), f0);
+            // a second pass: the window is wider than 64 cells, or the gap tail runs on behind lane 63
+            if (n0 - f0 > 64 || (lk == f0 + 63 && f0 + 64 < N)) pass(std::integral_constant<bool, false>(), f0 + 64);
+            XD_COUNT(n_rows2);
+            if (bb > best) { best = bb; ae = a; be = rowarg; }
+            if (fk < 0) { first_b = n0; stop = true; o.rows = a; break; }
+            first_b = fk;
+            S.rs[a] = (uint16_t)f0;                                          // (every lane, one address)
+            b_size = lk + 1;
+            if (b_size < N) { S.HF[b_size & (XW_RING - 1)] = make_int2(X_MIN_SCORE, X_MIN_SCORE); ++b_size; }      // the closing cell
+            if (b_size - first_b > XW_RING - 2 || b_size - f0 > XW_STRIDE - 2) { o.overflow = 2; return; }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (!stop) o.rows = aend;
+    }
+    for (int off = 32; off; off >>= 1) cellacc += __shfl_xor(cellacc, off);
+    o.cells += cellacc;
+    o.ae = ae; o.be = be;
+    XD_TICK(tk_rows);
+    // ---- traceback (:165-210) fused with script_to_aligned_string + trim_mismatch_end: whole diagonal runs per step (see xdrop_block_w)
+    __threadfence();
+    __builtin_amdgcn_wave_barrier();
+    // The script rows are read back through a 24-row LDS window that moves down the rows on a fixed grid (16 rows per move, 8 rows of
+    // overlap), so the window after the current one is known in advance: its loads are in flight (in registers) while the walk is
+    // still inside the current window, and a move costs an LDS copy instead of a memory round trip.  The bytes were written by this
+    // wave, so they are read past the L1 (agent scope).
+    constexpr int NW = XR_WIN / 2 / 4 / 64;             // words per lane and chunk array
+    constexpr int WROWS = XR_WIN / 2 / 64;
+    uint32_t nxt[NW], nxt2[NW];
+    bool nxt_two = false;
+    auto issue_window = [&](int row0) {
+#pragma unroll
+        for (int j = 0; j < NW; ++j) nxt[j] = __hip_atomic_load((const uint32_t*)st + row0 * 16 + lane + 64 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // rows row0 .. row0 + 23 lie in at most two words of the bit mask
+        const uint32_t w0 = S.two[row0 >> 5], w1 = S.two[(row0 >> 5) + 1];
+        const unsigned long long bits = (((unsigned long long)w1 << 32) | w0) >> (row0 & 31);
+        nxt_two = __builtin_amdgcn_readfirstlane((int)((uint32_t)bits & ((1u << WROWS) - 1u))) != 0;
+        if (nxt_two) {
+#pragma unroll
+            for (int j = 0; j < NW; ++j) nxt2[j] = __hip_atomic_load((const uint32_t*)st2 + row0 * 16 + lane + 64 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    auto commit_window = [&]() {
+#pragma unroll
+        for (int j = 0; j < NW; ++j) S.win[lane + 64 * j] = nxt[j];
+        if (nxt_two) {
+#pragma unroll
+            for (int j = 0; j < NW; ++j) S.win[XR_WIN / 8 + lane + 64 * j] = nxt2[j];
+        }
+    };
+    int a_index = ae, b_index = be;
+    int st_op = XS_SUB;
+    int n = 0, nmatch = 0, m = 0, found = 0, want_l1 = 0, first = 0, l1 = 0;
+    int sn_n = 0, sn_a = 0, sn_b = 0, sn_m = 0;
+    int wlo = max(ae - (WROWS - 1), 0);                  // first row in the window
+    issue_window(wlo);
+    commit_window();
+    if (wlo > 0) issue_window(max(wlo - 16, 0));
+    __builtin_amdgcn_wave_barrier();
+    XD_COUNT(n_win);
+    while (a_index > 0 || b_index > 0) {
+        if (wlo > 0 && a_index - wlo < 8) {              // (a step ends at row wlo - 1 at the lowest: inside the next window)
+            __builtin_amdgcn_wave_barrier();
+            commit_window();
+            wlo = max(wlo - 16, 0);
+            if (wlo > 0) issue_window(max(wlo - 16, 0));
+            __builtin_amdgcn_wave_barrier();
+            XD_COUNT(n_win);
+        }
+        XD_COUNT(n_steps);
+        const int ri = a_index - lane, bi = b_index - lane;
+        const bool vl = lane < WROWS && ri >= max(wlo, 1) && bi >= 1;
+        const int row = vl ? ri : a_index;
+        const int rs = S.rs[row];
+        const int ci = (vl ? bi : b_index) - rs;
+        const int cc = min(max(ci, 0), XW_STRIDE - 1);
+        // (a cell on the walk lies inside its row's window, so its chunk is in the window arrays; what an idle lane reads is not used)
+        const int byte = ((const uint8_t*)S.win)[(row - wlo) * 64 + (cc & 63) + (cc >= 64 ? XR_WIN / 2 : 0)];
+        const unsigned long long sm = __builtin_amdgcn_ballot_w64(vl && ci >= 0 && ci < XW_STRIDE && (byte & XS_OP_MASK) == XS_SUB);
+        const uint32_t mm = (uint32_t)__builtin_amdgcn_ballot_w64((byte & XS_MATCH) != 0);
+        const int byte0 = __builtin_amdgcn_readfirstlane(byte);
+        const int sh = 4 + (st_op & 1) + ((st_op >> 2) << 1);
+        const int op = ((byte0 >> sh) & 1) ? st_op : (byte0 & XS_OP_MASK);
+        st_op = op;
+        if (op != XS_SUB || !(sm & 1)) {
+            const int cq = op != XS_GAP_IN_A, ct = op != XS_GAP_IN_B;
+            const int cm = cq & ct & (byte0 >> 7);
+            a_index -= cq;
+            b_index -= ct;
+            const int pk = cq | (ct << 1) | (cm << 2);
+            first = n == 0 ? pk : first;
+            l1 = want_l1 ? pk : l1;
+            want_l1 = 0;
+            ++n;
+            nmatch += cm;
+            m = cm ? m + 1 : 0;
+            if (m == 4 && !found) { found = 1; want_l1 = 1; sn_n = n; sn_a = a_index; sn_b = b_index; sn_m = nmatch; }
+            continue;
+        }
+        const uint32_t s32 = (uint32_t)sm;
+        const int r = s32 == 0xffffffffu ? 32 : __builtin_ctz(~s32);
+        const uint32_t mask = r >= 32 ? 0xffffffffu : ((1u << r) - 1u);
+        const uint32_t Mm = mm & mask;
+        const int pk0 = 3 | ((Mm & 1u) << 2);
+        first = n == 0 ? pk0 : first;
+        l1 = want_l1 ? pk0 : l1;
+        want_l1 = 0;
+        const uint32_t inv = ~Mm & mask;
+        if (!found) {
+            const int z = inv ? __builtin_ctz(inv) : r;
+            int hit = -1;
+            if (m + z >= 4) hit = 3 - m;
+            else {
+                const uint32_t Q = Mm & (Mm >> 1) & (Mm >> 2) & (Mm >> 3);
+                if (Q) hit = __builtin_ctz(Q) + 3;
+            }
+            if (hit >= 0) {
+                found = 1;
+                sn_n = n + hit + 1; sn_a = a_index - (hit + 1); sn_b = b_index - (hit + 1);
+                sn_m = nmatch + __builtin_popcount(Mm & ((2u << hit) - 1u));
+                if (hit + 1 < r) l1 = 3 | (int)(((Mm >> (hit + 1)) & 1u) << 2);
+                else want_l1 = 1;
+            }
+        }
+        m = inv ? r - 1 - (31 - __builtin_clz(inv)) : m + r;
+        n += r;
+        nmatch += __builtin_popcount(Mm);
+        a_index -= r;
+        b_index -= r;
+    }
+    o.n = n; o.nmatch = nmatch;
+    o.l0q = first & 1; o.l0t = (first >> 1) & 1; o.l0m = first >> 2;
+    o.l1q = l1 & 1; o.l1t = (l1 >> 1) & 1; o.l1m = l1 >> 2;
+    o.acnt = found ? sn_n : n; o.qcnt = found ? ae - sn_a : ae; o.tcnt = found ? be - sn_b : be; o.mtail = found ? sn_m : nmatch;
+    o.trim_ok = found && (n - o.acnt >= 2);
+    XD_TICK(tk_trace);
+}
+
 template <bool WIDE>
 __global__ __launch_bounds__(XW_BLOCK) void xd_extend_w(const uint32_t* __restrict__ rpac, const mhip_offset_t* __restrict__ roffs,
                                                         const uint32_t* __restrict__ qpac, const mhip_offset_t* __restrict__ qoffs,
@@ -383,11 +695,15 @@ __global__ __launch_bounds__(XW_BLOCK) void xd_extend_w(const uint32_t* __restri
                                                         unsigned int* __restrict__ ovf_list, unsigned long long* __restrict__ counters,
                                                         const unsigned int* __restrict__ ulist, unsigned int nunits, int force_wide) {
     constexpr int HFN = WIDE ? XW_WIDE_HF : XW_RING;
-    __shared__ XwLds<HFN> lds[WIDE ? 1 : XW_WAVES];
-    XwLds<HFN>& S = lds[threadIdx.x >> 6];
+    __shared__ typename std::conditional<WIDE, XwLds<XW_WIDE_HF>, XrLds>::type lds[WIDE ? 1 : XW_WAVES];
+    auto& S = lds[threadIdx.x >> 6];
     const int lane = lane_id();
     uint8_t* st = scratch + (size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (WIDE ? XW_WIDE_BYTES : XW_STATE_BYTES);
     unsigned long long nblocks = 0, ncells = 0, nrows = 0;
+#ifdef MECAT_XD_STATS
+    unsigned long long xs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long tk_life = __builtin_amdgcn_s_memtime();
+#endif
     while (true) {
         unsigned int unit = 0;
         if (lane == 0) unit = atomicAdd(cursor, 1u);
@@ -422,7 +738,13 @@ __global__ __launch_bounds__(XW_BLOCK) void xd_extend_w(const uint32_t* __restri
             } else { qblk = X_SEG; tblk = X_SEG; last_block = 0; }
             XBlockOut o;
             o.overflow = 1;
-            if (!WIDE || !force_wide) xdrop_block_w<false, HFN>(S, q, qidx, qblk, t, tidx, tblk, st, o);
+            if constexpr (!WIDE) {
+                xdrop_block_ring(S, q, qidx, qblk, t, tidx, tblk, st, o);
+#ifdef MECAT_XD_STATS
+                xs[0] += o.tk_stage; xs[1] += o.tk_rows; xs[2] += o.tk_trace; xs[3] += o.n_rows2; xs[4] += o.n_win; xs[5] += o.n_steps; xs[6] += o.n_qfill;
+#endif
+            }
+            else if (!force_wide) xdrop_block_w<false, HFN>(S, q, qidx, qblk, t, tidx, tblk, st, o);      // (the round-1 ring code: the independent implementation)
             ++nblocks;
             R.blocks += 1;
             ncells += (unsigned)o.cells;
@@ -464,6 +786,13 @@ __global__ __launch_bounds__(XW_BLOCK) void xd_extend_w(const uint32_t* __restri
         atomicAdd(&counters[3], nblocks);
         atomicAdd(&counters[4], ncells);      // DP cells (the slot dw's d-path cells use)
         atomicAdd(&counters[9], nrows);
+#ifdef MECAT_XD_STATS
+        if (!WIDE) {
+            atomicAdd(&counters[16], __builtin_amdgcn_s_memtime() - tk_life);      // wave life, ticks
+            for (int i = 0; i < 7; ++i) atomicAdd(&counters[17 + i], xs[i]);         // stage, rows, trace ticks; two-pass rows, window loads, traceback steps, query refills
+            atomicAdd(&counters[24], 1ull);
+        }
+#endif
     }
 }
 

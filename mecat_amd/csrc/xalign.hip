@@ -421,13 +421,14 @@ __device__ void xdrop_block_ring(XrLds& S, const XView& q, int qidx, int M, cons
     if (lane == 0) S.rs[0] = 0;
     int b_size = n_init + 1, best = 0, first_b = 0, ae = 0, be = 0;
     int qreg = 0, cellacc = 0;
-    const bool special = N <= X;                         // row 0 ran off the end of the target: b_size = N + 1, every row through the general code
+    const int wmax = N <= X ? -1 : 64;                   // N <= X: row 0 ran off the end of the target (b_size = N + 1), every row through the general code
     bool stop = false;
     __builtin_amdgcn_wave_barrier();
     XD_TICK(tk_stage);
     for (int a0 = 1; a0 <= M && !stop; a0 += 64) {
       // the query bases of the next 64 rows in a register: one v_readlane per row
       qreg = (a0 - 1 + lane < M) ? xv_at(q, qidx + a0 - 1 + lane) : 0;
+      asm volatile("v_mov_b32 %0, %0" : "+v"(qreg));      // the load is waited for here, not at the row loop's first v_readlane (vmcnt also counts the rows' stores)
       XD_COUNT(n_qfill);
       const int aend = min(a0 + 63, M);
       for (int a = a0; a <= aend; ++a) {
@@ -439,8 +440,7 @@ __device__ void xdrop_block_ring(XrLds& S, const XView& q, int qidx, int M, cons
         // the check is redone by the general code below).  The scalar port is what bounds this kernel (profiles/r04_xd_breakdown.md):
         // masks are compared as masks (s_bfm), "none" is s_ff1's own -1, every lane behind or in front of the kept cells stores (MIN, MIN)
         // — the closing cell is one of them, the others are never read — and the DP cells are counted per lane.
-        bool done = false;
-        if (__builtin_expect(n0 - f0 <= 64 && !special, 1)) {
+        if (__builtin_expect(n0 - f0 <= wmax, 1)) {                     // (wmax = 64; -1 in a special block)
             const int b = f0 + lane;
             const bool in0 = b < n0;
             const bool live = b < N;                                     // (n0 <= N outside the special blocks)
@@ -466,12 +466,13 @@ __device__ void xdrop_block_ring(XrLds& S, const XView& q, int qidx, int M, cons
             const int nk = __builtin_popcountll(km);
             unsigned long long want;                                      // nk ones from bit fkl on (0 for nk = 64: such a row fails the test)
             asm("s_bfm_b64 %0, %1, %2" : "=s"(want) : "s"(nk), "s"(fkl));
-            if (__builtin_expect(km != 0ull && km == want && (long long)km >= 0, 1)) {
-                const int lkl = fkl + nk - 1;
+            const int lk1 = fkl + nk;                                     // one behind the last kept lane; no kept cell: -1, as unsigned above 63
+            // kept cells are one run that ends in front of lane 63 (a kept lane 63 may have a gap tail behind it: general code)
+            if (__builtin_expect(km == want && (unsigned)lk1 < 64u, 1)) {
                 const bool kept = live && ge;
                 cellacc += in0 ? 1 : 0;
-                const int Hlk = __builtin_amdgcn_readlane(Hc, lkl);
-                const int et = lane > lkl ? Hlk - 1 : X_MIN_SCORE;
+                const int Hlk = __builtin_amdgcn_readlane(Hc, lk1 - 1);
+                const int et = lane >= lk1 ? Hlk - 1 : X_MIN_SCORE;
                 int script = diag < Fp ? XS_GAP_IN_B : XS_SUB;
                 if (Mv < (kept ? Ec : et)) script = XS_GAP_IN_A;
                 const bool xa = kept && Fp >= Hc, xb = kept && in0 && Ec >= Hc, xm = mt && in0;
@@ -479,14 +480,18 @@ __device__ void xdrop_block_ring(XrLds& S, const XView& q, int qidx, int M, cons
                 S.HF[b & (XW_RING - 1)] = make_int2(kept ? Hc : X_MIN_SCORE, kept ? Hc - 1 : X_MIN_SCORE);
                 srow[lane] = (uint8_t)script;
                 S.rs[a] = (uint16_t)f0;                                  // (every lane, one address)
-                if (exm) { best += 1; ae = a; be = f0 + j1; }
+                const bool up = exm != 0ull;
+                best += up ? 1 : 0;
+                ae = up ? a : ae;
+                be = up ? f0 + j1 : be;
                 first_b = f0 + fkl;
-                b_size = f0 + lkl + 1;
-                if (b_size < N) ++b_size;                                 // the closing cell: lane lkl + 1 wrote its (MIN, MIN)
-                done = true;
+                b_size = f0 + lk1;
+                b_size += b_size < N ? 1 : 0;                             // the closing cell: lane lk1 wrote its (MIN, MIN)
+                __builtin_amdgcn_wave_barrier();
+                continue;
             }
         }
-        if (!done) {
+        {
             const int nlim = max(n0, N);                 // cells that may be kept: the window, and behind it the gap tail while b < N
             o.cells += n0 - f0;
             int bb = best, rowarg = -1, fk = -1, lk = -1, lkH = 0;
@@ -679,6 +684,10 @@ __device__ void xdrop_block_ring(XrLds& S, const XView& q, int qidx, int M, cons
         a_index -= r;
         b_index -= r;
     }
+    // a window that was asked for and never needed is waited for here: left pending, its loads would put a vmcnt(0) wait — which also
+    // waits for the stores of the row before — at the head of the next block's row loop
+#pragma unroll
+    for (int j = 0; j < NW; ++j) asm volatile("" :: "v"(nxt[j]), "v"(nxt2[j]));
     o.n = n; o.nmatch = nmatch;
     o.l0q = first & 1; o.l0t = (first >> 1) & 1; o.l0m = first >> 2;
     o.l1q = l1 & 1; o.l1t = (l1 >> 1) & 1; o.l1m = l1 >> 2;

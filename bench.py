@@ -91,6 +91,37 @@ def cpu_baseline(workload, nthreads):
             "candidates": ncan, "hot_path_s": dt}
 
 
+def cpu_full_size(workload, codes, lens, nthreads, gpu_candidates):
+    """north_star: "next to reference mecat2pw timed on the node's own host cores (core count stated) in the same run" — the unmodified
+    reference (oracle/_ref/mecat2pw -j 0) on the FULL workload's FASTA, once, on this host (-t = min(cores, 64): its index build has
+    every thread scan the whole volume for its own key range, lookup_table.cpp:36-58, so threads beyond the memory system add nothing)"""
+    from mecat_amd import workload as W
+    ref = os.path.join(ROOT, "oracle", "_ref", "mecat2pw")
+    if not os.path.exists(ref):
+        return None
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    d = tempfile.mkdtemp(prefix="mecat_cpufull_", dir=base)
+    try:
+        fa = os.path.join(d, "reads.fa")
+        W.write_fasta(fa, codes, lens)
+        out = os.path.join(d, "o.can")
+        t0 = time.time()
+        p = subprocess.run([ref, "-j", "0", "-d", fa, "-o", out, "-w", os.path.join(d, "w"), "-t", str(nthreads)], stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True, timeout=1500)
+        wall = time.time() - t0
+        if p.returncode != 0:
+            return {"error": p.stderr[-300:]}
+        tm = dict(re.findall(r"\[([a-z_ 0-9]+)\] takes ([0-9.]+) secs", p.stderr))
+        hot = float(tm.get("create_ref_index", 0)) + float(tm.get("process volume 0", 0))
+        nl = sum(1 for _ in open(out))
+        return {"kind": "reference", "what": "unmodified mecat2pw -j 0 on the full %s FASTA (%d bytes), this host, same run" % (workload, os.path.getsize(fa)),
+                "cores": nthreads, "host_cpus": os.cpu_count(), "candidates": nl, "same_count_as_gpu": nl == gpu_candidates,
+                "hot_path_s": hot, "create_ref_index_s": float(tm.get("create_ref_index", 0)), "wall_s": wall,
+                "candidates_per_s": nl / hot if hot > 0 else None, "candidates_per_s_wall": nl / wall}
+    finally:
+        subprocess.run(["rm", "-rf", d])
+
+
 def oracle_port_candidates(codes, lens, ont):
     """index + candidates of every read with oracle/liboracle.so (the checker; cpu_baseline leg only)"""
     lib = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
@@ -268,6 +299,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="config2")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-full", type=int, default=1, help="1 (default): also time the unmodified reference -j 0 on the full workload on this host, once")
     ap.add_argument("--no-align", action="store_true", help="-j 0 only (index + candidates)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed cns_realign / xdrop_extend measurements")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end CLI leg (FASTA -> .can / .m4 wall clock)")
@@ -321,7 +353,7 @@ def main():
     t0 = time.time()
     codes, lens = W.synth_reads(n, L, err, G, seed, ont)
     pac, offs, num_bases = W.pack_volume(codes, lens)
-    if rank != 0 or world > 1 or (args.no_e2e and (args.no_cpu or args.no_extras)):
+    if rank != 0 or world > 1 or (args.no_e2e and args.no_cpu):
         del codes
     if rank == 0:
         log("[bench] %s: %d reads, %d bases incl. pads, generated+packed in %.1fs" % (args.workload, n, num_bases, time.time() - t0))
@@ -431,7 +463,14 @@ def main():
             aln_ok = int(ok.sum().item())
             aligned_bases = int(((r[:, 2] - r[:, 1]).to(torch.int64) * ok).sum().item())
     else:
-        exch = {"bytes_received_per_step": comm.bytes_received() / max(1, args.steps + args.warmup)}
+        tr, nr = comm.info()
+        exch = {"bytes_received_per_step": comm.bytes_received() / max(1, args.steps + args.warmup),
+                "transport": "rccl" if tr == 0 else "host files (test hook)", "rccl_ranks": nr,
+                # HIP events around every exchange on the launch stream (rank 0's view), per step
+                "ms": kstats.get("xg_exchange", (0, 0.0))[1] / args.steps, "calls_per_step": kstats.get("xg_exchange", (0, 0.0))[0] / args.steps,
+                "index_exchange_ms": kstats.get("xg_exchange_index", (0, 0.0))[1] / args.steps,
+                "index_build_kernels_ms": sum(v[1] for k, v in kstats.items() if k.startswith(("ix_", "idx"))) / args.steps,
+                "index_rebase_slots_ms": sum(v[1] for k, v in kstats.items() if k.startswith("xg_index")) / args.steps}
         idx = comm.index_build_sharded(vol) if shard_index else M.Index(ctx, vol)
         _, h_cnt = comm.seed_reads_sharded(idx, vol, vol, 0, n, params, chunk=CH, cell_shift=0, host=True)
         ncand = int(h_cnt.sum())
@@ -712,6 +751,15 @@ def main():
                     line["cns_accept"]["cpu_baseline"] = {"error": repr(e)[:200]}
             try:
                 line["cpu_baseline"] = cpu_baseline(args.workload, os.cpu_count() or 1)
+                if args.cpu_full and args.workload == "config2":
+                    try:
+                        fs = cpu_full_size(args.workload, codes, lens, min(os.cpu_count() or 1, 64), ncand)
+                        if fs:
+                            line["cpu_baseline"]["full_size_same_host"] = fs
+                            if fs.get("candidates_per_s"):
+                                line["cpu_baseline"]["gpu_over_cpu_full_size_j0"] = (ncand / ((phase[0] + phase[1]) / 1e3)) / fs["candidates_per_s"]
+                    except Exception as e:  # noqa: BLE001
+                        line["cpu_baseline"]["full_size_same_host"] = {"error": repr(e)[:200]}
                 try:      # context: the unmodified reference on the FULL workload, timed in the build container (tests/golden/big.json)
                     big = json.load(open(os.path.join(ROOT, "tests", "golden", "big.json"))).get(args.workload)
                     if big and "j0_seconds" in big:

@@ -295,7 +295,13 @@ def run(args):
         aln_ok = sum(c.get("overlaps_ok", 0) for c in keep["cell"].values())
         aligned_bases = sum(c.get("aligned_bases", 0) for c in keep["cell"].values())
     else:
-        exch = {"bytes_received_per_step": comm.bytes_received() / max(1, args.steps + args.warmup)}
+        tr, nr = comm.info()
+        exch = {"bytes_received_per_step": comm.bytes_received() / max(1, args.steps + args.warmup),
+                "transport": "rccl" if tr == 0 else "host files (test hook)", "rccl_ranks": nr,
+                "ms": kstats.get("xg_exchange", (0, 0.0))[1] / args.steps, "calls_per_step": kstats.get("xg_exchange", (0, 0.0))[0] / args.steps,
+                "index_exchange_ms": kstats.get("xg_exchange_index", (0, 0.0))[1] / args.steps,
+                "index_build_kernels_ms": sum(v[1] for k, v in kstats.items() if k.startswith(("ix_", "idx"))) / args.steps,
+                "index_rebase_slots_ms": sum(v[1] for k, v in kstats.items() if k.startswith("xg_index")) / args.steps}
         ncand = int(counters["candidates"] // args.steps)
         aln_ok = int(counters["aln_ok"] // args.steps)
         aligned_bases = int(counters["aligned_bases"] // args.steps)

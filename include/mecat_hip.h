@@ -193,6 +193,10 @@ int  mhip_comm_unique_id(uint8_t id[MHIP_COMM_ID_BYTES]);
 int  mhip_comm_init(mhip_ctx* ctx, int nranks, int rank, const uint8_t id[MHIP_COMM_ID_BYTES], mhip_comm** out);
 int  mhip_comm_init_hostfile(mhip_ctx* ctx, int nranks, int rank, const char* dir, const char* run_id, mhip_comm** out);
 void mhip_comm_destroy(mhip_comm* comm);
+/* transport: 0 = RCCL, 1 = host files (test hook); rccl_ranks = ncclCommCount of the communicator (0 with host files).  With the
+ * context profiling (mhip_ctx_set_profiling) every exchange is timed on the stream under the kernel-stat names "xg_exchange"
+ * (candidate / result all-gathers) and "xg_exchange_index" (mhip_index_build_sharded). */
+int  mhip_comm_info(const mhip_comm* comm, int* transport, int* rccl_ranks);
 int  mhip_comm_rank(const mhip_comm* comm);
 int  mhip_comm_nranks(const mhip_comm* comm);
 int  mhip_comm_barrier(mhip_comm* comm);

@@ -47,6 +47,7 @@ struct RcclApi {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
 };
 
 RcclApi* rccl() {
@@ -66,7 +67,7 @@ RcclApi* rccl() {
 #define SYM(f)                                                                         \
     api.f = (decltype(api.f))dlsym(h, "nccl" #f);                                       \
     if (!api.f) { mhip_set_error("RCCL symbol nccl" #f " missing"); dlclose(h); return nullptr; }
-    SYM(GetUniqueId) SYM(CommInitRank) SYM(CommDestroy) SYM(AllGather) SYM(Send) SYM(Recv) SYM(GroupStart) SYM(GroupEnd) SYM(GetErrorString)
+    SYM(GetUniqueId) SYM(CommInitRank) SYM(CommDestroy) SYM(AllGather) SYM(Send) SYM(Recv) SYM(GroupStart) SYM(GroupEnd) SYM(GetErrorString) SYM(CommCount)
 #undef SYM
     api.handle = h;
     return &api;
@@ -118,6 +119,7 @@ struct mhip_comm {
     mhip_aln_result* d_all_res = nullptr;   // dense, read-major
     int64_t n_jobs_total = 0;
     int64_t bytes_received = 0;
+    const char* xlabel = "xg_exchange";     // name the exchanges are timed under (HIP events on the stream while the context profiles)
 };
 
 namespace {
@@ -237,6 +239,7 @@ int allgatherv(mhip_comm* cm, const void* d_send, void* d_recv, const std::vecto
     if (P == 1) return 0;
     for (int r = 0; r < P; ++r)
         if (r != me) cm->bytes_received += (int64_t)bytes[r];
+    LaunchTimer xt(c, cm->xlabel);
     if (!cm->hostfile) {
         RcclApi* R = rccl();
         if (!R) return -1;
@@ -434,6 +437,22 @@ int mhip_comm_selftest(mhip_ctx* c) {
     return 0;
 }
 
+// what the communicator really is: transport 0 = RCCL, 1 = host files (test hook); rccl_ranks = ncclCommCount of the RCCL
+// communicator (0 with the host-file transport) — a bench line that claims N GPUs shows that RCCL saw N ranks
+int mhip_comm_info(const mhip_comm* cm, int* transport, int* rccl_ranks) {
+    if (transport) *transport = cm->hostfile ? 1 : 0;
+    if (rccl_ranks) {
+        *rccl_ranks = 0;
+        if (!cm->hostfile && cm->nc) {
+            RcclApi* R = rccl();
+            if (!R) return -1;
+            int n = 0;
+            NCHK(R->CommCount(cm->nc, &n));
+            *rccl_ranks = n;
+        }
+    }
+    return 0;
+}
 int mhip_comm_rank(const mhip_comm* cm) { return cm->rank; }
 int mhip_comm_nranks(const mhip_comm* cm) { return cm->nranks; }
 int64_t mhip_comm_bytes_received(const mhip_comm* cm) { return cm->bytes_received; }
@@ -690,6 +709,7 @@ extern "C" {
 // pass instead of 2 more bytes per position over the links).  Per rank at config 2 and P = 8: 4.1 GB of positions + 1.2 GB of
 // table slices received, against a rebuild that is 23 ms whatever P is.
 int mhip_index_build_sharded(mhip_comm* cm, const mhip_volume* v, mhip_index** out) {
+    struct Label { mhip_comm* c; Label(mhip_comm* c_) : c(c_) { c->xlabel = "xg_exchange_index"; } ~Label() { c->xlabel = "xg_exchange"; } } label_guard(cm);
     mhip_ctx* c = cm->ctx;
     *out = nullptr;
     HIPCHK(hipSetDevice(c->device));

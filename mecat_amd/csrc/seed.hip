@@ -45,7 +45,8 @@
 #define KEY_OFF_BITS 11
 #define KEY_KM_BITS 16
 #define KEY_SEG_SHIFT (KEY_OFF_BITS + KEY_KM_BITS)   // 27
-#define MAXC_LIMIT 1024
+#define MAXC_LDS 1024                 // top-MAXC lists up to this size live in LDS; longer ones in the output array itself
+#define MAXC_LIMIT (1 << 20)
 #define FLT_BITS 15                 // relevance filter: 2^15 8-bit hit counters per strand, segment ids hashed by their low bits
 #define FLT_M (1 << FLT_BITS)
 #define REL_WORDS (FLT_M / 32)      // relevance bitmap over the same hashed ids
@@ -1487,10 +1488,16 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(7, 7))) vo
                                                   int reads_start_id, mhip_params P, mhip_candidate* __restrict__ out,
                                                   int32_t* __restrict__ out_counts, unsigned long long* __restrict__ counters) {
     extern __shared__ __attribute__((aligned(16))) int smem[];
-    int* clist = smem;                                  // [maxc][12]
-    CandLds* T = (CandLds*)(smem + P.maxc * 12);
     const int lane = lane_id();
     const int r = blockIdx.x;
+    // the list: [maxc][12] in LDS; a list too long for that (-n above 1024: the reference takes any positive -n, pw_options.cpp:9) is
+    // built in place in the read's slice of the output table — the same code on global memory, read past the L1 (the wave reads its
+    // own earlier stores)
+    const bool big = P.maxc > MAXC_LDS;
+    int* clist = big ? (int*)(out + (size_t)r * P.maxc) : smem;
+    CandLds* T = (CandLds*)(smem + (big ? 0 : P.maxc * 12));
+    auto cl_ld = [&](int i) -> int { return big ? __hip_atomic_load(clist + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : clist[i]; };
+    auto cl_st = [&](int i, int v) { if (big) __hip_atomic_store(clist + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else clist[i] = v; };
     const int rid = sel_rid(sel, ib + r);
     const int read_id = rid + reads_start_id;
     const int read_size = roffs[rid].size;
@@ -1725,7 +1732,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(7, 7))) vo
             const int cscore = vote + seedcount;
             // ---- stable insertion into the descending top-MAXC list (pw_impl.cpp:442-455)
             int ge = 0;
-            for (int i = lane; i < ncand; i += 64) ge += clist[i * 12 + 6] >= cscore ? 1 : 0;
+            for (int i = lane; i < ncand; i += 64) ge += cl_ld(i * 12 + 6) >= cscore ? 1 : 0;
             for (int o = 32; o > 0; o >>= 1) ge += __shfl_xor(ge, o);
             const int pos = ge;                                  // == high + 1
             const int last_src = (ncand < MAXC) ? ncand - 1 : ncand - 2;
@@ -1735,19 +1742,19 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(7, 7))) vo
                 int v[12];
                 if (i >= pos) {
 #pragma unroll
-                    for (int q = 0; q < 12; ++q) v[q] = clist[i * 12 + q];
+                    for (int q = 0; q < 12; ++q) v[q] = cl_ld(i * 12 + q);
                 }
                 __syncthreads();
                 if (i >= pos) {
 #pragma unroll
-                    for (int q = 0; q < 12; ++q) clist[(i + 1) * 12 + q] = v[q];
+                    for (int q = 0; q < 12; ++q) cl_st((i + 1) * 12 + q, v[q]);
                 }
                 __syncthreads();
             }
             if (pos < MAXC && lane == 0) {
-                int* c = clist + pos * 12;
-                c[0] = loc_list - sstart; c[1] = loc2; c[2] = left1; c[3] = left2; c[4] = right1; c[5] = right2;
-                c[6] = cscore; c[7] = num1; c[8] = num2; c[9] = sid; c[10] = sstart; c[11] = strand;
+                const int cv[12] = {loc_list - sstart, loc2, left1, left2, right1, right2, cscore, num1, num2, sid, sstart, strand};
+#pragma unroll
+                for (int q = 0; q < 12; ++q) cl_st(pos * 12 + q, cv[q]);
             }
             if (ncand < MAXC) ++ncand;
             __syncthreads();
@@ -1758,7 +1765,8 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(7, 7))) vo
     }
     __syncthreads();
     int* o = (int*)(out + (size_t)r * MAXC);
-    for (int i = lane; i < ncand * 12; i += 64) o[i] = clist[i];
+    if (!big)
+        for (int i = lane; i < ncand * 12; i += 64) o[i] = clist[i];
     if (lane == 0) {
         out_counts[r] = ncand;
         atomicAdd(&counters[2], (unsigned long long)ncand);
@@ -1908,7 +1916,7 @@ static int seed_batch(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref
         }
         LAUNCH(c, "seed_build", seed_build, ns, SEED_BLOCK, 0, B, in_b, (int)P->min_kmer_match, P->ddfs_cutoff, sel, ib, RR);
     }
-    const size_t lds = sizeof(int) * 12 * (size_t)P->maxc + sizeof(CandLds);
+    const size_t lds = sizeof(int) * 12 * (size_t)(P->maxc > MAXC_LDS ? 0 : P->maxc) + sizeof(CandLds);
     LAUNCH(c, "seed_cand", seed_cand, nr, WAVE, lds, F, B, (const mhip_offset_t*)ref->d_offs, (const uint32_t*)ref->d_blk2read, ref->num_reads,
            ref->start_read_id,
            (const mhip_offset_t*)reads->d_offs, sel, ib, reads->start_read_id, *P, d_out, d_counts, (unsigned long long*)c->d_counters);

@@ -106,6 +106,7 @@ def lib():
     L.mhip_comm_init_hostfile.argtypes = [vp, i32, i32, C.c_char_p, C.c_char_p, C.POINTER(vp)]
     L.mhip_comm_destroy.argtypes = [vp]
     L.mhip_comm_barrier.argtypes = [vp]
+    L.mhip_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.mhip_comm_selftest.argtypes = [vp]
     L.mhip_comm_bytes_received.restype = i64
     L.mhip_comm_bytes_received.argtypes = [vp]
@@ -402,6 +403,12 @@ class Comm:
 
     def barrier(self):
         _chk(lib().mhip_comm_barrier(self.h))
+
+    def info(self):
+        """-> (transport: 0 RCCL / 1 host files, ncclCommCount of the RCCL communicator)"""
+        t, n = C.c_int(), C.c_int()
+        _chk(lib().mhip_comm_info(self.h, C.byref(t), C.byref(n)))
+        return t.value, n.value
 
     def bytes_received(self):
         return int(lib().mhip_comm_bytes_received(self.h))

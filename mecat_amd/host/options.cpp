@@ -107,8 +107,9 @@ int parse_arguments(int argc, char* argv[], Options* o) {
     else if (!o->wrk_dir) { LOGF("working directory must be specified."); ret = 1; }
     else if (o->num_threads < 1) { LOGF("number of cpu threads must be > 0."); ret = 1; }
     else if (o->num_candidates < 1) { LOGF("number of candidates must be > 0."); ret = 1; }
-    // additive limit of this implementation (the reference accepts any positive -n): the per-read top-MAXC list lives in LDS
-    else if (o->num_candidates > 1024) { LOGF("number of candidates (-n) must be <= 1024 in the MI355X build (got %d).", o->num_candidates); ret = 1; }
+    // (any positive -n, as in the reference, pw_options.cpp:9: lists above 1024 entries are built in HBM instead of LDS; the candidate
+    // table of a slab — reads x n x 48 bytes — has to fit the device)
+    else if (o->num_candidates > (1 << 20)) { LOGF("number of candidates (-n) must be <= %d (got %d).", 1 << 20, o->num_candidates); ret = 1; }
     if (ret) return ret;
 
     DIR* dir = opendir(o->wrk_dir);

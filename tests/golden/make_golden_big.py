@@ -11,6 +11,7 @@ files); the read sets are re-generated from their seeds by mecat_amd/bin/synth_r
     python tests/golden/make_golden_big.py config3_j1         # config 3, `-j 1 -g 1`, grid row 1 = cells (1,1) and (1,2): dw extension
                                                               # across two real volumes (adds config3.m4_rows; rows 0 and 2 planted)
     python tests/golden/make_golden_big.py config5_row0       # config 5, `-j 0 -x 1`, grid row 0 = 19 cells (adds config5.rows["0"])
+    python tests/golden/make_golden_big.py config5_row17_j1   # config 5, `-j 1 -x 1 -g 1`, grid row 17 = cells (17,17) and (17,18) (adds config5.m4_row17)
 
 Rows that are not pinned are skipped with the reference's own resume protocol: an existing wrk/r_<i> means "volume i has been
 finished" (mecat2pw/pw.cpp:65-81), so empty r_<i> files are planted for them before the run.
@@ -138,6 +139,25 @@ def extra(big, name):
             c["lines"], c["sorted_sha256"] = sorted_sha(r, "$2 >= %d && $2 < %d" % (lo, lo + vols[j]["num_reads"]))
             row["cells"]["1,%d" % j] = c
         m.setdefault("m4_rows", {})["1"] = row
+    elif name == "config5_row17_j1":
+        # -j 1 -x 1 -g 1 (X-drop extension) of grid row 17 = the diagonal cell (17, 17) and the off-diagonal cell (17, 18) at real volume size
+        out = os.path.join(d, "c5r17.m4")
+        wrk = os.path.join(d, "w3")
+        secs = run_ref(fa, out, wrk, ["-j", "1", "-x", "1", "-g", "1"], skip_rows=[i for i in range(nv) if i != 17])
+        vols = volumes(wrk)
+        assert [(v["num_reads"], v["num_bases"], v["start_read_id"]) for v in vols] == \
+               [(v["num_reads"], v["num_bases"], v["start_read_id"]) for v in m["volumes"]]
+        r = os.path.join(wrk, "r_17")
+        row = {"seconds": secs, "threads": int(THREADS)}
+        row["lines"], row["sorted_sha256"] = sorted_sha(r)
+        row["aligned_bases"] = aligned_bases(r)
+        row["cells"] = {}
+        for j in (17, 18):
+            lo = vols[j]["start_read_id"]
+            c = {}
+            c["lines"], c["sorted_sha256"] = sorted_sha(r, "$2 >= %d && $2 < %d" % (lo, lo + vols[j]["num_reads"]))
+            row["cells"]["17,%d" % j] = c
+        m["m4_row17"] = row
     else:
         out = os.path.join(d, "c5r0.can")
         wrk = os.path.join(d, "w2")
@@ -163,7 +183,7 @@ def main():
     which = sys.argv[1:] or ["config2"]
     big = json.load(open(OUT)) if os.path.exists(OUT) else {}
     for name in which:
-        if name in ("config3_j1", "config5_row0"):
+        if name in ("config3_j1", "config5_row0", "config5_row17_j1"):
             extra(big, name)
             big = json.load(open(OUT))
             continue

@@ -32,6 +32,9 @@ def test_bench_line_one_rank_and_two_ranks_agree():
     b = _line(r2.stdout)
     assert b["n_gpus"] == 2 and b["scaling"] == "strong"
     assert b["candidates"] == a["candidates"] and b["overlaps_ok"] == a["overlaps_ok"]
+    # the line says what the communicator was and what the exchanges cost (the first run on a node must show rccl / N ranks here)
+    x = b["exchange"]
+    assert x["transport"].startswith("host files") and x["rccl_ranks"] == 0 and x["ms"] > 0 and x["calls_per_step"] >= 2
 
 
 @pytest.mark.parametrize("wl,tech", [("grid_tiny", 0), ("grid_tiny_ont", 1)])

@@ -124,6 +124,30 @@ def test_candidates_match_oracle(name, maxc, hip, ctx):
     assert int(cnt.sum()) > 0
 
 
+def test_candidate_lists_longer_than_the_lds_list(hip, ctx):
+    """-n above 1024 (the reference takes any positive -n, pw_options.cpp:9): the top-MAXC list of a read is then built in the output
+    table in HBM instead of LDS.  1 100 reads x 15 kb on an 18 kb genome (900x: a 13-mer survives 15 % error one time in eight, so the
+    buckets stay under the cap of 128 while a late read meets a thousand earlier ones): lists reach 1 097 entries — the eviction at
+    MAXC = 1050 is exercised in HBM, MAXC = 4000 keeps every entry, MAXC = 1024 is the last LDS size."""
+    codes, lens = H.synth_reads(1100, 15000, 0.15, 18000, 31)
+    ov = H.orc_pack(codes, lens)
+    oidx = H.orc().orc_index_build(ov)
+    offs, pac = H.vol_arrays(ov)
+    gv = hip.Volume(ctx, pac, offs, ov.contents.num_bases, 0)
+    gi = hip.Index(ctx, gv)
+    seen_long = False
+    for maxc in (1050, 4000, 1024):
+        p = hip.default_params(0, maxc=maxc)
+        got, cnt = hip.seed_reads(ctx, gi, gv, gv, 0, len(lens), p)
+        want = H.orc_seed_all(ov, ov, oidx, H.orc_params(tech=0, maxc=maxc))
+        bad = _cmp_cands(got, cnt, want)
+        assert not bad, "maxc %d: %d reads differ, first %d" % (maxc, len(bad), bad[0])
+        seen_long = seen_long or int(cnt.max()) > 1024
+    assert seen_long, "no list beyond 1024 entries: the test input does not reach the HBM path"
+    gi.free()
+    gv.free()
+
+
 @pytest.mark.parametrize("name", ["tiny", "tiny_ont", "config1"])
 def test_can_lines_match_golden(name, hip, ctx):
     d = dataset(name, hip, ctx)

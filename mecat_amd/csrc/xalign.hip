@@ -385,7 +385,10 @@ __device__ void xdrop_block_w(XwLds<HFN>& S, const XView& q, int qidx, int M, co
 //   * the score of a dropped cell's row gap (H of the nearest kept cell to the left - 1) is a scalar for every lane behind the last
 //     or in front of the first kept cell; only a row with a hole between kept cells takes the per-lane look-up;
 //   * the query bases of 64 rows sit in a register (one v_readlane per row instead of an LDS round trip).
-#define XR_WIN 3072                      // traceback window: 24 script rows
+#ifndef XR_WIN
+#define XR_WIN 3072                      // traceback window: 24 script rows (first chunks + second chunks)
+#endif
+#define XR_MOVE (XR_WIN / 128 - 8)       // rows the window moves by: 8 rows of overlap
 struct XrLds {
     int2 HF[XW_RING];
     uint8_t Tb[X_MAXN + 72 + 64];        // Tb[b] = target base b - 1 (idle and tail lanes read up to 128 cells behind the window)
@@ -611,7 +614,7 @@ __device__ void xdrop_block_ring(XrLds& S, const XView& q, int qidx, int M, cons
     int wlo = max(ae - (WROWS - 1), 0);                  // first row in the window
     issue_window(wlo);
     commit_window();
-    if (wlo > 0) issue_window(max(wlo - 16, 0));
+    if (wlo > 0) issue_window(max(wlo - XR_MOVE, 0));
     __builtin_amdgcn_wave_barrier();
     XD_COUNT(n_win);
     while (a_index > 0 || b_index > 0) {
@@ -619,7 +622,7 @@ __device__ void xdrop_block_ring(XrLds& S, const XView& q, int qidx, int M, cons
             __builtin_amdgcn_wave_barrier();
             commit_window();
             wlo = max(wlo - 16, 0);
-            if (wlo > 0) issue_window(max(wlo - 16, 0));
+            if (wlo > 0) issue_window(max(wlo - XR_MOVE, 0));
             __builtin_amdgcn_wave_barrier();
             XD_COUNT(n_win);
         }

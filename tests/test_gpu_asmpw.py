@@ -151,3 +151,36 @@ def test_drop_in_tool_equals_the_reference_run_on_this_machine(tmp_path, tool, s
     bad = [(a, b) for a, b in zip(got, want) if a != b]
     assert not bad, bad[:3]
     print("%s -S%d: %d lines, reference %.1f s on 32 threads, device tool %.1f s" % (tool, start, len(want), ref_s, dev_s))
+
+
+@pytest.mark.parametrize("tool,start", [("mecat2asmpw50", 1), ("mecat2asmpw50", 2), ("mecat2trimpw50", 1), ("mecat2trimpw50", 2)])
+def test_50_candidate_variants_equal_the_reference_output(tmp_path, tool, start):
+    """the `*50` names (MAXC 50, mecat2asmpw50.c:23) on a set dense enough that the top-MAXC cut decides which candidates survive (the
+    100-candidate tool writes 42 423 lines where this one writes 25 975; tests/golden/make_golden_asmpw50.py): the sorted output of the
+    drop-in equals the UNMODIFIED tool's, which on this set does not depend on its thread count (-T1 / -T2 / -T3 agree line for line),
+    i.e. the device's all-zero start state per read selects the same candidates as the reference's thread history."""
+    import hashlib
+    import json
+    import subprocess
+    import sys
+    sys.path.insert(0, H.GOLDEN)
+    import make_golden_asmpw50 as G
+    meta = json.load(open(os.path.join(H.GOLDEN, "asmpw50.json")))
+    m = meta["outputs"]["%s.S%d.sorted" % (tool, start)]
+    assert m["lines"] == m["lines_T2"] == m["lines_T3"] and not m["thread_dependent_lines"]
+    d = str(tmp_path)
+    G.layout(d)
+    exe = os.path.join(H.ROOT, "mecat_amd", "bin", tool)
+    r = subprocess.run([exe, "-P" + d, "-T3", "-S%d" % start, "-E%d" % len(G.BLOCKS)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = []
+    for t in range(3):
+        lines += open(os.path.join(d, "%d_%d.r" % (start, t))).read().splitlines()
+    lines.sort()
+    golden = os.path.join(H.GOLDEN, "%s.S%d.sorted" % (tool, start))
+    if os.path.exists(golden):
+        want = open(golden).read().splitlines()
+        bad = [(a, b) for a, b in zip(lines, want) if a != b]
+        assert len(lines) == len(want) and not bad, (len(lines), len(want), bad[:3])
+    assert len(lines) == m["lines"]
+    assert hashlib.sha256(("\n".join(lines) + "\n").encode()).hexdigest() == m["sha256"]

@@ -276,10 +276,11 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_seed(const uint32_t* __restrict
                     if (osc <= 0) continue;
                     const int sl = useg * AZV;
                     int agree = 0;
-                    for (int j0 = 0; j0 < osc; j0 += 64) {
+                    const int jend = min(osc, (nseg + 8 - useg) * AREC - A_SEED);      // entries inside this wave's image (the reference reads its own heap beyond)
+                    for (int j0 = 0; j0 < jend; j0 += 64) {
                         const int j = j0 + lane;
                         bool q = false;
-                        if (j < osc) q = fabs((double)(loc_list - sl - (int)o[A_LOC + j]) / ((double)(loc_seed - (int)o[A_SEED + j]) * BC * 1.0) - 1.0) < 0.10;
+                        if (j < jend) q = fabs((double)(loc_list - sl - (int)o[A_LOC + j]) / ((double)(loc_seed - (int)o[A_SEED + j]) * BC * 1.0) - 1.0) < 0.10;
                         agree += (int)__popcll(__ballot(q));
                     }
                     seedcount += agree;
@@ -291,10 +292,11 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_seed(const uint32_t* __restrict
                     if (osc <= 0) continue;
                     const int sl = useg * AZV;
                     int agree = 0;
-                    for (int j0 = 0; j0 < osc; j0 += 64) {
+                    const int jend = min(osc, (nseg + 8 - useg) * AREC - A_SEED);      // (as above)
+                    for (int j0 = 0; j0 < jend; j0 += 64) {
                         const int j = j0 + lane;
                         bool q = false;
-                        if (j < osc) q = fabs((double)(sl + (int)o[A_LOC + j] - loc_list) / ((double)((int)o[A_SEED + j] - loc_seed) * BC * 1.0) - 1.0) < 0.10;
+                        if (j < jend) q = fabs((double)(sl + (int)o[A_LOC + j] - loc_list) / ((double)((int)o[A_SEED + j] - loc_seed) * BC * 1.0) - 1.0) < 0.10;
                         agree += (int)__popcll(__ballot(q));
                     }
                     seedcount += agree;

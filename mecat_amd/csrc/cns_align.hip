@@ -421,11 +421,23 @@ int mhip_asm_extend(mhip_ctx* c, const mhip_volume* block, const mhip_volume* re
     HIPCHK(hipSetDevice(c->device));
     if (n <= 0) return 0;
     if (dir_cols_cap < 16 || (dir_cols_cap & 15)) { mhip_set_error("dir_cols_cap must be a positive multiple of 16"); return -1; }
-    for (int i = 0; i < n; ++i)
-        if (jobs[i].xid < 0 || jobs[i].xid >= block->num_reads || jobs[i].yid < 0 || jobs[i].yid >= reads->num_reads) {
+    for (int i = 0; i < n; ++i) {
+        const mhip_asm_job& j = jobs[i];
+        if (j.xid < 0 || j.xid >= block->num_reads || j.yid < 0 || j.yid >= reads->num_reads) {
             mhip_set_error("extension job %d: read index out of range", i);
             return -1;
         }
+        // start points inside the reads, lengths inside what lies in front of / behind them (the kernel and the host's string
+        // rebuild both index the packed reads with these)
+        const int xs = block->h_offs[(size_t)j.xid].size, ys = reads->h_offs[(size_t)j.yid].size;
+        const bool ok = j.lx >= 0 && j.lx < xs && j.rx >= 0 && j.rx < xs && j.ly >= 0 && j.ly < ys && j.ry >= 0 && j.ry < ys &&
+                        j.lnx >= 0 && j.lny >= 0 && j.rnx >= 0 && j.rny >= 0 && j.lnx <= j.lx + 1 && j.lny <= j.ly + 1 &&
+                        j.rnx <= xs - j.rx && j.rny <= ys - j.ry;
+        if (!ok) {
+            mhip_set_error("extension job %d: start points or lengths outside the reads (x %d bases, y %d bases)", i, xs, ys);
+            return -1;
+        }
+    }
     const int max_waves = c->num_cus * 24;
     const int grid = std::min(max_waves / CN_WAVES, (2 * n + CN_WAVES - 1) / CN_WAVES);
     CnsDir* d_dres;

@@ -378,6 +378,9 @@ int mhip_comm_init(mhip_ctx* ctx, int nranks, int rank, const uint8_t id[MHIP_CO
         ncclResult_t r = R->CommInitRank(&cm->nc, nranks, u, rank);
         if (r != ncclSuccess) { mhip_set_error("ncclCommInitRank(rank %d of %d) failed: %s", rank, nranks, R->GetErrorString(r)); delete cm; return -1; }
     }
+    // the status words of agree() exist from here on: reporting a failure never depends on an allocation made at the time of the failure
+    void* d_status;
+    if (ctx->scratch("xg_status", sizeof(int32_t) * (size_t)(nranks + 1), &d_status)) { mhip_comm_destroy(cm); return -1; }
     *out = cm;
     return 0;
 }
@@ -392,6 +395,8 @@ int mhip_comm_init_hostfile(mhip_ctx* ctx, int nranks, int rank, const char* dir
     cm->hostfile = true;
     cm->dir = dir;
     cm->run_id = run_id;
+    void* d_status;
+    if (ctx->scratch("xg_status", sizeof(int32_t) * (size_t)(nranks + 1), &d_status)) { delete cm; return -1; }
     *out = cm;
     return 0;
 }
@@ -761,7 +766,9 @@ int mhip_index_build_sharded(mhip_comm* cm, const mhip_volume* v, mhip_index** o
     if (c->scratch("xi_kept", sizeof(long long) * (size_t)(P + 1), (void**)&d_k)) lerr = 1;
     if (agree(cm, lerr, "mhip_index_build_sharded (count buffers)")) return -1;
     const long long mine = (long long)sl.num_kept;
-    HIPCHK(hipMemcpyAsync(d_k + P, &mine, sizeof(mine), hipMemcpyHostToDevice, c->stream));
+    lerr = hipMemcpyAsync(d_k + P, &mine, sizeof(mine), hipMemcpyHostToDevice, c->stream) != hipSuccess;
+    if (lerr) mhip_set_error("sharded index: cannot upload the kept count");
+    if (agree(cm, lerr, "mhip_index_build_sharded (kept counts)")) return -1;
     {
         std::vector<size_t> bytes((size_t)P, sizeof(long long)), displ((size_t)P);
         for (int r = 0; r < P; ++r) displ[(size_t)r] = sizeof(long long) * (size_t)r;
@@ -778,6 +785,7 @@ int mhip_index_build_sharded(mhip_comm* cm, const mhip_volume* v, mhip_index** o
     if (total > 0x7fffffffLL) { mhip_set_error("sharded index: %lld kept positions", total); return -1; }      // (the same on every rank)
     // 4. the table, complete on every rank
     mhip_index* idx = new mhip_index();
+    struct IdxGuard { mhip_index* p; ~IdxGuard() { if (p) mhip_index_free(p); } } guard{idx};      // freed on every path that does not hand it out
     idx->device = c->device;
     idx->num_bases = v->num_bases;
     idx->max_bucket = MAX_BUCKET;
@@ -788,27 +796,34 @@ int mhip_index_build_sharded(mhip_comm* cm, const mhip_volume* v, mhip_index** o
            dev_alloc_recycled(c->device, sizeof(uint4) * (size_t)NKMER, (void**)&idx->d_recs, &idx->cap_recs);
     uint32_t* d_tab = nullptr;
     if (!lerr) lerr = c->scratch("xi_tab", sizeof(uint32_t) * 2 * (size_t)(P + 1), (void**)&d_tab);
-    if (agree(cm, lerr, "mhip_index_build_sharded (table arrays)")) { mhip_index_free(idx); return -1; }
+    // the two small host tables go up before the status exchange, so that a failed copy is a reported failure of this rank and not an
+    // early return with the peers inside the payload exchange
+    if (!lerr && (hipMemcpyAsync(d_tab, ranges.data(), sizeof(uint32_t) * (size_t)(P + 1), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                  hipMemcpyAsync(d_tab + (P + 1), base.data(), sizeof(uint32_t) * (size_t)(P + 1), hipMemcpyHostToDevice, c->stream) != hipSuccess)) {
+        mhip_set_error("sharded index: cannot upload the range table");
+        lerr = 1;
+    }
+    if (agree(cm, lerr, "mhip_index_build_sharded (table arrays)")) return -1;
     {
         std::vector<size_t> bytes((size_t)P), displ((size_t)P);
         for (int r = 0; r < P; ++r) { bytes[(size_t)r] = sizeof(int32_t) * (size_t)kept[(size_t)r]; displ[(size_t)r] = sizeof(int32_t) * (size_t)base[(size_t)r]; }
-        if (allgatherv(cm, sl.d_offsets, idx->d_offsets, bytes, displ)) { mhip_index_free(idx); return -1; }
+        if (allgatherv(cm, sl.d_offsets, idx->d_offsets, bytes, displ)) return -1;
         for (int r = 0; r < P; ++r) {
             const size_t ids = (size_t)(lo[(size_t)r + 1] - lo[(size_t)r]) * IXP_IDS_PER_BIN;
             bytes[(size_t)r] = sizeof(uint32_t) * ids;
             displ[(size_t)r] = sizeof(uint32_t) * (size_t)ranges[(size_t)r];
         }
-        if (allgatherv(cm, sl.d_starts, idx->d_starts, bytes, displ)) { mhip_index_free(idx); return -1; }
+        if (allgatherv(cm, sl.d_starts, idx->d_starts, bytes, displ)) return -1;
         for (int r = 0; r < P; ++r) { bytes[(size_t)r] *= 4; displ[(size_t)r] *= 4; }      // 16-byte records
-        if (allgatherv(cm, d_recs_slice, idx->d_recs, bytes, displ)) { mhip_index_free(idx); return -1; }
+        if (allgatherv(cm, d_recs_slice, idx->d_recs, bytes, displ)) return -1;
     }
-    HIPCHK(hipMemcpyAsync(d_tab, ranges.data(), sizeof(uint32_t) * (size_t)(P + 1), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(d_tab + (P + 1), base.data(), sizeof(uint32_t) * (size_t)(P + 1), hipMemcpyHostToDevice, c->stream));
+    // (nothing is exchanged from here on: a local failure ends this rank's call; its peers learn of it at the next agree())
     LAUNCH(c, "xg_index_rebase", xg_index_rebase, NKMER / 256, 256, 0, idx->d_starts, idx->d_recs, (const uint32_t*)d_tab, (const uint32_t*)(d_tab + (P + 1)), P);
     HIPCHK(hipMemcpyAsync(idx->d_starts + NKMER, d_tab + (P + 1) + P, sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
-    if (index_add_slots(c, idx)) { mhip_index_free(idx); return -1; }
+    if (index_add_slots(c, idx)) return -1;
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));      // (the host tables above go out of scope)
+    guard.p = nullptr;
     *out = idx;
     return 0;
 }

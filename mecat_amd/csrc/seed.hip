@@ -1962,7 +1962,9 @@ static int next_batch_end(const mhip_index* idx, const mhip_volume* reads, const
     // three (~60 GB of batch arrays; 57.7 against 58.8 ms per pass: two tails of the one-wave-per-read kernel and two host round trips less)
     if (filter_enabled(P)) {
         size_t fr = 0, tot = 0;
-        if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr > ((size_t)150 << 30)) budget = 1.0e10;
+        // in proportion to what is free right now (the batch arrays cost ~6 bytes per estimated hit; a third of the free memory at most:
+        // several ranks folded onto one device, or another process on it, each see less and ask for less — ADVICE r03)
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) budget = std::max(budget, std::min(1.0e10, (double)fr / 3.0 / 6.0));
     }
     if (const char* e = getenv("MECAT_SEED_BATCH_HITS")) budget = std::max(1e6, atof(e));   // tuning knob
     double acc = 0;

@@ -6,7 +6,8 @@ C ABI -> text output), against hashes of the UNMODIFIED reference's output on th
   config 3   500 000 x 12 kb @ 15 %, three volumes: `-j 0`, every grid row r_<i> and every grid cell (i, j) hashed separately
              (real 2.14 Gbase volume limit, int32 coordinates up to the limit, no test knob); `-j 1 -g 1` grid row 1 = cells (1, 1)
              and (1, 2): dw extension across two real volumes
-  config 5   2 000 000 x 20 kb ONT-style, 19 volumes, `-x 1`: `-j 0` grid rows 17 and 18 and `-j 1 -g 1` (X-drop extension) row 18
+  config 5   2 000 000 x 20 kb ONT-style, 19 volumes, `-x 1`: `-j 0` grid rows 0, 17 and 18 and `-j 1 -g 1` (X-drop extension) rows 17
+             (cells (17, 17) and (17, 18): an off-diagonal X-drop cell of two real volumes, 365 463 overlaps) and 18
              against the reference (the rows before them are planted as finished through the reference's own resume protocol,
              as the golden run did);
              MECAT_TEST_CONFIG5_FULL=1 runs all 190 cells and checks the size-independent properties on the whole output.
@@ -184,13 +185,26 @@ def test_config5_nanopore_19_volume_grid(workdir):
                 open(os.path.join(wrk, "r_%d" % i), "w").close()
     secs = _run(["-j", "0", "-x", "1"], fa, out, wrk, threads=64)
     if "m4_row18" in g:
-        # X-drop extension at this scale: grid row 18 = cell (18, 18) with `-j 1 -x 1 -g 1`, the rows before it planted as finished
+        # X-drop extension at this scale, `-j 1 -x 1 -g 1`: grid row 18 = cell (18, 18), and (when pinned) grid row 17 = the diagonal
+        # cell (17, 17) and the off-diagonal cell (17, 18) of two real volumes; the other rows planted as finished
+        rows1 = [18] + ([17] if "m4_row17" in g else [])
         wrk1 = os.path.join(workdir, "w1")
         os.makedirs(wrk1)
-        for i in range(18):
-            open(os.path.join(wrk1, "r_%d" % i), "w").close()
+        for i in range(19):
+            if i not in rows1:
+                open(os.path.join(wrk1, "r_%d" % i), "w").close()
         _run(["-j", "1", "-x", "1", "-g", "1"], fa, os.path.join(workdir, "o.m4"), wrk1, threads=64)
         assert _sorted_sha(os.path.join(wrk1, "r_18")) == (g["m4_row18"]["lines"], g["m4_row18"]["sorted_sha256"])
+        if 17 in rows1:
+            r17 = os.path.join(wrk1, "r_17")
+            m = g["m4_row17"]
+            assert _sorted_sha(r17) == (m["lines"], m["sorted_sha256"])
+            ab = int(subprocess.run(["awk", "-F\t", "{s += $7 - $6} END {printf \"%.0f\", s}", r17], stdout=subprocess.PIPE, text=True, check=True).stdout)
+            assert ab == m["aligned_bases"]
+            for cell, c in m["cells"].items():              # .m4 field 2 = the query read (field 1 is the subject)
+                j = int(cell.split(",")[1])
+                lo = g["volumes"][j]["start_read_id"]
+                assert _sorted_sha(r17, "$2 >= %d && $2 < %d" % (lo, lo + g["volumes"][j]["num_reads"])) == (c["lines"], c["sorted_sha256"]), cell
         shutil.rmtree(wrk1, ignore_errors=True)
     os.unlink(fa)
     vols = _volumes(wrk)

@@ -825,7 +825,7 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                 }
                 if (ended) break;
                 // two-pass rows: a half has 33 .. 63 slots
-                while ((((rows_left - 1) | (two_a - ns_a) | (two_b - ns_b)) >= 0) && max(ns_a, ns_b) > 32) {
+                while (((rows_left - 1) | (two_a - ns_a) | (two_b - ns_b) | (max(ns_a, ns_b) - 33)) >= 0) {      // (one sign test: rows left, slot counts within 33 .. limit)
                     DWS_ROW(~0ull, ns_a, ns_b, 2);
                     NJ = 2;
                     rows_left -= 1;

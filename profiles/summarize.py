@@ -17,6 +17,8 @@ import sys
 
 def short(name):
     n = name.replace("void ", "").replace("(anonymous namespace)::", "")
+    if n.startswith("xd_extend_w<true>"):          # the overflow launch of the X-drop kernel: the library's own name for it (LAUNCH)
+        return "xd_extend_wide"
     return n.split("(")[0].split("<")[0][:60]
 
 

@@ -23,7 +23,8 @@ def main():
     for d in dirs:
         for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(fn)):
-                k = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].split("<")[0][:60]
+                k = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "")
+                k = "xd_extend_wide" if k.startswith("xd_extend_w<true>") else k.split("(")[0].split("<")[0][:60]
                 if "at::" in k or "rocclr" in k or "rocprim" in k.lower() or k.startswith("k_"):
                     continue
                 tot[k][r["Counter_Name"]] += float(r["Counter_Value"])

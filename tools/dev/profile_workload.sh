@@ -1,7 +1,7 @@
 #!/bin/bash
 # dev helper (GPU box): the rocprofv3 passes behind profiles/rNN_<workload>_*: kernel trace + stats, HBM counters (FETCH_SIZE and
 # WRITE_SIZE in separate passes), SQ instruction counters — all of `python bench.py --workload <workload> --steps 1 --warmup 1 --no-cpu`
-# (two passes of the hot path per run).  Summaries land in gpurun_out/profiles_out/ (copy them to profiles/ and commit).
+# (three passes of the hot path per run: warm-up, step, and the untimed pass that brings the cell tables to the host).  Summaries land in gpurun_out/profiles_out/ (copy them to profiles/ and commit).
 #   tools/dev/profile_workload.sh r04 config5_cell
 TAG=${1:-r04}; WL=${2:-config5_cell}
 R=$(pwd); O=$R/gpurun_out/prof_${TAG}_$WL
@@ -22,8 +22,8 @@ for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_INSTS
 done
 cd $R
 export PROFILES_OUT=$R/gpurun_out/profiles_out PROFILE_CMD="python bench.py $FLAGS" PROFILE_LABEL="$WL"
-python profiles/summarize.py ${TAG}_$WL $O/k $O/FETCH_SIZE $O/WRITE_SIZE 2
-python profiles/summarize_sq.py ${TAG}_$WL 2 $O/sq1 $O/sq2 $O/sq3
+python profiles/summarize.py ${TAG}_$WL $O/k $O/FETCH_SIZE $O/WRITE_SIZE 3      # warm-up + step + the untimed pass that collects the cell tables
+python profiles/summarize_sq.py ${TAG}_$WL 3 $O/sq1 $O/sq2 $O/sq3
 python - <<PY
 import json, sys
 sys.path.insert(0, "$R")

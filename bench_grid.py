@@ -6,6 +6,8 @@ the X-drop aligner for nanopore-style sets (`-x 1`, pw_impl.cpp:638-644).  Volum
   config3        BASELINE.json configs[2]: 500 000 x 12 kb @ 15 %, 30x of a 200 Mb genome, seed 3 — three volumes, six cells
   config5_cell   one off-diagonal cell of configs[4] (2 M ONT-style reads x 20 kb @ 12 %, seed 5: 19 volumes, 190 cells): volumes 0 and 1
                  exactly as the splitter cuts them, reads of volume 1 against the index of volume 0, -x 1 gates, X-drop extension
+  config5        configs[4] whole: 19 volumes (40 Gbase), all 190 cells, -x 1 -j 1 — minutes per step on one GPU (use --steps 1 --warmup 0);
+                 with N >= 2 ranks the grid rows are dealt out by cost as the driver's rows mode does (no data moves)
 
 Same contract line as the config-2 run (bench.py), with `roofline.phases` = algorithmic bytes / phase time for index,
 seeding and extension, and for the X-drop kernel its DP cells/s and issue rates.  N > 1: every cell sharded over the ranks by the
@@ -183,10 +185,18 @@ def run(args):
     maxc = params.maxc
     rows = sorted(set(i for i, _ in cells))
     nmax = max(len(hv[j]["lens"]) for _, j in cells)
+    # N > 1: as the driver chooses (host/main.cpp): with at least as many volumes as ranks the grid ROWS are dealt out by cost
+    # (mhip_shard_deal_rows: row i = V - i cells; no data moves, no communicator), otherwise every cell is sharded over the ranks
+    rows_mode = world > 1 and len(hv) >= world and os.environ.get("MECAT_HIP_SHARD", "") != "cells"
+    owner = None
+    if rows_mode:
+        owner, heaviest = M.deal_rows(len(hv), np.array(rows, dtype=np.int32), world)
+        rows = [i for i in rows if owner[i] == rank]
+        cells = [(i, j) for (i, j) in cells if owner[i] == rank]
 
     comm = None
     CH = M.SHARD_CHUNK
-    if world > 1:
+    if world > 1 and not rows_mode:
         if backend == "nccl":
             box = [M.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
@@ -196,7 +206,7 @@ def run(args):
             dist.broadcast_object_list(box, src=0)
             comm = M.Comm(ctx, world, rank, hostfile_dir=box[0], run_id="bench")
         comm.barrier()
-    else:
+    if comm is None:
         d_cands = torch.zeros((nmax, maxc, 12), dtype=torch.int32, device=dev)
         d_counts = torch.zeros((nmax,), dtype=torch.int32, device=dev)
         d_jobs = torch.empty((nmax * maxc + maxc, 5), dtype=torch.int32, device=dev)
@@ -206,6 +216,14 @@ def run(args):
         shard_index = comm is not None and os.environ["MECAT_HIP_INDEX_SHARD"] not in ("", "0")
     keep = {"num_kmers": {}, "cell": {}}
     L_ = M.lib()
+    # cells whose sorted `.can` lines the golden file pins; with many cells (config 5 whole) only those are formatted and hashed
+    golden_cells = None
+    if len(cells) > 8:
+        try:
+            big = json.load(open(os.path.join(ROOT, "tests", "golden", "big.json")))[name]
+            golden_cells = set(k for r in big.get("rows", {}).values() for k in r.get("cells", {}))
+        except Exception:  # noqa: BLE001
+            golden_cells = set()
 
     def one_step(collect=False):
         ms = {"index": 0.0, "seed": 0.0, "align": 0.0}
@@ -244,7 +262,7 @@ def run(args):
                     stream.synchronize()
                     h_cnt = d_counts[:nj_reads].cpu().numpy()
                     cell = {"candidates": int(h_cnt.sum()), "jobs": int(njobs)}
-                    if collect == "lines":
+                    if collect == "lines" and (golden_cells is None or "%d,%d" % (i, j) in golden_cells):
                         h_c = d_cands[:nj_reads].cpu().numpy().view(M.CAND_DTYPE).reshape(nj_reads, maxc)
                         lines = can_lines(h_c, h_cnt, hv[j]["lens"], hv[j]["start_read_id"], hv[i]["lens"], hv[i]["start_read_id"])
                         lines.sort()
@@ -289,11 +307,19 @@ def run(args):
 
     # result statistics and the reference pins, after the timed region: one more (untimed) pass that brings every cell's table to the host
     exch = None
-    if comm is None:
+    if world == 1:
         one_step(collect="lines" if not args.no_cpu or os.environ.get("MECAT_BENCH_PARITY") else True)
         ncand = sum(c["candidates"] for c in keep["cell"].values())
         aln_ok = sum(c.get("overlaps_ok", 0) for c in keep["cell"].values())
         aligned_bases = sum(c.get("aligned_bases", 0) for c in keep["cell"].values())
+    elif rows_mode:
+        exch = {"transport": "none (rows mode: every grid row is computed by one rank, nothing is exchanged)", "rccl_ranks": 0,
+                "rows_of_rank": [int(np.sum(owner == r)) for r in range(world)],
+                "cells_of_rank": [int(sum(len(hv) - i for i in range(len(hv)) if owner[i] == r)) for r in range(world)], "heaviest_rank_cells": int(heaviest)}
+        t = torch.tensor([counters["candidates"] // args.steps, counters["aln_ok"] // args.steps, counters["aligned_bases"] // args.steps],
+                         dtype=torch.int64, device=dev)
+        dist.all_reduce(t)
+        ncand, aln_ok, aligned_bases = (int(x) for x in t.tolist())
     else:
         tr, nr = comm.info()
         exch = {"bytes_received_per_step": comm.bytes_received() / max(1, args.steps + args.warmup),
@@ -318,7 +344,7 @@ def run(args):
         # positions; seeding = the query reads' 2-bit bases (both strands) + 8 B per lookup + 4 B per bucket hit + 48 B per candidate;
         # extension = the aligned spans of both reads at 2 bits per base + a 32-byte result
         b_idx = sum(2 * (hv[i]["num_bases"] / 4) + 3 * 4 * (1 << 26) + 4 * keep["num_kmers"][i] for i in rows)
-        b_seed = sum(2 * int(hv[j]["lens"].astype(np.int64).sum()) / 4 for _, j in cells) / world + 8 * lookups + 4 * hits + 48 * cands_c
+        b_seed = sum(2 * int(hv[j]["lens"].astype(np.int64).sum()) / 4 for _, j in cells) / (1 if comm is None else world) + 8 * lookups + 4 * hits + 48 * cands_c
         b_aln = per_step("aligned_bases") * 2 / 4 + 32 * cands_c
         pbytes = {"index": b_idx, "seed": b_seed, "align": b_aln}
         phases = {k: {"algorithmic_bytes": float(pbytes[k]), "ms": phase[k],
@@ -377,14 +403,15 @@ def run(args):
                                                                                              hv[0]["num_bases"]))
         else:
             wl += ("%d reads x %d bp @ %.0f%% error, genome %d, seed %d, k=13: %d volumes, all %d grid cells, -j 1 (index per row + seed + %s per cell)"
-                   % (n_all, L, err * 100, G, seed, len(hv), len(cells), "X-drop" if ont else "dw"))
+                   % (n_all, L, err * 100, G, seed, len(hv), len(W.GRIDS[args.workload][2]), "X-drop" if ont else "dw"))
         line = {
             "metric": "candidate overlaps/sec", "value": ncand / (ms_step / 1e3), "unit": "candidates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": wl, "volumes": [{"reads": len(v["lens"]), "bases": int(v["num_bases"]), "start_read_id": int(v["start_read_id"])} for v in hv],
-                       "cells": ["%d,%d" % c for c in cells],
-                       "parallelism": "1 GPU" if world == 1 else "every cell sharded: chunks of %d reads, chunk c of volume j -> rank (c + j) mod %d; RCCL count-then-payload "
+                       "cells": ["%d,%d" % c for c in cells] if len(cells) <= 32 else "%d cells" % len(cells),
+                       "parallelism": "1 GPU" if world == 1 else ("rows mode: the %d grid rows dealt out by cost (row i = V - i cells), heaviest rank %d cells; no data moves; "
+                                                                   "roofline / phase figures are rank 0's own rows" % (len(hv), int(heaviest))) if rows_mode else "every cell sharded: chunks of %d reads, chunk c of volume j -> rank (c + j) mod %d; RCCL count-then-payload "
                                       "all-gather; index %s" % (CH, world, "built in k-mer key-range shards + all-gather" if shard_index else "rebuilt on every rank")},
             "candidates": ncand, "overlaps_ok": aln_ok, "aligned_gbase_per_s": aligned_bases / 1e9 / (ms_step / 1e3),
             "overlaps_per_s": aln_ok / (ms_step / 1e3), "phase_ms": phase,
@@ -423,12 +450,12 @@ def run(args):
             vols = []
         if world == 1 and not args.no_cpu:
             try:
-                line["cpu_baseline"] = cpu_baseline_grid(args.workload, os.cpu_count() or 1)
+                line["cpu_baseline"] = cpu_baseline_grid("config5_cell" if args.workload == "config5" else args.workload, os.cpu_count() or 1)
                 gb = json.load(open(os.path.join(ROOT, "tests", "golden", "big.json"))).get(name, {})
-                if args.workload == "config5_cell" and "rows" in gb and "0" in gb["rows"] and "seconds" in gb["rows"]["0"]:
+                if args.workload in ("config5_cell", "config5") and "rows" in gb and "0" in gb["rows"] and "seconds" in gb["rows"]["0"]:
                     r0 = gb["rows"]["0"]
                     line["cpu_baseline"]["full_size_reference"] = {
-                        "what": "grid row 0 of config 5 (19 cells incl. this one), unmodified mecat2pw -j 0 -x 1", "threads": r0.get("threads"),
+                        "what": "grid row 0 of config 5 (19 of the 190 cells), unmodified mecat2pw -j 0 -x 1", "threads": r0.get("threads"),
                         "host": "build container, not this host", "seconds": r0["seconds"], "candidates": r0["lines"],
                         "candidates_per_s": r0["lines"] / r0["seconds"], "source": "tests/golden/big.json"}
                 elif "j0_seconds" in gb and "can_lines" in gb:

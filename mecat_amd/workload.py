@@ -25,8 +25,10 @@ MCS = 2_140_000_000      # bases per volume, pads included (common/split_databas
 GRIDS = {
     "config3": ("config3", 3, [(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)], MCS),
     "config5_cell": ("config5", 2, [(0, 1)], MCS),                   # one off-diagonal cell of config 5's 19 x 19 grid: volumes 0 and 1
+    "config5": ("config5", 19, [(i, j) for i in range(19) for j in range(i, 19)], MCS),      # BASELINE configs[4] whole: 190 cells, -x 1 -j 1
     "grid_tiny": ("tinyset", 3, [(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)], 3_500_000),          # tests only
     "grid_tiny_ont": ("tinyset_ont", 3, [(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)], 3_500_000),
+    "grid_tiny_rows": ("tinyset", 5, [(i, j) for i in range(5) for j in range(i, 5)], 2_000_000),       # five volumes: rows mode with two ranks
 }
 
 _lib = None

@@ -87,3 +87,22 @@ def test_bench_grid_workload_equals_the_drop_in_binary(tmp_path, wl, tech):
     assert r2.returncode == 0, r2.stderr[-3000:]
     b = _line(r2.stdout)
     assert b["n_gpus"] == 2 and b["candidates"] == a["candidates"] and b["overlaps_ok"] == a["overlaps_ok"]
+
+
+def test_bench_grid_rows_mode_two_ranks_equal_one():
+    """N > 1 with at least as many volumes as ranks: bench_grid deals the grid ROWS out by cost (mhip_shard_deal_rows), as the driver's rows mode
+    does, and moves no data — five toy volumes over two ranks give the candidates and overlaps of the one-rank run."""
+    bench = os.path.join(H.ROOT, "bench.py")
+    flags = ["--workload", "grid_tiny_rows", "--steps", "1", "--warmup", "0", "--no-cpu"]
+    r1 = subprocess.run([sys.executable, bench, "--gpus", "1"] + flags, capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    a = _line(r1.stdout)
+    assert len(a["config"]["volumes"]) == 5 and len(a["cells"]) == 15
+    env = dict(os.environ, MECAT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", "29545", bench, "--gpus", "2"] + flags, capture_output=True, text=True, timeout=900, env=env)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    b = _line(r2.stdout)
+    assert b["n_gpus"] == 2 and b["candidates"] == a["candidates"] and b["overlaps_ok"] == a["overlaps_ok"]
+    x = b["exchange"]
+    assert x["transport"].startswith("none") and sum(x["cells_of_rank"]) == 15 and max(x["cells_of_rank"]) == x["heaviest_rank_cells"] == 8

@@ -160,7 +160,9 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
     { TraceTimer tt("load_volume"); load_volume(vn[svid], &ref); }
 
     const char* slab_env = getenv("MECAT_HIP_SLAB");
-    int slab = slab_env ? std::max(1, atoi(slab_env)) : 20000;
+    // 20 000 reads per slab; nanopore extension: 60 000 — every X-drop call ends with a short second launch for the units whose window
+    // outgrew the ring (as long as its slowest unit: ~24 ms whatever the slab holds), so fewer, larger calls: 2 per config-5 cell instead of 6
+    int slab = slab_env ? std::max(1, atoi(slab_env)) : (opt.tech == TECH_NANOPORE && opt.task == TASK_ALN ? 60000 : 20000);
     if (comm) slab = std::max(shard_chunk, slab - slab % shard_chunk);      // slabs start on chunk boundaries
     const bool writes = out != NULL;
 

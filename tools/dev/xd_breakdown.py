@@ -5,10 +5,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import numpy as np, torch
 from mecat_amd import hip as M, workload as W
 n = int(os.environ.get("N", "5000"))
-codes, lens = W.synth_reads(n, 10000, 0.12, int(1_700_000 * n / 5000), 7, 1)
+if os.environ.get("PB"):      # PacBio-style candidates (bench.py's xdrop_extend extra runs the X-drop aligner on config 2's): 15 kb @ 15 %, 30x
+    codes, lens = W.synth_reads(n, 15000, 0.15, n * 15000 // 30, 2, 0)
+else:
+    codes, lens = W.synth_reads(n, 10000, 0.12, int(1_700_000 * n / 5000), 7, 1)
 pac, offs, nb = W.pack_volume(codes, lens)
 ctx = M.Context(0); vol = M.Volume(ctx, pac, offs, nb, 0); idx = M.Index(ctx, vol)
-p = M.default_params(1)
+p = M.default_params(0 if os.environ.get("PB") else 1)
 cands, cnt = M.seed_reads(ctx, idx, vol, vol, 0, len(lens), p)
 jobs = W.jobs_from_candidates(cands, cnt, 0)
 M.align_candidates(ctx, vol, vol, jobs, p.min_align_size, tech=1)

@@ -187,7 +187,7 @@ def run(args):
     nmax = max(len(hv[j]["lens"]) for _, j in cells)
     # N > 1: as the driver chooses (host/main.cpp): with at least as many volumes as ranks the grid ROWS are dealt out by cost
     # (mhip_shard_deal_rows: row i = V - i cells; no data moves, no communicator), otherwise every cell is sharded over the ranks
-    rows_mode = world > 1 and len(hv) >= world and os.environ.get("MECAT_HIP_SHARD", "") != "cells"
+    rows_mode = world > 1 and len(rows) >= world and os.environ.get("MECAT_HIP_SHARD", "") != "cells"      # (config5_cell: one row, always cells)
     owner = None
     if rows_mode:
         owner, heaviest = M.deal_rows(len(hv), np.array(rows, dtype=np.int32), world)

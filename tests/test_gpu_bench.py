@@ -81,12 +81,14 @@ def test_bench_grid_workload_equals_the_drop_in_binary(tmp_path, wl, tech):
         assert (c["can_lines"], c["can_sorted_sha256"]) == (len(per.get(key, [])), h.hexdigest()), key
     # the -j 1 side: every extension that reaches min_align_size is an overlap line before the per-read containment filter
     assert a["overlaps_ok"] >= len(want[1]) > 0
-    env = dict(os.environ, MECAT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    # two ranks, every cell sharded over them (three rows over two ranks would be dealt out as rows: the cells mode is asked for)
+    env = dict(os.environ, MECAT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MECAT_HIP_SHARD="cells")
     r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                          "--master-port", "29543", bench, "--gpus", "2"] + flags, capture_output=True, text=True, timeout=900, env=env)
     assert r2.returncode == 0, r2.stderr[-3000:]
     b = _line(r2.stdout)
     assert b["n_gpus"] == 2 and b["candidates"] == a["candidates"] and b["overlaps_ok"] == a["overlaps_ok"]
+    assert b["exchange"]["transport"].startswith("host files") and b["exchange"]["calls_per_step"] >= 2 * len(cells)
 
 
 def test_bench_grid_rows_mode_two_ranks_equal_one():

@@ -201,3 +201,25 @@ def test_bench_has_no_function_local_import_of_a_module_level_name():
             if isinstance(n, (ast.Import, ast.ImportFrom)):
                 local.update(a.asname or a.name.split(".")[0] for a in n.names)
         assert not (local & top), (f.name, sorted(local & top))
+
+
+def test_bench_volumes_are_the_splitter_s_volumes(tmp_path):
+    """mecat_amd.workload.synth_volumes (what bench.py --workload config3 | config5_cell | config5 uploads) cuts and packs a read set exactly
+    as the drop-in's splitter does (which the goldens pin to the reference's, split_database.cpp:221-266): same volume files, byte for byte,
+    at a volume size that gives three volumes (the split runs before any GPU call)."""
+    import struct
+    from mecat_amd import workload as W
+    name, nvols, cells, mcs = W.GRIDS["grid_tiny"]
+    n, L, err, G_, seed, ont = W.CONFIGS[name]
+    vols = W.synth_volumes(name, nvols, mcs=mcs)
+    codes, lens = W.synth_reads(n, L, err, G_, seed, ont)
+    fa = str(tmp_path / "r.fa")
+    W.write_fasta(fa, codes, lens)
+    wrk = str(tmp_path / "wrk")
+    subprocess.run([BIN, "-j", "0", "-d", fa, "-o", str(tmp_path / "o"), "-w", wrk], capture_output=True, env=dict(os.environ, MECAT_HIP_MCS=str(mcs)))
+    names = open(os.path.join(wrk, "fileindex.txt")).read().split()
+    assert len(names) == len(vols) == nvols
+    for v, p in zip(vols, names):
+        mine = struct.pack("<iii", len(v["lens"]), v["num_bases"], v["start_read_id"]) + v["offs"].tobytes() + v["pac"].tobytes()
+        assert mine == open(p, "rb").read(), p
+    assert sum(len(v["lens"]) for v in vols) == n

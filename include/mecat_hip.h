@@ -245,6 +245,13 @@ int  mhip_sharded_tables(mhip_comm* comm, void** d_cands, void** d_counts, void*
  * the tool, chain 0 = 'F', 1 = 'R'), out_counts[] their number (<= 100).  Every read starts from an all-zero segment array (the
  * tool's worker threads keep stale seeds of the reads they mapped before, which can move a score by a few votes: INTEGRATION.md). */
 typedef struct { int32_t loc1, loc2, left1, left2, right1, right2, score, num1, num2, readno, readstart, chain; } mhip_asm_candidate;
+/* Bases other than A, C, G, T (an N of a corrected read): the tools restart their k-mer at such a base in table and query
+ * (mecat2asmpw.c:445, 486, 316-335) and compare it as a character in the extension (N equals N only).  A volume may carry a second
+ * plane in its own 2-bit layout — 3 at every such base (stored as code 0 in the volume), 0 elsewhere; nplane = (num_bases + 3) / 4 bytes,
+ * NULL removes it.  mhip_asm_seed_reads skips the query k-mers that touch one, mhip_asm_extend compares with both planes; the table of a
+ * block with such bases is built from a volume whose read table ends a "read" at every one of them (the index never starts a k-mer inside
+ * the 13 positions in front of a read end: exactly the positions whose 13-mer would hold the base). */
+int  mhip_volume_set_nplane(mhip_ctx* ctx, mhip_volume* vol, const uint8_t* nplane);
 int  mhip_asm_seed_reads(mhip_ctx* ctx, const mhip_index* idx, const mhip_volume* block, const mhip_volume* reads, int rid_begin,
                          int rid_end, mhip_asm_candidate* out, int32_t* out_counts);
 int  mhip_asm_seed_reads_ex(mhip_ctx* ctx, const mhip_index* idx, const mhip_volume* block, const mhip_volume* reads, int rid_begin,

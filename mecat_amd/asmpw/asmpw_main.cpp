@@ -13,8 +13,8 @@
 // string_check's gap shuffling of the left pair (:199-281), the overlap of the two directions on the seed 13-mer, coordinates, the
 // 450-base test, jscore and the 12-field line (:843-948).  Line order inside the .r files is by read here and by thread timing in the
 // tool: the consumer (mecat2asmpwConvert) reads lines one by one.
-// Not supported: bases other than A, C, G, T (the tool skips k-mers with an N and aligns N as a character; 2-bit volumes cannot hold
-// it) — such input is refused with a message.
+// N in a read: the tool restarts its k-mer there in table and query and aligns it as a character (:445, 486, 316-335); here the N
+// positions travel as a second plane beside the 2-bit volume (mhip_volume_set_nplane).  Any other letter outside A, C, G, T is refused.
 #include <errno.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -48,10 +48,22 @@ struct Reads {                       // one fasta block: 2-bit volume (one pad b
     std::vector<uint8_t> pac;
     std::vector<mhip_offset_t> offs;
     int num_bases = 0, first_no = 0;
+    // bases that are not A, C, G, T (an N of a corrected read brought in from elsewhere): code 0 in pac, 3 in this second plane of the same
+    // layout (empty without such bases); frag = the read table with a "read" ending at every such base — what the look-up table is built
+    // from (the tools restart their k-mer there, :445, 486: no k-mer of the table holds one)
+    std::vector<uint8_t> npac;
+    std::vector<mhip_offset_t> frag;
+    bool has_n = false;
     int base(int r, int i) const {
         const int64_t idx = (int64_t)offs[(size_t)r].offset + i;
         return (pac[(size_t)(idx >> 2)] >> ((~idx & 3) << 1)) & 3;
     }
+    bool is_n(int r, int i) const {
+        if (!has_n) return false;
+        const int64_t idx = (int64_t)offs[(size_t)r].offset + i;
+        return ((npac[(size_t)(idx >> 2)] >> ((~idx & 3) << 1)) & 3) != 0;
+    }
+    char chr(int r, int i) const { return is_n(r, i) ? 'N' : "ACGT"[base(r, i)]; }
 };
 
 // load_read / load_fastq (:388-409, :982-1010): ">header" line, one sequence line; lower case is upper-cased
@@ -76,7 +88,10 @@ static void load_block(const std::string& path, int first_no, Reads* R) {
     }
     R->first_no = first_no;
     R->offs.clear();
+    R->frag.clear();
+    R->has_n = false;
     R->pac.assign(buf.size() / 4 + 16, 0);       // (never more bases + pads than bytes in the file)
+    R->npac.clear();
     int64_t at = 0;
     bool want_seq = false;
     const char* p = buf.data();
@@ -100,11 +115,31 @@ static void load_block(const std::string& path, int first_no, Reads* R) {
         o.offset = (int)at;
         o.size = (int)n;
         uint8_t* pac = R->pac.data();
+        int64_t fstart = 0;                      // first base of the open fragment (read-local)
         for (int64_t i = 0; i < n; ++i) {
-            const int c = code[(unsigned char)p[i]];
-            if (c < 0) DIE("%s: base '%c' in read %d: only A, C, G, T are supported on this path", path.c_str(), p[i], first_no + (int)R->offs.size());
+            int c = code[(unsigned char)p[i]];
             const int64_t idx = at + i;
+            if (c < 0) {
+                // N: atcttrans() gives it 4, like every character outside A, C, G, T (:296-304) — but the extension compares characters, so
+                // only N itself is taken (any other letter would have to stay distinct from N: refused)
+                if (p[i] != 'N' && p[i] != 'n')
+                    DIE("%s: base '%c' in read %d: only A, C, G, T and N are supported on this path", path.c_str(), p[i], first_no + (int)R->offs.size());
+                if (!R->has_n) { R->has_n = true; R->npac.assign(R->pac.size(), 0); R->frag = R->offs; }
+                R->npac[(size_t)(idx >> 2)] |= (uint8_t)(3 << ((~idx & 3) << 1));
+                mhip_offset_t fr;
+                fr.offset = (int)(at + fstart);
+                fr.size = (int)(i - fstart);
+                R->frag.push_back(fr);
+                fstart = i + 1;
+                c = 0;
+            }
             pac[idx >> 2] |= (uint8_t)(c << ((~idx & 3) << 1));
+        }
+        if (R->has_n) {
+            mhip_offset_t fr;
+            fr.offset = (int)(at + fstart);
+            fr.size = (int)(n - fstart);
+            R->frag.push_back(fr);
         }
         at += n + 1;                             // the pad base (code 0) = the tool's NUL behind every read
         R->offs.push_back(o);
@@ -113,6 +148,7 @@ static void load_block(const std::string& path, int first_no, Reads* R) {
     }
     R->num_bases = (int)at;
     R->pac.resize(((size_t)at + 3) / 4);
+    if (R->has_n) R->npac.resize(R->pac.size());
 }
 
 // string_check (:199-281): gaps of the left pair are moved over runs that also match one column further on.  a / b = the aligned
@@ -211,7 +247,16 @@ int main(int argc, char** argv) {
     mhip_volume* dblk = NULL;
     MCHK(mhip_volume_upload(ctx, blk.pac.data(), blk.offs.data(), (int)blk.offs.size(), blk.num_bases, blk.first_no, &dblk));
     mhip_index* idx = NULL;
-    MCHK(mhip_index_build_ex(ctx, dblk, 256, &idx));
+    if (!blk.has_n) MCHK(mhip_index_build_ex(ctx, dblk, 256, &idx));
+    else {
+        // the table of a block with such bases: built from the same bytes under a read table that ends a "read" at every one of them (the
+        // index never starts a k-mer in the 13 positions in front of a read end: exactly the positions whose 13-mer would hold the base)
+        MCHK(mhip_volume_set_nplane(ctx, dblk, blk.npac.data()));
+        mhip_volume* dfrag = NULL;
+        MCHK(mhip_volume_upload(ctx, blk.pac.data(), blk.frag.data(), (int)blk.frag.size(), blk.num_bases, blk.first_no, &dfrag));
+        MCHK(mhip_index_build_ex(ctx, dfrag, 256, &idx));
+        mhip_volume_free(dfrag);
+    }
     t_index += now() - t0;
 
     std::vector<FILE*> out((size_t)threads);
@@ -231,6 +276,7 @@ int main(int argc, char** argv) {
             load_block(block_path(bi), first_read[(size_t)bi - 1], &qs_own);
             qs = &qs_own;
             MCHK(mhip_volume_upload(ctx, qs->pac.data(), qs->offs.data(), (int)qs->offs.size(), qs->num_bases, qs->first_no, &dq));
+            if (qs->has_n) MCHK(mhip_volume_set_nplane(ctx, dq, qs->npac.data()));
             t_load += now() - t0;
         }
         const int nq = (int)qs->offs.size();
@@ -278,8 +324,10 @@ int main(int argc, char** argv) {
                         const int qrid = C->qrid[ji], read_len = qs->offs[(size_t)qrid].size, read_name = qs->first_no + qrid;
                         const mhip_asm_candidate& c = C->cand[ji];
                         const mhip_asm_job& jb = C->jobs[ji];
-                        auto ybase = [&](int pos) {                 // base at position pos of the mapped strand
-                            return jb.chain ? 3 - qs->base(qrid, read_len - 1 - pos) : qs->base(qrid, pos);
+                        auto ychr = [&](int pos) -> char {          // character at position pos of the mapped strand (the complement of N is N, :583-590)
+                            if (!jb.chain) return qs->chr(qrid, pos);
+                            const int rp = read_len - 1 - pos;
+                            return qs->is_n(qrid, rp) ? 'N' : "ACGT"[3 - qs->base(qrid, rp)];
                         };
                         auto build = [&](int d, std::string& s1, std::string& s2) {
                             const int cols = C->dirs[(ji * 2 + (size_t)d) * 6];
@@ -290,8 +338,8 @@ int main(int argc, char** argv) {
                             for (int m = 0; m < cols; ++m) {
                                 const int op = (int)((w[m >> 4] >> ((m & 15) << 1)) & 3u);
                                 char a = '-', b = '-';
-                                if (op != 1) { a = "ACGT"[blk.base(jb.xid, x)]; x += step; }
-                                if (op != 2) { b = "ACGT"[ybase(y)]; y += step; }
+                                if (op != 1) { a = blk.chr(jb.xid, x); x += step; }
+                                if (op != 2) { b = ychr(y); y += step; }
                                 s1[(size_t)m] = a; s2[(size_t)m] = b;
                             }
                         };

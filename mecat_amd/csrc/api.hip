@@ -251,9 +251,25 @@ void mhip_volume_free(mhip_volume* v) {
     if (!v) return;
     (void)hipSetDevice(v->device);
     if (v->d_pac) (void)hipFree(v->d_pac);
+    if (v->d_npac) (void)hipFree(v->d_npac);
     if (v->d_offs) (void)hipFree(v->d_offs);
     if (v->d_blk2read) (void)hipFree(v->d_blk2read);
     delete v;
+}
+
+// The bases that are not A, C, G or T (mecat2asmpw / mecat2trimpw only: the tools restart a k-mer at such a base and compare it as a
+// character, mecat2canu/src/mecat2asmpw/mecat2asmpw.c:445, 486, 316-335): a second plane in the volume's own 2-bit layout, 3 at every such
+// base (whose code in the volume itself is 0), 0 elsewhere.  nplane = (num_bases + 3) / 4 host bytes; NULL removes the plane.
+int mhip_volume_set_nplane(mhip_ctx* c, mhip_volume* v, const uint8_t* nplane) {
+    HIPCHK(hipSetDevice(c->device));
+    if (v->d_npac) { HIPCHK(hipFree(v->d_npac)); v->d_npac = nullptr; }
+    if (!nplane) return 0;
+    if (hipMalloc((void**)&v->d_npac, v->pac_bytes) != hipSuccess) { mhip_set_error("hipMalloc failed for a %zu-byte N plane", v->pac_bytes); return -1; }
+    HIPCHK(hipMemsetAsync(v->d_npac, 0, v->pac_bytes, c->stream));
+    const size_t nb = ((size_t)v->num_bases + 3) / 4;
+    if (nb) HIPCHK(hipMemcpyAsync(v->d_npac, nplane, nb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
 }
 
 int mhip_volume_num_reads(const mhip_volume* v) { return v->num_reads; }

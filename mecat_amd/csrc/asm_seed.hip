@@ -89,7 +89,7 @@ __global__ void asm_init_records(short* img, size_t nrec) {
 
 __global__ __launch_bounds__(ASM_BLOCK) void asm_seed(const uint32_t* __restrict__ bpac, const mhip_offset_t* __restrict__ boffs, int bnreads,
                                                      int bstart_id, const uint32_t* __restrict__ starts, const int32_t* __restrict__ offsets,
-                                                     const uint32_t* __restrict__ qpac, const mhip_offset_t* __restrict__ qoffs, int qstart_id,
+                                                     const uint32_t* __restrict__ qpac, const uint32_t* __restrict__ qnpac, const mhip_offset_t* __restrict__ qoffs, int qstart_id,
                                                      int rid_begin, int n, short* __restrict__ img_all, int* __restrict__ ilist_all,
                                                      short* __restrict__ iscore_all, int* __restrict__ dirty_all, int nseg, int gate, int maxc,
                                                      unsigned int* __restrict__ cursor, mhip_asm_candidate* __restrict__ out, int32_t* __restrict__ out_counts) {
@@ -120,8 +120,11 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_seed(const uint32_t* __restrict
             // ---- seeding (:601-641)
             for (int k = 0; k < K; ++k) {
                 uint32_t id;
-                if (!strand) id = pac_kmer(qpac, qoff + (int64_t)k * BC);
-                else id = kmer_revcomp(pac_kmer(qpac, qoff + L - MHIP_KMER_SIZE - (int64_t)k * BC));
+                const int64_t kpos = !strand ? qoff + (int64_t)k * BC : qoff + L - MHIP_KMER_SIZE - (int64_t)k * BC;
+                // a query k-mer that holds a base other than A, C, G, T is not looked up (transnum_buchang gives it -1, :316-335, :601)
+                if (qnpac && pac_kmer(qnpac, kpos) != 0u) continue;
+                if (!strand) id = pac_kmer(qpac, kpos);
+                else id = kmer_revcomp(pac_kmer(qpac, kpos));
                 const uint32_t s0 = starts[id], s1 = starts[id + 1];
                 int carry_seg = -1;
                 for (uint32_t base = s0; base < s1; base += 64) {
@@ -407,7 +410,7 @@ int mhip_asm_seed_reads_ex(mhip_ctx* c, const mhip_index* idx, const mhip_volume
     HIPCHK(hipMemsetAsync(d_cur, 0, 16, c->stream));
     LAUNCH(c, "asm_init_records", asm_init_records, (unsigned)((nrec + 255) / 256), 256, 0, d_img, nrec);
     LAUNCH(c, "asm_seed", asm_seed, grid, ASM_BLOCK, 0, (const uint32_t*)block->d_pac, (const mhip_offset_t*)block->d_offs, block->num_reads,
-           block->start_read_id, (const uint32_t*)idx->d_starts, (const int32_t*)idx->d_offsets, (const uint32_t*)reads->d_pac,
+           block->start_read_id, (const uint32_t*)idx->d_starts, (const int32_t*)idx->d_offsets, (const uint32_t*)reads->d_pac, (const uint32_t*)reads->d_npac,
            (const mhip_offset_t*)reads->d_offs, reads->start_read_id, rid_begin, n, d_img, d_ilist, d_iscore, d_dirty, nseg, gate, maxc, d_cur, d_out, d_cnt);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out_counts, d_cnt, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));

@@ -87,10 +87,17 @@ __global__ __launch_bounds__(CN_BLOCK, 6) void cns_extend(const uint32_t* __rest
                                                        const uint32_t* __restrict__ qpac, const mhip_offset_t* __restrict__ qoffs,
                                                        const void* __restrict__ jobs_v, int n, double error_rate, double band_frac, int dir_cols_cap,
                                                        uint32_t* __restrict__ ops, CnsDir* __restrict__ dres, uint16_t* __restrict__ gscratch,
-                                                       unsigned int* __restrict__ cursor, int* __restrict__ err_flag) {
+                                                       unsigned int* __restrict__ cursor, int* __restrict__ err_flag,
+                                                       const uint32_t* __restrict__ rnpac, const uint32_t* __restrict__ qnpac) {
     __shared__ CnsLds lds[CN_WAVES];
     CnsLds& S = lds[threadIdx.x >> 6];
     const int lane = lane_id();
+    // mecat2asmpw / mecat2trimpw only: the planes of the bases that are not A, C, G, T (mhip_volume_set_nplane; NULL without such bases), staged
+    // beside the blocks' 2-bit words in the part of V[] these tools never reach (their max_d is 120 of CN_MAX_D = 480: rows and path use the
+    // first 496 bytes of the union)
+    uint32_t* const Qn = (uint32_t*)&S.V[512];
+    uint32_t* const Tn = Qn + CN_SEQ_WORDS;
+    static_assert(1024 + 2 * CN_SEQ_WORDS * 4 <= CN_VLEN * 2, "the N planes fit behind the rows of an ASM block");
     uint16_t* grow = gscratch + (size_t)(blockIdx.x * CN_WAVES + (threadIdx.x >> 6)) * CN_GROW;
     const size_t dir_words = ((size_t)dir_cols_cap + 15) / 16;
     while (true) {
@@ -137,11 +144,21 @@ __global__ __launch_bounds__(CN_BLOCK, 6) void cns_extend(const uint32_t* __rest
             const int max_d = (int)(2.0 * error_rate * (seg + seg));
             const int koff = max_d, band_size = band_tol * 2;
             __builtin_amdgcn_wave_barrier();
+            bool has_n = false;                          // (wave-uniform) the staged range of either sequence holds a base that is not A, C, G, T
             for (int w = lane; w < CN_SEQ_WORDS; w += 64) {
                 const bool in = w > 0 && (w - 1) * 16 < seg + 32;
                 S.Qp[w] = in ? view_word(q, extend1 + (w - 1) * 16) : 0u;
                 S.Tp[w] = in ? view_word(t, extend2 + (w - 1) * 16) : 0u;
+                if (ASM && (qnpac || rnpac)) {
+                    SeqView qn = q, tn = t;
+                    qn.pac = qnpac; qn.comp = 0; tn.pac = rnpac; tn.comp = 0;
+                    const uint32_t a = (in && qnpac) ? view_word(qn, extend1 + (w - 1) * 16) : 0u;
+                    const uint32_t b = (in && rnpac) ? view_word(tn, extend2 + (w - 1) * 16) : 0u;
+                    Qn[w] = a; Tn[w] = b;
+                    has_n = (a | b) != 0u;
+                }
             }
+            if (ASM) has_n = __ballot(has_n) != 0ull;
             for (int i = lane; i < 2 * max_d + 4 && i < CN_VLEN; i += 64) S.V[i] = 0;     // :329-330
             __builtin_amdgcn_wave_barrier();
 
@@ -172,7 +189,8 @@ __global__ __launch_bounds__(CN_BLOCK, 6) void cns_extend(const uint32_t* __rest
                     bool again;
                     do {
                         const int lim = min(seg - x, seg - y);
-                        const int m = min(match16(S.Qp, x, S.Tp, y), lim);
+                        // (such a base equals only itself, `align` compares characters: mecat2asmpw.c:316-335 feed it the reads as they are)
+                        const int m = min((ASM && has_n) ? match16n(S.Qp, Qn, x, S.Tp, Tn, y) : match16(S.Qp, x, S.Tp, y), lim);
                         const int nn = min(m, 16);
                         x += nn; y += nn;
                         again = m > 16;
@@ -378,7 +396,7 @@ int mhip_cns_align_candidates_dev(mhip_ctx* c, const mhip_volume* ref, const mhi
     HIPCHK(hipMemsetAsync(d_ops, 0, sizeof(uint32_t) * dir_words * 2 * (size_t)n, c->stream));
     LAUNCH(c, "cns_extend", cns_extend<false>, grid, CN_BLOCK, 0, (const uint32_t*)ref->d_pac, (const mhip_offset_t*)ref->d_offs,
            (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs, (const void*)d_jobs, n, error_rate, 0.3, dir_cols_cap,
-           (uint32_t*)d_ops, d_dres, d_g, d_cur, d_err);
+           (uint32_t*)d_ops, d_dres, d_g, d_cur, d_err, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
     LAUNCH(c, "cns_stitch", cns_stitch, (n + 255) / 256, 256, 0, (const mhip_aln_job*)d_jobs, (const CnsDir*)d_dres, (const uint32_t*)d_ops,
            dir_cols_cap, n, min_align_size, (mhip_cns_result*)d_results);
     int err = 0;
@@ -457,7 +475,7 @@ int mhip_asm_extend(mhip_ctx* c, const mhip_volume* block, const mhip_volume* re
     // x = the block (the kernel's "reads" side), y = the mapped reads (its "ref" side); max_d = int(0.10 * (q + t)) = int(2 * 0.05 * ..)
     LAUNCH(c, "asm_extend", cns_extend<true>, grid, CN_BLOCK, 0, (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs,
            (const uint32_t*)block->d_pac, (const mhip_offset_t*)block->d_offs, (const void*)d_jobs, n, 0.05, 0.10, dir_cols_cap,
-           (uint32_t*)d_ops, d_dres, d_g, d_cur, d_err);
+           (uint32_t*)d_ops, d_dres, d_g, d_cur, d_err, (const uint32_t*)reads->d_npac, (const uint32_t*)block->d_npac);
     int err = 0;
     HIPCHK(hipMemcpyAsync(&err, d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(dirs, d_dres, sizeof(CnsDir) * 2 * (size_t)n, hipMemcpyDeviceToHost, c->stream));

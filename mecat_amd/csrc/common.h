@@ -70,6 +70,8 @@ struct mhip_volume {
     int num_bases = 0;          // incl. one pad base per read
     int start_read_id = 0;
     uint32_t* d_pac = nullptr;  // 2-bit store as big-endian-in-byte bytes, padded with >= 64 zero bytes
+    uint32_t* d_npac = nullptr; // optional second plane in the same layout: 3 at every base that is not A, C, G or T (code 0 in d_pac), else 0;
+                                // only the overlappers for corrected reads set it (mhip_volume_set_nplane), and only for input that holds an N
     mhip_offset_t* d_offs = nullptr;
     uint32_t* d_blk2read = nullptr;   // [num_bases / 1024 + 2] read holding base 1024 b (or the one before it when that base is a pad)
     std::vector<mhip_offset_t> h_offs;

@@ -78,6 +78,7 @@ def lib():
     L.mhip_debug_counter.argtypes = [vp, i32, C.POINTER(i64)]
     L.mhip_volume_upload.argtypes = [vp, vp, vp, i32, i32, i32, C.POINTER(vp)]
     L.mhip_volume_free.argtypes = [vp]
+    L.mhip_volume_set_nplane.argtypes = [vp, vp, vp]
     L.mhip_volume_num_reads.argtypes = [vp]
     L.mhip_volume_num_bases.argtypes = [vp]
     L.mhip_index_build.argtypes = [vp, vp, C.POINTER(vp)]

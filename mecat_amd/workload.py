@@ -214,9 +214,10 @@ def cns_templates(ec, num_reads, min_cov=4, min_size=5000):
     return np.ascontiguousarray(rec[sel]), tb, ids
 
 
-def asm_blocks_layout(d, nreads, L, genome, nblocks, seed, err=0.02):
+def asm_blocks_layout(d, nreads, L, genome, nblocks, seed, err=0.02, n_every=0):
     """corrected reads (2 % error) laid out as canu hands them to mecat2asmpw / mecat2trimpw (Overlapmecat2asmpw.pm:483-503): <d>/ovlprep
     with one "-allreads -allbases -b <first> -e <last>" line per block and <d>/%06d.fasta, reads numbered from 1.
+    n_every > 0: every n_every-th read carries Ns (one, three, a run of five, or one at either end and one inside).
     -> (blocks [(first, last)], total bases)"""
     codes, lens = synth_reads(nreads, L, err, genome, seed, 0)
     starts = np.concatenate([[0], np.cumsum(lens.astype(np.int64))])
@@ -226,10 +227,24 @@ def asm_blocks_layout(d, nreads, L, genome, nblocks, seed, err=0.02):
     with open(os.path.join(d, "ovlprep"), "w") as f:
         for b, e in blocks:
             f.write("-allreads -allbases -b %d -e %d\n" % (b, e))
+    rng = np.random.default_rng(seed + 1000)
     for k, (b, e) in enumerate(blocks):
         with open(os.path.join(d, "%06d.fasta" % (k + 1)), "wb") as f:
             for rid in range(b, e + 1):
-                f.write(b">%d\n" % rid + lut[codes[starts[rid - 1]: starts[rid]]].tobytes() + b"\n")
+                text = lut[codes[starts[rid - 1]: starts[rid]]].copy()
+                if n_every and rid % n_every == 0 and len(text) > 100:
+                    # bases that are not A, C, G, T: single Ns, a run of them, one at either end of the read
+                    kind = (rid // n_every) % 4
+                    pos = rng.integers(20, len(text) - 20, size=3)
+                    if kind == 0:
+                        text[pos[0]] = ord("N")
+                    elif kind == 1:
+                        text[pos] = ord("N")
+                    elif kind == 2:
+                        text[pos[0]: pos[0] + 5] = ord("N")
+                    else:
+                        text[0] = ord("N"); text[-1] = ord("N"); text[pos[1]] = ord("N")
+                f.write(b">%d\n" % rid + text.tobytes() + b"\n")
     return blocks, int(lens.sum())
 
 

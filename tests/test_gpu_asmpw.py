@@ -153,6 +153,31 @@ def test_drop_in_tool_equals_the_reference_run_on_this_machine(tmp_path, tool, s
     print("%s -S%d: %d lines, reference %.1f s on 32 threads, device tool %.1f s" % (tool, start, len(want), ref_s, dev_s))
 
 
+@pytest.mark.parametrize("tool,start", [("mecat2asmpw", 1), ("mecat2trimpw", 1), ("mecat2asmpw", 2)])
+def test_reads_with_n_equal_the_reference_run_on_this_machine(tmp_path, tool, start):
+    """Bases other than A, C, G, T: the tools restart their k-mer at such a base in table and query and compare it as a character in the
+    extension (mecat2asmpw.c:445, 486, 316-335).  2 000 corrected reads in two blocks, every fifth read with Ns (single, three, a run of five,
+    at both ends), the UNMODIFIED tool and the drop-in side by side on this machine: sorted outputs equal line by line; and the Ns matter
+    (the same reads without them give other lines)."""
+    from mecat_amd import workload as W
+    ref = os.path.join(H.ROOT, "oracle", "_ref", tool)
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref/%s is not built (make -C oracle ref, in the container)" % tool)
+    d = str(tmp_path / "n")
+    os.makedirs(d)
+    W.asm_blocks_layout(d, 2000, 8000, 500_000, 2, 78, n_every=5)
+    want, _, _ = W.asm_tool_run(ref, d, 16, start, 2)
+    got, _, _ = W.asm_tool_run(os.path.join(H.ROOT, "mecat_amd", "bin", tool), d, 16, start, 2)
+    assert len(want) > 10000
+    bad = [(a, b) for a, b in zip(got, want) if a != b]
+    assert len(got) == len(want) and not bad, (len(got), len(want), bad[:3])
+    d0 = str(tmp_path / "plain")
+    os.makedirs(d0)
+    W.asm_blocks_layout(d0, 2000, 8000, 500_000, 2, 78)
+    plain, _, _ = W.asm_tool_run(ref, d0, 16, start, 2)
+    assert plain != want
+
+
 @pytest.mark.parametrize("tool,start", [("mecat2asmpw50", 1), ("mecat2asmpw50", 2), ("mecat2trimpw50", 1), ("mecat2trimpw50", 2)])
 def test_50_candidate_variants_equal_the_reference_output(tmp_path, tool, start):
     """the `*50` names (MAXC 50, mecat2asmpw50.c:23) on a set dense enough that the top-MAXC cut decides which candidates survive (the

@@ -354,6 +354,9 @@ __global__ __launch_bounds__(AL_BLOCK) void dw_extend(const uint32_t* __restrict
         t.A = right ? jb.sstart : jb.sstart - 1; t.B = step;
         if (right) { query_size = qsize - jb.qstart; target_size = tsize - jb.sstart; }
         else { query_size = jb.qstart; target_size = jb.sstart; }
+        // a start point in front of a read (the reference's wrapped `short` seed numbers give a read beyond 327 670 bases negative query
+        // starts, pw_impl.cpp:388; there the reference extends from in front of its buffer): nothing to extend here
+        if (jb.qstart < 0 || jb.sstart < 0) { query_size = 0; target_size = 0; }
         while (true) {
             // retrieve_next_aln_block (gapalign.cpp:9-45)
             const int qleft = query_size - qidx, tleft = target_size - tidx;
@@ -567,6 +570,7 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                     t.A = right ? jb.sstart : jb.sstart - 1; t.B = step;
                     if (right) { query_size = qsize - jb.qstart; target_size = tsize - jb.sstart; }
                     else { query_size = jb.qstart; target_size = jb.sstart; }
+                    if (jb.qstart < 0 || jb.sstart < 0) { query_size = 0; target_size = 0; }      // (see dw_extend)
                     qidx = tidx = 0;
                     Rq = Rt = Rm = Rc = Rb = 0;
                     need_unit = false;
@@ -1186,7 +1190,7 @@ int mhip_align_candidates(mhip_ctx* c, const mhip_volume* ref, const mhip_volume
             return -1;
         }
         const int qs = reads->h_offs[(size_t)j.qid_local].size, ts = ref->h_offs[(size_t)j.sid_local].size;
-        if (j.qstart < 0 || j.qstart > qs || j.sstart < 0 || j.sstart > ts) {
+        if (j.qstart > qs || j.sstart > ts) {      // (a negative start point is a job without extension, see dw_extend)
             mhip_set_error("alignment job %d: start point outside the reads", i);
             return -1;
         }

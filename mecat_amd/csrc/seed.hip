@@ -32,7 +32,9 @@
 // FP: find_location is all f32, insert_loc divides in f32 and compares in f64, the sweeps are f64;
 // built with -ffp-contract=off and hipcc's default correctly-rounded f32 division.
 //
-// Known divergence: reads longer than 327 670 bases (seed numbers overflow the reference's `short`).
+// Reads longer than 327 670 bases: the reference's seed numbers are `short` and wrap.  ent_seed() sign-extends the stored 16
+// bits like the reference's loads do, the recording rule follows the wrapped `seednum` (seed_build, phase A), and such a strand always takes the
+// kernel chain (seed_strand stops at K = 32 767): candidates equal the reference's also there (test_reads_beyond_the_short_seed_numbers).
 #include <stdlib.h>
 #include <string.h>
 
@@ -649,7 +651,10 @@ __global__ __launch_bounds__(SEED_BLOCK) void seed_build(SeedArrays A, int sorte
         bool in = i < H;
         uint64_t key = in ? S[i] : 0, prev = (in && i > 0) ? S[i - 1] : 0;
         bool head = in && (i == 0 || key_seg(key) != key_seg(prev));
-        bool rec = in && (head || key_km(key) != key_km(prev));
+        // a hit is recorded when the segment is new or its last seed number is below this k-mer's (pw_impl.cpp:265): the first hit of each
+        // (segment, km) — until the reference's `short seednum` wraps: from seed number 32 768 on (reads beyond 327 670 bases) it is
+        // negative, below every k-mer number, and every further hit of the segment is recorded
+        bool rec = in && (head || key_km(key) != key_km(prev) || key_km(prev) >= 32767u);
         // one scan for both counts: recorded events in the low half, segment heads in the high half (<= 256 each per round)
         uint32_t both;
         const uint32_t ex = block_excl_scan((rec ? 1u : 0u) | (head ? 0x10000u : 0u), wtot, &both);

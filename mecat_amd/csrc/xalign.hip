@@ -737,8 +737,10 @@ __global__ __launch_bounds__(XW_BLOCK) void xd_extend_w(const uint32_t* __restri
         const int qs0 = right ? jb.qstart : jb.qstart - 1, step = right ? 1 : -1;
         if (jb.chain) { q.A = qsize - 1 - qs0; q.B = -step; } else { q.A = qs0; q.B = step; }
         t.A = right ? jb.sstart : jb.sstart - 1; t.B = step;
-        const int query_size = right ? qsize - jb.qstart : jb.qstart;
-        const int target_size = right ? tsize - jb.sstart : jb.sstart;
+        // (a start point in front of a read — the reference's wrapped seed numbers, pw_impl.cpp:388 — is a job without extension)
+        const bool dead = jb.qstart < 0 || jb.sstart < 0;
+        const int query_size = dead ? 0 : (right ? qsize - jb.qstart : jb.qstart);
+        const int target_size = dead ? 0 : (right ? tsize - jb.sstart : jb.sstart);
         bool handed_over = false;
         while (true) {      // align_ex (xdrop_gapalign.cpp:263-357)
             const int qleft = query_size - qidx, tleft = target_size - tidx;
@@ -889,7 +891,7 @@ int mhip_xalign_candidates(mhip_ctx* c, const mhip_volume* ref, const mhip_volum
             return -1;
         }
         const int qs = reads->h_offs[(size_t)j.qid_local].size, ts = ref->h_offs[(size_t)j.sid_local].size;
-        if (j.qstart < 0 || j.qstart > qs || j.sstart < 0 || j.sstart > ts) {
+        if (j.qstart > qs || j.sstart > ts) {      // (a negative start point is a job without extension)
             mhip_set_error("alignment job %d: start point outside the reads", i);
             return -1;
         }

@@ -391,3 +391,34 @@ def test_reserved_index_scratch_changes_nothing():
         idx.free()
         vol.free()
         ctx.close()
+
+
+@pytest.mark.parametrize("tech", [0, 1])
+def test_reads_beyond_the_short_seed_numbers(tech, hip, ctx):
+    """Reads of more than 327 670 bases (the reference accepts up to MAX_SEQ_SIZE = 500 000): the reference keeps seed numbers in `short`
+    (struct Back_List, pw_impl.h:31-35), which wrap negative from query k-mer 32 768 on — the recording rule `seednum < km + 1` then holds for
+    every hit, DDF votes and sweeps run on the wrapped numbers, a candidate's query start (seedno - 1) * 10 can go negative.  Six reads of
+    420 kb on a 450 kb genome plus forty of 8 kb: candidates equal the oracle's (which tests/test_oracle_vs_ref.py pins to the compiled
+    reference on the same reads), every field; the extension of all of them runs (a negative start point is a job without extension)."""
+    c1, l1 = H.synth_reads(6, 400000, 0.15, 450000, 41)
+    c2, l2 = H.synth_reads(40, 8000, 0.15, 450000, 42)
+    codes, lens = np.concatenate([c1, c2]), np.concatenate([l1, l2])
+    assert int(lens.max()) > 327670
+    ov = H.orc_pack(codes, lens)
+    oidx = H.orc().orc_index_build(ov)
+    offs, pac = H.vol_arrays(ov)
+    gv = hip.Volume(ctx, pac, offs, ov.contents.num_bases, 0)
+    gi = hip.Index(ctx, gv)
+    p = hip.default_params(tech)
+    got, cnt = hip.seed_reads(ctx, gi, gv, gv, 0, len(lens), p)
+    want = H.orc_seed_all(ov, ov, oidx, H.orc_params(tech=tech))
+    bad = _cmp_cands(got, cnt, want)
+    assert not bad, "%d reads differ, first %d: GPU %s ORC %s" % (len(bad), bad[0], got[bad[0]][: cnt[bad[0]]], want[bad[0]])
+    assert int(cnt.sum()) >= 30
+    from mecat_amd import workload as W
+    jobs = W.jobs_from_candidates(got, cnt, 0)
+    jobs["qstart"][0] = -25                      # what a wrapped seed number makes of a start point: must not be extended, must not fault
+    res = hip.align_candidates(ctx, gv, gv, jobs, p.min_align_size, tech=tech)
+    assert res["ok"][0] == 0 and int(res["ok"].sum()) >= 10
+    gi.free()
+    gv.free()

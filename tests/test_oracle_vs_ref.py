@@ -370,3 +370,36 @@ def test_cns_aligner_random(error_rate):
         oks += outs[0][0]
     assert oks > 20
     O.orc_cns_free(a)
+
+
+@pytest.mark.parametrize("tech", [0, 1])
+def test_candidates_identical_beyond_the_short_seed_numbers(tech):
+    """reads of 420 kb (the reference's `short` seed numbers wrap from read position 327 670 on): the oracle keeps them in int16 like the
+    reference and gives the reference's candidates there too — the pin behind tests/test_gpu_parity.py::test_reads_beyond_the_short_seed_numbers"""
+    c1, l1 = H.synth_reads(6, 400000, 0.15, 450000, 41)
+    c2, l2 = H.synth_reads(40, 8000, 0.15, 450000, 42)
+    codes, lens = np.concatenate([c1, c2]), np.concatenate([l1, l2])
+    d = tempfile.mkdtemp(prefix="orc_ref_long_")
+    fa = os.path.join(d, "x.fa")
+    H.write_fasta(fa, codes, lens)
+    wrk = os.path.join(d, "wrk")
+    os.makedirs(wrk)
+    R = H.ref()
+    assert R.refh_split(fa.encode(), wrk.encode()) == 1
+    rv = R.refh_load_volume(os.path.join(wrk, "vol0").encode())
+    ridx = R.refh_build_index(rv, 1)
+    ov = H.orc_pack(codes, lens)
+    oidx = H.orc().orc_index_build(ov)
+    p = H.orc_params(tech=tech, maxc=100)
+    R.refh_set_params(100, p.min_align_size, p.min_kmer_match, tech)
+    ours = H.orc_seed_all(ov, ov, oidx, p)
+    out = np.zeros((100, 12), dtype=np.int32)
+    tot = 0
+    for rid in range(len(lens)):
+        k = R.refh_seed_read(rv, rv, ridx, rid, 0, out.ctypes.data)
+        a = ours[rid]
+        assert k == len(a), rid
+        got = np.stack([a[n] for n in H.CAND_DTYPE.names], axis=1) if k else np.zeros((0, 12), np.int32)
+        assert np.array_equal(got, out[:k]), rid
+        tot += k
+    assert tot >= 30

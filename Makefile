@@ -45,7 +45,7 @@ $(BINDIR)/mecat2pw: $(HOST_SRCS) $(wildcard mecat_amd/host/*.h) include/mecat_hi
 # mecat2canu's overlappers for corrected reads: one program under the four names the canu job scripts start
 $(BINDIR)/mecat2asmpw: mecat_amd/asmpw/asmpw_main.cpp include/mecat_hip.h $(LIBDIR)/libmecat_hip.so
 	@mkdir -p $(BINDIR)
-	$(CXX) -O2 -std=c++17 -pthread -Wall -Iinclude mecat_amd/asmpw/asmpw_main.cpp -L$(LIBDIR) -lmecat_hip -Wl,-rpath,'$$ORIGIN/../lib' -o $@
+	$(CXX) -O3 -std=c++17 -pthread -Wall -Iinclude mecat_amd/asmpw/asmpw_main.cpp -L$(LIBDIR) -lmecat_hip -Wl,-rpath,'$$ORIGIN/../lib' -o $@
 	for n in mecat2trimpw mecat2asmpw50 mecat2trimpw50; do cp -f $@ $(BINDIR)/$$n; done
 
 $(BINDIR)/mecat2cns_partition: mecat_amd/tools/partition_main.cpp mecat_amd/host/partition.cpp mecat_amd/host/partition.h

@@ -269,6 +269,14 @@ int  mhip_asm_seed_reads_ex(mhip_ctx* ctx, const mhip_index* idx, const mhip_vol
 typedef struct { int32_t xid, yid, chain, lx, ly, lnx, lny, rx, ry, rnx, rny, pad; } mhip_asm_job;
 int  mhip_asm_extend(mhip_ctx* ctx, const mhip_volume* block, const mhip_volume* reads, const mhip_asm_job* jobs, int n, int dir_cols_cap,
                      int32_t* dirs /*[2 n][6]*/, uint32_t* ops /*[2 n][dir_cols_cap / 16]*/);
+/* The same extension with the columns handed over densely, in two calls (what the tools use: a direction fills a fraction of
+ * dir_cols_cap, so the fixed-stride form moves 5-10x the bytes over the PCIe link).  mhip_asm_extend_run extends the batch, leaves the
+ * results on the device and returns the number of 32-bit words the columns of all directions take (ceil(columns / 16) per direction);
+ * mhip_asm_extend_fetch — same context, same n, before the next _run — copies them out: direction k = 2 i + d occupies words
+ * [word_offs[k], word_offs[k + 1]) of ops_dense (total_words words).  Host buffers from mhip_host_alloc make the copies DMA. */
+int  mhip_asm_extend_run(mhip_ctx* ctx, const mhip_volume* block, const mhip_volume* reads, const mhip_asm_job* jobs, int n, int dir_cols_cap,
+                         int64_t* total_words);
+int  mhip_asm_extend_fetch(mhip_ctx* ctx, int n, int32_t* dirs /*[2 n][6]*/, uint64_t* word_offs /*[2 n + 1]*/, uint32_t* ops_dense /*[total_words]*/);
 
 /* mhip_index_build by all ranks of the communicator together (replaces create_ref_index, common/lookup_table.cpp:63-160, in a
  * multi-GPU cell): the 4^13 key space is cut into P contiguous ranges of equal occupancy, each rank builds the buckets of its range,

@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -232,20 +233,33 @@ int main(int argc, char** argv) {
 
     // MECAT_ASMPW_TIMES=1: where the wall time went, on stderr at the end
     const bool times = getenv("MECAT_ASMPW_TIMES") != NULL;
-    double t_load = 0, t_index = 0, t_seed = 0, t_jobs = 0, t_extend = 0, t_host = 0, t_flush = 0;
+    double t_load = 0, t_index = 0, t_seed = 0, t_jobs = 0, t_extend = 0, t_host = 0, t_flush = 0, t_drain = 0, t_close = 0;
     size_t n_jobs = 0;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now();
     mhip_ctx* ctx = NULL;
     const int device = getenv("MECAT_HIP_DEVICE") ? atoi(getenv("MECAT_HIP_DEVICE")) : 0;
-    MCHK(mhip_ctx_create(device, NULL, &ctx));
-    const double t_ctx = now() - t_begin;
+    // The context comes up (HIP runtime, device, stream) and the -T output files are opened beside the first block's read: neither needs
+    // the other, and each is a tenth of a second of waiting (the files are needed by the first chunk's lines, the context by the upload).
+    std::thread ctx_thread([&] { MCHK(mhip_ctx_create(device, NULL, &ctx)); });
+    std::vector<FILE*> out((size_t)threads);
+    std::thread open_thread([&] {
+        for (int t = 0; t < threads; ++t) {
+            const std::string p = dir + "/" + std::to_string(start) + "_" + std::to_string(t) + ".r";
+            out[(size_t)t] = fopen(p.c_str(), "w");
+            if (!out[(size_t)t]) DIE("cannot write '%s': %s", p.c_str(), strerror(errno));
+        }
+    });
     Reads blk;
     double t0 = now();
     load_block(block_path(start), first_read[(size_t)start - 1], &blk);
     t_load += now() - t0; t0 = now();
+    ctx_thread.join();
+    const double t_ctx = now() - t0;
+    t0 = now();
     mhip_volume* dblk = NULL;
     MCHK(mhip_volume_upload(ctx, blk.pac.data(), blk.offs.data(), (int)blk.offs.size(), blk.num_bases, blk.first_no, &dblk));
+    t_load += now() - t0; t0 = now();
     mhip_index* idx = NULL;
     if (!blk.has_n) MCHK(mhip_index_build_ex(ctx, dblk, 256, &idx));
     else {
@@ -258,26 +272,206 @@ int main(int argc, char** argv) {
         mhip_volume_free(dfrag);
     }
     t_index += now() - t0;
-
-    std::vector<FILE*> out((size_t)threads);
-    for (int t = 0; t < threads; ++t) {
-        const std::string p = dir + "/" + std::to_string(start) + "_" + std::to_string(t) + ".r";
-        out[(size_t)t] = fopen(p.c_str(), "w");
-        if (!out[(size_t)t]) DIE("cannot write '%s': %s", p.c_str(), strerror(errno));
-    }
     int next_file = 0;
 
+    // Candidates are found for `slab` query reads per launch (one wave per read; 2 048 by default: more resident waves thrash on their record
+    // arrays); their extensions run in chunks of at most `chunk` candidates, and the string work of a chunk runs on the -T threads while
+    // the device works on the next one — across block boundaries too: a chunk keeps its query block alive.
+    const int slab = std::max(1, getenv("MECAT_ASMPW_SLAB") ? atoi(getenv("MECAT_ASMPW_SLAB")) : 2048);
+    // MECAT_ASMPW_CHUNK_MB bounds the DEVICE array of a chunk (every direction at its worst-case length there); what crosses the PCIe
+    // link is the columns the directions really have, packed (mhip_asm_extend_run / _fetch), into page-locked buffers that grow on demand
+    const size_t chunk_bytes = (size_t)std::max(1, getenv("MECAT_ASMPW_CHUNK_MB") ? atoi(getenv("MECAT_ASMPW_CHUNK_MB")) : 256) << 20;
+    mhip_asm_candidate* cands = NULL;                // page-locked: a slab's lists are 10 MB, of which a third is filled
+    int32_t* counts = NULL;
+    MCHK(mhip_host_alloc((size_t)slab * 100 * sizeof(mhip_asm_candidate), (void**)&cands));
+    MCHK(mhip_host_alloc((size_t)slab * sizeof(int32_t), (void**)&counts));
+    struct Chunk {                                   // one extension call and what the host stage needs of it
+        std::vector<mhip_asm_job> jobs;
+        std::vector<mhip_asm_candidate> cand;
+        std::vector<int> qrid;                       // query read (index in its block) of every job
+        std::shared_ptr<const Reads> qkeep;          // the query block, when it is not the subject block
+        const Reads* q = NULL;
+        int32_t* dirs = NULL;                        // page-locked: [2 jobs][6]
+        uint64_t* woffs = NULL;                      // page-locked: [2 jobs + 1] first word of every direction in ops
+        size_t jobs_cap = 0;
+        uint32_t* ops = NULL;                        // page-locked, ops_cap words
+        size_t ops_cap = 0;
+        std::thread post;
+    } ck[2];
+    int cur = 0;
+    // ---- per candidate: the tool's string work and its output line (:843-948)
+    auto host_stage = [&](Chunk* C) {
+        const double th0 = now();
+        const size_t nj = C->jobs.size();
+        std::vector<std::string> text((size_t)threads);
+        std::atomic<size_t> next_job{0};
+        auto worker = [&](int t) {
+            std::string& o = text[(size_t)t];
+            std::string L1, L2, R1, R2, g1, g2, O1, O2;
+            char line[256];
+            for (;;) {
+                const size_t j0 = next_job.fetch_add(64);
+                if (j0 >= nj) break;
+                for (size_t ji = j0; ji < std::min(nj, j0 + 64); ++ji) {
+                    const int qrid = C->qrid[ji], read_len = C->q->offs[(size_t)qrid].size, read_name = C->q->first_no + qrid;
+                    const mhip_asm_candidate& c = C->cand[ji];
+                    const mhip_asm_job& jb = C->jobs[ji];
+                    // characters of the subject read and of the mapped strand (the complement of N is N, :583-590): bases and planes of
+                    // the two reads addressed directly, 16 columns of a word at a time
+                    const Reads& Q = *C->q;
+                    const int64_t xo = blk.offs[(size_t)jb.xid].offset, yo = Q.offs[(size_t)qrid].offset;
+                    const uint8_t* const xp = blk.pac.data();
+                    const uint8_t* const yp = Q.pac.data();
+                    const uint8_t* const xn = blk.has_n ? blk.npac.data() : NULL;
+                    const uint8_t* const yn = Q.has_n ? Q.npac.data() : NULL;
+                    auto at2 = [](const uint8_t* pl, int64_t idx) -> int { return (pl[(size_t)(idx >> 2)] >> ((~idx & 3) << 1)) & 3; };
+                    auto xchr = [&](int pos) -> char {
+                        const int64_t idx = xo + pos;
+                        return xn && at2(xn, idx) ? 'N' : "ACGT"[at2(xp, idx)];
+                    };
+                    auto ychr = [&](int pos) -> char {
+                        const int64_t idx = yo + (jb.chain ? read_len - 1 - pos : pos);
+                        if (yn && at2(yn, idx)) return 'N';
+                        return jb.chain ? "TGCA"[at2(yp, idx)] : "ACGT"[at2(yp, idx)];
+                    };
+                    auto build = [&](int d, std::string& s1, std::string& s2) {
+                        const int cols = C->dirs[(ji * 2 + (size_t)d) * 6];
+                        const uint32_t* w = C->ops + C->woffs[ji * 2 + (size_t)d];
+                        s1.resize((size_t)cols); s2.resize((size_t)cols);
+                        char* const a = &s1[0];
+                        char* const b = &s2[0];
+                        int x = d ? jb.rx : jb.lx, y = d ? jb.ry : jb.ly;
+                        const int step = d ? 1 : -1;
+                        for (int m0 = 0; m0 < cols; m0 += 16) {
+                            const uint32_t word = w[m0 >> 4];
+                            const int n = std::min(16, cols - m0);
+                            if (word == 0u) {                              // sixteen columns with both bases
+                                for (int m = 0; m < n; ++m) { a[m0 + m] = xchr(x); b[m0 + m] = ychr(y); x += step; y += step; }
+                                continue;
+                            }
+                            for (int m = 0; m < n; ++m) {
+                                const int op = (int)((word >> (m << 1)) & 3u);
+                                char ca = '-', cb = '-';
+                                if (op != 1) { ca = xchr(x); x += step; }
+                                if (op != 2) { cb = ychr(y); y += step; }
+                                a[m0 + m] = ca; b[m0 + m] = cb;
+                            }
+                        }
+                    };
+                    build(0, L1, L2);
+                    build(1, R1, R2);
+                    {
+                        // the two sequences of the left pair without their gaps
+                        const size_t n = L1.size();
+                        g1.resize(n); g2.resize(n);
+                        size_t k1 = 0, k2 = 0;
+                        for (size_t m = 0; m < n; ++m) {
+                            g1[k1] = L1[m]; k1 += L1[m] != '-';
+                            g2[k2] = L2[m]; k2 += L2[m] != '-';
+                        }
+                        g1.resize(k1); g2.resize(k2);
+                    }
+                    shuffle_gaps(g1, g2, L1, L2);
+                    const int u_k = (int)L1.size();
+                    O1.assign(L1.rbegin(), L1.rend());
+                    O2.assign(L2.rbegin(), L2.rend());
+                    int nl1 = 0, nl2 = 0;
+                    for (int m = 0; m < u_k; ++m) { nl1 += L1[(size_t)m] != '-'; nl2 += L2[(size_t)m] != '-'; }
+                    int left_loc1, left_loc, right_loc1, right_loc;
+                    if (u_k == SEED - 1) { left_loc1 = c.loc1 + SEED - nl1 - 1; left_loc = c.loc2 + SEED - nl2; }
+                    else if (u_k > 0) { left_loc1 = c.loc1 + SEED - nl1; left_loc = c.loc2 + SEED - nl2 + 1; }
+                    else { left_loc1 = c.loc1; left_loc = c.loc2 + 1; }
+                    const int s_k = (int)R1.size();
+                    int nr1 = 0, nr2 = 0;
+                    for (int m = 0; m < s_k; ++m) { nr1 += R1[(size_t)m] != '-'; nr2 += R2[(size_t)m] != '-'; }
+                    if (s_k > 0) { right_loc1 = c.loc1 + nr1 - 1; right_loc = c.loc2 + nr2; }
+                    else { right_loc1 = c.loc1 + SEED - 1; right_loc = c.loc2 + SEED; }
+                    if (s_k >= SEED && u_k >= SEED) { O1.append(R1, SEED, std::string::npos); O2.append(R2, SEED, std::string::npos); }
+                    else if (u_k < SEED) { O1 = R1; O2 = R2; }
+                    left_loc1 -= c.readstart;
+                    right_loc1 -= c.readstart;
+                    if (!(right_loc1 - left_loc1 > 450)) continue;
+                    int mism = 0;
+                    const int cols = (int)O1.size();
+                    for (int m = 0; m < cols; ++m) mism += !(O1[(size_t)m] == O2[(size_t)m] && O2[(size_t)m] != '-');
+                    float jscore;
+                    if (!tool.trim) { jscore = (float)(2 * cols - mism); jscore = jscore * 30 * 4 / (cols); }
+                    else { jscore = (float)mism; jscore = jscore / (4 * cols); }
+                    const int sno = blk.first_no + c.readno, slen = blk.offs[(size_t)c.readno].size;
+                    int w;
+                    if (!jb.chain) w = snprintf(line, sizeof(line), "%d %d %.3f 100 0 %d %d %d 0 %d %d %d\n", sno, read_name, jscore, left_loc1 - 1, right_loc1, slen,
+                                                left_loc - 1, right_loc, read_len);
+                    else w = snprintf(line, sizeof(line), "%d %d %.3f 100 0 %d %d %d 1 %d %d %d\n", sno, read_name, jscore, left_loc1 - 1, right_loc1, slen,
+                                      read_len - right_loc, read_len - left_loc + 1, read_len);
+                    o.append(line, (size_t)w);
+                }
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < threads; ++t) th.emplace_back(worker, t);
+        worker(0);
+        for (std::thread& x : th) x.join();
+        for (int t = 0; t < threads; ++t) {
+            FILE* f = out[(size_t)((next_file + t) % threads)];
+            if (!text[(size_t)t].empty() && fwrite(text[(size_t)t].data(), 1, text[(size_t)t].size(), f) != text[(size_t)t].size()) DIE("write error");
+        }
+        next_file = (next_file + 1) % threads;
+        t_host += now() - th0;
+    };
+    // extend the chunk's candidates (of query volume dq, at most cap columns per direction), then hand it to the host stage
+    auto flush = [&](Chunk* C, mhip_volume* dq, int cap) {
+        if (C->jobs.empty()) return;
+        const double tf0 = now();
+        const size_t nj = C->jobs.size();
+        if (nj > C->jobs_cap) {
+            if (C->dirs) mhip_host_free(C->dirs);
+            if (C->woffs) mhip_host_free(C->woffs);
+            C->jobs_cap = nj + nj / 4 + 64;
+            MCHK(mhip_host_alloc(C->jobs_cap * 2 * 6 * sizeof(int32_t), (void**)&C->dirs));
+            MCHK(mhip_host_alloc((C->jobs_cap * 2 + 1) * sizeof(uint64_t), (void**)&C->woffs));
+        }
+        int64_t words = 0;
+        MCHK(mhip_asm_extend_run(ctx, dblk, dq, C->jobs.data(), (int)nj, cap, &words));
+        if ((size_t)words > C->ops_cap) {
+            if (C->ops) mhip_host_free(C->ops);
+            C->ops_cap = (size_t)words + (size_t)words / 4 + 4096;
+            MCHK(mhip_host_alloc(C->ops_cap * sizeof(uint32_t), (void**)&C->ops));
+        }
+        MCHK(mhip_asm_extend_fetch(ctx, (int)nj, C->dirs, C->woffs, C->ops));
+        t_extend += now() - tf0;
+        n_jobs += nj;
+        Chunk* prev = &ck[cur ^ 1];
+        if (prev->post.joinable()) prev->post.join();          // the host stages run one after the other (they share the output files)
+        if (open_thread.joinable()) open_thread.join();
+        C->post = std::thread(host_stage, C);
+        cur ^= 1;
+        Chunk* nxt = &ck[cur];
+        if (nxt->post.joinable()) nxt->post.join();
+        nxt->jobs.clear(); nxt->cand.clear(); nxt->qrid.clear();
+        nxt->q = C->q; nxt->qkeep = C->qkeep;                  // (the next chunk continues in the same query block)
+        t_flush += now() - tf0;
+    };
+
+    std::shared_ptr<Reads> ahead;                    // the next query block, read and packed beside the current block's device work
+    std::thread ahead_thread;
     for (int bi = start; bi <= last; ++bi) {
-        Reads qs_own;
+        std::shared_ptr<Reads> qs_own;
         const Reads* qs = &blk;
         mhip_volume* dq = dblk;
         if (bi != start) {
             t0 = now();
-            load_block(block_path(bi), first_read[(size_t)bi - 1], &qs_own);
-            qs = &qs_own;
+            ahead_thread.join();
+            qs_own = ahead;
+            qs = qs_own.get();
             MCHK(mhip_volume_upload(ctx, qs->pac.data(), qs->offs.data(), (int)qs->offs.size(), qs->num_bases, qs->first_no, &dq));
             if (qs->has_n) MCHK(mhip_volume_set_nplane(ctx, dq, qs->npac.data()));
             t_load += now() - t0;
+        }
+        if (bi < last) {
+            ahead = std::make_shared<Reads>();
+            Reads* dst = ahead.get();
+            const int nb = bi + 1;
+            ahead_thread = std::thread([&, dst, nb] { load_block(block_path(nb), first_read[(size_t)nb - 1], dst); });
         }
         const int nq = (int)qs->offs.size();
         int maxlen = 16;
@@ -285,134 +479,12 @@ int main(int argc, char** argv) {
         for (const mhip_offset_t& o : qs->offs) maxlen = std::max(maxlen, o.size);
         const int cap = ((maxlen * 2 + 64 + 15) / 16) * 16;          // columns of one direction <= bases of both reads on that side
         const size_t dir_words = (size_t)cap / 16;
-        // Candidates are found for `slab` query reads per launch (one wave per read; 2 048 by default: more resident waves thrash on their record arrays); their extensions
-        // run in chunks of at most `chunk` candidates (the edit scripts of a chunk are what the host buffers hold), and the string work
-        // of a chunk runs on the -T threads while the device extends the next one.
-        const int slab = std::max(1, getenv("MECAT_ASMPW_SLAB") ? atoi(getenv("MECAT_ASMPW_SLAB")) : 2048);
-        const size_t chunk_bytes = (size_t)std::max(1, getenv("MECAT_ASMPW_CHUNK_MB") ? atoi(getenv("MECAT_ASMPW_CHUNK_MB")) : 128) << 20;
         const size_t chunk = std::max<size_t>(64, chunk_bytes / (2 * dir_words * sizeof(uint32_t)));
-        std::vector<mhip_asm_candidate> cands((size_t)slab * 100);
-        std::vector<int32_t> counts((size_t)slab);
-        struct Chunk {                                   // one extension call and what the host stage needs of it
-            std::vector<mhip_asm_job> jobs;
-            std::vector<mhip_asm_candidate> cand;
-            std::vector<int> qrid;                       // query read (index in its block) of every job
-            int32_t* dirs = NULL;
-            uint32_t* ops = NULL;
-            std::thread post;
-        } ck[2];
-        for (Chunk& c : ck) {
-            c.dirs = (int32_t*)malloc(chunk * 2 * 6 * sizeof(int32_t));
-            c.ops = (uint32_t*)malloc(chunk * 2 * dir_words * sizeof(uint32_t));
-            if (!c.dirs || !c.ops) DIE("out of memory (MECAT_ASMPW_CHUNK_MB)");
-        }
-        int cur = 0;
-        // ---- per candidate: the tool's string work and its output line (:843-948)
-        auto host_stage = [&](Chunk* C) {
-            const double th0 = now();
-            const size_t nj = C->jobs.size();
-            std::vector<std::string> text((size_t)threads);
-            std::atomic<size_t> next_job{0};
-            auto worker = [&](int t) {
-                std::string& o = text[(size_t)t];
-                std::string L1, L2, R1, R2, g1, g2, O1, O2;
-                char line[256];
-                for (;;) {
-                    const size_t j0 = next_job.fetch_add(64);
-                    if (j0 >= nj) break;
-                    for (size_t ji = j0; ji < std::min(nj, j0 + 64); ++ji) {
-                        const int qrid = C->qrid[ji], read_len = qs->offs[(size_t)qrid].size, read_name = qs->first_no + qrid;
-                        const mhip_asm_candidate& c = C->cand[ji];
-                        const mhip_asm_job& jb = C->jobs[ji];
-                        auto ychr = [&](int pos) -> char {          // character at position pos of the mapped strand (the complement of N is N, :583-590)
-                            if (!jb.chain) return qs->chr(qrid, pos);
-                            const int rp = read_len - 1 - pos;
-                            return qs->is_n(qrid, rp) ? 'N' : "ACGT"[3 - qs->base(qrid, rp)];
-                        };
-                        auto build = [&](int d, std::string& s1, std::string& s2) {
-                            const int cols = C->dirs[(ji * 2 + (size_t)d) * 6];
-                            const uint32_t* w = C->ops + (ji * 2 + (size_t)d) * dir_words;
-                            s1.resize((size_t)cols); s2.resize((size_t)cols);
-                            int x = d ? jb.rx : jb.lx, y = d ? jb.ry : jb.ly;
-                            const int step = d ? 1 : -1;
-                            for (int m = 0; m < cols; ++m) {
-                                const int op = (int)((w[m >> 4] >> ((m & 15) << 1)) & 3u);
-                                char a = '-', b = '-';
-                                if (op != 1) { a = blk.chr(jb.xid, x); x += step; }
-                                if (op != 2) { b = ychr(y); y += step; }
-                                s1[(size_t)m] = a; s2[(size_t)m] = b;
-                            }
-                        };
-                        build(0, L1, L2);
-                        build(1, R1, R2);
-                        g1.clear(); g2.clear();
-                        for (size_t m = 0; m < L1.size(); ++m) { if (L1[m] != '-') g1 += L1[m]; if (L2[m] != '-') g2 += L2[m]; }
-                        shuffle_gaps(g1, g2, L1, L2);
-                        const int u_k = (int)L1.size();
-                        O1.assign(L1.rbegin(), L1.rend());
-                        O2.assign(L2.rbegin(), L2.rend());
-                        int nl1 = 0, nl2 = 0;
-                        for (int m = 0; m < u_k; ++m) { nl1 += L1[(size_t)m] != '-'; nl2 += L2[(size_t)m] != '-'; }
-                        int left_loc1, left_loc, right_loc1, right_loc;
-                        if (u_k == SEED - 1) { left_loc1 = c.loc1 + SEED - nl1 - 1; left_loc = c.loc2 + SEED - nl2; }
-                        else if (u_k > 0) { left_loc1 = c.loc1 + SEED - nl1; left_loc = c.loc2 + SEED - nl2 + 1; }
-                        else { left_loc1 = c.loc1; left_loc = c.loc2 + 1; }
-                        const int s_k = (int)R1.size();
-                        int nr1 = 0, nr2 = 0;
-                        for (int m = 0; m < s_k; ++m) { nr1 += R1[(size_t)m] != '-'; nr2 += R2[(size_t)m] != '-'; }
-                        if (s_k > 0) { right_loc1 = c.loc1 + nr1 - 1; right_loc = c.loc2 + nr2; }
-                        else { right_loc1 = c.loc1 + SEED - 1; right_loc = c.loc2 + SEED; }
-                        if (s_k >= SEED && u_k >= SEED) { O1.append(R1, SEED, std::string::npos); O2.append(R2, SEED, std::string::npos); }
-                        else if (u_k < SEED) { O1 = R1; O2 = R2; }
-                        left_loc1 -= c.readstart;
-                        right_loc1 -= c.readstart;
-                        if (!(right_loc1 - left_loc1 > 450)) continue;
-                        int mism = 0;
-                        const int cols = (int)O1.size();
-                        for (int m = 0; m < cols; ++m) mism += !(O1[(size_t)m] == O2[(size_t)m] && O2[(size_t)m] != '-');
-                        float jscore;
-                        if (!tool.trim) { jscore = (float)(2 * cols - mism); jscore = jscore * 30 * 4 / (cols); }
-                        else { jscore = (float)mism; jscore = jscore / (4 * cols); }
-                        const int sno = blk.first_no + c.readno, slen = blk.offs[(size_t)c.readno].size;
-                        int w;
-                        if (!jb.chain) w = snprintf(line, sizeof(line), "%d %d %.3f 100 0 %d %d %d 0 %d %d %d\n", sno, read_name, jscore, left_loc1 - 1, right_loc1, slen,
-                                                    left_loc - 1, right_loc, read_len);
-                        else w = snprintf(line, sizeof(line), "%d %d %.3f 100 0 %d %d %d 1 %d %d %d\n", sno, read_name, jscore, left_loc1 - 1, right_loc1, slen,
-                                          read_len - right_loc, read_len - left_loc + 1, read_len);
-                        o.append(line, (size_t)w);
-                    }
-                }
-            };
-            std::vector<std::thread> th;
-            for (int t = 1; t < threads; ++t) th.emplace_back(worker, t);
-            worker(0);
-            for (std::thread& x : th) x.join();
-            for (int t = 0; t < threads; ++t) {
-                FILE* f = out[(size_t)((next_file + t) % threads)];
-                if (!text[(size_t)t].empty() && fwrite(text[(size_t)t].data(), 1, text[(size_t)t].size(), f) != text[(size_t)t].size()) DIE("write error");
-            }
-            next_file = (next_file + 1) % threads;
-            t_host += now() - th0;
-        };
-        auto flush = [&](Chunk* C) {                     // extend the chunk's candidates, then hand it to the host stage
-            if (C->jobs.empty()) return;
-            const double tf0 = now();
-            MCHK(mhip_asm_extend(ctx, dblk, dq, C->jobs.data(), (int)C->jobs.size(), cap, C->dirs, C->ops));
-            t_extend += now() - tf0;
-            n_jobs += C->jobs.size();
-            Chunk* prev = &ck[cur ^ 1];
-            if (prev->post.joinable()) prev->post.join();          // the host stages run one after the other (they share the output files)
-            C->post = std::thread(host_stage, C);
-            cur ^= 1;
-            Chunk* nxt = &ck[cur];
-            if (nxt->post.joinable()) nxt->post.join();
-            nxt->jobs.clear(); nxt->cand.clear(); nxt->qrid.clear();
-            t_flush += now() - tf0;
-        };
+        ck[cur].q = qs; ck[cur].qkeep = qs_own;
         for (int rb = 0; rb < nq; rb += slab) {
             const int re = std::min(nq, rb + slab), nr = re - rb;
             t0 = now();
-            MCHK(mhip_asm_seed_reads_ex(ctx, idx, dblk, dq, rb, re, tool.gate, tool.maxc, cands.data(), counts.data()));
+            MCHK(mhip_asm_seed_reads_ex(ctx, idx, dblk, dq, rb, re, tool.gate, tool.maxc, cands, counts));
             t_seed += now() - t0;
             const double tj0 = now(), tfl0 = t_flush;
             for (int r = 0; r < nr; ++r)
@@ -428,26 +500,35 @@ int main(int argc, char** argv) {
                     C->jobs.push_back(j);
                     C->cand.push_back(c);
                     C->qrid.push_back(rb + r);
-                    if (C->jobs.size() >= chunk) flush(C);
+                    if (C->jobs.size() >= chunk) flush(C, dq, cap);
                 }
             t_jobs += (now() - tj0) - (t_flush - tfl0);
         }
-        flush(&ck[cur]);
-        for (Chunk& c : ck) {
-            if (c.post.joinable()) c.post.join();
-            free(c.dirs);
-            free(c.ops);
-        }
+        flush(&ck[cur], dq, cap);
         if (dq != dblk) mhip_volume_free(dq);
     }
+    const double td0 = now();
+    if (open_thread.joinable()) open_thread.join();
+    for (Chunk& c : ck) {
+        if (c.post.joinable()) c.post.join();
+        if (c.dirs) mhip_host_free(c.dirs);
+        if (c.woffs) mhip_host_free(c.woffs);
+        if (c.ops) mhip_host_free(c.ops);
+    }
+    mhip_host_free(cands);
+    mhip_host_free(counts);
+    t_drain += now() - td0;
+    const double tc0 = now();
     for (FILE* f : out)
         if (fclose(f) != 0) DIE("write error");
     mhip_index_free(idx);
     mhip_volume_free(dblk);
     mhip_ctx_destroy(ctx);
+    t_close = now() - tc0;
     if (times)
-        fprintf(stderr, "[mecat2asmpw] %.2f s: context %.2f, blocks read + packed + uploaded %.2f, table %.2f, candidates %.2f, jobs %.2f, extension %.2f (%zu candidates), "
-                        "strings + lines on %d threads %.2f (beside the device's next chunk; the device stage waited %.2f for them)\n", now() - t_begin, t_ctx, t_load, t_index, t_seed,
-                t_jobs, t_extend, n_jobs, threads, t_host, t_flush - t_extend);
+        fprintf(stderr, "[mecat2asmpw] %.2f s: waited for the context %.2f, blocks read + packed + uploaded %.2f, table %.2f, candidates %.2f, jobs %.2f, "
+                        "extension %.2f (%zu candidates), strings + lines on %d threads %.2f (beside the device's next chunk; the device stage waited %.2f for "
+                        "them), last chunk's lines %.2f, files closed + device memory freed %.2f\n",
+                now() - t_begin, t_ctx, t_load, t_index, t_seed, t_jobs, t_extend, n_jobs, threads, t_host, t_flush - t_extend, t_drain, t_close);
     return 0;
 }

@@ -117,20 +117,32 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_seed(const uint32_t* __restrict
         int ncand = 0, ndirty = 0;
         for (int strand = 0; strand < 2; ++strand) {
             int touched = 0;
-            // ---- seeding (:601-641)
-            for (int k = 0; k < K; ++k) {
-                uint32_t id;
+            // ---- seeding (:601-641).  What a step looks up (the query k-mer, its bucket's bounds, the bucket's first 64 positions) does not
+            // depend on the records, only the updates are order dependent: the bounds are fetched two steps ahead and the positions one step
+            // ahead, so their memory round trips run beside the record round trips of the step in hand instead of in front of them.
+            auto bounds = [&](int k, uint32_t& s0, uint32_t& s1) {
+                s0 = s1 = 0;
+                if (k >= K) return;
                 const int64_t kpos = !strand ? qoff + (int64_t)k * BC : qoff + L - MHIP_KMER_SIZE - (int64_t)k * BC;
                 // a query k-mer that holds a base other than A, C, G, T is not looked up (transnum_buchang gives it -1, :316-335, :601)
-                if (qnpac && pac_kmer(qnpac, kpos) != 0u) continue;
-                if (!strand) id = pac_kmer(qpac, kpos);
-                else id = kmer_revcomp(pac_kmer(qpac, kpos));
-                const uint32_t s0 = starts[id], s1 = starts[id + 1];
+                if (qnpac && pac_kmer(qnpac, kpos) != 0u) return;
+                const uint32_t id = !strand ? pac_kmer(qpac, kpos) : kmer_revcomp(pac_kmer(qpac, kpos));
+                s0 = starts[id];
+                s1 = starts[id + 1];
+            };
+            uint32_t s0, s1, n0, n1;
+            bounds(0, s0, s1);
+            bounds(1, n0, n1);
+            int pfirst = s0 + (uint32_t)lane < s1 ? offsets[s0 + (uint32_t)lane] : 0;
+            for (int k = 0; k < K; ++k) {
+                const int pnext = n0 + (uint32_t)lane < n1 ? offsets[n0 + (uint32_t)lane] : 0;
+                uint32_t m0, m1;
+                bounds(k + 2, m0, m1);
                 int carry_seg = -1;
                 for (uint32_t base = s0; base < s1; base += 64) {
                     const uint32_t e = base + (uint32_t)lane;
                     const bool valid = e < s1;
-                    const int p = valid ? offsets[e] + 1 : 0;          // 1-based text position (:503)
+                    const int p = valid ? (base == s0 ? pfirst : offsets[e]) + 1 : 0;          // 1-based text position (:503)
                     const int seg = valid ? p / AZV : -2, off = p % AZV;
                     int seg_prev = __shfl_up(seg, 1);
                     if (lane == 0) seg_prev = carry_seg;
@@ -169,6 +181,8 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_seed(const uint32_t* __restrict
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 }
+                s0 = n0; s1 = n1; pfirst = pnext;
+                n0 = m0; n1 = m1;
             }
             // ---- candidates (:643-716)
             for (int i = 0; i < touched; ++i) {
@@ -406,9 +420,17 @@ int mhip_asm_seed_reads_ex(mhip_ctx* c, const mhip_index* idx, const mhip_volume
     if (c->scratch("as_out", sizeof(mhip_asm_candidate) * (size_t)n * AMAXC, (void**)&d_out)) return -1;
     if (c->scratch("as_cnt", sizeof(int32_t) * (size_t)n, (void**)&d_cnt)) return -1;
     const size_t nrec = waves * (size_t)(nseg + 8);
-    HIPCHK(hipMemsetAsync(d_img, 0, sizeof(short) * nrec * AREC, c->stream));
+    // The records are initialised (all zero, index -1) when the buffer is new or a call needs more of them than were initialised: the
+    // kernel clears what a read touched behind the read, so a completed call leaves the image as it found it — whatever the block's
+    // segment count was (the image is one flat array of records; only the waves' shares of it move).  It was 24 GB of fill per call.
+    if (d_img != c->as_clean_base || nrec > c->as_clean_nrec) {
+        c->as_clean_base = nullptr;
+        HIPCHK(hipMemsetAsync(d_img, 0, sizeof(short) * nrec * AREC, c->stream));
+        LAUNCH(c, "asm_init_records", asm_init_records, (unsigned)((nrec + 255) / 256), 256, 0, d_img, nrec);
+    }
+    const size_t nrec_clean = std::max(nrec, c->as_clean_base ? c->as_clean_nrec : (size_t)0);
+    c->as_clean_base = nullptr;               // (until this call has completed)
     HIPCHK(hipMemsetAsync(d_cur, 0, 16, c->stream));
-    LAUNCH(c, "asm_init_records", asm_init_records, (unsigned)((nrec + 255) / 256), 256, 0, d_img, nrec);
     LAUNCH(c, "asm_seed", asm_seed, grid, ASM_BLOCK, 0, (const uint32_t*)block->d_pac, (const mhip_offset_t*)block->d_offs, block->num_reads,
            block->start_read_id, (const uint32_t*)idx->d_starts, (const int32_t*)idx->d_offsets, (const uint32_t*)reads->d_pac, (const uint32_t*)reads->d_npac,
            (const mhip_offset_t*)reads->d_offs, reads->start_read_id, rid_begin, n, d_img, d_ilist, d_iscore, d_dirty, nseg, gate, maxc, d_cur, d_out, d_cnt);
@@ -416,6 +438,8 @@ int mhip_asm_seed_reads_ex(mhip_ctx* c, const mhip_index* idx, const mhip_volume
     HIPCHK(hipMemcpyAsync(out_counts, d_cnt, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(out, d_out, sizeof(mhip_asm_candidate) * (size_t)n * AMAXC, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    c->as_clean_base = d_img;
+    c->as_clean_nrec = nrec_clean;
     return 0;
 }
 

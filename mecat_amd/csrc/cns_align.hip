@@ -426,18 +426,55 @@ int mhip_cns_align_candidates(mhip_ctx* c, const mhip_volume* ref, const mhip_vo
 
 }  // extern "C"
 
-extern "C" {
-
 // The extension of mecat2asmpw / mecat2trimpw for a batch of candidates (mecat2canu/src/mecat2asmpw/mecat2asmpw.c:723-841): per job and
 // direction the columns of the alignment the tool strings together in left_store / right_store (2 bits each, in extension order: 0 both
 // bases, 1 y base only — a gap in the subject's row —, 2 x base only) and the bases of either sequence they cover.  x = reads of
 // `block`, y = reads of `reads`.  dirs[2 * i + d] = {cols, xbases, ybases, ins, del, 0} for direction d (0 left, 1 right) of job i,
 // ops[(2 * i + d) * dir_cols_cap / 16 ...] its columns.  What the tool does with them afterwards (string_check, the seed overlap of the
 // two directions, coordinates, jscore, the output line) is host work: mecat_amd/host/asmpw.cpp.
-int mhip_asm_extend(mhip_ctx* c, const mhip_volume* block, const mhip_volume* reads, const mhip_asm_job* jobs, int n, int dir_cols_cap,
-                    int32_t* dirs, uint32_t* ops) {
-    HIPCHK(hipSetDevice(c->device));
-    if (n <= 0) return 0;
+namespace {
+
+// exclusive prefix over the directions' word counts (ceil(cols / 16)); one block, the total behind the last entry
+__global__ __launch_bounds__(1024) void ae_word_offsets(const CnsDir* __restrict__ dres, int nd, unsigned long long* __restrict__ offs) {
+    __shared__ unsigned long long wsum[16];
+    __shared__ unsigned long long carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int t0 = 0; t0 < nd; t0 += 1024) {
+        const int i = t0 + (int)threadIdx.x;
+        const unsigned long long w = i < nd ? (unsigned long long)((dres[i].cols + 15) >> 4) : 0ull;
+        unsigned long long incl = w;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long v = __shfl_up(incl, o);
+            if ((int)(threadIdx.x & 63) >= o) incl += v;
+        }
+        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        unsigned long long before = carry;
+        for (int k = 0; k < (int)(threadIdx.x >> 6); ++k) before += wsum[k];
+        if (i < nd) offs[i] = before + incl - w;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = before + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) offs[nd] = carry;
+}
+
+// one wave per direction: its words from the fixed-stride array to their place in the dense one
+__global__ __launch_bounds__(256) void ae_pack(const CnsDir* __restrict__ dres, int nd, const uint32_t* __restrict__ ops, size_t dir_words,
+                                               const unsigned long long* __restrict__ offs, uint32_t* __restrict__ dense) {
+    const int lane = (int)threadIdx.x & 63;
+    for (size_t k = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); k < (size_t)nd; k += (size_t)gridDim.x * 4) {
+        const int w = (dres[k].cols + 15) >> 4;
+        const uint32_t* src = ops + k * dir_words;
+        uint32_t* dst = dense + offs[k];
+        for (int j = lane; j < w; j += 64) dst[j] = src[j];
+    }
+}
+
+// validation + launch shared by mhip_asm_extend and mhip_asm_extend_run: results stay in the context's scratch (cn_dres, cn_ops)
+int asm_extend_launch(mhip_ctx* c, const mhip_volume* block, const mhip_volume* reads, const mhip_asm_job* jobs, int n, int dir_cols_cap,
+                      CnsDir** out_dres, uint32_t** out_ops) {
     if (dir_cols_cap < 16 || (dir_cols_cap & 15)) { mhip_set_error("dir_cols_cap must be a positive multiple of 16"); return -1; }
     for (int i = 0; i < n; ++i) {
         const mhip_asm_job& j = jobs[i];
@@ -476,13 +513,84 @@ int mhip_asm_extend(mhip_ctx* c, const mhip_volume* block, const mhip_volume* re
     LAUNCH(c, "asm_extend", cns_extend<true>, grid, CN_BLOCK, 0, (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs,
            (const uint32_t*)block->d_pac, (const mhip_offset_t*)block->d_offs, (const void*)d_jobs, n, 0.05, 0.10, dir_cols_cap,
            (uint32_t*)d_ops, d_dres, d_g, d_cur, d_err, (const uint32_t*)reads->d_npac, (const uint32_t*)block->d_npac);
+    *out_dres = d_dres;
+    *out_ops = (uint32_t*)d_ops;
+    return 0;
+}
+
+int asm_extend_check(mhip_ctx* c, int dir_cols_cap) {
+    unsigned int* d_cur;
+    if (c->scratch("cn_cursor", 64, (void**)&d_cur)) return -1;
     int err = 0;
-    HIPCHK(hipMemcpyAsync(&err, d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(dirs, d_dres, sizeof(CnsDir) * 2 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(ops, d_ops, ops_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(&err, (int*)(d_cur + 8), sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipGetLastError());
     if (err) { mhip_set_error("mecat2asmpw extension: a direction needed more than dir_cols_cap = %d columns", dir_cols_cap); return -1; }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mhip_asm_extend(mhip_ctx* c, const mhip_volume* block, const mhip_volume* reads, const mhip_asm_job* jobs, int n, int dir_cols_cap,
+                    int32_t* dirs, uint32_t* ops) {
+    HIPCHK(hipSetDevice(c->device));
+    if (n <= 0) return 0;
+    CnsDir* d_dres;
+    uint32_t* d_ops;
+    if (asm_extend_launch(c, block, reads, jobs, n, dir_cols_cap, &d_dres, &d_ops)) return -1;
+    const size_t ops_bytes = sizeof(uint32_t) * ((size_t)dir_cols_cap / 16) * 2 * (size_t)n;
+    HIPCHK(hipMemcpyAsync(dirs, d_dres, sizeof(CnsDir) * 2 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(ops, d_ops, ops_bytes, hipMemcpyDeviceToHost, c->stream));
+    return asm_extend_check(c, dir_cols_cap);
+}
+
+// The same extension with the columns handed over densely, in two calls: _run extends the batch, leaves the results on the device and
+// says how many 32-bit words the columns of all directions take (ceil(cols / 16) each); _fetch copies them out — direction k = 2 i + d
+// occupies words [word_offs[k], word_offs[k + 1]) of ops_dense.  A direction uses a fraction of dir_cols_cap (the bound is both reads'
+// bases on that side), so the fixed-stride form moves 5-10x the bytes over the PCIe link; page-locked host buffers (mhip_host_alloc)
+// make the copies asynchronous DMA.  _fetch belongs to the last _run on the context.
+int mhip_asm_extend_run(mhip_ctx* c, const mhip_volume* block, const mhip_volume* reads, const mhip_asm_job* jobs, int n, int dir_cols_cap,
+                        int64_t* total_words) {
+    HIPCHK(hipSetDevice(c->device));
+    *total_words = 0;
+    c->ae_n = 0;
+    if (n <= 0) return 0;
+    CnsDir* d_dres;
+    uint32_t* d_ops;
+    if (asm_extend_launch(c, block, reads, jobs, n, dir_cols_cap, &d_dres, &d_ops)) return -1;
+    const size_t dir_words = (size_t)dir_cols_cap / 16;
+    unsigned long long* d_offs;
+    uint32_t* d_dense;
+    if (c->scratch("cn_woffs", sizeof(unsigned long long) * (2 * (size_t)n + 1), (void**)&d_offs)) return -1;
+    LAUNCH(c, "ae_word_offsets", ae_word_offsets, 1, 1024, 0, (const CnsDir*)d_dres, 2 * n, d_offs);
+    unsigned long long total = 0;
+    HIPCHK(hipMemcpyAsync(&total, d_offs + 2 * (size_t)n, sizeof(total), hipMemcpyDeviceToHost, c->stream));
+    if (asm_extend_check(c, dir_cols_cap)) return -1;
+    if (c->scratch("cn_dense", sizeof(uint32_t) * (size_t)std::max<unsigned long long>(total, 1), (void**)&d_dense)) return -1;
+    LAUNCH(c, "ae_pack", ae_pack, (unsigned)std::min<size_t>((2 * (size_t)n + 3) / 4, (size_t)c->num_cus * 32), 256, 0, (const CnsDir*)d_dres, 2 * n,
+           (const uint32_t*)d_ops, dir_words, (const unsigned long long*)d_offs, d_dense);
+    c->ae_n = n;
+    c->ae_total = (int64_t)total;
+    *total_words = (int64_t)total;
+    return 0;
+}
+
+int mhip_asm_extend_fetch(mhip_ctx* c, int n, int32_t* dirs, uint64_t* word_offs, uint32_t* ops_dense) {
+    HIPCHK(hipSetDevice(c->device));
+    if (n != c->ae_n) { mhip_set_error("mhip_asm_extend_fetch: %d jobs asked for, the last mhip_asm_extend_run on this context had %d", n, c->ae_n); return -1; }
+    if (n <= 0) return 0;
+    CnsDir* d_dres;
+    unsigned long long* d_offs;
+    uint32_t* d_dense;
+    if (c->scratch("cn_dres", sizeof(CnsDir) * 2 * (size_t)n, (void**)&d_dres)) return -1;
+    if (c->scratch("cn_woffs", sizeof(unsigned long long) * (2 * (size_t)n + 1), (void**)&d_offs)) return -1;
+    if (c->scratch("cn_dense", sizeof(uint32_t) * (size_t)std::max<int64_t>(c->ae_total, 1), (void**)&d_dense)) return -1;
+    HIPCHK(hipMemcpyAsync(dirs, d_dres, sizeof(CnsDir) * 2 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(word_offs, d_offs, sizeof(uint64_t) * (2 * (size_t)n + 1), hipMemcpyDeviceToHost, c->stream));
+    if (c->ae_total) HIPCHK(hipMemcpyAsync(ops_dense, d_dense, sizeof(uint32_t) * (size_t)c->ae_total, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
 

@@ -8,8 +8,8 @@
 //     ...trimpw...   seeding gate > 8 instead of > 10 (:644), jscore = mismatches / (4 * columns) instead of (2 cols - mism) * 120 / cols (:942-943)
 //     ...50          at most 50 candidates per read instead of 100 (:23)
 // On the device (C ABI, include/mecat_hip.h): the look-up table with bucket cap 256 (mhip_index_build_ex), seeding + candidate
-// selection (mhip_asm_seed_reads_ex, asm_seed.hip), the O(ND) extension of every candidate in both directions (mhip_asm_extend,
-// cns_align.hip).  On the host, per candidate and on -T threads: what the tool does with the two aligned string pairs afterwards —
+// selection (mhip_asm_seed_reads_ex, asm_seed.hip), the O(ND) extension of every candidate in both directions (mhip_asm_extend_run /
+// _fetch, cns_align.hip: the columns come back packed, into page-locked buffers).  On the host, per candidate and on -T threads: what the tool does with the two aligned string pairs afterwards —
 // string_check's gap shuffling of the left pair (:199-281), the overlap of the two directions on the seed 13-mer, coordinates, the
 // 450-base test, jscore and the 12-field line (:843-948).  Line order inside the .r files is by read here and by thread timing in the
 // tool: the consumer (mecat2asmpwConvert) reads lines one by one.
@@ -274,10 +274,10 @@ int main(int argc, char** argv) {
     t_index += now() - t0;
     int next_file = 0;
 
-    // Candidates are found for `slab` query reads per launch (one wave per read; 2 048 by default: more resident waves thrash on their record
-    // arrays); their extensions run in chunks of at most `chunk` candidates, and the string work of a chunk runs on the -T threads while
-    // the device works on the next one — across block boundaries too: a chunk keeps its query block alive.
-    const int slab = std::max(1, getenv("MECAT_ASMPW_SLAB") ? atoi(getenv("MECAT_ASMPW_SLAB")) : 2048);
+    // Candidates are found for `slab` query reads per launch (one wave per read, 4 096 by default = 16 waves per CU); their extensions run
+    // in chunks of at most `chunk` candidates, and the string work of a chunk runs on the -T threads while the device works on the next
+    // one — across block boundaries too: a chunk keeps its query block alive.
+    const int slab = std::max(1, getenv("MECAT_ASMPW_SLAB") ? atoi(getenv("MECAT_ASMPW_SLAB")) : 4096);
     // MECAT_ASMPW_CHUNK_MB bounds the DEVICE array of a chunk (every direction at its worst-case length there); what crosses the PCIe
     // link is the columns the directions really have, packed (mhip_asm_extend_run / _fetch), into page-locked buffers that grow on demand
     const size_t chunk_bytes = (size_t)std::max(1, getenv("MECAT_ASMPW_CHUNK_MB") ? atoi(getenv("MECAT_ASMPW_CHUNK_MB")) : 256) << 20;

@@ -9,9 +9,14 @@
 //   read start is never written by the tool and reads as 0), sweeps that start two segments to the left / one to the right and run
 //   over `score` entries although 60 exist (:689-703).
 // That last point decides the data layout: the sweeps read past loczhi[60] / seedno[60] into the rest of the segment record and
-// into the following records, so the segments are kept as the reference's own `struct Back_List` images (124 shorts, 248 bytes) in
-// one dense array per wave in HBM (block bases / 1000 + 5 records: 248 KB per million bases; 288 GB of HBM is what lets every
-// resident wave own one), and the sweeps index it as a flat array of shorts exactly like the reference's out-of-range indices do.
+// into the following records, so the segments are kept as the reference's own `struct Back_List` images (124 shorts, 248 bytes) and the
+// sweeps index them as a flat array of shorts exactly like the reference's out-of-range indices do.  The array is VIRTUAL: a read touches
+// one or two thousand of a block's 80 000 segments, and a dense 20 MB image per wave meant every record access missed every level of
+// address translation (24 GB of images: 2.6 us per dependent access).  Each wave has a directory (one 32-bit slot number per segment, 0 =
+// untouched) and a pool of records handed out in order of first touch; slot 0 is the untouched record (all zero, index -1), never
+// written with anything else, so reads need no branch and the zero-over-zero writes the algorithm makes to untouched segments land there.
+// A wave's working set is its directory (320 KB) plus the first few hundred KB of its pool, whatever the block size.  A pool holds
+// ASM_POOL records; a read that needs more gives up and is redone by a second launch whose pools hold one record per segment.
 // Every read starts from an all-zero array (the reference's worker threads keep the stale seeds of the reads they mapped before,
 // which can move a candidate's score by a few votes: INTEGRATION.md, divergences); the forward strand's leftovers stay for
 // the reverse strand, as there.
@@ -27,9 +32,11 @@
 //                  the sweeps 64 entries per step, the top-100 list in LDS
 // Parity: tests/test_gpu_asmpw.py against the CPU restatement of the test-suite (fresh mode; itself pinned to the unmodified
 // pairwise_mapping), and the whole tool against the sorted output of the unmodified binaries.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <algorithm>
+#include <vector>
 
 #include "common.h"
 
@@ -43,6 +50,7 @@
 #define A_SEEDNUM (1 + 2 * ASM)
 #define A_INDEX (2 + 2 * ASM)        // int at short offset 122 (byte 244)
 #define ASM_BLOCK 256
+#define ASM_POOL 16384                // records of a wave's pool (a read that needs more is redone with a worst-case pool)
 #define ASM_WAVES (ASM_BLOCK / WAVE)
 
 namespace {
@@ -80,42 +88,53 @@ __device__ __forceinline__ bool asm_ddf(int dloc, int dseed) {
     return (double)fabsf(r) < 0.10;
 }
 
-__global__ void asm_init_records(short* img, size_t nrec) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nrec) return;
-    img[i * AREC + A_INDEX] = (short)-1;
-    img[i * AREC + A_INDEX + 1] = (short)-1;
-}
-
 __global__ __launch_bounds__(ASM_BLOCK) void asm_seed(const uint32_t* __restrict__ bpac, const mhip_offset_t* __restrict__ boffs, int bnreads,
                                                      int bstart_id, const uint32_t* __restrict__ starts, const int32_t* __restrict__ offsets,
                                                      const uint32_t* __restrict__ qpac, const uint32_t* __restrict__ qnpac, const mhip_offset_t* __restrict__ qoffs, int qstart_id,
-                                                     int rid_begin, int n, short* __restrict__ img_all, int* __restrict__ ilist_all,
-                                                     short* __restrict__ iscore_all, int* __restrict__ dirty_all, int nseg, int gate, int maxc,
-                                                     unsigned int* __restrict__ cursor, mhip_asm_candidate* __restrict__ out, int32_t* __restrict__ out_counts) {
+                                                     int rid_begin, int n, const int* __restrict__ rid_list, short* __restrict__ pool_all, uint32_t* __restrict__ dir_all,
+                                                     int* __restrict__ hw_all, int* __restrict__ ilist_all, short* __restrict__ iscore_all, int* __restrict__ slotseg_all,
+                                                     int nseg, int pcap, int gate, int maxc, unsigned int* __restrict__ cursor, mhip_asm_candidate* __restrict__ out,
+                                                     int32_t* __restrict__ out_counts) {
     __shared__ AsmWaveLds lds[ASM_WAVES];
     AsmWaveLds& S = lds[threadIdx.x >> 6];
     const int lane = lane_id();
     const size_t gw = (size_t)blockIdx.x * ASM_WAVES + (threadIdx.x >> 6);
-    vshort* img = img_all + gw * (size_t)(nseg + 8) * AREC;
-    int* ilist = ilist_all + gw * (size_t)nseg;
-    volatile short* iscore = iscore_all + gw * (size_t)nseg;
-    int* dirty = dirty_all + gw * (size_t)nseg * 2;
+    vshort* pool = pool_all + gw * (size_t)pcap * AREC;                    // pcap records; record 0 = the untouched record
+    volatile uint32_t* dir = dir_all + gw * (size_t)(nseg + 8);
+    int* ilist = ilist_all + gw * (size_t)pcap;
+    volatile short* iscore = iscore_all + gw * (size_t)pcap;
+    volatile int* slotseg = slotseg_all + gw * (size_t)pcap;
     const unsigned long long below = (1ull << lane) - 1ull;
     auto lloc = [&](int i) { return i < bnreads ? boffs[i].offset : 0; };
-    auto rec = [&](int seg) { return img + (size_t)seg * AREC; };
+    auto rec = [&](int seg) { return pool + (size_t)dir[seg] * AREC; };
+    // records [0, hw) of the pool have been initialised (by this or an earlier launch on the same buffer) and are in the untouched state
+    int hw = hw_all[gw];
+    auto init_records = [&](int from, int to) {
+        for (int r = from; r < to; ++r) {
+            vshort* q = pool + (size_t)r * AREC;
+            for (int j = lane; j < AREC - 2; j += 64) q[j] = 0;
+            if (lane == 0) rec_set_index(q, -1);
+        }
+    };
+    if (hw == 0) { init_records(0, 1); hw = 1; }
+    int nslots = 1;                                                      // records handed out to the read in hand: [1, nslots)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
     while (true) {
         unsigned int u = 0;
         if (lane == 0) u = atomicAdd(cursor, 1u);
         u = __shfl(u, 0);
         if (u >= (unsigned)n) break;
-        const int rid = rid_begin + (int)u;
+        const int rid = rid_list ? rid_list[u] : rid_begin + (int)u;
+        const size_t uo = (size_t)(rid - rid_begin);                       // the read's place in the output
         const int L = qoffs[rid].size, read_name = qstart_id + rid;
         const int64_t qoff = qoffs[rid].offset;
         const int K = L < MHIP_KMER_SIZE ? 0 : (L - MHIP_KMER_SIZE) / BC + 1;
-        int ncand = 0, ndirty = 0;
-        for (int strand = 0; strand < 2; ++strand) {
+        int ncand = 0;
+        bool ovf = false;                    // the read needs more records than the pool has: given up here, redone by the launch with full pools
+        for (int strand = 0; strand < 2 && !ovf; ++strand) {
             int touched = 0;
             // ---- seeding (:601-641).  What a step looks up (the query k-mer, its bucket's bounds, the bucket's first 64 positions) does not
             // depend on the records, only the updates are order dependent: the bounds are fetched two steps ahead and the positions one step
@@ -150,6 +169,27 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_seed(const uint32_t* __restrict
                     const bool head = valid && seg != seg_prev;        // the first hit of this k-mer in its segment
                     bool ev = false;
                     int newscore = 0;
+                    // a segment's first hit of the read takes the next record of the pool (records are handed out in order; what lies beyond the
+                    // initialised ones is initialised first)
+                    const bool fresh_rec = head && dir[seg] == 0u;
+                    const unsigned long long fm = __ballot(fresh_rec);
+                    if (fm && nslots + (int)__popcll(fm) > pcap) { ovf = true; break; }
+                    if (fm) {
+                        const int nnew = (int)__popcll(fm);
+                        if (nslots + nnew > hw) {
+                            init_records(hw, nslots + nnew);
+                            hw = nslots + nnew;
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                            __builtin_amdgcn_wave_barrier();
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        }
+                        if (fresh_rec) {
+                            const int sl = nslots + (int)__popcll(fm & below);
+                            dir[seg] = (uint32_t)sl;
+                            slotseg[sl] = seg;
+                        }
+                        nslots += nnew;
+                    }
                     if (head) {
                         vshort* r = rec(seg);
                         const int sc = r[A_SCORE], sn = r[A_SEEDNUM];
@@ -181,9 +221,11 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_seed(const uint32_t* __restrict
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 }
+                if (ovf) break;
                 s0 = n0; s1 = n1; pfirst = pnext;
                 n0 = m0; n1 = m1;
             }
+            if (ovf) break;
             // ---- candidates (:643-716)
             for (int i = 0; i < touched; ++i) {
                 const int seg = ((volatile int*)ilist)[i];
@@ -286,18 +328,23 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_seed(const uint32_t* __restrict
                 if (c.num1 + c.num2 < 400) continue;
                 c.loc1 = loc0; c.loc2 = loc1;
                 int seedcount = 0;
-                // sweeps (:689-703): entries j < score of the neighbour's record, read as a flat array of shorts
+                // sweeps (:689-703): entries j < score of the neighbour's record, read as a flat array of shorts — past the record's end that
+                // is the record of the segment behind it (and so on), wherever the pool holds it
+                auto flat = [&](int useg, vshort* o, int fi) -> int {
+                    if (fi < AREC) return (int)o[fi];
+                    return (int)rec(useg + fi / AREC)[fi % AREC];
+                };
                 for (int useg = seg - 2, kk = c.num1 / AZV; useg >= 0 && kk >= 0; --useg, --kk) {
                     vshort* o = rec(useg);
                     const int osc = o[A_SCORE];
                     if (osc <= 0) continue;
                     const int sl = useg * AZV;
                     int agree = 0;
-                    const int jend = min(osc, (nseg + 8 - useg) * AREC - A_SEED);      // entries inside this wave's image (the reference reads its own heap beyond)
+                    const int jend = min(osc, (nseg + 8 - useg) * AREC - A_SEED);      // entries inside this wave's (virtual) image (the reference reads its own heap beyond)
                     for (int j0 = 0; j0 < jend; j0 += 64) {
                         const int j = j0 + lane;
                         bool q = false;
-                        if (j < jend) q = fabs((double)(loc_list - sl - (int)o[A_LOC + j]) / ((double)(loc_seed - (int)o[A_SEED + j]) * BC * 1.0) - 1.0) < 0.10;
+                        if (j < jend) q = fabs((double)(loc_list - sl - flat(useg, o, A_LOC + j)) / ((double)(loc_seed - flat(useg, o, A_SEED + j)) * BC * 1.0) - 1.0) < 0.10;
                         agree += (int)__popcll(__ballot(q));
                     }
                     seedcount += agree;
@@ -313,7 +360,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_seed(const uint32_t* __restrict
                     for (int j0 = 0; j0 < jend; j0 += 64) {
                         const int j = j0 + lane;
                         bool q = false;
-                        if (j < jend) q = fabs((double)(sl + (int)o[A_LOC + j] - loc_list) / ((double)((int)o[A_SEED + j] - loc_seed) * BC * 1.0) - 1.0) < 0.10;
+                        if (j < jend) q = fabs((double)(sl + flat(useg, o, A_LOC + j) - loc_list) / ((double)(flat(useg, o, A_SEED + j) - loc_seed) * BC * 1.0) - 1.0) < 0.10;
                         agree += (int)__popcll(__ballot(q));
                     }
                     seedcount += agree;
@@ -349,30 +396,37 @@ __global__ __launch_bounds__(ASM_BLOCK) void asm_seed(const uint32_t* __restrict
                 if (ncand < maxc) ++ncand;
                 __builtin_amdgcn_wave_barrier();
             }
-            // ---- the strand's touched segments: score and index reset (:717); remembered for the clean-up behind the read
+            // ---- the strand's touched segments: score and index reset (:717)
             for (int t = lane; t < touched; t += 64) {
                 const int seg = ((volatile int*)ilist)[t];
                 rec(seg)[A_SCORE] = 0;
                 rec_set_index(rec(seg), -1);
-                dirty[ndirty + t] = seg;
             }
-            ndirty += touched;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
-        // every read starts from an all-zero array: the records both strands touched are cleared whole
-        for (int t = 0; t < ndirty; ++t) {
-            vshort* r = rec(((volatile int*)dirty)[t]);
-            for (int j = lane; j < AREC - 2; j += 64) r[j] = 0;
-            if (lane == 0) rec_set_index(r, -1);
+        // every read starts from an all-zero array: the records the read took go back to the untouched state (they are one contiguous
+        // stretch of the pool) and their segments' directory entries to 0
+        {
+            volatile uint32_t* w = (volatile uint32_t*)(pool + AREC);           // (AREC shorts = 62 words per record)
+            const int nw = (nslots - 1) * (AREC / 2);
+            for (int j = lane; j < nw; j += 64) w[j] = (j % (AREC / 2)) == (AREC / 2 - 1) ? 0xffffffffu : 0u;
+            for (int sl = 1 + lane; sl < nslots; sl += 64) dir[slotseg[sl]] = 0u;
+            nslots = 1;
         }
-        for (int j = lane; j < ncand; j += 64) out[(size_t)u * AMAXC + j] = S.cand[j];
-        if (lane == 0) out_counts[u] = ncand;
+        if (ovf) ncand = 0;
+        for (int j = lane; j < ncand; j += 64) out[uo * AMAXC + j] = S.cand[j];
+        if (lane == 0) {
+            out_counts[uo] = ovf ? -1 : ncand;
+            atomicMax(cursor + 4, (unsigned int)hw);
+            if (ovf) atomicAdd(cursor + 5, 1u);
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
+    if (lane == 0) hw_all[gw] = hw;
 }
 
 }  // namespace
@@ -394,52 +448,98 @@ int mhip_asm_seed_reads_ex(mhip_ctx* c, const mhip_index* idx, const mhip_volume
     const int n = rid_end - rid_begin;
     if (n == 0) return 0;
     const int nseg = block->num_bases / AZV + 5;
-    // one dense array of segment records per resident wave: as many waves as fit a budget of the free memory, at most 16 per CU
+    // One directory + record pool per resident wave, 16 waves per CU.  A pool holds ASM_POOL records (4 MB; a read of 8 kb takes about
+    // 2 000, and records are touched from the front) or the worst case if that is less; a read that needs more gives up (count -1) and
+    // is redone below with worst-case pools on a few waves.  Allocating for the worst case everywhere (20 MB per wave, 86 GB) made the
+    // allocation itself the cost: tens of GB of fresh device memory take the driver seconds, erratically.  MECAT_ASM_POOL overrides.
+    const char* pe = getenv("MECAT_ASM_POOL");
+    const int pcap = std::min(nseg + 9, std::max(64, pe && atoi(pe) > 0 ? atoi(pe) : ASM_POOL));
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
-    const size_t per_wave = (size_t)(nseg + 8) * AREC * sizeof(short) + (size_t)nseg * (sizeof(int) + sizeof(short) + 2 * sizeof(int));
-    // (measured on 80 Mbase blocks, 20 MB of records per wave: 24 GB and 48 GB of records are equally fast, 12 GB 45 % slower; with 48 GB
-    // one run in three took four times as long, with 80 GB every run — the random record updates then miss every level of address
-    // translation.  MECAT_ASM_RECORDS_GB overrides the 24.)
-    const char* gb = getenv("MECAT_ASM_RECORDS_GB");
-    const size_t budget = std::min<size_t>(free_b / 2, (size_t)(gb && atoi(gb) > 0 ? atoi(gb) : 24) << 30);
-    size_t waves = std::min<size_t>((size_t)c->num_cus * 16, std::max<size_t>(1, budget / per_wave));
+    auto per_wave = [&](int cap) { return (size_t)cap * (AREC * sizeof(short) + sizeof(int) + sizeof(short) + sizeof(int)) + (size_t)(nseg + 8) * sizeof(uint32_t); };
+    const size_t max_waves = (size_t)c->num_cus * 16;
+    size_t waves = std::min<size_t>(max_waves, std::max<size_t>(1, free_b / 2 / per_wave(pcap)));
     waves = std::min<size_t>(waves, (size_t)n);
-    const unsigned grid = (unsigned)((waves + ASM_WAVES - 1) / ASM_WAVES);
+    unsigned grid = (unsigned)((waves + ASM_WAVES - 1) / ASM_WAVES);
     waves = (size_t)grid * ASM_WAVES;
-    short *d_img, *d_iscore;
-    int *d_ilist, *d_dirty;
+    short *d_pool, *d_iscore;
+    uint32_t* d_dir;
+    int *d_ilist, *d_slotseg, *d_hw;
     unsigned int* d_cur;
     mhip_asm_candidate* d_out;
     int32_t* d_cnt;
-    if (c->scratch("as_img", sizeof(short) * waves * (size_t)(nseg + 8) * AREC, (void**)&d_img)) return -1;
-    if (c->scratch("as_ilist", sizeof(int) * waves * (size_t)nseg, (void**)&d_ilist)) return -1;
-    if (c->scratch("as_iscore", sizeof(short) * waves * (size_t)nseg, (void**)&d_iscore)) return -1;
-    if (c->scratch("as_dirty", sizeof(int) * waves * (size_t)nseg * 2, (void**)&d_dirty)) return -1;
+    if (c->scratch("as_pool", sizeof(short) * waves * (size_t)pcap * AREC, (void**)&d_pool)) return -1;
+    if (c->scratch("as_dir", sizeof(uint32_t) * waves * (size_t)(nseg + 8), (void**)&d_dir)) return -1;
+    if (c->scratch("as_hw", sizeof(int) * max_waves, (void**)&d_hw)) return -1;
+    if (c->scratch("as_ilist", sizeof(int) * waves * (size_t)pcap, (void**)&d_ilist)) return -1;
+    if (c->scratch("as_iscore", sizeof(short) * waves * (size_t)pcap, (void**)&d_iscore)) return -1;
+    if (c->scratch("as_slotseg", sizeof(int) * waves * (size_t)pcap, (void**)&d_slotseg)) return -1;
     if (c->scratch("as_cursor", 64, (void**)&d_cur)) return -1;
     if (c->scratch("as_out", sizeof(mhip_asm_candidate) * (size_t)n * AMAXC, (void**)&d_out)) return -1;
     if (c->scratch("as_cnt", sizeof(int32_t) * (size_t)n, (void**)&d_cnt)) return -1;
-    const size_t nrec = waves * (size_t)(nseg + 8);
-    // The records are initialised (all zero, index -1) when the buffer is new or a call needs more of them than were initialised: the
-    // kernel clears what a read touched behind the read, so a completed call leaves the image as it found it — whatever the block's
-    // segment count was (the image is one flat array of records; only the waves' shares of it move).  It was 24 GB of fill per call.
-    if (d_img != c->as_clean_base || nrec > c->as_clean_nrec) {
-        c->as_clean_base = nullptr;
-        HIPCHK(hipMemsetAsync(d_img, 0, sizeof(short) * nrec * AREC, c->stream));
-        LAUNCH(c, "asm_init_records", asm_init_records, (unsigned)((nrec + 255) / 256), 256, 0, d_img, nrec);
+    // State that outlives a call: a completed call leaves every directory all zero and every record it initialised (the first hw of a
+    // wave's pool) untouched, so nothing is set up again for as long as the buffers and the layout (segments and records per wave) are
+    // the same.  A new layout moves the waves' shares: the directories are zeroed and the pools count as uninitialised (hw = 0; the
+    // kernel initialises records as it hands them out).
+    const bool same = d_pool == c->as_clean_base && d_dir == c->as_clean_dir && nseg == c->as_clean_nseg && pcap == c->as_clean_pcap;
+    size_t waves_clean = same ? c->as_clean_nrec : 0;
+    if (!same) HIPCHK(hipMemsetAsync(d_hw, 0, sizeof(int) * max_waves, c->stream));
+    if (waves > waves_clean) {
+        // (more waves than any call on these buffers had: the directories of the new ones)
+        HIPCHK(hipMemsetAsync(d_dir + waves_clean * (size_t)(nseg + 8), 0, sizeof(uint32_t) * (waves - waves_clean) * (size_t)(nseg + 8), c->stream));
+        waves_clean = waves;
     }
-    const size_t nrec_clean = std::max(nrec, c->as_clean_base ? c->as_clean_nrec : (size_t)0);
     c->as_clean_base = nullptr;               // (until this call has completed)
-    HIPCHK(hipMemsetAsync(d_cur, 0, 16, c->stream));
+    HIPCHK(hipMemsetAsync(d_cur, 0, 64, c->stream));
     LAUNCH(c, "asm_seed", asm_seed, grid, ASM_BLOCK, 0, (const uint32_t*)block->d_pac, (const mhip_offset_t*)block->d_offs, block->num_reads,
            block->start_read_id, (const uint32_t*)idx->d_starts, (const int32_t*)idx->d_offsets, (const uint32_t*)reads->d_pac, (const uint32_t*)reads->d_npac,
-           (const mhip_offset_t*)reads->d_offs, reads->start_read_id, rid_begin, n, d_img, d_ilist, d_iscore, d_dirty, nseg, gate, maxc, d_cur, d_out, d_cnt);
+           (const mhip_offset_t*)reads->d_offs, reads->start_read_id, rid_begin, n, (const int*)nullptr, d_pool, d_dir, d_hw, d_ilist, d_iscore, d_slotseg, nseg, pcap,
+           gate, maxc, d_cur, d_out, d_cnt);
     HIPCHK(hipGetLastError());
+    unsigned int st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(st, d_cur, sizeof(st), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(out_counts, d_cnt, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->as_clean_base = d_pool;
+    c->as_clean_dir = d_dir;
+    c->as_clean_nseg = nseg;
+    c->as_clean_pcap = pcap;
+    c->as_clean_nrec = waves_clean;
+    if (getenv("MECAT_ASM_STATS")) fprintf(stderr, "[asm_seed] %d reads on %zu waves, pools of %d records: most records a wave initialised %u, reads given up %u\n", n, waves, pcap, st[4], st[5]);
+    if (st[5]) {
+        // the reads that ran out of records, again, with pools that cannot (one record per segment of the block): few waves, their own pool
+        // buffer; directories (all zero again), lists and output are the first launch's
+        std::vector<int> redo;
+        for (int i = 0; i < n; ++i)
+            if (out_counts[i] < 0) redo.push_back(rid_begin + i);
+        const int full = nseg + 9;
+        size_t w2 = std::min<size_t>(std::min<size_t>(waves, redo.size()), std::max<size_t>(1, ((size_t)8 << 30) / ((size_t)full * (AREC * sizeof(short) + 10))));
+        const unsigned grid2 = (unsigned)((w2 + ASM_WAVES - 1) / ASM_WAVES);
+        w2 = (size_t)grid2 * ASM_WAVES;
+        short *d_pool2, *d_iscore2;
+        int *d_ilist2, *d_slotseg2, *d_redo, *d_hw2;
+        if (w2 > waves) { mhip_set_error("asm_seed: no room for the worst-case pools of %zu reads", redo.size()); return -1; }
+        if (c->scratch("as_pool_full", sizeof(short) * w2 * (size_t)full * AREC, (void**)&d_pool2)) return -1;
+        if (c->scratch("as_ilist_full", sizeof(int) * w2 * (size_t)full, (void**)&d_ilist2)) return -1;
+        if (c->scratch("as_iscore_full", sizeof(short) * w2 * (size_t)full, (void**)&d_iscore2)) return -1;
+        if (c->scratch("as_slotseg_full", sizeof(int) * w2 * (size_t)full, (void**)&d_slotseg2)) return -1;
+        if (c->scratch("as_hw_full", sizeof(int) * max_waves, (void**)&d_hw2)) return -1;
+        if (c->scratch("as_redo", sizeof(int) * redo.size(), (void**)&d_redo)) return -1;
+        HIPCHK(hipMemsetAsync(d_hw2, 0, sizeof(int) * max_waves, c->stream));        // (these pools always start uninitialised)
+        HIPCHK(hipMemsetAsync(d_cur, 0, 64, c->stream));
+        HIPCHK(hipMemcpyAsync(d_redo, redo.data(), sizeof(int) * redo.size(), hipMemcpyHostToDevice, c->stream));
+        c->as_clean_base = nullptr;
+        LAUNCH(c, "asm_seed_full", asm_seed, grid2, ASM_BLOCK, 0, (const uint32_t*)block->d_pac, (const mhip_offset_t*)block->d_offs, block->num_reads,
+               block->start_read_id, (const uint32_t*)idx->d_starts, (const int32_t*)idx->d_offsets, (const uint32_t*)reads->d_pac, (const uint32_t*)reads->d_npac,
+               (const mhip_offset_t*)reads->d_offs, reads->start_read_id, rid_begin, (int)redo.size(), (const int*)d_redo, d_pool2, d_dir, d_hw2, d_ilist2, d_iscore2,
+               d_slotseg2, nseg, full, gate, maxc, d_cur, d_out, d_cnt);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(out_counts, d_cnt, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        c->as_clean_base = d_pool;
+    }
     HIPCHK(hipMemcpyAsync(out, d_out, sizeof(mhip_asm_candidate) * (size_t)n * AMAXC, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    c->as_clean_base = d_img;
-    c->as_clean_nrec = nrec_clean;
     return 0;
 }
 

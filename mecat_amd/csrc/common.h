@@ -57,9 +57,11 @@ struct mhip_ctx {
     std::mutex bufs_mu;                   // scratch() vs mhip_ctx_reserve_index on another thread
     int64_t* d_counters = nullptr;        // 8 work counters (see mecat_hip.h)
     int num_cus = 256;
-    // asm_seed's segment records (scratch "as_img"): the kernel leaves every record it touched as it found it (all zero, index -1),
-    // so the image is initialised once and stays valid for as long as the buffer is the same and a call needs no more records
+    // asm_seed's per-wave directories and record pools (scratch "as_dir", "as_pool", "as_hw"): a completed call leaves them in the state
+    // the next one needs, so they are set up once per buffer and layout (asm_seed.hip); as_clean_nrec = waves whose directories are zero
     const void* as_clean_base = nullptr;
+    const void* as_clean_dir = nullptr;
+    int as_clean_nseg = 0, as_clean_pcap = 0;
     size_t as_clean_nrec = 0;
     int ae_n = 0;                         // jobs and dense words of the last mhip_asm_extend_run (what mhip_asm_extend_fetch copies)
     int64_t ae_total = 0;

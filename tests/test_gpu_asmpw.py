@@ -100,6 +100,46 @@ def test_candidate_stage_equals_the_restatement(start):
     idx.free(); block.free(); reads.free(); ctx.close()
 
 
+def test_reads_that_outgrow_their_record_pool_are_redone_with_full_pools(capfd):
+    """asm_seed hands a wave's segment records out of a pool of ASM_POOL records; a read that needs more gives up and is redone by a second
+    launch whose pools hold one record per segment.  With pools of 96 records most reads of the golden set take that way: same candidates,
+    field for field, as with the default pools (themselves pinned to the restatement above), and the same again on a context whose buffers
+    were laid out for the other pool size before."""
+    import sys
+    import mecat_amd.hip as M
+    from mecat_amd import workload as W
+    sys.path.insert(0, H.GOLDEN)
+    import make_golden_asmpw as G
+    codes, lens = H.synth_reads(G.GEN["nreads"], G.GEN["L"], G.GEN["err"], G.GEN["genome"], G.GEN["seed"], G.GEN["ont"])
+    starts = np.concatenate([[0], np.cumsum(lens.astype(np.int64))])
+    b, e = G.BLOCKS[0]
+    ctx = M.Context(0)
+    bpac, boffs, bnb = W.pack_volume(codes[starts[b - 1]: starts[e]], lens[b - 1: e])
+    block = M.Volume(ctx, bpac, boffs, bnb, b)
+    idx = M.Index(ctx, block, max_bucket=256)
+    qpac, qoffs, qnb = W.pack_volume(codes[starts[b - 1]:], lens[b - 1:])
+    reads = M.Volume(ctx, qpac, qoffs, qnb, b)
+    nq = G.GEN["nreads"] - b + 1
+    want, wcnt = M.asm_seed_reads(ctx, idx, block, reads, 0, nq)
+    assert int(wcnt.sum()) > 2000
+    capfd.readouterr()
+    os.environ["MECAT_ASM_POOL"] = "96"
+    os.environ["MECAT_ASM_STATS"] = "1"
+    try:
+        got, cnt = M.asm_seed_reads(ctx, idx, block, reads, 0, nq)
+        err = capfd.readouterr().err
+    finally:
+        del os.environ["MECAT_ASM_POOL"], os.environ["MECAT_ASM_STATS"]
+    given_up = int(err.split("reads given up")[1].split()[0])
+    assert given_up > nq // 4, err
+    assert np.array_equal(cnt, wcnt)
+    mask = np.arange(want.shape[1])[None, :] < wcnt[:, None]
+    assert got[mask].tobytes() == want[mask].tobytes()
+    again, acnt = M.asm_seed_reads(ctx, idx, block, reads, 0, nq)          # back to the default layout on the same buffers
+    assert np.array_equal(acnt, wcnt) and again[mask].tobytes() == want[mask].tobytes()
+    idx.free(); block.free(); reads.free(); ctx.close()
+
+
 @pytest.mark.parametrize("tool,start", [("mecat2asmpw", 1), ("mecat2asmpw", 2), ("mecat2trimpw", 1), ("mecat2trimpw", 2)])
 def test_drop_in_tool_equals_the_reference_output(tmp_path, tool, start):
     """mecat_amd/bin/mecat2asmpw / mecat2trimpw through the tools' own command line (-P<dir> -T<n> -S<start> -E<last>, reading ovlprep and

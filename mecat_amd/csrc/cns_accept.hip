@@ -14,11 +14,13 @@
 // re-aligned speculatively in ONE device launch (mhip_cns_align_candidates_dev), the sequential accept decisions are replayed
 // over the results on host threads, only the 2-bit column strings of the ACCEPTED alignments are gathered on the device and
 // brought back, and the gap-normalised strings are rebuilt from them and the host copy of the reads.
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <set>
 #include <thread>
 #include <vector>
@@ -80,12 +82,54 @@ void push_gaps(char* q, char* t, int64_t n) {
     }
 }
 
-// rows of 2-bit columns of the accepted jobs -> one compact buffer
-__global__ void cns_gather_ops(const uint32_t* __restrict__ ops, const int32_t* __restrict__ sel, int nsel, int row_words, uint32_t* __restrict__ out) {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t i = t / (size_t)row_words, w = t % (size_t)row_words;
-    if (i >= (size_t)nsel) return;
-    out[i * row_words + w] = ops[(size_t)sel[i] * row_words + w];
+// the 2-bit columns of the accepted jobs -> one dense buffer: one wave per accepted alignment, its left words then its right words at
+// woff[i] (a direction fills a fraction of its worst-case stride: 119 MB instead of 424 MB cross the PCIe link at config 2's 28 000 accepted)
+__global__ __launch_bounds__(256) void cns_gather_ops(const uint32_t* __restrict__ ops, const int32_t* __restrict__ sel, const int32_t* __restrict__ lw,
+                                                      const int32_t* __restrict__ rw, const unsigned long long* __restrict__ woff, int nsel, int row_words,
+                                                      uint32_t* __restrict__ out) {
+    const int lane = (int)threadIdx.x & 63;
+    for (size_t i = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < (size_t)nsel; i += (size_t)gridDim.x * 4) {
+        const uint32_t* src = ops + (size_t)sel[i] * row_words;
+        uint32_t* dst = out + woff[i];
+        const int nl = lw[i], nr = rw[i];
+        for (int j = lane; j < nl; j += 64) dst[j] = src[j];
+        for (int j = lane; j < nr; j += 64) dst[nl + j] = src[row_words / 2 + j];
+    }
+}
+
+// four bases of a packed byte as characters (first base in the high bits: packed_db.h:103-107), forward and reverse-complemented
+struct BaseLut {
+    uint32_t fwd[256], rc[256];
+    BaseLut() {
+        for (int b = 0; b < 256; ++b) {
+            char f[4], r[4];
+            for (int k = 0; k < 4; ++k) {
+                const int c = (b >> ((3 - k) << 1)) & 3;
+                f[k] = "ACGT"[c];
+                r[3 - k] = "ACGT"[3 - c];
+            }
+            memcpy(&fwd[b], f, 4);
+            memcpy(&rc[b], r, 4);
+        }
+    }
+};
+const BaseLut g_lut;
+
+// bases [from, from + n) of the read at `off` as characters (n + up to 7 bytes of dst are written)
+void decode_fwd(const uint8_t* pac, int64_t off, int from, int n, char* dst) {
+    int64_t idx = off + from;
+    int k = 0;
+    for (; k < n && (idx & 3); ++k, ++idx) dst[k] = "ACGT"[host_base(pac, idx)];
+    for (; k < n; k += 4, idx += 4) memcpy(dst + k, &g_lut.fwd[pac[idx >> 2]], 4);
+}
+// the same range of the read's reverse complement: position i of the strand is the complement of base size - 1 - i
+void decode_rc(const uint8_t* pac, int64_t off, int size, int from, int n, char* dst) {
+    // strand positions from .. from + n - 1  <->  read positions size - 1 - from  down to  size - from - n
+    int64_t idx = off + size - 1 - from;                 // read index of the first character, walking down
+    int k = 0;
+    for (; k < n && ((idx & 3) != 3); ++k, --idx) dst[k] = "ACGT"[3 - host_base(pac, idx)];
+    for (; k + 4 <= n; k += 4, idx -= 4) memcpy(dst + k, &g_lut.rc[pac[idx >> 2]], 4);
+    for (; k < n; ++k, --idx) dst[k] = "ACGT"[3 - host_base(pac, idx)];
 }
 
 }  // namespace
@@ -108,6 +152,12 @@ int mhip_cns_accept_templates(mhip_ctx* c, const mhip_volume* vol, const uint8_t
     const double ratio = min_mapping_ratio - 0.02;                   // :406
     const int start_id = vol->start_read_id, nreads = vol->num_reads;
     num_threads = std::max(1, num_threads);
+    // MECAT_CNS_TIMES=1: where the call's wall time went, on stderr
+    const bool times = getenv("MECAT_CNS_TIMES") != nullptr;
+    double tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_last = now();
+    auto lap = [&](int k) { const double t = now(); tk[k] += t - t_last; t_last = t; };
 
     // 1. order of the reference's walk
     std::atomic<int> bad{0};
@@ -132,6 +182,7 @@ int mhip_cns_accept_templates(mhip_ctx* c, const mhip_volume* vol, const uint8_t
     if (bad.load() == 2) { mhip_set_error("cns accept: a candidate's qsize / ssize differs from the read lengths of the volume"); return -1; }
     if (bad.load()) { mhip_set_error("cns accept: a candidate is outside the volume, has sdir != 0 or sits in another template's range"); return -1; }
 
+    lap(0);
     // 2. the first <= 200 candidates of every template, as alignment jobs
     std::vector<int64_t> jfirst((size_t)num_templates + 1, 0);
     for (int t = 0; t < num_templates; ++t) jfirst[(size_t)t + 1] = jfirst[(size_t)t] + std::min<int64_t>(max_ext, tmpl_begin[t + 1] - tmpl_begin[t]);
@@ -159,6 +210,7 @@ int mhip_cns_accept_templates(mhip_ctx* c, const mhip_volume* vol, const uint8_t
     const int cap = (int)(((int64_t)max_len * 2 + 64 + 15) / 16 * 16);
     const int row_words = 2 * (cap / 16);
 
+    lap(1);
     // 3. one speculative device launch
     mhip_aln_job* d_jobs;
     mhip_cns_result* d_res;
@@ -172,6 +224,7 @@ int mhip_cns_accept_templates(mhip_ctx* c, const mhip_volume* vol, const uint8_t
     HIPCHK(hipMemcpyAsync(res.data(), d_res, sizeof(mhip_cns_result) * (size_t)nj, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
 
+    lap(2);
     // 4. the sequential accept decisions, per template
     std::vector<std::vector<int32_t>> acc((size_t)num_templates);      // accepted job indices, in acceptance order
     parallel_for(num_templates, num_threads, [&](int64_t t) {
@@ -204,22 +257,40 @@ int mhip_cns_accept_templates(mhip_ctx* c, const mhip_volume* vol, const uint8_t
     const int64_t na = afirst[(size_t)num_templates];
     if (na == 0) return 0;
 
-    // 5. the accepted alignments' columns
-    std::vector<int32_t> sel((size_t)na);
+    lap(3);
+    // 5. the accepted alignments' columns, packed: left words then right words of every accepted alignment
+    std::vector<int32_t> sel((size_t)na), lw((size_t)na), rw((size_t)na);
+    std::vector<unsigned long long> woff((size_t)na + 1);
     for (int t = 0; t < num_templates; ++t) std::copy(acc[(size_t)t].begin(), acc[(size_t)t].end(), sel.begin() + afirst[(size_t)t]);
-    int32_t* d_sel;
+    woff[0] = 0;
+    for (int64_t a = 0; a < na; ++a) {
+        const mhip_cns_result& r = res[(size_t)sel[(size_t)a]];
+        lw[(size_t)a] = (r.left_cols + 15) >> 4;
+        rw[(size_t)a] = (r.right_cols + 15) >> 4;
+        woff[(size_t)a + 1] = woff[(size_t)a] + (unsigned long long)(lw[(size_t)a] + rw[(size_t)a]);
+    }
+    const size_t dense_words = (size_t)woff[(size_t)na];
+    int32_t *d_sel, *d_lw, *d_rw;
+    unsigned long long* d_woff;
     uint32_t* d_pack;
     if (c->scratch("ca_sel", sizeof(int32_t) * (size_t)na, (void**)&d_sel)) return -1;
-    if (c->scratch("ca_pack", sizeof(uint32_t) * (size_t)row_words * (size_t)na, (void**)&d_pack)) return -1;
+    if (c->scratch("ca_lw", sizeof(int32_t) * (size_t)na, (void**)&d_lw)) return -1;
+    if (c->scratch("ca_rw", sizeof(int32_t) * (size_t)na, (void**)&d_rw)) return -1;
+    if (c->scratch("ca_woff", sizeof(unsigned long long) * ((size_t)na + 1), (void**)&d_woff)) return -1;
+    if (c->scratch("ca_pack", sizeof(uint32_t) * std::max<size_t>(dense_words, 1), (void**)&d_pack)) return -1;
     HIPCHK(hipMemcpyAsync(d_sel, sel.data(), sizeof(int32_t) * (size_t)na, hipMemcpyHostToDevice, c->stream));
-    {
-        const size_t nt = (size_t)na * (size_t)row_words;
-        LAUNCH(c, "cns_gather_ops", cns_gather_ops, (unsigned)((nt + 255) / 256), 256, 0, (const uint32_t*)d_ops, (const int32_t*)d_sel, (int)na, row_words, d_pack);
-    }
-    std::vector<uint32_t> ops((size_t)row_words * (size_t)na);
-    HIPCHK(hipMemcpyAsync(ops.data(), d_pack, sizeof(uint32_t) * ops.size(), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(d_lw, lw.data(), sizeof(int32_t) * (size_t)na, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d_rw, rw.data(), sizeof(int32_t) * (size_t)na, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d_woff, woff.data(), sizeof(unsigned long long) * ((size_t)na + 1), hipMemcpyHostToDevice, c->stream));
+    LAUNCH(c, "cns_gather_ops", cns_gather_ops, (unsigned)std::min<size_t>(((size_t)na + 3) / 4, (size_t)c->num_cus * 32), 256, 0, (const uint32_t*)d_ops,
+           (const int32_t*)d_sel, (const int32_t*)d_lw, (const int32_t*)d_rw, (const unsigned long long*)d_woff, (int)na, row_words, d_pack);
+    uint32_t* ops = nullptr;                                   // page-locked: the copy is one DMA
+    HIPCHK(hipHostMalloc((void**)&ops, sizeof(uint32_t) * std::max<size_t>(dense_words, 1), hipHostMallocDefault));
+    struct HostFree { uint32_t* p; ~HostFree() { (void)hipHostFree(p); } } ops_guard{ops};
+    HIPCHK(hipMemcpyAsync(ops, d_pack, sizeof(uint32_t) * dense_words, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
 
+    lap(4);
     // 6. strings: m5qaln / m5saln from the columns and the reads, then normalize_gaps(push = true)
     mhip_cns_accepted* A = (mhip_cns_accepted*)malloc(sizeof(mhip_cns_accepted) * (size_t)na);
     if (!A) { mhip_set_error("out of memory"); return -1; }
@@ -233,6 +304,7 @@ int mhip_cns_accept_templates(mhip_ctx* c, const mhip_volume* vol, const uint8_t
     char* S = (char*)malloc((size_t)std::max<int64_t>(sbytes, 1));
     if (!S) { free(A); mhip_set_error("out of memory (%lld bytes of aligned strings)", (long long)sbytes); return -1; }
     parallel_for(num_templates, num_threads, [&](int64_t t) {
+        std::vector<char> qbuf, tbuf;
         for (int64_t a = afirst[(size_t)t]; a < afirst[(size_t)t + 1]; ++a) {
             const int64_t ji = sel[(size_t)a];
             const mhip_cns_result& r = res[(size_t)ji];
@@ -245,35 +317,41 @@ int mhip_cns_accept_templates(mhip_ctx* c, const mhip_volume* vol, const uint8_t
             o.qoff = r.qoff; o.qend = r.qend; o.soff = r.soff; o.send = r.send;
             char* qa = S + o.str_offset;
             char* sa = qa + o.aln_size + 1;
-            const uint32_t* row = ops.data() + (size_t)a * row_words;
-            const uint32_t* left = row;
-            const uint32_t* right = row + cap / 16;
+            const uint32_t* left = ops + woff[(size_t)a];
+            const uint32_t* right = left + lw[(size_t)a];
             const mhip_offset_t qo = vol->h_offs[(size_t)jb.qid_local], so = vol->h_offs[(size_t)jb.sid_local];
-            // merged column m: reverse(left) then right; query / template positions advance from the untrimmed start points
-            int qi = r.query_start, ti = r.target_start;
+            // the bases the columns cover, as characters: query (in the mapped strand's orientation) from the untrimmed start point,
+            // template likewise — the column loop below then only picks from them
             const int ncols = r.left_cols + r.right_cols;
-            for (int m = 0; m < ncols; ++m) {
-                int op;
-                if (m < r.left_cols) { const int k = r.left_cols - 1 - m; op = (left[k >> 4] >> ((k & 15) << 1)) & 3; }
-                else { const int k = m - r.left_cols; op = (right[k >> 4] >> ((k & 15) << 1)) & 3; }
+            const int nq = r.query_end - r.query_start, nt = r.target_end - r.target_start;
+            qbuf.resize((size_t)nq + 8);
+            tbuf.resize((size_t)nt + 8);
+            if (jb.chain) decode_rc(host_pac, qo.offset, qo.size, r.query_start, nq, qbuf.data());
+            else decode_fwd(host_pac, qo.offset, r.query_start, nq, qbuf.data());
+            decode_fwd(host_pac, so.offset, r.target_start, nt, tbuf.data());
+            // merged column m: reverse(left) then right; columns [first_col, last_col) are kept (GetAlignment's trimming)
+            int qi = 0, ti = 0;
+            auto put = [&](int m, int op) {
+                const int hq = op != 1, ht = op != 2;
                 if (m >= r.first_col && m < r.last_col) {
-                    char qc = '-', tc = '-';
-                    if (op != 1) {
-                        const int b = jb.chain ? 3 - host_base(host_pac, (int64_t)qo.offset + (qo.size - 1 - qi)) : host_base(host_pac, (int64_t)qo.offset + qi);
-                        qc = "ACGT"[b];
-                    }
-                    if (op != 2) tc = "ACGT"[host_base(host_pac, (int64_t)so.offset + ti)];
-                    qa[m - r.first_col] = qc;
-                    sa[m - r.first_col] = tc;
+                    qa[m - r.first_col] = hq ? qbuf[(size_t)qi] : '-';
+                    sa[m - r.first_col] = ht ? tbuf[(size_t)ti] : '-';
                 }
-                qi += op != 1;
-                ti += op != 2;
-            }
+                qi += hq;
+                ti += ht;
+            };
+            for (int m = 0; m < r.left_cols; ++m) { const int k = r.left_cols - 1 - m; put(m, (int)((left[k >> 4] >> ((k & 15) << 1)) & 3u)); }
+            for (int k = 0; k < r.right_cols; ++k) put(r.left_cols + k, (int)((right[k >> 4] >> ((k & 15) << 1)) & 3u));
+            (void)ncols;
             qa[o.aln_size] = 0;
             sa[o.aln_size] = 0;
             push_gaps(qa, sa, o.aln_size);
         }
     });
+    lap(5);
+    if (times)
+        fprintf(stderr, "[cns_accept] %d templates, %lld jobs, %lld accepted: sort + checks %.3f s, jobs %.3f, re-alignment on the device %.3f, accept replay %.3f, "
+                        "columns gathered + copied %.3f, strings %.3f\n", num_templates, (long long)nj, (long long)na, tk[0], tk[1], tk[2], tk[3], tk[4], tk[5]);
     *out_accepted = A;
     *out_count = na;
     *out_strings = S;

@@ -359,7 +359,7 @@ assert EXT_CAND_DTYPE.itemsize == 52 and ACCEPTED_DTYPE.itemsize == 48
 
 def cns_accept_templates(ctx, vol, host_pac, cands, tmpl_begin, tech, min_align_size, min_mapping_ratio, threads=8):
     """mecat2cns' accept loop for a batch of templates.  cands: [n] EXT_CAND_DTYPE (or [n, 13] int32) grouped by template, sorted in
-    place.  -> (accepted [k] ACCEPTED_DTYPE, strings bytes, number of alignments computed)"""
+    place.  -> (accepted [k] ACCEPTED_DTYPE, strings as a uint8 array over the library's buffer, number of alignments computed)"""
     cands = np.ascontiguousarray(cands)
     tb = np.ascontiguousarray(tmpl_begin, dtype=np.int64)
     pac = np.ascontiguousarray(host_pac, dtype=np.uint8)
@@ -368,9 +368,14 @@ def cns_accept_templates(ctx, vol, host_pac, cands, tmpl_begin, tech, min_align_
     _chk(lib().mhip_cns_accept_templates(ctx.h, vol.h, pac.ctypes.data, cands.ctypes.data, tb.ctypes.data, len(tb) - 1, tech, min_align_size,
                                          float(min_mapping_ratio), threads, C.byref(acc), C.byref(na), C.byref(st), C.byref(sb), C.byref(nj)))
     a = np.ctypeslib.as_array(C.cast(acc, C.POINTER(C.c_uint8)), shape=(na.value * 48,)).view(ACCEPTED_DTYPE).copy() if na.value else np.zeros(0, ACCEPTED_DTYPE)
-    s = bytes(np.ctypeslib.as_array(C.cast(st, C.POINTER(C.c_uint8)), shape=(sb.value,))) if sb.value else b""
     lib().mhip_cns_free(acc)
-    lib().mhip_cns_free(st)
+    if not sb.value:
+        lib().mhip_cns_free(st)
+        return a, np.zeros(0, np.uint8), nj.value
+    # the strings stay where the library put them (a gigabyte at config 2: no copy): a uint8 array over the C buffer, freed with the array
+    import weakref
+    s = np.ctypeslib.as_array(C.cast(st, C.POINTER(C.c_uint8)), shape=(sb.value,))
+    weakref.finalize(s, lib().mhip_cns_free, C.c_void_p(st.value))
     return a, s, nj.value
 
 

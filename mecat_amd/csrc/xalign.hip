@@ -66,11 +66,13 @@ struct XBlockOut {
 // scratch with a fixed row stride (coalesced 64-byte stores), plus bit 7 = "the diagonal step into this cell is a match" so
 // that the traceback needs nothing but these bytes.  The traceback is a scalar walk: a row's bytes sit in two registers
 // (one cell per lane), fetched one row ahead from a 4 KB LDS window over the scratch, and are read with v_readlane.
-// A window wider than XW_RING - 2 cells hands the unit over (overflow list: unit, position and partial result) to a second
-// launch with a bigger per-wave scratch, which resumes it there and runs the WIDE instantiation of the same code for the
-// blocks that overflow: scores in
-// per-wave global arrays instead of the ring, rows of XW_WSTRIDE bytes, traceback reading byte by byte through the LDS
-// window — slower per row, but only a fraction of a percent of the units (low-complexity sequence) have such blocks.
+// A block whose window grows wider than XW_RING - 2 cells is redone at once by the same wave with the WIDE instantiation of the
+// round-1 code: scores indexed by b, rows of XW_WSTRIDE bytes, traceback reading byte by byte through a window — with its whole
+// state (scores, bases, row starts, window) in the wave's share of a global buffer instead of LDS: slower per row, but only a
+// fraction of a percent of the units (low-complexity sequence) have such a block, and the unit then goes on in the ring.
+// (Round 1-3 handed such units to a second launch — overflow list: unit, position and partial result — which was as long as its
+// slowest unit: 17.6 ms of 136 on 134 k jobs.  That launch is still there behind MECAT_XD_HANDOVER=1, and MECAT_XD_WIDE=1 runs
+// every block through the WIDE code in LDS: the tests compare all three.)
 #define XW_WAVES 4
 #define XW_BLOCK (XW_WAVES * 64)
 #define XW_RING 128
@@ -80,6 +82,8 @@ struct XBlockOut {
 #define XW_WSTRIDE 768                   // WIDE: any window fits a row (N + 1 <= 737 cells)
 #define XW_WIDE_BYTES ((size_t)(X_MAXN + 2) * XW_WSTRIDE)
 #define XW_WIDE_HF (X_MAXN + 8)
+#define XW_INPLACE_STATE 16384           // bytes in front of a ring wave's wide rows: its XwLds<XW_WIDE_HF> image
+#define XW_INPLACE_BYTES (XW_INPLACE_STATE + XW_WIDE_BYTES)
 #define XW_NEG (-(1 << 30))
 #define XS_MATCH 0x80
 template <int HFN> struct XwLds {
@@ -88,6 +92,8 @@ template <int HFN> struct XwLds {
     int16_t rstart[HFN == XW_RING ? 2 : X_MAXN + 2];     // WIDE blocks only; 128-byte rows carry their first column in bytes 126-127
     uint32_t win[XW_WIN / 4];
 };
+
+static_assert(sizeof(XwLds<XW_WIDE_HF>) <= XW_INPLACE_STATE, "the in-place wide state holds one XwLds<XW_WIDE_HF>");
 
 template <int CTRL, int RMASK> __device__ __forceinline__ int xw_dpp_max(int v) {
     // old = the identity of max: lets the DPP combiner fuse mov_dpp + max into one v_max_i32_dpp and schedule around the hazard
@@ -700,18 +706,21 @@ __device__ void xdrop_block_ring(XrLds& S, const XView& q, int qidx, int M, cons
 }
 
 template <bool WIDE>
-__global__ __launch_bounds__(XW_BLOCK) void xd_extend_w(const uint32_t* __restrict__ rpac, const mhip_offset_t* __restrict__ roffs,
+__global__ __launch_bounds__(XW_BLOCK, 6) void xd_extend_w(const uint32_t* __restrict__ rpac, const mhip_offset_t* __restrict__ roffs,
                                                         const uint32_t* __restrict__ qpac, const mhip_offset_t* __restrict__ qoffs,
                                                         const mhip_aln_job* __restrict__ jobs, int n, XDir* __restrict__ dres,
                                                         uint8_t* __restrict__ scratch, unsigned int* __restrict__ cursor,
                                                         unsigned int* __restrict__ ovf_list, unsigned long long* __restrict__ counters,
-                                                        const unsigned int* __restrict__ ulist, unsigned int nunits, int force_wide) {
+                                                        const unsigned int* __restrict__ ulist, unsigned int nunits, int force_wide,
+                                                        uint8_t* __restrict__ wide_state) {
     constexpr int HFN = WIDE ? XW_WIDE_HF : XW_RING;
     __shared__ typename std::conditional<WIDE, XwLds<XW_WIDE_HF>, XrLds>::type lds[WIDE ? 1 : XW_WAVES];
     auto& S = lds[threadIdx.x >> 6];
     const int lane = lane_id();
     uint8_t* st = scratch + (size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (WIDE ? XW_WIDE_BYTES : XW_STATE_BYTES);
-    unsigned long long nblocks = 0, ncells = 0, nrows = 0;
+    // the ring kernel's own wide state (a block whose window outgrows the ring is redone in place, below): in global memory
+    uint8_t* wst = WIDE ? nullptr : wide_state + (size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * XW_INPLACE_BYTES;
+    unsigned long long nblocks = 0, ncells = 0, nrows = 0, nredone = 0;
 #ifdef MECAT_XD_STATS
     unsigned long long xs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long tk_life = __builtin_amdgcn_s_memtime();
@@ -764,7 +773,18 @@ __global__ __launch_bounds__(XW_BLOCK) void xd_extend_w(const uint32_t* __restri
             ncells += (unsigned)o.cells;
             nrows += (unsigned)o.rows;
             if (o.overflow) {
-                if (!WIDE) { handed_over = true; R.blocks -= 1; break; }      // the block is counted again when it is redone
+                if constexpr (!WIDE) {
+                    // A window wider than the ring (a fraction of a percent of the units have such a block, low-complexity sequence): the
+                    // block again, at once, with the WIDE code — its scores, bases and row starts in this wave's global state instead of
+                    // LDS (slower per row, and rare), rows of XW_WSTRIDE bytes behind it.  The unit then goes on in the ring.  (Handing
+                    // the unit to a second launch made that launch as long as its slowest unit: 13 % of the kernel time on 134 k jobs.)
+                    if (wst) {
+                        xdrop_block_w<true, XW_WIDE_HF>(*reinterpret_cast<XwLds<XW_WIDE_HF>*>(wst), q, qidx, qblk, t, tidx, tblk, wst + XW_INPLACE_STATE, o);
+                        ncells += (unsigned)o.cells;
+                        nrows += (unsigned)o.rows;
+                        ++nredone;
+                    } else { handed_over = true; R.blocks -= 1; break; }      // (no wide state: the block is counted again when it is redone)
+                }
                 if constexpr (WIDE) {      // only the blocks that need it
                     xdrop_block_w<true, HFN>(S, q, qidx, qblk, t, tidx, tblk, st, o);
                     ncells += (unsigned)o.cells;
@@ -800,6 +820,7 @@ __global__ __launch_bounds__(XW_BLOCK) void xd_extend_w(const uint32_t* __restri
         atomicAdd(&counters[3], nblocks);
         atomicAdd(&counters[4], ncells);      // DP cells (the slot dw's d-path cells use)
         atomicAdd(&counters[9], nrows);
+        if (nredone) atomicAdd(&counters[11], nredone);      // debug slot 11: blocks redone in place with the wide window
 #ifdef MECAT_XD_STATS
         if (!WIDE) {
             atomicAdd(&counters[16], __builtin_amdgcn_s_memtime() - tk_life);      // wave life, ticks
@@ -855,13 +876,22 @@ int mhip_xalign_candidates_dev(mhip_ctx* c, const mhip_volume* ref, const mhip_v
         const int waves = c->num_cus * (getenv("MECAT_XW_WAVES") ? atoi(getenv("MECAT_XW_WAVES")) : 24);
         const int grid = std::min(waves / XW_WAVES, (2 * n + XW_WAVES - 1) / XW_WAVES);
         if (c->scratch("xw_state", XW_STATE_BYTES * (size_t)waves, (void**)&d_s)) return -1;
+        // MECAT_XD_HANDOVER=1: blocks that outgrow the ring go to the second launch (the round-1 arrangement; tests compare the two)
+        uint8_t* d_wst = nullptr;
+        if (!(getenv("MECAT_XD_HANDOVER") && atoi(getenv("MECAT_XD_HANDOVER")) == 1) && c->scratch("xw_inplace", XW_INPLACE_BYTES * (size_t)waves, (void**)&d_wst)) return -1;
         HIPCHK(hipMemsetAsync(d_ovf, 0, sizeof(unsigned int), c->stream));
         LAUNCH(c, "xd_extend_w", xd_extend_w<false>, grid, XW_BLOCK, 0, (const uint32_t*)ref->d_pac, (const mhip_offset_t*)ref->d_offs,
                (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs, (const mhip_aln_job*)d_jobs, n, d_dres, d_s, d_cur,
-               d_ovf, (unsigned long long*)c->d_counters, (const unsigned int*)nullptr, 2u * (unsigned)n, 0);
+               d_ovf, (unsigned long long*)c->d_counters, (const unsigned int*)nullptr, 2u * (unsigned)n, 0, d_wst);
         HIPCHK(hipMemcpyAsync(&nwide, d_ovf, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
-        if (getenv("MECAT_TRACE")) fprintf(stderr, "[mecat_hip] X-drop: %u of %d units need the wide-window path\n", nwide, 2 * n);
+        if (getenv("MECAT_TRACE")) {
+            if (d_wst) {
+                unsigned long long redone = 0;
+                HIPCHK(hipMemcpy(&redone, (unsigned long long*)c->d_counters + 11, sizeof(redone), hipMemcpyDeviceToHost));
+                fprintf(stderr, "[mecat_hip] X-drop: %d units, %llu blocks so far redone in place with the wide window\n", 2 * n, redone);
+            } else fprintf(stderr, "[mecat_hip] X-drop: %u of %d units need the wide-window path\n", nwide, 2 * n);
+        }
     }
     if (nwide > 0 || all_wide) {
         const unsigned int nu = all_wide ? 2u * (unsigned)n : nwide;
@@ -871,7 +901,7 @@ int mhip_xalign_candidates_dev(mhip_ctx* c, const mhip_volume* ref, const mhip_v
         LAUNCH(c, "xd_extend_wide", xd_extend_w<true>, wgrid, 64, 0, (const uint32_t*)ref->d_pac, (const mhip_offset_t*)ref->d_offs,
                (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs, (const mhip_aln_job*)d_jobs, n, d_dres, d_w, d_cur + 2,
                d_ovf + 6 * (size_t)n + 4, (unsigned long long*)c->d_counters, all_wide ? (const unsigned int*)nullptr : (const unsigned int*)(d_ovf + 1),
-               nu, all_wide ? 1 : 0);
+               nu, all_wide ? 1 : 0, (uint8_t*)nullptr);
     }
     LAUNCH(c, "xd_stitch", xd_stitch, (n + 255) / 256, 256, 0, (const mhip_aln_job*)d_jobs, (const XDir*)d_dres, n, min_align_size,
            (mhip_aln_result*)d_out, (unsigned long long*)c->d_counters);

@@ -122,8 +122,9 @@ def test_cli_m4_nanopore_mode(tmp_path):
 
 
 def test_xdrop_wide_windows_low_complexity(hip, ctx, capfd):
-    """Homopolymer / short-period tandem stretches keep hundreds of cells within X of the best score: those units leave the
-    128-cell fast path for the wide-window instantiation.  Ring instantiation (+ hand-over) == oracle == the WIDE instantiation run on every block."""
+    """Homopolymer / short-period tandem stretches keep hundreds of cells within X of the best score: those blocks leave the
+    128-cell ring for the wide-window code — in place, on the wave's global state (the default), or handed to a second launch
+    (MECAT_XD_HANDOVER=1, the round-1 arrangement).  Both == the oracle == the WIDE instantiation run on every block."""
     rng = np.random.default_rng(4242)
     O = H.orc()
     xa = O.orc_xaligner_new()
@@ -159,14 +160,20 @@ def test_xdrop_wide_windows_low_complexity(hip, ctx, capfd):
     O.orc_xaligner_free(xa)
     gv = _vol(hip, ctx, seqs)
     ja = np.array(jobs, dtype=hip.JOB_DTYPE)
+    ctx.reset_stats()
+    out = hip.align_candidates(ctx, gv, gv, ja, 500, tech=1).copy()
+    assert ctx.debug_counter(11) > 5                          # blocks redone in place with the wide window: the path really ran
     os.environ["MECAT_TRACE"] = "1"
+    os.environ["MECAT_XD_HANDOVER"] = "1"
     try:
-        out = hip.align_candidates(ctx, gv, gv, ja, 500, tech=1).copy()
+        handed = hip.align_candidates(ctx, gv, gv, ja, 500, tech=1).copy()
     finally:
         os.environ.pop("MECAT_TRACE")
+        os.environ.pop("MECAT_XD_HANDOVER")
     err = capfd.readouterr().err
     nwide = int(err.split("X-drop: ")[1].split(" of ")[0])
-    assert nwide > 5, err                                     # the wide path really ran
+    assert nwide > 5, err                                     # and so did the hand-over
+    assert handed.tobytes() == out.tobytes()
     os.environ["MECAT_XD_WIDE"] = "1"
     try:
         wide = hip.align_candidates(ctx, gv, gv, ja, 500, tech=1).copy()
@@ -181,7 +188,7 @@ def test_xdrop_wide_windows_low_complexity(hip, ctx, capfd):
 
 def test_xdrop_ring_equals_wide_instantiation_at_scale(hip, ctx):
     """133 855 candidates of 5 000 ONT-style 10 kb reads (2.1 M blocks, a few hundred of them through the wide-window path):
-    the default launch (128-cell LDS ring, two-register row traceback, hand-over of overflowing blocks) and the WIDE
+    the default launch (128-cell LDS ring, overflowing blocks redone in place with the wide window on global state) and the WIDE
     instantiation run on every block (scores indexed by b, 768-byte rows, byte-by-byte traceback; MECAT_XD_WIDE=1) must agree
     on every field of every result.  Oracle parity of both is pinned at small size by the tests above."""
     from mecat_amd import workload as W

@@ -727,7 +727,7 @@ def main():
                 alines, asecs, aerr = min(runs, key=lambda r: r[1])
                 line["asm_overlap"] = {"tool": "mecat2asmpw -T%d -S1 -E2" % T, "reads": 20000, "bases": abases, "overlaps": len(alines), "seconds": asecs,
                                        "runs_s": [r[1] for r in runs],
-                                       "mbases_per_s": abases / 1e6 / asecs, "stages": [ln for ln in aerr.splitlines() if ln.startswith("[mecat2asmpw]")][-1:]}
+                                       "mbases_per_s": abases / 1e6 / asecs, "stages": [ln for ln in aerr.splitlines() if ln.startswith("[mecat2asmpw]")][-1:] + [ln for ln in aerr.splitlines() if ln.startswith("[asm_seed]")][:3]}
                 if not args.no_cpu:
                     ref = os.path.join(ROOT, "oracle", "_ref", "mecat2asmpw")
                     if os.path.exists(ref):

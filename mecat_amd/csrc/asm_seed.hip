@@ -50,7 +50,7 @@
 #define A_SEEDNUM (1 + 2 * ASM)
 #define A_INDEX (2 + 2 * ASM)        // int at short offset 122 (byte 244)
 #define ASM_BLOCK 256
-#define ASM_POOL 16384                // records of a wave's pool (a read that needs more is redone with a worst-case pool)
+#define ASM_POOL 8192                 // records of a wave's pool: 2 MB, a read of 30 kb (one that needs more is redone with a worst-case pool)
 #define ASM_WAVES (ASM_BLOCK / WAVE)
 
 namespace {
@@ -448,10 +448,11 @@ int mhip_asm_seed_reads_ex(mhip_ctx* c, const mhip_index* idx, const mhip_volume
     const int n = rid_end - rid_begin;
     if (n == 0) return 0;
     const int nseg = block->num_bases / AZV + 5;
-    // One directory + record pool per resident wave, 16 waves per CU.  A pool holds ASM_POOL records (4 MB; a read of 8 kb takes about
-    // 2 000, and records are touched from the front) or the worst case if that is less; a read that needs more gives up (count -1) and
+    // One directory + record pool per resident wave, 16 waves per CU.  A pool holds ASM_POOL records (2 MB; a read of 8 kb takes about
+    // 2 500, and records are touched from the front) or the worst case if that is less; a read that needs more gives up (count -1) and
     // is redone below with worst-case pools on a few waves.  Allocating for the worst case everywhere (20 MB per wave, 86 GB) made the
-    // allocation itself the cost: tens of GB of fresh device memory take the driver seconds, erratically.  MECAT_ASM_POOL overrides.
+    // allocation itself the cost: device memory that another process has just given back, or that is handed out for the first time, is
+    // cleared by the driver when it is allocated — a second and more for tens of GB, a tenth of that for these 10 GB.  MECAT_ASM_POOL overrides.
     const char* pe = getenv("MECAT_ASM_POOL");
     const int pcap = std::min(nseg + 9, std::max(64, pe && atoi(pe) > 0 ? atoi(pe) : ASM_POOL));
     size_t free_b = 0, total_b = 0;

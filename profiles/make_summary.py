@@ -34,6 +34,9 @@ row("config3 (configs[2]: 3 volumes, 6 cells)", R + "_bench_config3.json", c3)
 row("config5_cell (cell (0,1) of configs[4], `-x 1`)", R + "_config5_cell_bench.json", cc)
 row("config5 (configs[4] whole: 19 volumes, 190 cells, `-x 1`)", R + "_bench_config5.json", c5)
 out.append("")
+if c5["roofline"].get("kernel_source_digest") != cc["roofline"].get("kernel_source_digest"):
+    out.append("(The whole-config-5 line takes six minutes and was taken one commit before the others: the sources differ in the record-pool size of "
+               "`asm_seed`, a kernel this workload does not run.)\n")
 b2, bc = c2["cpu_baseline"], cc.get("cpu_baseline", c5["cpu_baseline"])
 fs = b2["full_size_same_host"]
 out.append("CPU side, same runs.  Config 2: the unmodified `mecat2pw -j 0` on the full FASTA with %d threads of the box's %d CPUs — %.0f s hot path "

@@ -391,16 +391,26 @@ __device__ void xdrop_block_w(XwLds<HFN>& S, const XView& q, int qidx, int M, co
 //   * the score of a dropped cell's row gap (H of the nearest kept cell to the left - 1) is a scalar for every lane behind the last
 //     or in front of the first kept cell; only a row with a hole between kept cells takes the per-lane look-up;
 //   * the query bases of 64 rows sit in a register (one v_readlane per row instead of an LDS round trip).
-#ifndef XR_WIN
-#define XR_WIN 3072                      // traceback window: 24 script rows (first chunks + second chunks)
-#endif
-#define XR_MOVE (XR_WIN / 128 - 8)       // rows the window moves by: 8 rows of overlap
+// Script cells are 4 bits (round 5; one byte per cell before: 64 bytes per row written and read back were 400 GB per launch on a
+// config-5 grid cell against 1.8 GB of algorithmic bytes):
+//   bits 0-1  the cell's own op: 0 = substitution over a mismatch, 1 = substitution over a match, 2 = GAP_IN_A, 3 = GAP_IN_B
+//   bit 2     EXT_A (the column gap into this cell extends), bit 3 EXT_B (the row gap extends)          (xdrop_gapalign.h:13-34)
+// A lane keeps the nibbles of EIGHT consecutive rows in a register (row a in bits 4 (a & 7) ..) and stores the register once per
+// group of eight rows: group g of a wave's scratch = 64 dwords, lane l's dword = the cells rs[a] + l of rows 8 g .. 8 g + 7 — one
+// coalesced 256-byte store per eight rows instead of a 64-byte store per row.  Cells 64.. of the rows that have them (one row in ten)
+// go the same way into a second array of groups behind the first; a bit per group says whether it was written.
+#define XR_GROUPS ((X_MAXN + 2 + 7) / 8)                     // groups of eight rows
+#define XR_STATE_BYTES ((size_t)XR_GROUPS * 256 * 2)        // first chunks, second chunks
+#define XN_GA 2
+#define XN_GB 3
+#define XN_EXT_A 4
+#define XN_EXT_B 8
 struct XrLds {
     int2 HF[XW_RING];
     uint8_t Tb[X_MAXN + 72 + 64];        // Tb[b] = target base b - 1 (idle and tail lanes read up to 128 cells behind the window)
-    uint16_t rs[X_MAXN + 4];             // first column of every row's script bytes
-    uint32_t win[XR_WIN / 4];            // rows [wlo, wlo + 24): first chunks (64 B each), then second chunks
-    uint32_t two[(X_MAXN + 2 + 31) / 32 + 1];   // rows that wrote a second chunk
+    uint16_t rs[X_MAXN + 4];             // first column of every row's script cells
+    uint32_t win[2][4][64];              // traceback window: [chunk][group & 3][lane], 32 rows
+    uint32_t two[4];                     // groups that wrote a second chunk
 };
 
 __device__ void xdrop_block_ring(XrLds& S, const XView& q, int qidx, int M, const XView& t, int tidx, int N, uint8_t* __restrict__ st, XBlockOut& o) {
@@ -424,31 +434,48 @@ __device__ void xdrop_block_ring(XrLds& S, const XView& q, int qidx, int M, cons
     __builtin_amdgcn_wave_barrier();
     for (int i = lane; i < N; i += 64) S.Tb[i + 1] = (uint8_t)xv_at(t, tidx + i);
     const int n_init = min(N, X);
-    uint8_t* __restrict__ st2 = st + (size_t)(X_MAXN + 2) * 64;      // second chunks
-    if (lane <= n_init) { S.HF[lane] = make_int2(-lane, -lane - 1); if (lane) st[lane] = XS_GAP_IN_A; }
-    if (lane < (int)(sizeof(S.two) / 4)) S.two[lane] = 0;
+    uint32_t* __restrict__ st32 = (uint32_t*)st;                    // first chunks: group g at dwords 64 g ..
+    uint32_t* __restrict__ st32b = st32 + (size_t)XR_GROUPS * 64;   // second chunks
+    if (lane <= n_init) S.HF[lane] = make_int2(-lane, -lane - 1);
+    if (lane < 4) S.two[lane] = 0;
     if (lane == 0) S.rs[0] = 0;
+    // row 0 (xdrop_gapalign.cpp:45-57): cells 1 .. n_init are GAP_IN_A
+    uint32_t acc = (lane >= 1 && lane <= n_init) ? (uint32_t)XN_GA : 0u, acc2 = 0u;
+    bool g2 = false;                                     // a row of the current group wrote second-chunk cells
+    auto flush = [&](const int g) __attribute__((always_inline)) {
+        st32[g * 64 + lane] = acc;
+        acc = 0u;
+        if (g2) {
+            st32b[g * 64 + lane] = acc2;
+            acc2 = 0u;
+            S.two[g >> 5] |= 1u << (g & 31);              // (every lane, one address)
+            g2 = false;
+        }
+    };
     int b_size = n_init + 1, best = 0, first_b = 0, ae = 0, be = 0;
     int qreg = 0, cellacc = 0;
     const int wmax = N <= X ? -1 : 64;                   // N <= X: row 0 ran off the end of the target (b_size = N + 1), every row through the general code
     bool stop = false;
+    int arow = 0;                                        // the last row that was run
     __builtin_amdgcn_wave_barrier();
     XD_TICK(tk_stage);
     for (int a0 = 1; a0 <= M && !stop; a0 += 64) {
       // the query bases of the next 64 rows in a register: one v_readlane per row
       qreg = (a0 - 1 + lane < M) ? xv_at(q, qidx + a0 - 1 + lane) : 0;
-      asm volatile("v_mov_b32 %0, %0" : "+v"(qreg));      // the load is waited for here, not at the row loop's first v_readlane (vmcnt also counts the rows' stores)
+      asm volatile("v_mov_b32 %0, %0" : "+v"(qreg));      // the load is waited for here, not at the row loop's first v_readlane (vmcnt also counts the groups' stores)
       XD_COUNT(n_qfill);
       const int aend = min(a0 + 63, M);
       for (int a = a0; a <= aend; ++a) {
+        if ((a & 7) == 0) flush((a >> 3) - 1);
+        arow = a;
+        const int sh = (a & 7) << 2;
         const int AC = __builtin_amdgcn_readlane(qreg, a - a0);
         const int f0 = first_b, n0 = b_size;
-        uint8_t* srow = st + (size_t)a * 64;
         // The common row — one pass, kept cells without a hole between them, gap tail inside the pass — with nothing but what it needs:
         // no carries, no selects for the cases it excludes (checked on the kept mask before anything is stored; a row that fails
-        // the check is redone by the general code below).  The scalar port is what bounds this kernel (profiles/r04_xd_breakdown.md):
-        // masks are compared as masks (s_bfm), "none" is s_ff1's own -1, every lane behind or in front of the kept cells stores (MIN, MIN)
-        // — the closing cell is one of them, the others are never read — and the DP cells are counted per lane.
+        // the check is redone by the general code below).  Masks are compared as masks (s_bfm), "none" is s_ff1's own -1, every lane behind
+        // or in front of the kept cells stores (MIN, MIN) — the closing cell is one of them, the others are never read — and the DP cells
+        // are counted per lane.
         if (__builtin_expect(n0 - f0 <= wmax, 1)) {                     // (wmax = 64; -1 in a special block)
             const int b = f0 + lane;
             const bool in0 = b < n0;
@@ -482,12 +509,13 @@ __device__ void xdrop_block_ring(XrLds& S, const XView& q, int qidx, int M, cons
                 cellacc += in0 ? 1 : 0;
                 const int Hlk = __builtin_amdgcn_readlane(Hc, lk1 - 1);
                 const int et = lane >= lk1 ? Hlk - 1 : X_MIN_SCORE;
-                int script = diag < Fp ? XS_GAP_IN_B : XS_SUB;
-                if (Mv < (kept ? Ec : et)) script = XS_GAP_IN_A;
-                const bool xa = kept && Fp >= Hc, xb = kept && in0 && Ec >= Hc, xm = mt && in0;
-                script |= (xa ? XS_EXT_A : 0) | (xb ? XS_EXT_B : 0) | (xm ? XS_MATCH : 0);
+                int nib = (mt && in0) ? 1 : 0;
+                nib = diag < Fp ? XN_GB : nib;
+                nib = Mv < (kept ? Ec : et) ? XN_GA : nib;
+                const bool xa = kept && Fp >= Hc, xb = kept && in0 && Ec >= Hc;
+                nib |= (xa ? XN_EXT_A : 0) | (xb ? XN_EXT_B : 0);
+                acc |= (uint32_t)nib << sh;
                 S.HF[b & (XW_RING - 1)] = make_int2(kept ? Hc : X_MIN_SCORE, kept ? Hc - 1 : X_MIN_SCORE);
-                srow[lane] = (uint8_t)script;
                 S.rs[a] = (uint16_t)f0;                                  // (every lane, one address)
                 const bool up = exm != 0ull;
                 best += up ? 1 : 0;
@@ -545,13 +573,14 @@ __device__ void xdrop_block_ring(XrLds& S, const XView& q, int qidx, int M, cons
                     const int Hj = __shfl(Hc, jsrc);
                     et = lower ? Hj - 1 : et_carry;
                 }
-                int script = diag < Fp ? XS_GAP_IN_B : XS_SUB;
-                if (Mv < (kept ? Ec : et)) script = XS_GAP_IN_A;
-                const bool xa = kept && Fp >= Hc, xb = kept && in0 && Ec >= Hc, xm = mt && in0;
-                script |= (xa ? XS_EXT_A : 0) | (xb ? XS_EXT_B : 0) | (xm ? XS_MATCH : 0);
+                int nib = (mt && in0) ? 1 : 0;
+                nib = diag < Fp ? XN_GB : nib;
+                nib = Mv < (kept ? Ec : et) ? XN_GA : nib;
+                const bool xa = kept && Fp >= Hc, xb = kept && in0 && Ec >= Hc;
+                nib |= (xa ? XN_EXT_A : 0) | (xb ? XN_EXT_B : 0);
                 S.HF[b & (XW_RING - 1)] = make_int2(kept ? Hc : X_MIN_SCORE, kept ? Hc - 1 : Fp);
-                (FIRST ? srow : st2 + (size_t)a * 64)[lane] = (uint8_t)script;
-                if (!FIRST) S.two[a >> 5] |= 1u << (a & 31);                 // (every lane, one address)
+                if (FIRST) acc |= (uint32_t)nib << sh;
+                else { acc2 |= (uint32_t)nib << sh; g2 = true; }
                 // carries
                 if (exm) { if (rowarg < 0) rowarg = c0 + j1; bb = bb + 1; }
                 if (km) {
@@ -578,88 +607,104 @@ __device__ void xdrop_block_ring(XrLds& S, const XView& q, int qidx, int M, cons
       }
       if (!stop) o.rows = aend;
     }
+    flush(arow >> 3);                                    // the rows of the last, partial group
     for (int off = 32; off; off >>= 1) cellacc += __shfl_xor(cellacc, off);
     o.cells += cellacc;
     o.ae = ae; o.be = be;
     XD_TICK(tk_rows);
-    // ---- traceback (:165-210) fused with script_to_aligned_string + trim_mismatch_end: whole diagonal runs per step (see xdrop_block_w)
+    // ---- traceback (:165-210) fused with script_to_aligned_string + trim_mismatch_end: whole diagonal runs per step (see xdrop_block_w),
+    // and the gap step behind a run in the same turn (the cell the run stopped at is already in a lane's hands).
     __threadfence();
     __builtin_amdgcn_wave_barrier();
-    // The script rows are read back through a 24-row LDS window that moves down the rows on a fixed grid (16 rows per move, 8 rows of
-    // overlap), so the window after the current one is known in advance: its loads are in flight (in registers) while the walk is
-    // still inside the current window, and a move costs an LDS copy instead of a memory round trip.  The bytes were written by this
-    // wave, so they are read past the L1 (agent scope).
-    constexpr int NW = XR_WIN / 2 / 4 / 64;             // words per lane and chunk array
-    constexpr int WROWS = XR_WIN / 2 / 64;
-    uint32_t nxt[NW], nxt2[NW];
+    // The groups are read back through a 32-row LDS window (four group slots, group g in slot g & 3) that moves down the rows 16 at a
+    // time, so the two groups it needs next are known in advance: their loads are in flight (in registers) while the walk is still
+    // inside the current window.  The dwords were written by this wave, so they are read past the L1 (agent scope).
+    uint32_t nxt[2], nxt2[2];
     bool nxt_two = false;
-    auto issue_window = [&](int row0) {
-#pragma unroll
-        for (int j = 0; j < NW; ++j) nxt[j] = __hip_atomic_load((const uint32_t*)st + row0 * 16 + lane + 64 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // rows row0 .. row0 + 23 lie in at most two words of the bit mask
-        const uint32_t w0 = S.two[row0 >> 5], w1 = S.two[(row0 >> 5) + 1];
-        const unsigned long long bits = (((unsigned long long)w1 << 32) | w0) >> (row0 & 31);
-        nxt_two = __builtin_amdgcn_readfirstlane((int)((uint32_t)bits & ((1u << WROWS) - 1u))) != 0;
+    auto issue_groups = [&](const int g0) __attribute__((always_inline)) {         // groups g0, g0 + 1
+        nxt[0] = __hip_atomic_load(st32 + g0 * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        nxt[1] = __hip_atomic_load(st32 + g0 * 64 + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t tw = (uint32_t)((((unsigned long long)S.two[(g0 >> 5) + 1] << 32) | S.two[g0 >> 5]) >> (g0 & 31)) & 3u;
+        nxt_two = __builtin_amdgcn_readfirstlane((int)tw) != 0;
         if (nxt_two) {
-#pragma unroll
-            for (int j = 0; j < NW; ++j) nxt2[j] = __hip_atomic_load((const uint32_t*)st2 + row0 * 16 + lane + 64 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            nxt2[0] = __hip_atomic_load(st32b + g0 * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            nxt2[1] = __hip_atomic_load(st32b + g0 * 64 + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
-    auto commit_window = [&]() {
-#pragma unroll
-        for (int j = 0; j < NW; ++j) S.win[lane + 64 * j] = nxt[j];
+    auto commit_groups = [&](const int g0) __attribute__((always_inline)) {
+        S.win[0][g0 & 3][lane] = nxt[0];
+        S.win[0][(g0 + 1) & 3][lane] = nxt[1];
         if (nxt_two) {
-#pragma unroll
-            for (int j = 0; j < NW; ++j) S.win[XR_WIN / 8 + lane + 64 * j] = nxt2[j];
+            S.win[1][g0 & 3][lane] = nxt2[0];
+            S.win[1][(g0 + 1) & 3][lane] = nxt2[1];
         }
     };
     int a_index = ae, b_index = be;
-    int st_op = XS_SUB;
+    int st_op = 0;                                       // the op of the step before: 0 = substitution, XN_GA, XN_GB
     int n = 0, nmatch = 0, m = 0, found = 0, want_l1 = 0, first = 0, l1 = 0;
     int sn_n = 0, sn_a = 0, sn_b = 0, sn_m = 0;
-    int wlo = max(ae - (WROWS - 1), 0);                  // first row in the window
-    issue_window(wlo);
-    commit_window();
-    if (wlo > 0) issue_window(max(wlo - XR_MOVE, 0));
+    int wlo = max((ae & ~15) - 16, 0);                   // first row in the window (a multiple of 16): rows [wlo, wlo + 32)
+    issue_groups((wlo >> 3) + 2);
+    commit_groups((wlo >> 3) + 2);
+    issue_groups(wlo >> 3);
+    commit_groups(wlo >> 3);
+    if (wlo > 0) issue_groups((wlo >> 3) - 2);
     __builtin_amdgcn_wave_barrier();
     XD_COUNT(n_win);
+    auto gap_step = [&](const int op) __attribute__((always_inline)) {              // one step that is not a substitution
+        const int cq = op != XN_GA, ct = op != XN_GB;
+        a_index -= cq;
+        b_index -= ct;
+        const int pk = cq | (ct << 1);
+        first = n == 0 ? pk : first;
+        l1 = want_l1 ? pk : l1;
+        want_l1 = 0;
+        ++n;
+        m = 0;
+    };
     while (a_index > 0 || b_index > 0) {
         if (wlo > 0 && a_index - wlo < 8) {              // (a step ends at row wlo - 1 at the lowest: inside the next window)
             __builtin_amdgcn_wave_barrier();
-            commit_window();
-            wlo = max(wlo - 16, 0);
-            if (wlo > 0) issue_window(max(wlo - XR_MOVE, 0));
+            commit_groups((wlo >> 3) - 2);
+            wlo -= 16;
+            if (wlo > 0) issue_groups((wlo >> 3) - 2);
             __builtin_amdgcn_wave_barrier();
             XD_COUNT(n_win);
         }
         XD_COUNT(n_steps);
         const int ri = a_index - lane, bi = b_index - lane;
-        const bool vl = lane < WROWS && ri >= max(wlo, 1) && bi >= 1;
+        const bool vl = lane < 32 && ri >= max(wlo, 1) && bi >= 1;
         const int row = vl ? ri : a_index;
         const int rs = S.rs[row];
         const int ci = (vl ? bi : b_index) - rs;
         const int cc = min(max(ci, 0), XW_STRIDE - 1);
         // (a cell on the walk lies inside its row's window, so its chunk is in the window arrays; what an idle lane reads is not used)
-        const int byte = ((const uint8_t*)S.win)[(row - wlo) * 64 + (cc & 63) + (cc >= 64 ? XR_WIN / 2 : 0)];
-        const unsigned long long sm = __builtin_amdgcn_ballot_w64(vl && ci >= 0 && ci < XW_STRIDE && (byte & XS_OP_MASK) == XS_SUB);
-        const uint32_t mm = (uint32_t)__builtin_amdgcn_ballot_w64((byte & XS_MATCH) != 0);
-        const int byte0 = __builtin_amdgcn_readfirstlane(byte);
-        const int sh = 4 + (st_op & 1) + ((st_op >> 2) << 1);
-        const int op = ((byte0 >> sh) & 1) ? st_op : (byte0 & XS_OP_MASK);
+        const uint32_t word = S.win[cc >> 6][(row >> 3) & 3][cc & 63];
+        const int nib = (int)((word >> ((row & 7) << 2)) & 15u);
+        const unsigned long long vm = __builtin_amdgcn_ballot_w64(vl && ci >= 0 && ci < XW_STRIDE);
+        const unsigned long long sm = __builtin_amdgcn_ballot_w64((nib & 2) == 0) & vm;
+        const uint32_t mm = (uint32_t)__builtin_amdgcn_ballot_w64((nib & 1) != 0);
+        const int nib0 = __builtin_amdgcn_readfirstlane(nib);
+        // the op is the previous one while its extension bit is set in this cell, else the cell's own
+        const int ext = st_op == XN_GA ? (nib0 & XN_EXT_A) : st_op == XN_GB ? (nib0 & XN_EXT_B) : 0;
+        const int own = (nib0 & 2) ? (nib0 & 3) : 0;
+        const int op = ext ? st_op : own;
         st_op = op;
-        if (op != XS_SUB || !(sm & 1)) {
-            const int cq = op != XS_GAP_IN_A, ct = op != XS_GAP_IN_B;
-            const int cm = cq & ct & (byte0 >> 7);
-            a_index -= cq;
-            b_index -= ct;
-            const int pk = cq | (ct << 1) | (cm << 2);
-            first = n == 0 ? pk : first;
-            l1 = want_l1 ? pk : l1;
-            want_l1 = 0;
-            ++n;
-            nmatch += cm;
-            m = cm ? m + 1 : 0;
-            if (m == 4 && !found) { found = 1; want_l1 = 1; sn_n = n; sn_a = a_index; sn_b = b_index; sn_m = nmatch; }
+        if (op != 0 || !(sm & 1)) {
+            if (op != 0) gap_step(op);
+            else {                                       // a substitution at a cell the window does not vouch for (row or column 0): alone
+                const int cm = nib0 & 1;
+                a_index -= 1;
+                b_index -= 1;
+                const int pk = 3 | (cm << 2);
+                first = n == 0 ? pk : first;
+                l1 = want_l1 ? pk : l1;
+                want_l1 = 0;
+                ++n;
+                nmatch += cm;
+                m = cm ? m + 1 : 0;
+                if (m == 4 && !found) { found = 1; want_l1 = 1; sn_n = n; sn_a = a_index; sn_b = b_index; sn_m = nmatch; }
+            }
             continue;
         }
         const uint32_t s32 = (uint32_t)sm;
@@ -692,11 +737,17 @@ __device__ void xdrop_block_ring(XrLds& S, const XView& q, int qidx, int M, cons
         nmatch += __builtin_popcount(Mm);
         a_index -= r;
         b_index -= r;
+        // the cell the run stopped at, when the window vouches for it, holds a gap op of its own (after a substitution the cell's own
+        // op counts): that step now
+        if (r < 32 && ((vm >> r) & 1ull)) {
+            const int gop = __builtin_amdgcn_readlane(nib, r) & 3;
+            st_op = gop;
+            gap_step(gop);
+        }
     }
-    // a window that was asked for and never needed is waited for here: left pending, its loads would put a vmcnt(0) wait — which also
-    // waits for the stores of the row before — at the head of the next block's row loop
-#pragma unroll
-    for (int j = 0; j < NW; ++j) asm volatile("" :: "v"(nxt[j]), "v"(nxt2[j]));
+    // groups that were asked for and never needed are waited for here: left pending, their loads would put a vmcnt(0) wait — which also
+    // waits for the stores of the groups before — at the head of the next block's row loop
+    asm volatile("" :: "v"(nxt[0]), "v"(nxt[1]), "v"(nxt2[0]), "v"(nxt2[1]));
     o.n = n; o.nmatch = nmatch;
     o.l0q = first & 1; o.l0t = (first >> 1) & 1; o.l0m = first >> 2;
     o.l1q = l1 & 1; o.l1t = (l1 >> 1) & 1; o.l1m = l1 >> 2;
@@ -717,7 +768,7 @@ __global__ __launch_bounds__(XW_BLOCK, 6) void xd_extend_w(const uint32_t* __res
     __shared__ typename std::conditional<WIDE, XwLds<XW_WIDE_HF>, XrLds>::type lds[WIDE ? 1 : XW_WAVES];
     auto& S = lds[threadIdx.x >> 6];
     const int lane = lane_id();
-    uint8_t* st = scratch + (size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (WIDE ? XW_WIDE_BYTES : XW_STATE_BYTES);
+    uint8_t* st = scratch + (size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (WIDE ? XW_WIDE_BYTES : XR_STATE_BYTES);
     // the ring kernel's own wide state (a block whose window outgrows the ring is redone in place, below): in global memory
     uint8_t* wst = WIDE ? nullptr : wide_state + (size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * XW_INPLACE_BYTES;
     unsigned long long nblocks = 0, ncells = 0, nrows = 0, nredone = 0;
@@ -956,7 +1007,7 @@ int mhip_xalign_candidates_dev(mhip_ctx* c, const mhip_volume* ref, const mhip_v
     if (!all_wide) {
         const int waves = c->num_cus * (getenv("MECAT_XW_WAVES") ? atoi(getenv("MECAT_XW_WAVES")) : 24);
         const int grid = std::min(waves / XW_WAVES, (2 * n + XW_WAVES - 1) / XW_WAVES);
-        if (c->scratch("xw_state", XW_STATE_BYTES * (size_t)waves, (void**)&d_s)) return -1;
+        if (c->scratch("xw_state", XR_STATE_BYTES * (size_t)waves, (void**)&d_s)) return -1;
         // MECAT_XD_HANDOVER=1: blocks that outgrow the ring go to the second launch (the round-1 arrangement; tests compare the two)
         uint8_t* d_wst = nullptr;
         if (!(getenv("MECAT_XD_HANDOVER") && atoi(getenv("MECAT_XD_HANDOVER")) == 1) && c->scratch("xw_inplace", XW_INPLACE_BYTES * (size_t)waves, (void**)&d_wst)) return -1;

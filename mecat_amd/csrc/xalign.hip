@@ -455,27 +455,38 @@ __device__ void xdrop_block_ring(XrLds& S, const XView& q, int qidx, int M, cons
     int b_size = n_init + 1, best = 0, first_b = 0, ae = 0, be = 0;
     int qreg = 0, cellacc = 0;
     const int wmax = N <= X ? -1 : 64;                   // N <= X: row 0 ran off the end of the target (b_size = N + 1), every row through the general code
-    bool stop = false;
-    int arow = 0;                                        // the last row that was run
     __builtin_amdgcn_wave_barrier();
     XD_TICK(tk_stage);
-    for (int a0 = 1; a0 <= M && !stop; a0 += 64) {
-      // the query bases of the next 64 rows in a register: one v_readlane per row
-      qreg = (a0 - 1 + lane < M) ? xv_at(q, qidx + a0 - 1 + lane) : 0;
-      asm volatile("v_mov_b32 %0, %0" : "+v"(qreg));      // the load is waited for here, not at the row loop's first v_readlane (vmcnt also counts the groups' stores)
-      XD_COUNT(n_qfill);
-      const int aend = min(a0 + 63, M);
-      for (int a = a0; a <= aend; ++a) {
-        if ((a & 7) == 0) flush((a >> 3) - 1);
-        arow = a;
+    // One flat loop with one exit: the compiler lays out a loop nest with early exits as a state machine of flag registers and
+    // re-tested branches — 30 scalar instructions per row of pure control flow in the round-4 kernel, and the scalar side is what
+    // bounds the row (moving five vector instructions of the common row to nine scalar ones cost 10 %).  A row that ends the block
+    // (no kept cell, or a window the ring cannot hold) ends the loop through its bound.
+    int status = 0;                                      // 1: no kept cell in the row (the block's last), 2: the window outgrew the ring
+    int Mlim = M;
+    // the query bases of 64 rows in a register, row a in lane a & 63: one v_readlane per row (idle lanes load a valid base: no divergent branch)
+    qreg = xv_at(q, qidx + min(max(lane - 1, 0), M - 1));
+    asm volatile("v_mov_b32 %0, %0" : "+v"(qreg));      // the load is waited for here, not at the row loop's first v_readlane (vmcnt also counts the groups' stores)
+    XD_COUNT(n_qfill);
+    int a = 1;
+    for (; a <= Mlim; ++a) {
+        if ((a & 7) == 0) {
+            flush((a >> 3) - 1);
+            if ((a & 63) == 0) {
+                qreg = xv_at(q, qidx + min(a + lane - 1, M - 1));
+                asm volatile("v_mov_b32 %0, %0" : "+v"(qreg));
+                XD_COUNT(n_qfill);
+            }
+        }
         const int sh = (a & 7) << 2;
-        const int AC = __builtin_amdgcn_readlane(qreg, a - a0);
+        const int AC = __builtin_amdgcn_readlane(qreg, a & 63);
         const int f0 = first_b, n0 = b_size;
+        S.rs[a] = (uint16_t)f0;                                          // the row's first column (every lane, one address)
         // The common row — one pass, kept cells without a hole between them, gap tail inside the pass — with nothing but what it needs:
         // no carries, no selects for the cases it excludes (checked on the kept mask before anything is stored; a row that fails
         // the check is redone by the general code below).  Masks are compared as masks (s_bfm), "none" is s_ff1's own -1, every lane behind
         // or in front of the kept cells stores (MIN, MIN) — the closing cell is one of them, the others are never read — and the DP cells
         // are counted per lane.
+        bool done = false;
         if (__builtin_expect(n0 - f0 <= wmax, 1)) {                     // (wmax = 64; -1 in a special block)
             const int b = f0 + lane;
             const bool in0 = b < n0;
@@ -516,19 +527,18 @@ __device__ void xdrop_block_ring(XrLds& S, const XView& q, int qidx, int M, cons
                 nib |= (xa ? XN_EXT_A : 0) | (xb ? XN_EXT_B : 0);
                 acc |= (uint32_t)nib << sh;
                 S.HF[b & (XW_RING - 1)] = make_int2(kept ? Hc : X_MIN_SCORE, kept ? Hc - 1 : X_MIN_SCORE);
-                S.rs[a] = (uint16_t)f0;                                  // (every lane, one address)
-                const bool up = exm != 0ull;
-                best += up ? 1 : 0;
-                ae = up ? a : ae;
-                be = up ? f0 + j1 : be;
+                // a new best (all cells above the old one hold old + 1) moves (ae, be) to the first of them; the window of the next row:
+                // from the first kept cell to one behind the last, where lane lk1 wrote the closing (MIN, MIN) cell unless the block ends
+                // there.  Written out: the compiler tests each condition twice over (compare, select a mask, compare the mask).
+                const int nbe = f0 + j1;
+                asm("s_cmp_lg_u64 %[ex], 0\n\ts_cselect_b32 %[ae], %[a], %[ae]\n\ts_cselect_b32 %[be], %[nbe], %[be]\n\ts_addc_u32 %[best], %[best], 0"
+                    : [ae] "+s"(ae), [be] "+s"(be), [best] "+s"(best) : [ex] "s"(exm), [a] "s"(a), [nbe] "s"(nbe) : "scc");
                 first_b = f0 + fkl;
-                b_size = f0 + lk1;
-                b_size += b_size < N ? 1 : 0;                             // the closing cell: lane lk1 wrote its (MIN, MIN)
-                __builtin_amdgcn_wave_barrier();
-                continue;
+                asm("s_add_i32 %[bs], %[f0], %[lk1]\n\ts_cmp_lt_i32 %[bs], %[N]\n\ts_addc_u32 %[bs], %[bs], 0" : [bs] "=&s"(b_size) : [f0] "s"(f0), [lk1] "s"(lk1), [N] "s"(N) : "scc");
+                done = true;
             }
         }
-        {
+        if (!done) {
             const int nlim = max(n0, N);                 // cells that may be kept: the window, and behind it the gap tail while b < N
             o.cells += n0 - f0;
             int bb = best, rowarg = -1, fk = -1, lk = -1, lkH = 0;
@@ -596,17 +606,19 @@ __device__ void xdrop_block_ring(XrLds& S, const XView& q, int qidx, int M, cons
             if (n0 - f0 > 64 || (lk == f0 + 63 && f0 + 64 < N)) pass(std::integral_constant<bool, false>(), f0 + 64);
             XD_COUNT(n_rows2);
             if (bb > best) { best = bb; ae = a; be = rowarg; }
-            if (fk < 0) { first_b = n0; stop = true; o.rows = a; break; }
-            first_b = fk;
-            S.rs[a] = (uint16_t)f0;                                          // (every lane, one address)
-            b_size = lk + 1;
-            if (b_size < N) { S.HF[b_size & (XW_RING - 1)] = make_int2(X_MIN_SCORE, X_MIN_SCORE); ++b_size; }      // the closing cell
-            if (b_size - first_b > XW_RING - 2 || b_size - f0 > XW_STRIDE - 2) { o.overflow = 2; return; }
+            if (fk < 0) { first_b = n0; status = 1; Mlim = 0; }
+            else {
+                first_b = fk;
+                b_size = lk + 1;
+                if (b_size < N) { S.HF[b_size & (XW_RING - 1)] = make_int2(X_MIN_SCORE, X_MIN_SCORE); ++b_size; }      // the closing cell
+                if (b_size - first_b > XW_RING - 2 || b_size - f0 > XW_STRIDE - 2) { status = 2; Mlim = 0; }
+            }
         }
         __builtin_amdgcn_wave_barrier();
-      }
-      if (!stop) o.rows = aend;
     }
+    const int arow = a - 1;                              // the last row that was run
+    o.rows = arow;
+    if (status == 2) { o.overflow = 2; return; }
     flush(arow >> 3);                                    // the rows of the last, partial group
     for (int off = 32; off; off >>= 1) cellacc += __shfl_xor(cellacc, off);
     o.cells += cellacc;

@@ -515,7 +515,9 @@ __device__ void xdrop_block_ring(XrLds& S, const XView& q, int qidx, int M, cons
             asm("s_bfm_b64 %0, %1, %2" : "=s"(want) : "s"(nk), "s"(fkl));
             const int lk1 = fkl + nk;                                     // one behind the last kept lane; no kept cell: -1, as unsigned above 63
             // kept cells are one run that ends in front of lane 63 (a kept lane 63 may have a gap tail behind it: general code)
-            if (__builtin_expect(km == want && (unsigned)lk1 < 64u, 1)) {
+            int runend;                                                   // lk1 if the kept cells are one run, else 64 (compare + select: the compiler's version is seven instructions)
+            asm("s_cmp_eq_u64 %1, %2\n\ts_cselect_b32 %0, %3, 64" : "=s"(runend) : "s"(km), "s"(want), "s"(lk1) : "scc");
+            if (__builtin_expect((unsigned)runend < 64u, 1)) {
                 const bool kept = live && ge;
                 cellacc += in0 ? 1 : 0;
                 const int Hlk = __builtin_amdgcn_readlane(Hc, lk1 - 1);

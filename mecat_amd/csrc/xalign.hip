@@ -665,18 +665,13 @@ __device__ void xdrop_block_ring(XrLds& S, const XView& q, int qidx, int M, cons
     if (wlo > 0) issue_groups((wlo >> 3) - 2);
     __builtin_amdgcn_wave_barrier();
     XD_COUNT(n_win);
-    auto gap_step = [&](const int op) __attribute__((always_inline)) {              // one step that is not a substitution
-        const int cq = op != XN_GA, ct = op != XN_GB;
-        a_index -= cq;
-        b_index -= ct;
-        const int pk = cq | (ct << 1);
-        first = n == 0 ? pk : first;
-        l1 = want_l1 ? pk : l1;
-        want_l1 = 0;
-        ++n;
-        m = 0;
-    };
-    while (a_index > 0 || b_index > 0) {
+    // One turn of the walk: the cells (a - i, b - i) of the diagonal in the lanes, the op of the step (the previous one while its extension
+    // bit is set in this cell, else the cell's own), then either a step that is not a substitution, or the whole run of substitutions the
+    // cells' own ops vouch for plus the gap step behind it.  Two loops share it: the first also looks for the tail's run of four matches
+    // (trim_mismatch_end) and notes the column types the stitching needs; once those are known (a turn or two into the walk) the second
+    // only counts columns and matches — the walk is a scalar program, and the bookkeeping of the first loop is most of its instructions.
+    auto turn = [&](auto lean_tag) __attribute__((always_inline)) {
+        constexpr bool LEAN = decltype(lean_tag)::value;
         if (wlo > 0 && a_index - wlo < 8) {              // (a step ends at row wlo - 1 at the lowest: inside the next window)
             __builtin_amdgcn_wave_barrier();
             commit_groups((wlo >> 3) - 2);
@@ -695,70 +690,70 @@ __device__ void xdrop_block_ring(XrLds& S, const XView& q, int qidx, int M, cons
         // (a cell on the walk lies inside its row's window, so its chunk is in the window arrays; what an idle lane reads is not used)
         const uint32_t word = S.win[cc >> 6][(row >> 3) & 3][cc & 63];
         const int nib = (int)((word >> ((row & 7) << 2)) & 15u);
-        const unsigned long long vm = __builtin_amdgcn_ballot_w64(vl && ci >= 0 && ci < XW_STRIDE);
-        const unsigned long long sm = __builtin_amdgcn_ballot_w64((nib & 2) == 0) & vm;
+        const uint32_t vm = (uint32_t)__builtin_amdgcn_ballot_w64(vl && ci >= 0 && ci < XW_STRIDE);      // cells the window vouches for
+        const uint32_t sm = (uint32_t)__builtin_amdgcn_ballot_w64((nib & 2) == 0) & vm;                  // ... whose own op is a substitution
         const uint32_t mm = (uint32_t)__builtin_amdgcn_ballot_w64((nib & 1) != 0);
         const int nib0 = __builtin_amdgcn_readfirstlane(nib);
-        // the op is the previous one while its extension bit is set in this cell, else the cell's own
         const int ext = st_op == XN_GA ? (nib0 & XN_EXT_A) : st_op == XN_GB ? (nib0 & XN_EXT_B) : 0;
         const int own = (nib0 & 2) ? (nib0 & 3) : 0;
-        const int op = ext ? st_op : own;
-        st_op = op;
-        if (op != 0 || !(sm & 1)) {
-            if (op != 0) gap_step(op);
-            else {                                       // a substitution at a cell the window does not vouch for (row or column 0): alone
-                const int cm = nib0 & 1;
-                a_index -= 1;
-                b_index -= 1;
-                const int pk = 3 | (cm << 2);
-                first = n == 0 ? pk : first;
-                l1 = want_l1 ? pk : l1;
-                want_l1 = 0;
-                ++n;
-                nmatch += cm;
-                m = cm ? m + 1 : 0;
-                if (m == 4 && !found) { found = 1; want_l1 = 1; sn_n = n; sn_a = a_index; sn_b = b_index; sn_m = nmatch; }
-            }
-            continue;
+        int op = ext ? st_op : own;
+        int r = 1, cq = 1, ct = 1;                       // steps of this turn; what the (single) step takes when it is not a run
+        uint32_t Mm = (uint32_t)nib0 & 1u;                 // match bits of the turn's substitution steps
+        if (op != 0) { cq = op != XN_GA; ct = op != XN_GB; Mm = 0u; }
+        else if (sm & 1u) {                              // (else: a substitution at a cell of row or column 0, alone)
+            r = sm == 0xffffffffu ? 32 : __builtin_ctz(~sm);
+            Mm = mm & (r >= 32 ? 0xffffffffu : ((1u << r) - 1u));
         }
-        const uint32_t s32 = (uint32_t)sm;
-        const int r = s32 == 0xffffffffu ? 32 : __builtin_ctz(~s32);
-        const uint32_t mask = r >= 32 ? 0xffffffffu : ((1u << r) - 1u);
-        const uint32_t Mm = mm & mask;
-        const int pk0 = 3 | ((Mm & 1u) << 2);
-        first = n == 0 ? pk0 : first;
-        l1 = want_l1 ? pk0 : l1;
-        want_l1 = 0;
-        const uint32_t inv = ~Mm & mask;
-        if (!found) {
-            const int z = inv ? __builtin_ctz(inv) : r;
-            int hit = -1;
-            if (m + z >= 4) hit = 3 - m;
+        if (!LEAN) {
+            const int pk0 = cq | (ct << 1) | ((int)(Mm & 1u) << 2);
+            first = n == 0 ? pk0 : first;
+            l1 = want_l1 ? pk0 : l1;
+            want_l1 = 0;
+            if (op != 0) m = 0;
             else {
-                const uint32_t Q = Mm & (Mm >> 1) & (Mm >> 2) & (Mm >> 3);
-                if (Q) hit = __builtin_ctz(Q) + 3;
-            }
-            if (hit >= 0) {
-                found = 1;
-                sn_n = n + hit + 1; sn_a = a_index - (hit + 1); sn_b = b_index - (hit + 1);
-                sn_m = nmatch + __builtin_popcount(Mm & ((2u << hit) - 1u));
-                if (hit + 1 < r) l1 = 3 | (int)(((Mm >> (hit + 1)) & 1u) << 2);
-                else want_l1 = 1;
+                const uint32_t mask = r >= 32 ? 0xffffffffu : ((1u << r) - 1u);
+                const uint32_t inv = ~Mm & mask;
+                if (!found) {
+                    const int z = inv ? __builtin_ctz(inv) : r;
+                    int hit = -1;
+                    if (m + z >= 4) hit = 3 - m;
+                    else {
+                        const uint32_t Q = Mm & (Mm >> 1) & (Mm >> 2) & (Mm >> 3);
+                        if (Q) hit = __builtin_ctz(Q) + 3;
+                    }
+                    if (hit >= 0) {
+                        found = 1;
+                        sn_n = n + hit + 1; sn_a = a_index - (hit + 1); sn_b = b_index - (hit + 1);
+                        sn_m = nmatch + __builtin_popcount(Mm & ((2u << hit) - 1u));
+                        if (hit + 1 < r) l1 = 3 | (int)(((Mm >> (hit + 1)) & 1u) << 2);
+                        else want_l1 = 1;
+                    }
+                }
+                m = inv ? r - 1 - (31 - __builtin_clz(inv)) : m + r;
             }
         }
-        m = inv ? r - 1 - (31 - __builtin_clz(inv)) : m + r;
         n += r;
         nmatch += __builtin_popcount(Mm);
-        a_index -= r;
-        b_index -= r;
-        // the cell the run stopped at, when the window vouches for it, holds a gap op of its own (after a substitution the cell's own
-        // op counts): that step now
-        if (r < 32 && ((vm >> r) & 1ull)) {
-            const int gop = __builtin_amdgcn_readlane(nib, r) & 3;
-            st_op = gop;
-            gap_step(gop);
+        a_index -= cq ? r : 0;
+        b_index -= ct ? r : 0;
+        // the cell a run stopped at, when the window vouches for it, holds a gap op of its own (after a substitution the cell's own
+        // op counts): that step in the same turn
+        if (op == 0 && r < 32 && ((vm >> r) & 1u)) {
+            op = __builtin_amdgcn_readlane(nib, r) & 3;
+            const int gq = op != XN_GA, gt = op != XN_GB;
+            a_index -= gq;
+            b_index -= gt;
+            if (!LEAN) {
+                l1 = want_l1 ? (gq | (gt << 1)) : l1;
+                want_l1 = 0;
+                m = 0;
+            }
+            ++n;
         }
-    }
+        st_op = op;
+    };
+    while ((a_index > 0 || b_index > 0) && (!found || want_l1)) turn(std::false_type{});
+    while (a_index > 0 || b_index > 0) turn(std::true_type{});
     // groups that were asked for and never needed are waited for here: left pending, their loads would put a vmcnt(0) wait — which also
     // waits for the stores of the groups before — at the head of the next block's row loop
     asm volatile("" :: "v"(nxt[0]), "v"(nxt[1]), "v"(nxt2[0]), "v"(nxt2[1]));

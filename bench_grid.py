@@ -302,7 +302,7 @@ def run(args):
     dt = float(tmax.item())
     kstats = ctx.kernel_stats()
     counters = ctx.counters()
-    dbg = {s: ctx.debug_counter(s) for s in (9, 12, 15)}
+    dbg = {s: ctx.debug_counter(s) for s in (9, 12, 15, 32)}
     ctx.set_profiling(False)
 
     # result statistics and the reference pins, after the timed region: one more (untimed) pass that brings every cell's table to the host
@@ -383,8 +383,8 @@ def run(args):
             # and, from the committed SQ passes, its instruction issue rates against the nominal per-SIMD rates (one wave64 VALU
             # instruction per 4 cycles for everything but the plain 32-bit class, one SALU instruction per 4 cycles)
             xs = {"dp_cells_per_step": per_step("dw_cells"), "dp_cells_per_s": per_step("dw_cells") / (phase["align"] / 1e3) if phase["align"] > 0 else None,
-                  "rows_per_step": dbg[9] / args.steps, "blocks_per_step": per_step("dw_blocks"),
-                  "cells_per_row": per_step("dw_cells") / max(1.0, dbg[9] / args.steps)}
+                  "rows_per_step": dbg[32] / args.steps, "blocks_per_step": per_step("dw_blocks"),
+                  "cells_per_row": per_step("dw_cells") / max(1.0, dbg[32] / args.steps)}
             if pmc is not None and dname in pmc["instruction_mix"] and avg_ms > 0:
                 im = pmc["instruction_mix"][dname]
                 nominal = 1024 * 2.4 / 4

@@ -357,9 +357,16 @@ int mhip_ctx::scratch(const char* name, size_t bytes, void** out) {
             return -1;
         }
         b.cap = want;
+        b.gen += 1;
     }
     *out = b.p;
     return 0;
+}
+
+uint64_t mhip_ctx::scratch_generation(const char* name) {
+    std::lock_guard<std::mutex> lk(bufs_mu);
+    auto it = bufs.find(name);
+    return it == bufs.end() ? 0 : it->second.gen;
 }
 
 hipEvent_t mhip_ctx::get_event() {

@@ -482,7 +482,11 @@ int mhip_asm_seed_reads_ex(mhip_ctx* c, const mhip_index* idx, const mhip_volume
     // wave's pool) untouched, so nothing is set up again for as long as the buffers and the layout (segments and records per wave) are
     // the same.  A new layout moves the waves' shares: the directories are zeroed and the pools count as uninitialised (hw = 0; the
     // kernel initialises records as it hands them out).
-    const bool same = d_pool == c->as_clean_base && d_dir == c->as_clean_dir && nseg == c->as_clean_nseg && pcap == c->as_clean_pcap;
+    // (keyed on the buffers' allocation generations as well as their addresses: a buffer that grew may come back at its old address
+    // with undefined contents)
+    const uint64_t gens[3] = {c->scratch_generation("as_pool"), c->scratch_generation("as_dir"), c->scratch_generation("as_hw")};
+    const bool same = d_pool == c->as_clean_base && d_dir == c->as_clean_dir && nseg == c->as_clean_nseg && pcap == c->as_clean_pcap &&
+                      gens[0] == c->as_clean_gen[0] && gens[1] == c->as_clean_gen[1] && gens[2] == c->as_clean_gen[2];
     size_t waves_clean = same ? c->as_clean_nrec : 0;
     if (!same) HIPCHK(hipMemsetAsync(d_hw, 0, sizeof(int) * max_waves, c->stream));
     if (waves > waves_clean) {
@@ -503,6 +507,7 @@ int mhip_asm_seed_reads_ex(mhip_ctx* c, const mhip_index* idx, const mhip_volume
     HIPCHK(hipStreamSynchronize(c->stream));
     c->as_clean_base = d_pool;
     c->as_clean_dir = d_dir;
+    c->as_clean_gen[0] = gens[0]; c->as_clean_gen[1] = gens[1]; c->as_clean_gen[2] = gens[2];
     c->as_clean_nseg = nseg;
     c->as_clean_pcap = pcap;
     c->as_clean_nrec = waves_clean;

@@ -43,6 +43,7 @@ struct PendingEv {
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    uint64_t gen = 0;             // bumped by every (re)allocation: what state that outlives a call is keyed on (an address can come back)
 };
 
 struct mhip_ctx {
@@ -61,6 +62,7 @@ struct mhip_ctx {
     // the next one needs, so they are set up once per buffer and layout (asm_seed.hip); as_clean_nrec = waves whose directories are zero
     const void* as_clean_base = nullptr;
     const void* as_clean_dir = nullptr;
+    uint64_t as_clean_gen[3] = {0, 0, 0};   // allocation generations of as_pool, as_dir, as_hw the clean state belongs to
     int as_clean_nseg = 0, as_clean_pcap = 0;
     size_t as_clean_nrec = 0;
     int ae_n = 0;                         // jobs and dense words of the last mhip_asm_extend_run (what mhip_asm_extend_fetch copies)
@@ -68,6 +70,7 @@ struct mhip_ctx {
 
     // returns a device buffer of at least `bytes` (contents undefined)
     int scratch(const char* name, size_t bytes, void** out);
+    uint64_t scratch_generation(const char* name);      // 0: never allocated
     int drain_events();
     hipEvent_t get_event();
 };

@@ -880,8 +880,8 @@ __global__ __launch_bounds__(XW_BLOCK, 6) void xd_extend_w(const uint32_t* __res
     if (lane == 0) {
         atomicAdd(&counters[3], nblocks);
         atomicAdd(&counters[4], ncells);      // DP cells (the slot dw's d-path cells use)
-        atomicAdd(&counters[9], nrows);
-        if (nredone) atomicAdd(&counters[11], nredone);      // debug slot 11: blocks redone in place with the wide window
+        atomicAdd(&counters[32], nrows);                     // slots 32 / 33 are X-drop's own (9 and 11 belong to seed_cand and dw)
+        if (nredone) atomicAdd(&counters[33], nredone);      // blocks redone in place with the wide window
 #ifdef MECAT_XD_STATS
         if (!WIDE) {
             atomicAdd(&counters[16], __builtin_amdgcn_s_memtime() - tk_life);      // wave life, ticks
@@ -1016,10 +1016,11 @@ int mhip_xalign_candidates_dev(mhip_ctx* c, const mhip_volume* ref, const mhip_v
     if (!all_wide) {
         const int waves = c->num_cus * (getenv("MECAT_XW_WAVES") ? atoi(getenv("MECAT_XW_WAVES")) : 24);
         const int grid = std::min(waves / XW_WAVES, (2 * n + XW_WAVES - 1) / XW_WAVES);
-        if (c->scratch("xw_state", XR_STATE_BYTES * (size_t)waves, (void**)&d_s)) return -1;
+        const size_t launched = (size_t)grid * XW_WAVES;      // both per-wave buffers are sized for the waves this call launches
+        if (c->scratch("xw_state", XR_STATE_BYTES * launched, (void**)&d_s)) return -1;
         // MECAT_XD_HANDOVER=1: blocks that outgrow the ring go to the second launch (the round-1 arrangement; tests compare the two)
         uint8_t* d_wst = nullptr;
-        if (!(getenv("MECAT_XD_HANDOVER") && atoi(getenv("MECAT_XD_HANDOVER")) == 1) && c->scratch("xw_inplace", XW_INPLACE_BYTES * (size_t)waves, (void**)&d_wst)) return -1;
+        if (!(getenv("MECAT_XD_HANDOVER") && atoi(getenv("MECAT_XD_HANDOVER")) == 1) && c->scratch("xw_inplace", XW_INPLACE_BYTES * launched, (void**)&d_wst)) return -1;
         HIPCHK(hipMemsetAsync(d_ovf, 0, sizeof(unsigned int), c->stream));
         // MECAT_XD_ORDER=0: jobs in candidate order
         unsigned int* d_order = nullptr;
@@ -1043,7 +1044,7 @@ int mhip_xalign_candidates_dev(mhip_ctx* c, const mhip_volume* ref, const mhip_v
         if (getenv("MECAT_TRACE")) {
             if (d_wst) {
                 unsigned long long redone = 0;
-                HIPCHK(hipMemcpy(&redone, (unsigned long long*)c->d_counters + 11, sizeof(redone), hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(&redone, (unsigned long long*)c->d_counters + 33, sizeof(redone), hipMemcpyDeviceToHost));
                 fprintf(stderr, "[mecat_hip] X-drop: %d units, %llu blocks so far redone in place with the wide window\n", 2 * n, redone);
             } else fprintf(stderr, "[mecat_hip] X-drop: %u of %d units need the wide-window path\n", nwide, 2 * n);
         }

@@ -171,8 +171,9 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
     { TraceTimer tt("load_volume"); load_volume(vn[svid], &ref); }
 
     const char* slab_env = getenv("MECAT_HIP_SLAB");
-    // 20 000 reads per slab; nanopore extension: 60 000 — every X-drop call ends with a short second launch for the units whose window
-    // outgrew the ring (as long as its slowest unit: ~24 ms whatever the slab holds), so fewer, larger calls: 2 per config-5 cell instead of 6
+    // 20 000 reads per slab; nanopore extension: 60 000 — an X-drop call ends with the tail of its longest units (the waves pull units,
+    // longest first, from one cursor: the last ones run on a chip that is emptying), so fewer, larger calls: 2 per config-5 cell instead
+    // of 6.  (The second launch that used to end every call — rounds 1-3, the first reason for this size — is gone since round 4.)
     int slab = slab_env ? std::max(1, atoi(slab_env)) : (opt.tech == TECH_NANOPORE && opt.task == TASK_ALN ? 60000 : 20000);
     if (comm) slab = std::max(shard_chunk, slab - slab % shard_chunk);      // slabs start on chunk boundaries
     const bool writes = out != NULL;
@@ -732,17 +733,24 @@ int main(int argc, char* argv[]) {
         unlink(g_fail_marker);
         signal(SIGSEGV, [](int) { leave_fail_marker(); _exit(139); });
         signal(SIGTERM, [](int) { leave_fail_marker(); _exit(143); });
+        signal(SIGABRT, [](int) { leave_fail_marker(); _exit(134); });      // the reader's and the splitter's ERROR() abort, like the reference's
+        signal(SIGBUS, [](int) { leave_fail_marker(); _exit(135); });       // (an mmap'd input that shrank under the reader)
         const std::string alive = rf.alive(rank);
         std::vector<std::string> peer_failed, peer_alive;
         for (int r = 0; r < world; ++r)
             if (r != rank) { peer_failed.push_back(rf.failed(r)); peer_alive.push_back(rf.alive(r)); }
         const bool watch = !getenv("MECAT_HIP_NO_WATCHDOG");
-        // Markers and heartbeats are only believed when they are younger than this process (a token can be reused — a fixed
-        // MECAT_HIP_RUN_ID, ranks started by hand from one shell — and a failed attempt leaves every rank's failure marker and possibly a
-        // stale heartbeat behind; a rank of the next attempt must not take those for its peers' state before they have started and
-        // cleared them).  The 60 s silence rule applies to a peer only once a heartbeat of THIS attempt has been seen from it.
+        // A token can be reused (a fixed MECAT_HIP_RUN_ID, ranks started by hand from one shell), and a failed attempt leaves every
+        // rank's failure marker and possibly a stale heartbeat behind.  Every rank removes its OWN failure marker when it
+        // starts, so a peer's marker says "the peer failed in the last attempt it started": younger than this process — this attempt, believed
+        // at once; older — either the attempt before (and the peer of this one has not started yet: it will remove it), or this attempt
+        // with the peer started, and dead, more than a launcher's skew before this rank (that peer also removed its heartbeat,
+        // so nothing else would ever notice).  The two are told apart by waiting: an older marker that is still there `grace` seconds
+        // after this rank started (MECAT_HIP_PEER_GRACE_S, default 15) is believed.  The 60 s silence rule applies to a peer only once a
+        // heartbeat of THIS attempt has been seen from it.
         const double t_mine = t_start - 1.0;                     // st_mtime has one-second granularity on some file systems
-        beat = std::thread([&beat_stop, alive, peer_failed, peer_alive, watch, rank, t_mine]() {
+        const double grace = env_int("MECAT_HIP_PEER_GRACE_S", NULL, 15);
+        beat = std::thread([&beat_stop, alive, peer_failed, peer_alive, watch, rank, t_mine, grace]() {
             std::vector<char> seen(peer_alive.size(), 0);
             auto mtime_of = [](const struct stat& sb) { return (double)sb.st_mtim.tv_sec + 1e-9 * (double)sb.st_mtim.tv_nsec; };
             while (!beat_stop.load()) {
@@ -753,7 +761,7 @@ int main(int argc, char* argv[]) {
                     if (!watch || i % 5) continue;
                     for (size_t k = 0; k < peer_failed.size(); ++k) {
                         struct stat sb;
-                        bool dead = stat(peer_failed[k].c_str(), &sb) == 0 && mtime_of(sb) >= t_mine;
+                        bool dead = stat(peer_failed[k].c_str(), &sb) == 0 && (mtime_of(sb) >= t_mine || now_s() - (t_mine + 1.0) > grace);
                         const char* why = "left a failure marker";
                         if (!dead && stat(peer_alive[k].c_str(), &sb) == 0) {
                             if (mtime_of(sb) >= t_mine) seen[k] = 1;
@@ -921,7 +929,10 @@ int main(int argc, char* argv[]) {
         const double w0 = now_s();
         while (world > 1 && !cells && access(fin.c_str(), F_OK) != 0) {
             struct stat sb;
-            if (stat(rf.failed(owner).c_str(), &sb) == 0 && (double)sb.st_mtime >= t_start - 1.0) DIE("rank %d failed before it finished volume %d", owner, i);
+            // (by now every rank that started in this attempt has removed the failure marker of an earlier one: a marker that is there is
+            // this attempt's, or that of a rank that never started — dead either way; same rule as the watchdog's)
+            if (stat(rf.failed(owner).c_str(), &sb) == 0 && ((double)sb.st_mtime >= t_start - 1.0 || now_s() - t_start > env_int("MECAT_HIP_PEER_GRACE_S", NULL, 15)))
+                DIE("rank %d failed before it finished volume %d", owner, i);
             const double now = now_s();
             if (stat(rf.alive(owner).c_str(), &sb) == 0) {
                 if (now - (double)sb.st_mtime > 60.0) DIE("rank %d stopped responding (volume %d unfinished)", owner, i);

@@ -162,7 +162,7 @@ def test_xdrop_wide_windows_low_complexity(hip, ctx, capfd):
     ja = np.array(jobs, dtype=hip.JOB_DTYPE)
     ctx.reset_stats()
     out = hip.align_candidates(ctx, gv, gv, ja, 500, tech=1).copy()
-    assert ctx.debug_counter(11) > 5                          # blocks redone in place with the wide window: the path really ran
+    assert ctx.debug_counter(33) > 5                          # blocks redone in place with the wide window: the path really ran
     os.environ["MECAT_TRACE"] = "1"
     os.environ["MECAT_XD_HANDOVER"] = "1"
     try:

@@ -223,3 +223,22 @@ def test_bench_volumes_are_the_splitter_s_volumes(tmp_path):
         mine = struct.pack("<iii", len(v["lens"]), v["num_bases"], v["start_read_id"]) + v["offs"].tobytes() + v["pac"].tobytes()
         assert mine == open(p, "rb").read(), p
     assert sum(len(v["lens"]) for v in vols) == n
+
+
+def test_a_rank_that_starts_after_a_peer_died_still_notices(tmp_path):
+    """rank 0 dies on a bad input and leaves its failure marker; a rank of the same attempt that starts seconds later (launcher
+    skew) must not ignore that marker for being older than itself — rank 0 also removed its heartbeat, so nothing else would end the
+    wait for the split marker (6 h by default).  An older marker is believed once it has outlived the grace period."""
+    import time
+    wrk = tmp_path / "w"
+    wrk.mkdir()
+    env = dict(os.environ, MECAT_HIP_WORLD="2", MECAT_HIP_RUN_ID="skew", MECAT_HIP_PEER_GRACE_S="2", MECAT_HIP_NO_RESERVE="1")
+    args = [BIN, "-j", "0", "-d", str(tmp_path / "missing.fa"), "-o", str(tmp_path / "o"), "-w", str(wrk)]
+    r0 = subprocess.run(args, capture_output=True, text=True, env=dict(env, MECAT_HIP_RANK="0"), timeout=60)
+    assert r0.returncode != 0
+    assert (wrk / "rank_0.failed.xskew").exists()
+    time.sleep(2.5)                                # more than the one second the marker's age is compared with
+    t0 = time.time()
+    r1 = subprocess.run(args, capture_output=True, text=True, env=dict(env, MECAT_HIP_RANK="1"), timeout=60)
+    assert r1.returncode != 0 and time.time() - t0 < 30, (r1.returncode, r1.stderr[-300:])
+    assert "a peer left a failure marker" in r1.stderr

@@ -18,7 +18,7 @@ M.align_candidates(ctx, vol, vol, jobs, p.min_align_size, tech=1)
 ctx.set_profiling(True); ctx.reset_stats()
 t0 = time.time(); res = M.align_candidates(ctx, vol, vol, jobs, p.min_align_size, tech=1); dt = time.time() - t0
 ks = ctx.kernel_stats(); c = ctx.counters()
-d = {s: ctx.debug_counter(s) for s in range(9, 25)}
+d = {s: ctx.debug_counter(s) for s in range(9, 25)}; d[9] = ctx.debug_counter(32)
 life, stage, rows, trace, rows2, nwin, nsteps, nq, waves = d[16], d[17], d[18], d[19], d[20], d[21], d[22], d[23], max(1, d[24])
 nrows, blocks, cells = d[9], c["dw_blocks"], c["dw_cells"]
 print("jobs %d, %.1f ms (%s)" % (len(jobs), dt * 1e3, ", ".join("%s %.1f" % (k, v[1]) for k, v in ks.items() if k.startswith("xd"))))

@@ -395,9 +395,16 @@ def main():
 
     # the index of the cell's reference volume: from four ranks on built by the ranks together (key-range shards + all-gather,
     # mhip_index_build_sharded), below that rebuilt on every rank; MECAT_HIP_INDEX_SHARD=0 / 1 overrides, as in the driver
-    shard_index = comm is not None and world >= 4
-    if os.environ.get("MECAT_HIP_INDEX_SHARD") is not None:
-        shard_index = comm is not None and os.environ["MECAT_HIP_INDEX_SHARD"] not in ("", "0")
+    # (the library decides by measurement: mhip_index_build_auto builds the first table both ways, timed barrier to barrier, and keeps the
+    # faster way — done here, before the warm-up, so that no timed step carries the measurement)
+    index_how = {"chosen": "replicated", "measured": False}
+    if comm is not None:
+        i0, index_how = comm.index_build_auto(vol)
+        i0.free()
+        index_how["bytes_received_measuring"] = comm.bytes_received()
+        tr0, nr0 = comm.info()
+        if tr0 == 0 and nr0 != world:      # the bench contract: N ranks means N GPUs in one RCCL communicator
+            raise SystemExit("[bench] rank %d: the RCCL communicator has %d ranks, --gpus %d asked for %d" % (rank, nr0, args.gpus, world))
     keep = {}
     released = False
 
@@ -405,7 +412,7 @@ def main():
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         h0 = time.perf_counter()
         ev[0].record(stream)
-        idx = comm.index_build_sharded(vol) if shard_index else M.Index(ctx, vol)
+        idx = comm.index_build_auto(vol)[0] if comm is not None else M.Index(ctx, vol)
         ev[1].record(stream)
         keep["num_kmers"] = idx.num_kmers
         njobs = 0
@@ -464,14 +471,14 @@ def main():
             aligned_bases = int(((r[:, 2] - r[:, 1]).to(torch.int64) * ok).sum().item())
     else:
         tr, nr = comm.info()
-        exch = {"bytes_received_per_step": comm.bytes_received() / max(1, args.steps + args.warmup),
+        exch = {"bytes_received_per_step": (comm.bytes_received() - index_how.get("bytes_received_measuring", 0)) / max(1, args.steps + args.warmup),
                 "transport": "rccl" if tr == 0 else "host files (test hook)", "rccl_ranks": nr,
                 # HIP events around every exchange on the launch stream (rank 0's view), per step
                 "ms": kstats.get("xg_exchange", (0, 0.0))[1] / args.steps, "calls_per_step": kstats.get("xg_exchange", (0, 0.0))[0] / args.steps,
                 "index_exchange_ms": kstats.get("xg_exchange_index", (0, 0.0))[1] / args.steps,
                 "index_build_kernels_ms": sum(v[1] for k, v in kstats.items() if k.startswith(("ix_", "idx"))) / args.steps,
                 "index_rebase_slots_ms": sum(v[1] for k, v in kstats.items() if k.startswith("xg_index")) / args.steps}
-        idx = comm.index_build_sharded(vol) if shard_index else M.Index(ctx, vol)
+        idx = comm.index_build_auto(vol)[0]
         _, h_cnt = comm.seed_reads_sharded(idx, vol, vol, 0, n, params, chunk=CH, cell_shift=0, host=True)
         ncand = int(h_cnt.sum())
         aln_ok = aligned_bases = 0
@@ -483,6 +490,13 @@ def main():
             aligned_bases = int((h_res["query_end"].astype(np.int64) - h_res["query_start"])[okm].sum())
         idx.free()
         exch["records_per_step"] = ncand
+        exch["index_build"] = index_how          # how the cell's table is built, and the two measured times the choice rests on
+        # every rank's own phase times (HIP events on its stream, mean over the timed steps) and wall time: where a short curve fell short
+        mine = {"rank": rank, "phase_ms": [float(x) for x in np.mean([o["ms"] for o in outs], axis=0)],
+                "host_ms_per_step": float(np.mean([sum(o["host_ms"]) for o in outs]))}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        exch["per_rank"] = allr
         exch["note"] = "count-then-payload: 4 B per read + 48 B per candidate (+ 32 B per extension result) from the P - 1 peers"
 
     if rank == 0:
@@ -587,7 +601,7 @@ def main():
             "config": {"workload": "%s: %d reads x %d bp @ %.0f%% error, genome %d, seed %d, k=13, all-vs-all, -j 1 (index+seed+dw)"
                                    % (args.workload, n, L, err * 100, G, seed), "reads": n, "bases": int(num_bases),
                        "parallelism": "1 GPU" if world == 1 else "grid cell sharded: chunks of %d reads, chunk c -> rank c mod %d; RCCL count-then-payload all-gather; index %s"
-                                      % (CH, world, "built in k-mer key-range shards + all-gather" if shard_index else "rebuilt on every rank")},
+                                      % (CH, world, "built in k-mer key-range shards + all-gather" if index_how["chosen"] == "sharded" else "rebuilt on every rank")},
             "candidates": ncand, "overlaps_ok": aln_ok, "aligned_gbase_per_s": aligned_bases / 1e9 / (ms_step / 1e3),
             "overlaps_per_s": aln_ok / (ms_step / 1e3),
             "phase_ms": {"index": float(phase[0]), "seed": float(phase[1]), "align": float(phase[2])},

@@ -211,9 +211,16 @@ def run(args):
         d_counts = torch.zeros((nmax,), dtype=torch.int32, device=dev)
         d_jobs = torch.empty((nmax * maxc + maxc, 5), dtype=torch.int32, device=dev)
         d_res = torch.empty((d_jobs.shape[0], 8), dtype=torch.int32, device=dev)
-    shard_index = comm is not None and world >= 4
-    if os.environ.get("MECAT_HIP_INDEX_SHARD") is not None:
-        shard_index = comm is not None and os.environ["MECAT_HIP_INDEX_SHARD"] not in ("", "0")
+    # (the library decides by measurement: mhip_index_build_auto builds the first table both ways, timed, and keeps the faster way — done
+    # here, before the warm-up, so that no timed step carries the measurement)
+    index_how = {"chosen": "replicated", "measured": False}
+    if comm is not None:
+        i0, index_how = comm.index_build_auto(vols[rows[0]])
+        i0.free()
+        index_how["bytes_received_measuring"] = comm.bytes_received()
+        tr0, nr0 = comm.info()
+        if tr0 == 0 and nr0 != world:
+            raise SystemExit("[bench] rank %d: the RCCL communicator has %d ranks, --gpus asked for %d" % (rank, nr0, world))
     keep = {"num_kmers": {}, "cell": {}}
     L_ = M.lib()
     # cells whose sorted `.can` lines the golden file pins; with many cells (config 5 whole) only those are formatted and hashed
@@ -230,7 +237,7 @@ def run(args):
         evs = []
         for i in rows:
             e0 = torch.cuda.Event(enable_timing=True); e0.record(stream)
-            idx = comm.index_build_sharded(vols[i]) if shard_index else M.Index(ctx, vols[i])
+            idx = comm.index_build_auto(vols[i])[0] if comm is not None else M.Index(ctx, vols[i])
             e1 = torch.cuda.Event(enable_timing=True); e1.record(stream)
             evs.append(("index", e0, e1))
             keep["num_kmers"][i] = idx.num_kmers
@@ -322,8 +329,8 @@ def run(args):
         ncand, aln_ok, aligned_bases = (int(x) for x in t.tolist())
     else:
         tr, nr = comm.info()
-        exch = {"bytes_received_per_step": comm.bytes_received() / max(1, args.steps + args.warmup),
-                "transport": "rccl" if tr == 0 else "host files (test hook)", "rccl_ranks": nr,
+        exch = {"bytes_received_per_step": (comm.bytes_received() - index_how.get("bytes_received_measuring", 0)) / max(1, args.steps + args.warmup),
+                "transport": "rccl" if tr == 0 else "host files (test hook)", "rccl_ranks": nr, "index_build": index_how,
                 "ms": kstats.get("xg_exchange", (0, 0.0))[1] / args.steps, "calls_per_step": kstats.get("xg_exchange", (0, 0.0))[0] / args.steps,
                 "index_exchange_ms": kstats.get("xg_exchange_index", (0, 0.0))[1] / args.steps,
                 "index_build_kernels_ms": sum(v[1] for k, v in kstats.items() if k.startswith(("ix_", "idx"))) / args.steps,
@@ -334,6 +341,12 @@ def run(args):
         t = torch.tensor([ncand, aln_ok, aligned_bases], dtype=torch.int64, device=dev)
         dist.all_reduce(t)          # every rank counted the candidates of its own reads
         ncand, aln_ok, aligned_bases = (int(x) for x in t.tolist())
+    if world > 1 and exch is not None:
+        # every rank's own phase times (HIP events on its stream, mean over the timed steps): where a short curve fell short
+        mine = {"rank": rank, "phase_ms": {k: float(np.mean([o[k] for o in outs])) for k in ("index", "seed", "align")}}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        exch["per_rank"] = allr
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
@@ -412,7 +425,7 @@ def run(args):
                        "cells": ["%d,%d" % c for c in cells] if len(cells) <= 32 else "%d cells" % len(cells),
                        "parallelism": "1 GPU" if world == 1 else ("rows mode: the %d grid rows dealt out by cost (row i = V - i cells), heaviest rank %d cells; no data moves; "
                                                                    "roofline / phase figures are rank 0's own rows" % (len(hv), int(heaviest))) if rows_mode else "every cell sharded: chunks of %d reads, chunk c of volume j -> rank (c + j) mod %d; RCCL count-then-payload "
-                                      "all-gather; index %s" % (CH, world, "built in k-mer key-range shards + all-gather" if shard_index else "rebuilt on every rank")},
+                                      "all-gather; index %s" % (CH, world, "built in k-mer key-range shards + all-gather" if index_how["chosen"] == "sharded" else "rebuilt on every rank")},
             "candidates": ncand, "overlaps_ok": aln_ok, "aligned_gbase_per_s": aligned_bases / 1e9 / (ms_step / 1e3),
             "overlaps_per_s": aln_ok / (ms_step / 1e3), "phase_ms": phase,
             "candidates_per_s_index_seed_phases": ncand / ((phase["index"] + phase["seed"]) / 1e3),

@@ -283,6 +283,11 @@ int  mhip_asm_extend_fetch(mhip_ctx* ctx, int n, int32_t* dirs /*[2 n][6]*/, uin
  * positions and table slices are all-gathered (counts first, then payload), and every rank returns the complete table — equal, array
  * for array, to the one mhip_index_build makes.  Collective: every rank of `comm` calls it with the same volume. */
 int  mhip_index_build_sharded(mhip_comm* comm, const mhip_volume* v, mhip_index** out);
+/* The faster of mhip_index_build on every rank and mhip_index_build_sharded, decided by measurement: the first call on a communicator runs
+ * both (once to warm up, once timed barrier to barrier; the slowest rank's time counts) and keeps the faster one for this and every later
+ * call; MECAT_HIP_INDEX_SHARD=0 / 1 decides without measuring.  ms[0] / ms[1] (may be NULL): the replicated / sharded build times the
+ * decision rests on, 0 when nothing was measured; *sharded (may be NULL): what was used.  No counterpart in the reference. */
+int  mhip_index_build_auto(mhip_comm* comm, const mhip_volume* v, mhip_index** out, double ms[2], int* sharded);
 
 /* ---- mecat2cns re-aligner: ns_banded_sw::GetAlignment of src/mecat2cns/dw.cpp:482-553, which
  * mecat2cns calls for up to 200 candidates per template read (mecat_correction.cpp:286, 347, 431, 494) -------------------

@@ -23,6 +23,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -120,6 +121,9 @@ struct mhip_comm {
     int64_t n_jobs_total = 0;
     int64_t bytes_received = 0;
     const char* xlabel = "xg_exchange";     // name the exchanges are timed under (HIP events on the stream while the context profiles)
+    // mhip_index_build_auto: -1 undecided, 0 every rank rebuilds the table, 1 key-range shards + all-gather; the two times it measured
+    int index_choice = -1;
+    double index_ms[2] = {0.0, 0.0};
 };
 
 namespace {
@@ -825,6 +829,57 @@ int mhip_index_build_sharded(mhip_comm* cm, const mhip_volume* v, mhip_index** o
     HIPCHK(hipStreamSynchronize(c->stream));      // (the host tables above go out of scope)
     guard.p = nullptr;
     *out = idx;
+    return 0;
+}
+
+// The table of a volume, built the faster of the two ways — every rank for itself (mhip_index_build) or together
+// (mhip_index_build_sharded).  Which one wins depends on what the links of the node at hand deliver (DESIGN.md §5 priced it at an assumed
+// 55 GB/s per xGMI link and put the break-even at four ranks; nobody has measured it on more than one GPU: VERDICT r04), so the first
+// call on a communicator measures: both builds once to warm their buffers up, both again timed (barrier to barrier, the slowest rank's
+// time counts), the faster one is kept for this and every later call.  MECAT_HIP_INDEX_SHARD=0 / 1 decides without measuring.
+// ms[0] / ms[1] = the replicated / sharded times the decision rests on (0 when it was not measured); *sharded = what was used.
+int mhip_index_build_auto(mhip_comm* cm, const mhip_volume* v, mhip_index** out, double ms[2], int* sharded) {
+    mhip_ctx* c = cm->ctx;
+    *out = nullptr;
+    if (cm->index_choice < 0) {
+        if (const char* e = getenv("MECAT_HIP_INDEX_SHARD")) cm->index_choice = atoi(e) != 0 && cm->nranks > 1;
+        else if (cm->nranks == 1) cm->index_choice = 0;
+    }
+    if (cm->index_choice < 0) {
+        double t[2] = {0.0, 0.0};
+        mhip_index* keep[2] = {nullptr, nullptr};
+        for (int pass = 0; pass < 2; ++pass)
+            for (int how = 0; how < 2; ++how) {
+                if (keep[how]) { mhip_index_free(keep[how]); keep[how] = nullptr; }
+                if (mhip_comm_barrier(cm)) return -1;
+                const auto t0 = std::chrono::steady_clock::now();
+                const int rc = how ? mhip_index_build_sharded(cm, v, &keep[how]) : mhip_index_build(c, v, &keep[how]);
+                if (agree(cm, rc, "mhip_index_build_auto")) return -1;      // (ends with every rank's stream drained)
+                t[how] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            }
+        // the slowest rank's times, the same on every rank: one exchange of two doubles per rank
+        const int P = cm->nranks;
+        double* d;
+        if (c->scratch("xg_auto", sizeof(double) * 2 * (size_t)(P + 1), (void**)&d)) return -1;
+        HIPCHK(hipMemcpyAsync(d + 2 * P, t, sizeof(t), hipMemcpyHostToDevice, c->stream));
+        std::vector<size_t> bytes((size_t)P, sizeof(t)), displ((size_t)P);
+        for (int r = 0; r < P; ++r) displ[(size_t)r] = sizeof(t) * (size_t)r;
+        if (allgatherv(cm, d + 2 * P, d, bytes, displ)) return -1;
+        std::vector<double> all((size_t)(2 * P));
+        HIPCHK(hipMemcpyAsync(all.data(), d, sizeof(double) * 2 * (size_t)P, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        for (int r = 0; r < P; ++r) { cm->index_ms[0] = std::max(cm->index_ms[0], all[(size_t)(2 * r)]); cm->index_ms[1] = std::max(cm->index_ms[1], all[(size_t)(2 * r + 1)]); }
+        cm->index_choice = cm->index_ms[1] < cm->index_ms[0] ? 1 : 0;
+        if (getenv("MECAT_TRACE") && cm->rank == 0)
+            fprintf(stderr, "[mecat_hip] index build over %d ranks: every rank for itself %.1f ms, key-range shards + all-gather %.1f ms -> %s\n", P,
+                    cm->index_ms[0], cm->index_ms[1], cm->index_choice ? "sharded" : "replicated");
+        mhip_index_free(keep[1 - cm->index_choice]);
+        *out = keep[cm->index_choice];
+    } else {
+        if (cm->index_choice ? mhip_index_build_sharded(cm, v, out) : mhip_index_build(c, v, out)) return -1;
+    }
+    if (ms) { ms[0] = cm->index_ms[0]; ms[1] = cm->index_ms[1]; }
+    if (sharded) *sharded = cm->index_choice;
     return 0;
 }
 

@@ -428,6 +428,19 @@ class Comm:
         _chk(lib().mhip_index_build_sharded(self.h, vol.h, C.byref(idx.h)))
         return idx
 
+    def index_build_auto(self, vol):
+        """mhip_index_build_auto: the faster of Index(ctx, vol) on every rank and index_build_sharded, measured by the first call on this
+        communicator.  -> (index, {"replicated_ms", "sharded_ms", "chosen"})"""
+        idx = Index.__new__(Index)
+        idx.h = C.c_void_p()
+        idx.ctx = self.ctx
+        ms = (C.c_double * 2)()
+        sh = C.c_int()
+        lib().mhip_index_build_auto.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        _chk(lib().mhip_index_build_auto(self.h, vol.h, C.byref(idx.h), ms, C.byref(sh)))
+        return idx, {"replicated_ms": ms[0], "sharded_ms": ms[1], "chosen": "sharded" if sh.value else "replicated",
+                     "measured": ms[0] > 0 or ms[1] > 0}
+
     def seed_reads_sharded(self, idx, ref, reads, rid_begin, rid_end, params, chunk=SHARD_CHUNK, cell_shift=0, host=True):
         """-> (cands [n, maxc] structured, counts [n]) on the host when host=True, else None (tables stay on the device)"""
         n = rid_end - rid_begin

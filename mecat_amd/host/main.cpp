@@ -204,13 +204,12 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
     mhip_index* idx = NULL;
     {
         ScopedTimer t("create_ref_index");
-        // cells mode: from four ranks on the ranks build the table together, each the buckets of its own k-mer key range, and gather
-        // positions and table slices (mhip_index_build_sharded) — a replicated rebuild is the part of a sharded cell that does not
-        // shrink with the number of GPUs; with two or three ranks the 4.7 GB of positions over one or two xGMI links cost more than
-        // the rebuild.  MECAT_HIP_INDEX_SHARD=0 / 1 overrides.
-        bool shard_index = comm && mhip_comm_nranks(comm) >= 4;
-        if (const char* e = getenv("MECAT_HIP_INDEX_SHARD")) shard_index = comm && atoi(e) != 0;
-        if (shard_index) MCHK(mhip_index_build_sharded(comm, dref, &idx));
+        // cells mode: the ranks either build the table together, each the buckets of its own k-mer key range, and gather positions and
+        // table slices (mhip_index_build_sharded) — a replicated rebuild is the part of a sharded cell that does not shrink with the
+        // number of GPUs — or every rank rebuilds it for itself (with few ranks the 4.7 GB of positions over one or two xGMI links can
+        // cost more than the rebuild).  The first table of a run is built both ways, timed, and the faster way is kept
+        // (mhip_index_build_auto; MECAT_HIP_INDEX_SHARD=0 / 1 decides without measuring).
+        if (comm) MCHK(mhip_index_build_auto(comm, dref, &idx, NULL, NULL));
         else MCHK(mhip_index_build(ctx, dref, &idx));
     }
     printf("number of kmers: %lld\n", (long long)mhip_index_num_kmers(idx));
@@ -790,6 +789,7 @@ int main(int argc, char* argv[]) {
     memset(comm_id, 0, sizeof(comm_id));
     if (rank == 0) {
         if (world > 1) unlink(marker.c_str());
+        for (int r = 0; world > 1 && r < world; ++r) unlink(partition_meta_name(opt.output, r).c_str());      // (no rank has started its partition streams yet)
         volume_set_async_dump(world == 1);       // other ranks read the volume files as soon as the run marker exists
         num_vols = split_raw_dataset(opt.reads, opt.wrk_dir, opt.num_threads);
         for (int i = 0; i < num_vols; ++i)
@@ -850,8 +850,9 @@ int main(int argc, char* argv[]) {
 
     // MECAT_HIP_PARTITION=<batch_size>[,<min_read_size>[,<mapping_ratio>]] (additive): also write mecat2cns' partition files
     // <output>.part<k> + <output>.partition_files (partition.h) — partition_candidates for -j 0, partition_m4records for
-    // -j 1 -g 1.  Records are taken straight from the result arrays when this process computes every row itself; after a
-    // resume or in multi-process mode the merged text is partitioned.
+    // -j 1 -g 1.  Records are taken straight from the result arrays: in a one-process run by the one writer, in a multi-process run by a
+    // writer per rank whose streams rank 0 merges at the end (partition.h: same bytes as the one-process files, no text parsed).  Only
+    // after a resume — finished rows' records are on disk as text alone — the merged text is partitioned.
     long part_batch = 0;
     int part_min = opt.tech == TECH_NANOPORE ? 2000 : 5000;      // mecat2cns defaults -l and -r, options.cpp:13-27
     double part_ratio = opt.tech == TECH_NANOPORE ? 0.4 : 0.9;
@@ -878,8 +879,8 @@ int main(int argc, char* argv[]) {
             fprintf(stderr, "[trace] rows dealt: heaviest rank %d cells of %ld (mean %.2f)\n", heaviest, total, (double)total / world);
         }
     }
-    PartitionWriter* pw = (part_batch > 0 && world == 1) ? new PartitionWriter(opt.output, part_batch, part_min) : NULL;
-    if (pw && (int)todo.size() != num_vols) { pw->abandon(); delete pw; pw = NULL; }      // finished rows' records are only on disk
+    PartitionWriter* pw = part_batch > 0 ? new PartitionWriter(opt.output, part_batch, part_min, world > 1 ? rank : -1) : NULL;
+    if (pw && (int)todo.size() != num_vols) { pw->abandon(); delete pw; pw = NULL; }      // finished rows' records are only on disk (every rank sees the same list)
     for (int i = 0; i < num_vols; ++i) {
         if (std::find(todo.begin(), todo.end(), i) == todo.end()) {
             if (rank == 0) fprintf(stderr, "[%s, %u] volume %d has been finished\n\n", __func__, __LINE__, i);
@@ -892,6 +893,7 @@ int main(int argc, char* argv[]) {
         const std::string mine = cells ? fin + ".part" + std::to_string(rank) : wrk;
         FILE* out = fopen(mine.c_str(), "w");
         if (!out) DIE("failed to open file '%s' with mode 'ios::out'", mine.c_str());
+        if (pw) pw->set_row(i);
         process_one_volume(opt, ctx, i, vn, out, pw, part_ratio, comm, shard_chunk);
         if (fclose(out) != 0) DIE("write error!");
         if (cells) {
@@ -918,7 +920,10 @@ int main(int argc, char* argv[]) {
         mhip_ctx_destroy(ctx);
     }
     if (getenv("MECAT_TRACE")) fprintf(stderr, "[trace] main up to here     %.3f s\n", now_s() - t_start);
-    if (rank != 0) return 0;
+    if (rank != 0) {
+        if (pw) { pw->finish(); delete pw; }      // this rank's record streams, complete (rank 0 merges them)
+        return 0;
+    }
 
     // merge_results, pw.cpp:34-46 (rank 0; in rows mode it waits for the rows of the other ranks, but not for a dead one)
     TraceTimer tt_merge("merge_results");
@@ -960,6 +965,19 @@ int main(int argc, char* argv[]) {
         TraceTimer tt("partition_files");
         pw->finish();
         delete pw;
+        if (world > 1) {
+            // the other ranks' streams are complete when their meta files are there (same patience, and the same eye on failure markers, as
+            // for their rows above)
+            const double w0 = now_s();
+            for (int r = 1; r < world; ++r)
+                while (access(partition_meta_name(opt.output, r).c_str(), F_OK) != 0) {
+                    struct stat sb;
+                    if (stat(rf.failed(r).c_str(), &sb) == 0) DIE("rank %d failed before it finished its partition streams", r);
+                    if (now_s() - w0 > merge_wait) DIE("gave up waiting for the partition streams of rank %d after %.0f s", r, merge_wait);
+                    usleep(20 * 1000);
+                }
+            partition_merge_ranks(opt.output, world, part_batch);
+        }
     } else if (part_batch > 0) {
         TraceTimer tt("partition_files(text)");
         if (opt.task == TASK_SEED) partition_candidates_text(opt.output, part_batch, part_min, opt.num_threads);

@@ -18,17 +18,20 @@
 
 static const size_t kFlushRecords = 1u << 16;      // 3.3 MB per batch buffer
 
-PartitionWriter::PartitionWriter(const std::string& can_path, long batch_size, int min_read_size)
-    : can_(can_path), batch_size_(batch_size), min_read_size_(min_read_size), max_id_seen_(-1), total_(0), finished_(false) {
+PartitionWriter::PartitionWriter(const std::string& can_path, long batch_size, int min_read_size, int rank)
+    : can_(can_path), batch_size_(batch_size), min_read_size_(min_read_size), rank_(rank), row_(0), max_id_seen_(-1), total_(0), finished_(false) {
     if (batch_size <= 0) PDIE("batch size must be positive");
+    if (rank_ >= 0) unlink(partition_meta_name(can_.c_str(), rank_).c_str());
 }
+
+std::string partition_meta_name(const char* can_path, int rank) { return std::string(can_path) + ".partmeta.rank" + std::to_string(rank); }
 
 PartitionWriter::~PartitionWriter() {
     if (!finished_) finish();
 }
 
 std::string PartitionWriter::part_name(long batch) const {      // generate_partition_file_name, overlaps_partition.cpp:113-121
-    return can_ + ".part" + std::to_string(batch);
+    return can_ + ".part" + std::to_string(batch) + (rank_ >= 0 ? ".rank" + std::to_string(rank_) : std::string());
 }
 
 void PartitionWriter::flush(long b) {
@@ -39,19 +42,29 @@ void PartitionWriter::flush(long b) {
     B.created = true;
     if (!B.buf.empty() && fwrite(B.buf.data(), sizeof(PartRecord), B.buf.size(), f) != B.buf.size()) PDIE("write error on %s", part_name(b).c_str());
     if (fclose(f) != 0) PDIE("write error on %s", part_name(b).c_str());
+    if (rank_ >= 0) {
+        const std::string kn = part_name(b) + ".key";
+        FILE* k = fopen(kn.c_str(), B.written ? "ab" : "wb");
+        if (!k) PDIE("cannot open %s: %s", kn.c_str(), strerror(errno));
+        if (!B.keys.empty() && fwrite(B.keys.data(), sizeof(Key), B.keys.size(), k) != B.keys.size()) PDIE("write error on %s", kn.c_str());
+        if (fclose(k) != 0) PDIE("write error on %s", kn.c_str());
+        B.keys.clear();
+    }
+    B.written += (long)B.buf.size();
     B.buf.clear();
 }
 
-void PartitionWriter::put(long b, int32_t seq_id, const PartRecord& r) {
+void PartitionWriter::put(long b, int32_t seq_id, const PartRecord& r, int32_t line_read) {
     if ((size_t)b >= batches_.size()) {
         const size_t old = batches_.size();
         batches_.resize((size_t)b + 1);
-        for (size_t i = old; i < batches_.size(); ++i) { batches_[i].min_id = INT_MAX; batches_[i].max_id = INT_MIN; batches_[i].created = false; }
+        for (size_t i = old; i < batches_.size(); ++i) { batches_[i].min_id = INT_MAX; batches_[i].max_id = INT_MIN; batches_[i].created = false; batches_[i].written = 0; }
     }
     Batch& B = batches_[(size_t)b];
     B.min_id = std::min(B.min_id, seq_id);
     B.max_id = std::max(B.max_id, seq_id);
     B.buf.push_back(r);
+    if (rank_ >= 0) B.keys.push_back(Key{row_, line_read});
     ++total_;
     if (B.buf.size() >= kFlushRecords) flush(b);
 }
@@ -76,9 +89,9 @@ void PartitionWriter::add(const CanRec* recs, size_t n) {
         max_id_seen_ = std::max(max_id_seen_, std::max(c.qid, c.sid));
         if (c.qsize < min_read_size_ || c.ssize < min_read_size_) continue;
         normalise(c, false, &r);
-        put(c.qid / batch_size_, c.qid, r);
+        put(c.qid / batch_size_, c.qid, r, c.qid);      // (a `.can` line belongs to the query read in its first column)
         normalise(c, true, &r);
-        put(c.sid / batch_size_, c.sid, r);
+        put(c.sid / batch_size_, c.sid, r, c.qid);
     }
 }
 
@@ -104,22 +117,35 @@ void PartitionWriter::add_m4(const M4Rec* recs, size_t n, double min_cov_ratio) 
         const long sm = (long)m.send - m.soff, ss = (long)(m.ssize * min_cov_ratio);
         if (!(qm >= qs || sm >= ss)) continue;
         normalise_m4(m, false, &r);
-        put(m.qid / batch_size_, m.qid, r);
+        put(m.qid / batch_size_, m.qid, r, m.sid);      // (an `.m4` line carries its query read in the second column, pw_impl.cpp:467-506)
         normalise_m4(m, true, &r);
-        put(m.sid / batch_size_, m.sid, r);
+        put(m.sid / batch_size_, m.sid, r, m.sid);
     }
 }
 
 void PartitionWriter::finish() {
     if (finished_) return;
     finished_ = true;
+    if (rank_ >= 0) {
+        // a rank's streams: what is buffered, then the meta file — its appearance (a rename) tells rank 0 that the streams are complete
+        for (long b = 0; b < (long)batches_.size(); ++b)
+            if (!batches_[(size_t)b].buf.empty()) flush(b);
+        const std::string mn = partition_meta_name(can_.c_str(), rank_), tmp = mn + ".tmp";
+        FILE* f = fopen(tmp.c_str(), "w");
+        if (!f) PDIE("cannot open %s: %s", tmp.c_str(), strerror(errno));
+        fprintf(f, "%d %ld\n", max_id_seen_, (long)batches_.size());
+        for (long b = 0; b < (long)batches_.size(); ++b)
+            if (batches_[(size_t)b].written) fprintf(f, "%ld %ld\n", b, batches_[(size_t)b].written);
+        if (fclose(f) != 0 || rename(tmp.c_str(), mn.c_str()) != 0) PDIE("write error on %s", mn.c_str());
+        return;
+    }
     // the reference opens (creates) a file for every batch below num_batches, also the ones that stay empty (overlaps_store.h:41-58)
     const long num_reads = (long)max_id_seen_ + 1;
     const long num_batches = (num_reads + batch_size_ - 1) / batch_size_;
     if ((long)batches_.size() < num_batches) {
         const size_t old = batches_.size();
         batches_.resize((size_t)num_batches);
-        for (size_t i = old; i < batches_.size(); ++i) { batches_[i].min_id = INT_MAX; batches_[i].max_id = INT_MIN; batches_[i].created = false; }
+        for (size_t i = old; i < batches_.size(); ++i) { batches_[i].min_id = INT_MAX; batches_[i].max_id = INT_MIN; batches_[i].created = false; batches_[i].written = 0; }
     }
     for (long b = 0; b < (long)batches_.size(); ++b)
         if (!batches_[(size_t)b].buf.empty() || !batches_[(size_t)b].created) flush(b);
@@ -133,6 +159,96 @@ void PartitionWriter::finish() {
         fprintf(stderr, "%s contains reads %d --- %d\n", part_name(b).c_str(), B.min_id, B.max_id);
     }
     if (fclose(f) != 0) PDIE("write error on %s", idx.c_str());
+}
+
+template <class T>
+static std::vector<T> read_all(const std::string& path, long count) {
+    std::vector<T> v((size_t)count);
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) PDIE("cannot open %s: %s", path.c_str(), strerror(errno));
+    if (count && fread(v.data(), sizeof(T), (size_t)count, f) != (size_t)count) PDIE("%s is shorter than its rank's meta file says", path.c_str());
+    fclose(f);
+    return v;
+}
+
+long partition_merge_ranks(const char* can_path, int world, long batch_size) {
+    struct KeyT { int32_t row, read; };
+    const std::string can(can_path);
+    int32_t max_id = -1;
+    std::vector<std::vector<long>> count((size_t)world);       // [rank][batch] records
+    for (int r = 0; r < world; ++r) {
+        const std::string mn = partition_meta_name(can_path, r);
+        FILE* f = fopen(mn.c_str(), "r");
+        if (!f) PDIE("cannot open %s: %s", mn.c_str(), strerror(errno));
+        int mid;
+        long nb, b, c;
+        if (fscanf(f, "%d %ld", &mid, &nb) != 2) PDIE("%s: malformed", mn.c_str());
+        max_id = std::max(max_id, (int32_t)mid);
+        count[(size_t)r].assign((size_t)std::max(0L, nb), 0L);
+        while (fscanf(f, "%ld %ld", &b, &c) == 2) {
+            if (b < 0 || b >= nb) PDIE("%s: malformed", mn.c_str());
+            count[(size_t)r][(size_t)b] = c;
+        }
+        fclose(f);
+    }
+    const long num_reads = (long)max_id + 1, num_batches = (num_reads + batch_size - 1) / batch_size;
+    long nfiles = num_batches;
+    for (int r = 0; r < world; ++r) nfiles = std::max(nfiles, (long)count[(size_t)r].size());
+    const std::string idx = can + ".partition_files";
+    FILE* fi = fopen(idx.c_str(), "w");
+    if (!fi) PDIE("cannot open %s: %s", idx.c_str(), strerror(errno));
+    long total = 0;
+    for (long b = 0; b < nfiles; ++b) {
+        std::vector<std::vector<PartRecord>> recs((size_t)world);
+        std::vector<std::vector<KeyT>> keys((size_t)world);
+        long n = 0;
+        for (int r = 0; r < world; ++r) {
+            const long c = b < (long)count[(size_t)r].size() ? count[(size_t)r][(size_t)b] : 0;
+            if (!c) continue;
+            const std::string pn = can + ".part" + std::to_string(b) + ".rank" + std::to_string(r);
+            recs[(size_t)r] = read_all<PartRecord>(pn, c);
+            keys[(size_t)r] = read_all<KeyT>(pn + ".key", c);
+            unlink(pn.c_str());
+            unlink((pn + ".key").c_str());
+            n += c;
+        }
+        // a rank's stream is in (row, read) order, and the lines of one (row, read) are all on one rank: merge by the smallest head
+        std::vector<PartRecord> out;
+        out.reserve((size_t)n);
+        std::vector<size_t> head((size_t)world, 0);
+        int32_t mn = INT_MAX, mx = INT_MIN;
+        for (long k = 0; k < n;) {
+            int best = -1;
+            for (int r = 0; r < world; ++r) {
+                if (head[(size_t)r] >= keys[(size_t)r].size()) continue;
+                if (best < 0) { best = r; continue; }
+                const KeyT &a = keys[(size_t)r][head[(size_t)r]], &c = keys[(size_t)best][head[(size_t)best]];
+                if (a.row < c.row || (a.row == c.row && a.read < c.read)) best = r;
+            }
+            const KeyT key = keys[(size_t)best][head[(size_t)best]];
+            size_t& h = head[(size_t)best];
+            while (h < keys[(size_t)best].size() && keys[(size_t)best][h].row == key.row && keys[(size_t)best][h].read == key.read) {
+                const PartRecord& pr = recs[(size_t)best][h];
+                mn = std::min(mn, pr.sid);                  // (a record sits in the batch of its template read, PartitionWriter::add)
+                mx = std::max(mx, pr.sid);
+                out.push_back(pr);
+                ++h;
+                ++k;
+            }
+        }
+        const std::string pn = can + ".part" + std::to_string(b);
+        FILE* f = fopen(pn.c_str(), "wb");
+        if (!f) PDIE("cannot open %s: %s", pn.c_str(), strerror(errno));
+        if (!out.empty() && fwrite(out.data(), sizeof(PartRecord), out.size(), f) != out.size()) PDIE("write error on %s", pn.c_str());
+        if (fclose(f) != 0) PDIE("write error on %s", pn.c_str());
+        total += n;
+        if (mx == INT_MIN) continue;
+        fprintf(fi, "%s\t%d\t%d\n", pn.c_str(), mn, mx);
+        fprintf(stderr, "%s contains reads %d --- %d\n", pn.c_str(), mn, mx);
+    }
+    if (fclose(fi) != 0) PDIE("write error on %s", idx.c_str());
+    for (int r = 0; r < world; ++r) unlink(partition_meta_name(can_path, r).c_str());
+    return total;
 }
 
 // whitespace separated numbers; column `skip` (the m4 identity, a real) is stepped over.  Returns the number of integers read.

@@ -30,9 +30,15 @@ struct PartRecord {        // ExtensionCandidate, 13 ints = 52 bytes (common/ali
 // The reference leaves qoff/qend/soff/send of the records uninitialised (the `.can` parser fills nine fields); they are
 // written as 0 here.  The reference opens at most num_files partition files at a time and re-reads the text once per
 // group; the bytes written do not depend on that, so this writer has no such parameter.
+//
+// Multi-process runs (rank >= 0): every rank writes the records of ITS lines as streams of its own, `<can_path>.part<k>.rank<r>`, with a
+// key per record beside them (`.key`: grid row, query read of the line — the order the lines have in a one-process run's output) and,
+// in finish(), `<can_path>.partmeta.rank<r>`; partition_merge_ranks() on rank 0 merges the streams of a batch by key into
+// `<can_path>.part<k>` and writes the index file: the same bytes a one-process run writes, and no text is parsed.
 class PartitionWriter {
 public:
-    PartitionWriter(const std::string& can_path, long batch_size, int min_read_size);
+    PartitionWriter(const std::string& can_path, long batch_size, int min_read_size, int rank = -1);
+    void set_row(int row) { row_ = row; }      // the grid row (reference volume) the lines added from now on belong to
     ~PartitionWriter();
     void add(const CanRec* recs, size_t n);
     // the `-j 1 -g 1` flavour (partition_m4records, overlaps_partition.cpp:344-412): lines whose reads are long enough and of
@@ -45,12 +51,15 @@ public:
     long records_written() const { return total_; }
 
 private:
+    struct Key { int32_t row, read; };
     struct Batch {
         std::vector<PartRecord> buf;
+        std::vector<Key> keys;     // rank streams only
         int32_t min_id, max_id;
         bool created;
+        long written;
     };
-    void put(long batch, int32_t seq_id, const PartRecord& r);
+    void put(long batch, int32_t seq_id, const PartRecord& r, int32_t line_read);
     void flush(long batch);
     std::string part_name(long batch) const;
 
@@ -58,10 +67,16 @@ private:
     long batch_size_;
     int min_read_size_;
     std::vector<Batch> batches_;
+    int rank_, row_;
     int32_t max_id_seen_;      // over ALL lines, as get_num_reads (overlaps_partition.cpp:125-139)
     long total_;
     bool finished_;
 };
+
+// rank 0 of a multi-process run, once every rank's `<can_path>.partmeta.rank<r>` exists: merges the ranks' streams (see PartitionWriter)
+// into the partition files and the index file of a one-process run and removes the streams.  Returns the number of records written.
+long partition_merge_ranks(const char* can_path, int world, long batch_size);
+std::string partition_meta_name(const char* can_path, int rank);
 
 // The same from the text file itself (what mecat2cns would parse), scanned by `num_threads` threads over the mapped file.
 // Returns the number of records written.

@@ -12,6 +12,7 @@
 #include "mecat2pw/pw_impl.cpp"
 
 #include <cstring>
+#include <sstream>
 
 /* defined (non-static) in common/xdrop_gapalign.cpp:10 */
 int xdrop_align(const char* A, const int M, const char* B, const int N, int matrix[][4], int gap_open, int gap_extend,
@@ -164,6 +165,24 @@ int refh_xdrop_align(const char* A, int M, const char* B, int N, int forward, in
     res[0] = ae; res[1] = be; res[2] = g_xa->edit_block.num_ops;
     for (int i = 0; i < g_xa->edit_block.num_ops; ++i) { ops[2 * i] = g_xa->edit_block.edit_ops[i].op_type; ops[2 * i + 1] = g_xa->edit_block.edit_ops[i].num; }
     return sc;
+}
+
+/* append_m4v (pw_impl.cpp:576-610) on a caller-made list of n M4Records (104 bytes each, alignment.h:21-37): the per-read sort
+ * (std::sort in this build's mode: libstdc++ parallel mode, compiled the way the reference's release build compiles it) and the
+ * containment filter.  out receives the records append_m4v keeps, in its order; returns their number.  (n <= kResultListSize.) */
+int refh_append_m4v(const void* recs, int n, void* out)
+{
+    M4Record* llist = new M4Record[n > 0 ? n : 1];
+    M4Record* glist = new M4Record[PWThreadData::kResultListSize + (n > 0 ? n : 1)];
+    memcpy((void*)llist, recs, sizeof(M4Record) * (size_t)n);
+    int gsz = 0, lsz = n;
+    std::ostringstream sink;
+    pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+    append_m4v(glist, &gsz, llist, &lsz, &sink, &mu);
+    memcpy(out, (const void*)glist, sizeof(M4Record) * (size_t)gsz);
+    delete[] llist;
+    delete[] glist;
+    return gsz;
 }
 
 int refh_sizeof(int what)

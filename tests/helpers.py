@@ -320,3 +320,36 @@ def cns_pair(rng, n, err, it):
     if it % 13 == 0:
         ts = len(t) - 1
     return q, t, qs, ts
+
+
+def dense_reads(n=1400, L=10000, flank=6250, seed=77, err=0.135):
+    """A deep, repeat-rich set for the `-n >= 1000` paths: n reads of L bases from a genome of 2 * flank + 1500
+    bases that holds a 500-base unit three times in tandem (several candidates for one pair of reads), every tenth read an exact copy
+    of the one before it.  Every pair of reads overlaps by 2 kb or more; the error rate keeps the k-mer buckets under the index's cap
+    of 128 (depth / 2 x 0.865^13), and with `-k 2 -n 1500` the reads late in the file keep more than 1 000 overlaps each, so the
+    reference's per-read m4 sort (pw_impl.cpp:581) sees lists of >= 1000 records.  -> (codes uint8[total], lens int32[n]), ACGT only."""
+    rng = np.random.default_rng(seed)
+    unit = rng.integers(0, 4, 500, dtype=np.uint8)
+    unit2 = unit.copy()
+    unit2[rng.integers(0, 500, 15)] = rng.integers(0, 4, 15, dtype=np.uint8)
+    g = np.concatenate([rng.integers(0, 4, flank, dtype=np.uint8), unit, unit2, unit, rng.integers(0, 4, flank, dtype=np.uint8)])
+    reads, prev = [], None
+    for i in range(n):
+        if i % 10 == 9 and prev is not None:
+            reads.append(prev.copy())
+            continue
+        s = int(rng.integers(0, len(g) - L + 1))
+        t = g[s:s + L]
+        if rng.random() < 0.5:
+            t = (3 - t[::-1]).astype(np.uint8)
+        u = rng.random(L)
+        kept = u >= 0.25 * err
+        sub = (u >= 0.25 * err) & (u < 0.40 * err)
+        bases = np.where(sub, rng.integers(0, 4, L, dtype=np.uint8), t).astype(np.uint8)
+        ins = rng.random(L) < 0.60 * err
+        slots = np.stack([bases, rng.integers(0, 4, L, dtype=np.uint8)], axis=1).ravel()
+        r = slots[np.stack([kept, ins], axis=1).ravel()]
+        reads.append(r)
+        prev = r
+    lens = np.array([len(r) for r in reads], dtype=np.int32)
+    return np.concatenate(reads).astype(np.uint8), lens

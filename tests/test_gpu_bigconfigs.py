@@ -111,6 +111,47 @@ def test_config2_cli_equals_reference(workdir):
     assert ab == g["m4_aligned_bases"]
 
 
+def test_config2_partition_files_two_ranks_equal_one_process(workdir):
+    """SURVEY.md §8f row N4 at config-2 size in a multi-process run: two ranks (both on GPU 0, host-file transport)
+    write the partition records of their own lines as streams, rank 0 merges them by (row, query read) — no text is parsed — and every
+    partition file has the bytes of the one-process run's (2.2 M candidate lines, 4.4 M records of 52 bytes, 20 batches of 5 000 reads)."""
+    import uuid
+    g = _golden("config2")
+    fa = _gen(workdir, g)
+    os.mkdir(os.path.join(workdir, "a"))
+    os.mkdir(os.path.join(workdir, "b"))
+    one = os.path.join(workdir, "a", "o.can")
+    env = {"MECAT_HIP_PARTITION": "5000"}
+    _run(["-j", "0"], fa, one, os.path.join(workdir, "w_one"), env=env)
+    assert _sorted_sha(one) == (g["can_lines"], g["can_sorted_sha256"])
+    two = os.path.join(workdir, "b", "o.can")
+    run = uuid.uuid4().hex[:10]
+    procs = []
+    for rank in (1, 0):
+        e = dict(os.environ, MECAT_HIP_WORLD="2", MECAT_HIP_RANK=str(rank), MECAT_HIP_DEVICE="0", MECAT_HIP_SHARD="cells", MECAT_HIP_COMM="file",
+                 MECAT_HIP_RUN_ID=run, MECAT_HIP_COMM_TIMEOUT_S="300", MECAT_HIP_WAIT_S="600", **env)
+        procs.append(subprocess.Popen([BIN, "-j", "0", "-d", fa, "-o", two, "-w", os.path.join(workdir, "w_two"), "-t", "16"], stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True, env=e))
+    errs = ""
+    for p in procs:
+        out, err = p.communicate(timeout=900)
+        errs += err
+        assert p.returncode == 0, err[-3000:]
+    assert "partition_files(text)" not in errs
+    assert _sorted_sha(two) == (g["can_lines"], g["can_sorted_sha256"])
+    names = sorted(f for f in os.listdir(os.path.join(workdir, "a")) if f.startswith("o.can.part"))
+    assert names == sorted(f for f in os.listdir(os.path.join(workdir, "b")) if f.startswith("o.can.part")) and len(names) == 21
+    total = 0
+    for f in names:
+        a, b = open(os.path.join(workdir, "a", f), "rb").read(), open(os.path.join(workdir, "b", f), "rb").read()
+        if f.endswith(".partition_files"):
+            assert a.replace(one.encode(), b"<out>") == b.replace(two.encode(), b"<out>")
+        else:
+            assert a == b, f
+            total += len(a)
+    assert 0.98 * 104 * g["can_lines"] < total <= 104 * g["can_lines"]      # (two records per line whose reads both reach the 5 000-base minimum)
+
+
 @pytest.mark.parametrize("name", ["config3", "config3_ecoli"])
 def test_config3_three_volume_grid_equals_reference(workdir, name):
     g = _golden(name)

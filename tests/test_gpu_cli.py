@@ -311,3 +311,52 @@ def test_cli_cells_mode_stops_when_a_peer_fails(tmp_path):
                         env=dict(env, MECAT_HIP_RANK="0"), timeout=200)
     assert r0.returncode != 0 and "a peer" in r0.stderr, r0.stderr[-1500:]
     assert time.time() - t0 < 120
+
+
+def _part_files(can):
+    """{suffix: bytes} of <can>.part* and the index file with the output path taken out of its lines"""
+    d, base = os.path.dirname(can), os.path.basename(can)
+    out = {}
+    for f in sorted(os.listdir(d)):
+        if f.startswith(base + ".part"):
+            b = open(os.path.join(d, f), "rb").read()
+            out[f[len(base):]] = b.replace(can.encode(), b"<out>") if f.endswith(".partition_files") else b
+    return out
+
+
+@pytest.mark.parametrize("task,nproc,vols,mode", [("0", 2, 1, "cells"), ("1", 2, 1, "cells"), ("0", 2, 3, "rows"), ("1", 3, 3, "cells")])
+def test_cli_partition_files_of_a_multi_process_run(tmp_path, task, nproc, vols, mode):
+    """SURVEY.md §8f row N4 in a multi-process run: every rank writes the partition records of its own lines as
+    streams of its own (with a (row, query read) key per record), rank 0 merges the streams by key — no text is parsed — and the
+    files are, byte for byte, those of the one-process run (whose record order is the order of ITS output lines: rows, then reads)."""
+    import uuid
+    fa = _fasta(tmp_path, "config1" if vols == 1 else "tiny")
+    env = dict(os.environ, MECAT_HIP_PARTITION="40,1000,0.5" if vols == 1 else "7,1000,0.5", MECAT_HIP_SLAB="300" if vols == 1 else "41")
+    if vols > 1:
+        env["MECAT_HIP_MCS"] = "250000"
+    args = ["-j", task, "-g", "1"]
+    os.mkdir(tmp_path / "a")
+    os.mkdir(tmp_path / "b")
+    one = str(tmp_path / "a" / "o.out")
+    r = subprocess.run([BIN, "-d", fa, "-o", one, "-w", str(tmp_path / "w_one"), "-t", "4"] + args, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    many = str(tmp_path / "b" / "o.out")
+    wrk = str(tmp_path / "w_many")
+    run = uuid.uuid4().hex[:10]
+    procs = []
+    for rank in reversed(range(nproc)):
+        e = dict(env, MECAT_HIP_WORLD=str(nproc), MECAT_HIP_RANK=str(rank), MECAT_HIP_DEVICE="0", MECAT_HIP_SHARD=mode, MECAT_HIP_COMM="file",
+                 MECAT_HIP_RUN_ID=run, MECAT_HIP_SHARD_CHUNK="100", MECAT_HIP_COMM_TIMEOUT_S="60", MECAT_HIP_WAIT_S="120")
+        procs.append(subprocess.Popen([BIN, "-d", fa, "-o", many, "-w", wrk, "-t", "4"] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                      text=True, env=e))
+    errs = []
+    for p in procs:
+        out, err = p.communicate(timeout=300)
+        errs.append(err)
+        assert p.returncode == 0, err[-2000:]
+    assert "partition_files(text)" not in "".join(errs)
+    a, b = _part_files(one), _part_files(many)
+    assert sorted(a) == sorted(b), (sorted(a), sorted(b))          # (no rank streams, keys or meta files left behind either)
+    assert sum(len(v) for k, v in a.items() if k != ".partition_files") > 52 * 200
+    for k in a:
+        assert a[k] == b[k], k

@@ -35,3 +35,24 @@ def test_same_output_as_reference_binary(tmp_path, tech, nreads, L, err, genome,
         got = _lines(BIN, tmp_path, "hip" + tag, fa, a)
         assert len(want) > 1000
         assert got == want, "%s: %d vs %d lines" % (a, len(got), len(want))
+
+
+def test_n1500_on_the_dense_set(tmp_path):
+    """`-n 1500 -k 2` on helpers.dense_reads(): 17 query reads keep 1 000 candidates or more, 14 keep 1 000 overlaps or more — the
+    reference's per-read m4 sort (pw_impl.cpp:581) then works on lists beyond libstdc++ parallel mode's 1 000-element threshold
+    (oracle/_ref is built with the reference's own release flags, oracle/Makefile).  Pins: the sorted outputs of
+    the unmodified reference (tests/golden/dense.json, make_golden_dense.py: six minutes of 32 host threads, not repeated here); the
+    candidate stage is also run side by side where the reference binary travelled."""
+    import json
+    g = json.load(open(os.path.join(H.GOLDEN, "dense.json")))
+    codes, lens = H.dense_reads()
+    fa = str(tmp_path / "dense.fa")
+    H.write_fasta(fa, codes, lens)
+    assert H.sha256_lines(open(fa).read().splitlines()) == g["fasta_sha256"]
+    for name in ("can", "m4_g1"):
+        got = _lines(BIN, tmp_path, "hip_" + name, fa, g[name]["args"])
+        assert len(got) == g[name]["lines"], name
+        assert H.sha256_lines(got) == g[name]["sorted_sha256"], name
+        assert g[name]["query_reads_with_1000_lines_or_more"] >= 10
+    if os.path.exists(REF):
+        assert _lines(REF, tmp_path, "ref_can", fa, g["can"]["args"]) == _lines(BIN, tmp_path, "hip_can2", fa, g["can"]["args"])

@@ -403,3 +403,34 @@ def test_candidates_identical_beyond_the_short_seed_numbers(tech):
         assert np.array_equal(got, out[:k]), rid
         tot += k
     assert tot >= 30
+
+
+@pytest.mark.parametrize("n", [60, 999, 1000, 1500, 4000])
+def test_m4_sort_and_containment_filter_tie_order(n):
+    """append_m4v (pw_impl.cpp:576-610) on lists with MANY ties, through the 1 000-element threshold of libstdc++'s parallel-mode
+    std::sort (VERDICT r04: the repository takes -n up to 2^20, the reference's per-read sort is std::sort under -D_GLIBCXX_PARALLEL).
+    oracle/_ref is compiled the way the reference's release build is (no -fopenmp on compile lines): the parallel-mode sort then runs as
+    one piece and keeps the sequential introsort's order of equal keys — which is what the restatement (plain std::sort, m4sort.cpp) and
+    the product's driver (plain std::sort) produce.  Records carry their input position in vscore, so the comparison sees the order."""
+    R, O = H.ref(), H.orc()
+    R.refh_append_m4v.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    R.refh_append_m4v.restype = C.c_int
+    rng = np.random.default_rng(1000 + n)
+    for it in range(6):
+        recs = (H.OrcM4 * n)()
+        nq = max(1, n // (3 + 4 * it))                       # few subjects: long runs of equal qid
+        for i in range(n):
+            m = recs[i]
+            m.qid = int(rng.integers(0, nq)); m.sid = 7; m.ident = 90.0; m.vscore = i; m.qdir = 0
+            size = int(rng.choice([2000, 2500, 3000, 3000, 4000]))      # few sizes: many ties inside a qid
+            m.qoff = int(rng.integers(0, 300)) * (it % 2); m.qend = m.qoff + size; m.qsize = 20000
+            m.sdir = int(rng.integers(0, 2))
+            m.soff = int(rng.integers(0, 300)) * (it % 3 == 0); m.send = m.soff + size + int(rng.integers(0, 50)); m.ssize = 20000
+            m.qext = m.qoff + 10; m.sext = m.soff + 10
+        a = (H.OrcM4 * n)(); b = (H.OrcM4 * n)(); work = (H.OrcM4 * n)()
+        C.memmove(work, recs, C.sizeof(recs))
+        ka = R.refh_append_m4v(C.byref(recs), n, C.byref(a))
+        kb = O.orc_m4_postfilter(C.byref(work), n, C.byref(b))
+        assert ka == kb, (n, it, ka, kb)
+        assert [a[i].vscore for i in range(ka)] == [b[i].vscore for i in range(kb)], (n, it)
+        assert bytes(a)[: ka * C.sizeof(H.OrcM4)] == bytes(b)[: kb * C.sizeof(H.OrcM4)]

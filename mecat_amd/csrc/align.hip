@@ -823,8 +823,11 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                     lin_l += row_bytes;
                     if (full) ring_st(rbase, lin_l - 2u * sl - 2u, sepv);
                     band_update(1, last_m0, last_mp, std::true_type{}, ns_a, ns_b);
-                    if (ended) break;
-                    d += 1;
+                    // (a row that reached an end leaves the loop through its bound: a second exit makes the compiler build a machine of
+                    // flag registers and re-tested branches around every row)
+                    const int go = ended ? 0 : 1;
+                    rows_left = go ? rows_left : -1;
+                    d += go;
                     __builtin_amdgcn_wave_barrier();
                 }
                 if (ended) break;
@@ -836,8 +839,9 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                     row_passes(2, ns_a, ns_b, fast2{});
                     band_update(2, last_m0, last_mp, std::true_type{}, ns_a, ns_b);
                     lin_l += row_bytes;
-                    if (ended) break;
-                    d += 1;
+                    const int go = ended ? 0 : 1;
+                    rows_left = go ? rows_left : -1;
+                    d += go;
                     __builtin_amdgcn_wave_barrier();
                 }
                 if (ended) break;

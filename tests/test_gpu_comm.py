@@ -131,6 +131,48 @@ def test_sharded_index_build_equals_single_build(data, nranks):
         assert nbytes < 4 * idx.num_kmers + (4 + 16) * (1 << 26) + 4096, (nbytes, idx.num_kmers)
 
 
+@pytest.mark.parametrize("nranks,force", [(2, None), (3, None), (2, "1"), (2, "0")])
+def test_index_build_auto_measures_then_keeps_one_way(data, nranks, force, monkeypatch):
+    """mhip_index_build_auto: the first call on a communicator builds the table both ways, timed barrier to barrier,
+    every rank arrives at the same choice (the slowest rank's times), later calls build that way without measuring; the table is the
+    single build's either way.  MECAT_HIP_INDEX_SHARD decides without measuring."""
+    M, vol, idx = data["M"], data["vol"], data["idx"]
+    want_c, want_o = idx.download()
+    if force is None:
+        monkeypatch.delenv("MECAT_HIP_INDEX_SHARD", raising=False)
+    else:
+        monkeypatch.setenv("MECAT_HIP_INDEX_SHARD", force)
+    d = tempfile.mkdtemp(prefix="mecat_comm_")
+    run = uuid.uuid4().hex[:8]
+
+    def rank_body(r):
+        ctx = M.Context(0)
+        cm = M.Comm(ctx, nranks, r, hostfile_dir=d, run_id=run)
+        cm.barrier()
+        got = []
+        for call in range(2):
+            ix, how = cm.index_build_auto(vol)
+            got.append((how, ix.download(), ix.num_kmers))
+            ix.free()
+        cm.barrier()
+        cm.close()
+        ctx.close()
+        return got
+
+    outs = _run_ranks(nranks, rank_body)
+    first = outs[0][0][0]
+    assert first["measured"] == (force is None)
+    if force is None:
+        assert first["replicated_ms"] > 0 and first["sharded_ms"] > 0
+        assert first["chosen"] == ("sharded" if first["sharded_ms"] < first["replicated_ms"] else "replicated")
+    else:
+        assert first["chosen"] == ("sharded" if force == "1" else "replicated")
+    for r, calls in enumerate(outs):
+        for how, (c, o), nk in calls:
+            assert how == first, (r, how, first)              # same times and the same choice on every rank, unchanged by the second call
+            assert nk == idx.num_kmers and np.array_equal(c, want_c) and np.array_equal(o, want_o), r
+
+
 def test_rccl_loads_and_moves_bytes_on_this_device(data):
     """the RCCL transport itself cannot run two ranks on one GPU; this checks what can be checked here: librccl is found,
     every symbol the library uses resolves, a communicator comes up on the context's device and both transport forms

@@ -30,11 +30,13 @@
 // HBM fraction is small by construction; cells and snake bases are counted for the VALU/LDS view.
 #include <stddef.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 #include <type_traits>
 
 #include "common.h"
+#include "cns_fwd.h"
 
 #define AL_BLOCK 256
 #define AL_WAVES (AL_BLOCK / WAVE)
@@ -497,11 +499,20 @@ template <int OFF> __device__ __forceinline__ unsigned long long clamped_bits_at
 #ifndef DW2_WAVES_PER_SIMD
 #define DW2_WAVES_PER_SIMD 8
 #endif
-__global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const uint32_t* __restrict__ rpac, const mhip_offset_t* __restrict__ roffs,
+// CNS = false: mecat2pw's aligner (DiffAligner::go).  CNS = true: the forward rows of mecat2cns' re-aligner (dw.cpp:146-375; cns_fwd.h) —
+// the same d-rows under its block rules (square blocks of 500, or the rest when it is <= 600; max_d from the error rate; a block that
+// reaches no end ends the direction: no best-point fallback; every block but the last is cut in front of its last four matches), plus
+// a 16-byte record per row in the row log and a record per block that contributes columns, for cns_trace to find the paths.
+#ifndef CNS_FWD_WAVES_PER_SIMD
+#define CNS_FWD_WAVES_PER_SIMD 8
+#endif
+template <bool CNS>
+__global__ __launch_bounds__(AL_BLOCK, CNS ? CNS_FWD_WAVES_PER_SIMD : DW2_WAVES_PER_SIMD) void dw_extend2(const uint32_t* __restrict__ rpac, const mhip_offset_t* __restrict__ roffs,
                                                        const uint32_t* __restrict__ qpac, const mhip_offset_t* __restrict__ qoffs,
                                                        const mhip_aln_job* __restrict__ jobs, int n, DirResult* __restrict__ dres,
                                                        DwHandover* __restrict__ hand, unsigned int* __restrict__ hand_count,
-                                                       unsigned int* __restrict__ cursor, unsigned long long* __restrict__ counters) {
+                                                       unsigned int* __restrict__ cursor, unsigned long long* __restrict__ counters,
+                                                       const CnsFwdArgs ca) {
     __shared__ HalfLds lds[AL_WAVES][2];
     __shared__ __attribute__((aligned(2 * RCAP))) uint16_t rings[AL_WAVES * 2][RCAP];
     const int lane = lane_id(), hh = lane >> 5, sl = lane & 31;
@@ -544,6 +555,12 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
     unsigned int pb_l = 0;      // ring position of the previous row's entry for diagonal (this row's min_k) - 1, + 2 sl
     unsigned int rlin_l = 0;    // ring position of the row that ran last, + 2 sl
     int dlim = 0;               // rows run while d < dlim: max_d of the block, 0 once an end was reached / without a block
+    // CNS: the unit's share of the row log [logpos, logend), the record of the current block's row 0, and whether the unit met something
+    // the log cannot hold (a row of more than 64 diagonals, a cut of 127 or more, more rows than its share): such a unit is handed over
+    unsigned int logpos = 0, logend = 0, blk_log0 = 0, blkpos = 0, blkend = 0;
+    bool cns_bad = false;
+    unsigned long long fl0 = 0, fl1 = 0;       // lanes whose diagonal came from k - 1, first / second pass of the row that ran last
+    int last_ns = 0;                           // its slots
 
     while (true) {
 #ifdef MECAT_DW_STATS
@@ -574,11 +591,20 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                     qidx = tidx = 0;
                     Rq = Rt = Rm = Rc = Rb = 0;
                     need_unit = false;
+                    if (CNS) { logpos = ca.logbase[u]; logend = ca.logbase[u + 1]; blkpos = ca.blockbase[u]; blkend = ca.blockbase[u + 1]; cns_bad = false; }
                 }
             }
             // ---- 2. block setup: retrieve_next_aln_block (gapalign.cpp:9-45) + staging
             if (setup) {
                 const int qleft = query_size - qidx, tleft = target_size - tidx;
+                if (CNS) {      // dw_in_one_direction, dw.cpp:319-332
+                    const int ext = min(qleft, tleft);
+                    if (ext > SEG_BLK + 100) { qblk = SEG_BLK; last_block = 0; } else { qblk = max(ext, 0); last_block = 1; }
+                    tblk = qblk;
+                    band_tol = (int)(0.3 * qblk);
+                    max_d = (int)(2.0 * ca.error_rate * (qblk + qblk));
+                    blk_log0 = logpos;
+                } else {
                 if (qleft < SEG_BLK + 100 || tleft < SEG_BLK + 100) {
                     qblk = min(qleft, (int)(tleft + tleft * 0.2));
                     tblk = min(tleft, (int)(qleft + qleft * 0.2));
@@ -588,6 +614,7 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                 tblk = max(tblk, 0);
                 band_tol = (int)(0.3 * (qblk > tblk ? qblk : tblk));
                 max_d = (int)(.3 * (qblk + tblk));
+                }
                 for (int w = sl; w < SEQ_WORDS2; w += 32) {      // word w = logical bases 16w .. 16w+15, first base in the low bits
                     S.Qp[w] = (w * 16 < qblk + 32) ? view_word_le(q, qidx + w * 16) : 0u;
                     S.Tp[w] = (w * 16 < tblk + 32) ? view_word_le(t, tidx + w * 16) : 0u;
@@ -713,6 +740,7 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
             constexpr int FAST = decltype(fast_tag)::value;
 
             row_bytes = 2u * (unsigned)nslot + 2u;
+            last_ns = nslot;
             int mmax = -0x40000000, m0 = -0x40000000, mp = -0x40000000;
             unsigned long long e = 0;
             int j = 0;
@@ -744,6 +772,12 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                     int v1;
                     asm("v_add_u16 %0, 1, %1" : "=v"(v1) : "v"(vl));
                     asm("v_max_i16 %0, %1, %2" : "=v"(x) : "v"(v1), "v"(vr));
+                }
+                if (CNS) {
+                    // the step the reference's traceback will read off V (dw.cpp:176-179: from k + 1 when k == min_k, or k != max_k and
+                    // V[k - 1] < V[k + 1]): with the entries the ring holds at a band's two edges (see above) that is "vl >= vr" everywhere
+                    const unsigned long long fb = BALLOT(vl >= vr) & amask;
+                    if (j == 0) fl0 = fb; else if (j == 1) fl1 = fb;
                 }
                 // 0 <= y <= t_len and x <= q_len on every live diagonal (a diagonal at an end stops the block); idle lanes sit
                 // at (q_len, 0), where lim == 0
@@ -800,6 +834,19 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
 #else
 #define DWS_ROW(rmask, a, b, nj)
 #endif
+        // CNS: the record of the row that just ran and of the band update behind it (cns_fwd.h).  Every lane of a half stores the same 16
+        // bytes at the same place: no lane predicate to set up, and the coalescer makes one write of it.
+        auto log_row = [&](const int NJ, auto both_tag) __attribute__((always_inline)) {
+            if constexpr (CNS) {
+                constexpr bool BOTH = decltype(both_tag)::value;
+                if (BOTH || inblock) {
+                    const uint32_t lo = (uint32_t)(fl0 >> (hh << 5)), hi = NJ >= 2 ? (uint32_t)(fl1 >> (hh << 5)) : 0u;
+                    if (NJ > 2 || cut >= 127 || logpos >= logend) cns_bad = true;
+                    else if (sl == 0) ca.rowlog[logpos] = CnsRowRec{lo, hi, (uint32_t)last_ns | ((uint32_t)cut << 8), 0u};
+                    logpos += 1;
+                }
+            }
+        };
         int ns_a = __builtin_amdgcn_readlane(nslot, 0), ns_b = __builtin_amdgcn_readlane(nslot, 32);
         if (inmask == ~0ull) {
             // Both halves in a block (98.6 % of the dual rows; it stays that way for as long as the loop runs): the band update writes
@@ -823,6 +870,7 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                     lin_l += row_bytes;
                     if (full) ring_st(rbase, lin_l - 2u * sl - 2u, sepv);
                     band_update(1, last_m0, last_mp, std::true_type{}, ns_a, ns_b);
+                    log_row(1, std::true_type{});
                     // (a row that reached an end leaves the loop through its bound: a second exit makes the compiler build a machine of
                     // flag registers and re-tested branches around every row)
                     const int go = ended ? 0 : 1;
@@ -838,6 +886,7 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                     rows_left -= 1;
                     row_passes(2, ns_a, ns_b, fast2{});
                     band_update(2, last_m0, last_mp, std::true_type{}, ns_a, ns_b);
+                    log_row(2, std::true_type{});
                     lin_l += row_bytes;
                     const int go = ended ? 0 : 1;
                     rows_left = go ? rows_left : -1;
@@ -856,6 +905,7 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                 lin_l += row_bytes;
                 if ((ns_max & 31) == 0) ring_st(rbase, lin_l - 2u * sl - 2u, sepv);      // a half fills its last pass: no idle lane for the entry behind its row
                 band_update(NJ, last_m0, last_mp, std::true_type{}, ns_a, ns_b);
+                log_row(NJ, std::true_type{});
                 if (ended) break;
                 d += 1;
                 __builtin_amdgcn_wave_barrier();
@@ -874,6 +924,7 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
                 lin_l += row_bytes;
                 if ((ns_max & 31) == 0) ring_st(rbase, lin_l - 2u * sl - 2u, sepv);
                 band_update(NJ, last_m0, last_mp, std::false_type{}, ns_a, ns_b);
+                log_row(NJ, std::false_type{});
                 if (ended) break;
                 d += 1;
                 __builtin_amdgcn_wave_barrier();
@@ -915,12 +966,13 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
 
         // ---- 4. tail traceback == trim_mismatch_end(.., 4, ..) (gapalign.cpp:47-68), for the halves whose rows just ended
         bool has_aln = fin && aligned;
-        bool handover = fin && d > 0 && !aligned;       // rows ran without reaching an end: needs the best point (dw_extend)
+        // rows ran without reaching an end: needs the best point (dw_extend).  CNS: Align has failed, the direction ends (dw.cpp:302-304)
+        bool handover = !CNS && fin && d > 0 && !aligned;
         const int end_y = end_x - end_k;
         const int aln_size = (end_x + end_y + end_d) / 2;
         int cd = end_d, ck = end_k, cx2 = end_x;
         int qcnt = 0, tcnt = 0, acnt = 0, found = 0;
-        bool tracing = has_aln;
+        bool tracing = CNS ? (has_aln && !last_block) : has_aln;      // (CNS: a last block keeps all of its columns, dw.cpp:353-358)
         // Rows are walked back over the entries between them: behind row r sits ~(slots of r | left cut of row r - 1 << 8).  clin / cmin /
         // cns: ring position, first diagonal and slots of row cd (the row that reached the end is the row that ran last).
         const unsigned int lin_u = lin_l - 2u * sl;
@@ -970,7 +1022,44 @@ __global__ __launch_bounds__(AL_BLOCK, DW2_WAVES_PER_SIMD) void dw_extend2(const
         // ---- 5. block accounting (dw_in_one_direction, diff_gapalign.cpp:259-290); a block this kernel cannot finish (0.07 %: the
         // tail needs a row that left the ring, or no end was reached) hands the unit over to dw_extend, which redoes that block
         // and the rest of the unit with every row kept
-        if (fin) {
+        if (CNS && fin) {
+            // dw_in_one_direction, dw.cpp:333-373.  A block that reached an end contributes the columns in front of its last run of four
+            // matches (all of them when it is the direction's last block) and the next block starts there; a block without such a run, or
+            // one that would contribute no query base, ends the direction without contributing.
+            bool done = true;
+            if (handover || cns_bad) {
+                if (sl == 0) {
+                    ca.hand_units[1u + atomicAdd(ca.hand_units, 1u)] = unit;
+                    CnsDir D = {0, 0, 0, 0, 0, -1};
+                    ca.dres[unit] = D;
+                    nhand += 1;
+                }
+            } else {
+                nblocks += (sl == 0) ? 1u : 0u;
+                cells += (sl == 0) ? ((lin_l - 6u) >> 1) - (unsigned)d : 0u;
+                bool keep = has_aln && (last_block || found);
+                const int kept_q = end_x - qcnt, kept_t = end_y - tcnt, kept_cols = aln_size - acnt;      // (last block: nothing was walked)
+                keep = keep && kept_q != 0;
+                if (keep && Rc + kept_cols > ca.dir_cols_cap) { keep = false; if (sl == 0) atomicExch(ca.err_flag, 1); }
+                if (keep) {
+                    if (sl == 0) {
+                        if (blkpos < blkend) {
+                            CnsBlockRec B = {unit, qidx, tidx, qblk, end_d, end_k, end_mk, end_x, Rc, kept_cols, blk_log0, 0};
+                            ca.blocks[blkpos] = B;
+                        } else atomicExch(ca.err_flag, 2);
+                    }
+                    blkpos += 1;
+                    Rc += kept_cols; Rq += kept_q; Rt += kept_t;
+                    if (!last_block) { qidx += kept_q; tidx += kept_t; done = false; }
+                }
+                if (done && sl == 0) { CnsDir D = {Rc, Rq, Rt, 0, 0, 0}; ca.dres[unit] = D; }
+            }
+            if (done) need_unit = true;
+            inblock = false;
+            setup = true;
+            dlim = 0;
+        }
+        if (!CNS && fin) {
             bool stop;
             if (handover) {
                 if (sl == 0) {
@@ -1114,6 +1203,19 @@ __global__ __launch_bounds__(256) void dw_make_jobs(const mhip_candidate* __rest
     jobs[slot] = jb;
 }
 
+// the forward pass of the mecat2cns re-aligner (cns_fwd.h): dw_extend2 under mecat2cns' block rules, 24 waves per CU
+int cns_forward_launch(mhip_ctx* c, const mhip_volume* ref, const mhip_volume* reads, const void* d_jobs, int n, const CnsFwdArgs& args) {
+    unsigned int* d_cur;
+    if (c->scratch("cnf_cursor", 64, (void**)&d_cur)) return -1;
+    HIPCHK(hipMemsetAsync(d_cur, 0, 16, c->stream));
+    const int waves = getenv("MECAT_CNS_WAVES") ? std::max(4, std::min(32, atoi(getenv("MECAT_CNS_WAVES")))) : 4 * CNS_FWD_WAVES_PER_SIMD;
+    const int grid = std::min(c->num_cus * waves / AL_WAVES, (n + AL_WAVES - 1) / AL_WAVES);
+    LAUNCH(c, "cns_forward", dw_extend2<true>, grid, AL_BLOCK, 0, (const uint32_t*)ref->d_pac, (const mhip_offset_t*)ref->d_offs,
+           (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs, (const mhip_aln_job*)d_jobs, n, (DirResult*)nullptr,
+           (DwHandover*)nullptr, (unsigned int*)nullptr, d_cur, (unsigned long long*)c->d_counters, args);
+    return 0;
+}
+
 extern "C" {
 
 int mhip_jobs_from_candidates_dev(mhip_ctx* c, const void* d_cands, const void* d_counts, int n_reads, int maxc, int rid_begin,
@@ -1165,12 +1267,14 @@ int mhip_align_candidates_dev(mhip_ctx* c, const mhip_volume* ref, const mhip_vo
         const int grid2 = std::min(c->num_cus * waves2 / AL_WAVES, (n + AL_WAVES - 1) / AL_WAVES);
         if (getenv("MECAT_TRACE")) {
             int nb = 0;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dw_extend2, AL_BLOCK, 0);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dw_extend2<false>, AL_BLOCK, 0);
             fprintf(stderr, "[dw trace] occupancy query: %d blocks of %d threads per CU; grid %d; HalfLds %zu bytes\n", nb, AL_BLOCK, grid2, sizeof(HalfLds));
         }
-        LAUNCH(c, "dw_extend2", dw_extend2, grid2, AL_BLOCK, 0, (const uint32_t*)ref->d_pac, (const mhip_offset_t*)ref->d_offs,
+        CnsFwdArgs none;
+        memset(&none, 0, sizeof(none));
+        LAUNCH(c, "dw_extend2", dw_extend2<false>, grid2, AL_BLOCK, 0, (const uint32_t*)ref->d_pac, (const mhip_offset_t*)ref->d_offs,
                (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs, (const mhip_aln_job*)d_jobs, n, d_dres, d_hand, d_cur + 1,
-               d_cur, (unsigned long long*)c->d_counters);
+               d_cur, (unsigned long long*)c->d_counters, none);
         // the units it handed over (a fraction of a percent), finished by the one-unit kernel with every row kept; the launch reads
         // their number on the device, so nothing waits for the host
         LAUNCH(c, "dw_extend", dw_extend, grid, AL_BLOCK, 0, (const uint32_t*)ref->d_pac, (const mhip_offset_t*)ref->d_offs,

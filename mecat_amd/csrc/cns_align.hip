@@ -16,6 +16,7 @@
 // (coalesced copies), which keeps the LDS footprint at 6.3 KB per wave = 24 waves per CU.
 #include <algorithm>
 
+#include "cns_fwd.h"
 #include "dw_helpers.h"
 
 #define CN_BLOCK 256
@@ -43,10 +44,6 @@ struct CnsLds {
 };
 
 static_assert(CN_RING >= CN_MAX_D, "the ring doubles as the per-row column prefix");
-
-struct CnsDir {                    // one direction of one candidate
-    int32_t cols, qbases, tbases, ins, del, pad;
-};
 
 __device__ __forceinline__ int cns_cell(const CnsLds& S, int r, int k) {
     return (int)S.ring[(int)S.woff[r & 63] + ((k - (int)S.rmin[r]) >> 1)];
@@ -88,7 +85,8 @@ __global__ __launch_bounds__(CN_BLOCK, 6) void cns_extend(const uint32_t* __rest
                                                        const void* __restrict__ jobs_v, int n, double error_rate, double band_frac, int dir_cols_cap,
                                                        uint32_t* __restrict__ ops, CnsDir* __restrict__ dres, uint16_t* __restrict__ gscratch,
                                                        unsigned int* __restrict__ cursor, int* __restrict__ err_flag,
-                                                       const uint32_t* __restrict__ rnpac, const uint32_t* __restrict__ qnpac) {
+                                                       const uint32_t* __restrict__ rnpac, const uint32_t* __restrict__ qnpac,
+                                                       const unsigned int* __restrict__ ulist /*NULL: every unit; else [0] = how many, then the units*/) {
     __shared__ CnsLds lds[CN_WAVES];
     CnsLds& S = lds[threadIdx.x >> 6];
     const int lane = lane_id();
@@ -104,7 +102,8 @@ __global__ __launch_bounds__(CN_BLOCK, 6) void cns_extend(const uint32_t* __rest
         unsigned int unit = 0;
         if (lane == 0) unit = atomicAdd(cursor, 1u);
         unit = __shfl(unit, 0);
-        if (unit >= 2u * (unsigned)n) break;
+        if (unit >= (ulist ? ulist[0] : 2u * (unsigned)n)) break;
+        if (ulist) unit = ulist[1u + unit];
         const int right = unit & 1;
         SeqView q, t;
         q.pac = qpac; t.pac = rpac;
@@ -321,6 +320,135 @@ __global__ __launch_bounds__(CN_BLOCK, 6) void cns_extend(const uint32_t* __rest
     }
 }
 
+
+// ---- the two-kernel re-aligner (cns_fwd.h): shares of the row log, and the paths ---------------------------------------------------
+
+// rows a unit may log: an O(ND) block of size s runs at most max_d = 4 e s rows (dw.cpp:163) and typically (e_q + e_t) s of them; the
+// share is 2.7 e of the unit's reach plus one block that fails at max_d (a unit that outgrows it is handed over to cns_extend).
+// blocks: one per 256 bases of reach + 4 (a block that contributes advances by about its size; fewer records than blocks is an error).
+__global__ __launch_bounds__(256) void cns_caps(const mhip_offset_t* __restrict__ roffs, const mhip_offset_t* __restrict__ qoffs,
+                                                const mhip_aln_job* __restrict__ jobs, int n, double error_rate, uint32_t* __restrict__ caps,
+                                                uint32_t* __restrict__ bcaps) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u < 2 * n) {
+        const mhip_aln_job jb = jobs[u >> 1];
+        const int right = u & 1;
+        const int qsize = qoffs[jb.qid_local].size, tsize = roffs[jb.sid_local].size;
+        const int qs = right ? qsize - jb.qstart : jb.qstart, ts = right ? tsize - jb.sstart : jb.sstart;
+        const int ext = (jb.qstart < 0 || jb.sstart < 0) ? 0 : max(min(qs, ts), 0);
+        caps[u] = (uint32_t)(2.7 * error_rate * ext) + (uint32_t)(4.0 * error_rate * (CN_SEG + 100)) + 64u;
+        bcaps[u] = (uint32_t)(ext >> 8) + 4u;
+    }
+}
+// caps -> first record of every unit, out[m] = total; one workgroup
+__global__ __launch_bounds__(1024) void cns_scan(const uint32_t* __restrict__ caps, int m, uint32_t* __restrict__ out, unsigned long long* __restrict__ total) {
+    __shared__ unsigned long long wsum[16];
+    __shared__ unsigned long long carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int t0 = 0; t0 < m; t0 += 1024) {
+        const int i = t0 + (int)threadIdx.x;
+        const unsigned long long w = i < m ? (unsigned long long)caps[i] : 0ull;
+        unsigned long long incl = w;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long v = __shfl_up(incl, o);
+            if ((int)(threadIdx.x & 63) >= o) incl += v;
+        }
+        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        unsigned long long before = carry;
+        for (int k = 0; k < (int)(threadIdx.x >> 6); ++k) before += wsum[k];
+        if (i < m) out[i] = (uint32_t)(before + incl - w);
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = before + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[m] = (uint32_t)carry; *total = carry; }
+}
+
+// cns_trace — one LANE per block record.  Backwards over the block's row records from its end cell: bit (k - min_k) / 2 of a row says
+// which neighbour of the row below the cell came from (the reference's traceback reads the same off its stored V values, dw.cpp:222-240),
+// min_k of the row below follows from that row's cut; the steps go into a per-lane bit array in LDS.  Forwards again from (0, 0): row d
+// is one column with a base of one sequence only — the query's when the step came from k - 1 — and then the snake, re-measured on the
+// packed reads (the forward pass compared exactly these bases); columns at or beyond kept_cols (the cut in front of the last four
+// matches) are dropped.  Columns: 0 = both bases (the buffer is zero-filled), 1 = target base only, 2 = query base only.
+#define CT_BLOCK 256
+#define CT_WORDS ((CN_MAX_D + 31) / 32)
+__global__ __launch_bounds__(CT_BLOCK) void cns_trace(const uint32_t* __restrict__ rpac, const mhip_offset_t* __restrict__ roffs,
+                                                      const uint32_t* __restrict__ qpac, const mhip_offset_t* __restrict__ qoffs,
+                                                      const mhip_aln_job* __restrict__ jobs, const CnsBlockRec* __restrict__ blocks, unsigned int nb,
+                                                      const CnsRowRec* __restrict__ rowlog, CnsDir* __restrict__ dres, uint32_t* __restrict__ ops,
+                                                      size_t dir_words, int* __restrict__ err_flag) {
+    __shared__ uint32_t path[CT_BLOCK / 64][CT_WORDS][64];
+    const int lane = lane_id(), wv = (int)threadIdx.x >> 6;
+    for (unsigned int b0 = blockIdx.x * CT_BLOCK; b0 < nb; b0 += gridDim.x * CT_BLOCK) {
+        const unsigned int b = b0 + threadIdx.x;
+        if (b >= nb) continue;
+        const CnsBlockRec B = blocks[b];
+        if (B.unit == 0xffffffffu) continue;                     // (a record of its unit's share that no block took)
+        if (dres[B.unit].pad < 0 || B.end_d >= CN_MAX_D) {      // (a unit that was handed over after this block: cns_extend redoes it)
+            if (B.end_d >= CN_MAX_D) atomicExch(err_flag, 3);
+            continue;
+        }
+        // ---- backwards: the steps
+        {
+            int ck = B.end_k, mk = B.end_mk, wi = B.end_d >> 5;
+            uint32_t word = 0;
+            CnsRowRec R = rowlog[B.log0 + (unsigned)B.end_d];
+            for (int cd = B.end_d; cd >= 1; --cd) {
+                const int t = (ck - mk) >> 1;
+                if (t < 0 || t >= (int)(R.meta & 0xffu)) atomicExch(err_flag, 3);      // (never: the path stays inside its rows)
+                const uint32_t bit = ((t < 32 ? R.lo >> (t & 31) : R.hi >> ((t - 32) & 31)) & 1u);
+                if ((cd >> 5) != wi) { path[wv][wi][lane] = word; word = 0; wi = cd >> 5; }
+                word |= bit << (cd & 31);
+                ck += bit ? -1 : 1;
+                R = rowlog[B.log0 + (unsigned)(cd - 1)];
+                mk = mk - 2 * (int)((R.meta >> 8) & 0x7fu) + 1;
+            }
+            path[wv][wi][lane] = word;
+        }
+        // ---- forwards: the columns
+        const mhip_aln_job jb = jobs[B.unit >> 1];
+        const int right = (int)(B.unit & 1u);
+        SeqView q, t;
+        q.pac = qpac; t.pac = rpac;
+        {
+            const int qsize = qoffs[jb.qid_local].size;
+            q.off = qoffs[jb.qid_local].offset; q.comp = jb.chain;
+            t.off = roffs[jb.sid_local].offset; t.comp = 0;
+            const int qs0 = right ? jb.qstart : jb.qstart - 1, step = right ? 1 : -1;
+            if (jb.chain) { q.A = qsize - 1 - qs0; q.B = -step; } else { q.A = qs0; q.B = step; }
+            t.A = right ? jb.sstart : jb.sstart - 1; t.B = step;
+        }
+        uint32_t* uops = ops + (size_t)B.unit * dir_words;
+        int x = 0, y = 0, c = 0, n_ins = 0, n_del = 0;
+        auto snake = [&]() {
+            const int lim = min(B.seg - x, B.seg - y);
+            int run = 0;
+            while (run < lim) {
+                const uint32_t dlt = view_word_le(q, B.qidx + x + run) ^ view_word_le(t, B.tidx + y + run);
+                const int m = min(dlt ? (__builtin_ctz(dlt) >> 1) : 16, lim - run);
+                run += m;
+                if (m < 16) break;
+            }
+            x += run; y += run; c += run;
+        };
+        snake();
+        for (int d = 1; d <= B.end_d && c < B.kept_cols; ++d) {
+            const uint32_t bit = (path[wv][d >> 5][lane] >> (d & 31)) & 1u;
+            x += (int)bit; y += 1 - (int)bit;
+            n_del += (int)bit; n_ins += 1 - (int)bit;
+            const int gc = B.col0 + c;
+            atomicOr(&uops[gc >> 4], (bit ? 2u : 1u) << ((gc & 15) << 1));
+            c += 1;
+            snake();
+        }
+        if (B.kept_cols == (B.end_x + (B.end_x - B.end_k) + B.end_d) / 2 && x != B.end_x) atomicExch(err_flag, 4);      // (a whole block ends in its end cell)
+        if (n_ins) atomicAdd(&dres[B.unit].ins, n_ins);
+        if (n_del) atomicAdd(&dres[B.unit].del, n_del);
+    }
+}
+
 __device__ __forceinline__ int cns_op(const uint32_t* __restrict__ w, int c) { return (int)((w[c >> 4] >> ((c & 15) << 1)) & 3u); }
 
 // dw's merge + GetAlignment's trimming (dw.cpp:397-480, 495-531).  Merged column c: c < L.cols -> left op L.cols - 1 - c, else
@@ -380,9 +508,8 @@ int mhip_cns_align_candidates_dev(mhip_ctx* c, const mhip_volume* ref, const mhi
     if (n <= 0) return 0;
     if (dir_cols_cap < 16 || (dir_cols_cap & 15)) { mhip_set_error("dir_cols_cap must be a positive multiple of 16"); return -1; }
     if (!(error_rate > 0.0) || error_rate > 0.20) { mhip_set_error("error_rate %.3f outside (0, 0.20]", error_rate); return -1; }
-    const int waves_per_cu = getenv("MECAT_CNS_WAVES") ? atoi(getenv("MECAT_CNS_WAVES")) : 24;      // 6.3 KB of LDS per wave, <= 80 VGPRs
+    const int waves_per_cu = 24;                                    // cns_extend: 6.3 KB of LDS per wave, <= 80 VGPRs
     const int max_waves = c->num_cus * waves_per_cu;
-    const int grid = std::min(max_waves / CN_WAVES, (2 * n + CN_WAVES - 1) / CN_WAVES);
     CnsDir* d_dres;
     uint16_t* d_g;
     unsigned int* d_cur;
@@ -394,16 +521,80 @@ int mhip_cns_align_candidates_dev(mhip_ctx* c, const mhip_volume* ref, const mhi
     HIPCHK(hipMemsetAsync(d_cur, 0, 64, c->stream));
     const size_t dir_words = (size_t)dir_cols_cap / 16;
     HIPCHK(hipMemsetAsync(d_ops, 0, sizeof(uint32_t) * dir_words * 2 * (size_t)n, c->stream));
-    LAUNCH(c, "cns_extend", cns_extend<false>, grid, CN_BLOCK, 0, (const uint32_t*)ref->d_pac, (const mhip_offset_t*)ref->d_offs,
-           (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs, (const void*)d_jobs, n, error_rate, 0.3, dir_cols_cap,
-           (uint32_t*)d_ops, d_dres, d_g, d_cur, d_err, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+    // MECAT_CNS_KERNEL=1: every unit through cns_extend (rounds 1-4: one unit per wave, every row kept; the tests compare the two)
+    if (getenv("MECAT_CNS_KERNEL") && atoi(getenv("MECAT_CNS_KERNEL")) == 1) {
+        const int grid = std::min(max_waves / CN_WAVES, (2 * n + CN_WAVES - 1) / CN_WAVES);
+        LAUNCH(c, "cns_extend", cns_extend<false>, grid, CN_BLOCK, 0, (const uint32_t*)ref->d_pac, (const mhip_offset_t*)ref->d_offs,
+               (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs, (const void*)d_jobs, n, error_rate, 0.3, dir_cols_cap,
+               (uint32_t*)d_ops, d_dres, d_g, d_cur, d_err, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const unsigned int*)nullptr);
+    } else {
+        // forward rows (dw_extend2 under mecat2cns' rules, a 16-byte record per row) -> paths (one lane per block) -> the units the
+        // forward pass could not finish, redone by cns_extend.  The row log is sized by the units' shares: jobs are taken in slices whose
+        // log stays under MECAT_CNS_LOG_GB (default 24).
+        const unsigned long long budget = (unsigned long long)(getenv("MECAT_CNS_LOG_GB") ? std::max(1, atoi(getenv("MECAT_CNS_LOG_GB"))) : 24) << 30;
+        int slice = std::min(n, 1 << 18);
+        unsigned long long* d_tot;
+        if (c->scratch("cnf_totals", 64, (void**)&d_tot)) return -1;
+        for (int j0 = 0; j0 < n;) {
+            const int nj = std::min(slice, n - j0), nu = 2 * nj;
+            const mhip_aln_job* jobs = (const mhip_aln_job*)d_jobs + j0;
+            uint32_t *d_caps, *d_base, *d_hand;
+            if (c->scratch("cnf_caps", sizeof(uint32_t) * 2 * (size_t)nu, (void**)&d_caps)) return -1;
+            if (c->scratch("cnf_base", sizeof(uint32_t) * 2 * ((size_t)nu + 1), (void**)&d_base)) return -1;
+            uint32_t* d_bbase = d_base + nu + 1;
+            if (c->scratch("cnf_hand", sizeof(uint32_t) * ((size_t)nu + 1), (void**)&d_hand)) return -1;
+            HIPCHK(hipMemsetAsync(d_tot, 0, 64, c->stream));
+            HIPCHK(hipMemsetAsync(d_hand, 0, sizeof(uint32_t), c->stream));
+            LAUNCH(c, "cns_caps", cns_caps, (nu + 255) / 256, 256, 0, (const mhip_offset_t*)ref->d_offs, (const mhip_offset_t*)reads->d_offs, jobs, nj,
+                   error_rate, d_caps, d_caps + nu);
+            LAUNCH(c, "cns_scan", cns_scan, 1, 1024, 0, (const uint32_t*)d_caps, nu, d_base, d_tot);
+            LAUNCH(c, "cns_scan", cns_scan, 1, 1024, 0, (const uint32_t*)(d_caps + nu), nu, d_bbase, d_tot + 1);
+            unsigned long long tot[2] = {0, 0};
+            HIPCHK(hipMemcpyAsync(tot, d_tot, sizeof(tot), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if ((tot[0] * sizeof(CnsRowRec) > budget || tot[0] >= (1ull << 32)) && nj > 1024) { slice = std::max(1024, nj / 2); continue; }
+            if (tot[0] >= (1ull << 32)) { mhip_set_error("mecat2cns aligner: the row log of %d jobs does not fit 32-bit record numbers", nj); return -1; }
+            CnsFwdArgs a;
+            a.error_rate = error_rate;
+            a.logbase = d_base;
+            if (tot[1] >= (1ull << 32)) { mhip_set_error("mecat2cns aligner: too many block records for %d jobs", nj); return -1; }
+            const unsigned int block_cap = (unsigned int)tot[1];
+            a.blockbase = d_bbase;
+            if (c->scratch("cnf_rowlog", sizeof(CnsRowRec) * (size_t)std::max<unsigned long long>(tot[0], 1), (void**)&a.rowlog)) return -1;
+            if (c->scratch("cnf_blocks", sizeof(CnsBlockRec) * (size_t)std::max(block_cap, 1u), (void**)&a.blocks)) return -1;
+            HIPCHK(hipMemsetAsync(a.blocks, 0xff, sizeof(CnsBlockRec) * (size_t)block_cap, c->stream));
+            a.hand_units = d_hand;
+            a.dres = d_dres + 2 * (size_t)j0;
+            a.dir_cols_cap = dir_cols_cap;
+            a.err_flag = d_err;
+            if (cns_forward_launch(c, ref, reads, jobs, nj, a)) return -1;
+            uint32_t* ops_slice = (uint32_t*)d_ops + 2 * (size_t)j0 * dir_words;
+            LAUNCH(c, "cns_trace", cns_trace, c->num_cus * 8, CT_BLOCK, 0, (const uint32_t*)ref->d_pac, (const mhip_offset_t*)ref->d_offs,
+                   (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs, jobs, (const CnsBlockRec*)a.blocks, block_cap,
+                   (const CnsRowRec*)a.rowlog, a.dres, ops_slice, dir_words, d_err);
+            // (cns_extend reads the number of its units on the device: nothing waits for the host)
+            HIPCHK(hipMemsetAsync(d_cur, 0, sizeof(unsigned int), c->stream));
+            LAUNCH(c, "cns_extend", cns_extend<false>, std::min(max_waves / CN_WAVES, (nu + CN_WAVES - 1) / CN_WAVES), CN_BLOCK, 0, (const uint32_t*)ref->d_pac,
+                   (const mhip_offset_t*)ref->d_offs, (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs, (const void*)jobs, nj, error_rate, 0.3,
+                   dir_cols_cap, ops_slice, a.dres, d_g, d_cur, d_err, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const unsigned int*)d_hand);
+            if (getenv("MECAT_TRACE")) {
+                unsigned int st = 0;
+                HIPCHK(hipStreamSynchronize(c->stream));
+                HIPCHK(hipMemcpy(&st, d_hand, sizeof(unsigned int), hipMemcpyDeviceToHost));
+                fprintf(stderr, "[mecat_hip] cns re-aligner: jobs %d..%d, row log %.2f GB, room for %u block records, %u of %d units handed over\n", j0, j0 + nj,
+                        (double)tot[0] * sizeof(CnsRowRec) / 1e9, block_cap, st, nu);
+            }
+            j0 += nj;
+        }
+    }
     LAUNCH(c, "cns_stitch", cns_stitch, (n + 255) / 256, 256, 0, (const mhip_aln_job*)d_jobs, (const CnsDir*)d_dres, (const uint32_t*)d_ops,
            dir_cols_cap, n, min_align_size, (mhip_cns_result*)d_results);
     int err = 0;
     HIPCHK(hipMemcpyAsync(&err, d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipGetLastError());
-    if (err) { mhip_set_error("mecat2cns aligner: a direction needed more than dir_cols_cap = %d columns", dir_cols_cap); return -1; }
+    if (err == 1) { mhip_set_error("mecat2cns aligner: a direction needed more than dir_cols_cap = %d columns", dir_cols_cap); return -1; }
+    if (err) { mhip_set_error("mecat2cns aligner: internal error %d (2: more blocks than records; 3: a path left its rows; 4: a path missed its end)", err); return -1; }
     return 0;
 }
 
@@ -512,7 +703,7 @@ int asm_extend_launch(mhip_ctx* c, const mhip_volume* block, const mhip_volume* 
     // x = the block (the kernel's "reads" side), y = the mapped reads (its "ref" side); max_d = int(0.10 * (q + t)) = int(2 * 0.05 * ..)
     LAUNCH(c, "asm_extend", cns_extend<true>, grid, CN_BLOCK, 0, (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs,
            (const uint32_t*)block->d_pac, (const mhip_offset_t*)block->d_offs, (const void*)d_jobs, n, 0.05, 0.10, dir_cols_cap,
-           (uint32_t*)d_ops, d_dres, d_g, d_cur, d_err, (const uint32_t*)reads->d_npac, (const uint32_t*)block->d_npac);
+           (uint32_t*)d_ops, d_dres, d_g, d_cur, d_err, (const uint32_t*)reads->d_npac, (const uint32_t*)block->d_npac, (const unsigned int*)nullptr);
     *out_dres = d_dres;
     *out_ops = (uint32_t*)d_ops;
     return 0;

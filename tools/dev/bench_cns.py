@@ -32,12 +32,20 @@ def main():
     dops = torch.empty((len(jobs), 2, cap // 16), dtype=torch.int32, device="cuda")
     L_ = M.lib()
     for rep in range(2):
+        ctx.set_profiling(True); ctx.reset_stats()
+        c0 = ctx.counters()
         torch.cuda.synchronize()
         t0 = time.time()
         rc = L_.mhip_cns_align_candidates_dev(ctx.h, vol.h, vol.h, dj.data_ptr(), len(jobs), 0.15, 500, cap, dres.data_ptr(), dops.data_ptr())
         assert rc == 0, L_.mhip_last_error()
         torch.cuda.synchronize()
         dt = time.time() - t0
+    print("cns counters:", {k: ctx.counters()[k] - c0[k] for k in ("dw_blocks", "dw_cells")})
+    print("kernels (ms): " + ", ".join("%s %.1f" % (k, v[1]) for k, v in sorted(ctx.kernel_stats().items(), key=lambda kv: -kv[1][1])[:8]))
+    ctx.reset_stats()
+    M.align_candidates(ctx, vol, vol, jobs, 500)
+    print("same jobs through mecat2pw's aligner (ms): " + ", ".join("%s %.1f" % (k, v[1]) for k, v in sorted(ctx.kernel_stats().items(), key=lambda kv: -kv[1][1])[:4]),
+          {k: ctx.counters()[k] for k in ("dw_blocks", "dw_cells")})
     r = dres.cpu().numpy()
     ok = r[:, 0] != 0
     aligned = int((r[:, 2] - r[:, 1])[ok].sum())

@@ -559,7 +559,7 @@ __global__ __launch_bounds__(AL_BLOCK, CNS ? CNS_FWD_WAVES_PER_SIMD : DW2_WAVES_
     // the log cannot hold (a row of more than 64 diagonals, a cut of 127 or more, more rows than its share): such a unit is handed over
     unsigned int logpos = 0, logend = 0, blk_log0 = 0, blkpos = 0, blkend = 0;
     bool cns_bad = false;
-    unsigned long long fl0 = 0, fl1 = 0;       // lanes whose diagonal came from k - 1, first / second pass of the row that ran last
+    unsigned long long fl0 = 0, fl1 = 0, fl2 = 0;      // lanes whose diagonal came from k - 1, first / second / third pass of the row that ran last
     int last_ns = 0;                           // its slots
 
     while (true) {
@@ -604,6 +604,7 @@ __global__ __launch_bounds__(AL_BLOCK, CNS ? CNS_FWD_WAVES_PER_SIMD : DW2_WAVES_
                     band_tol = (int)(0.3 * qblk);
                     max_d = (int)(2.0 * ca.error_rate * (qblk + qblk));
                     blk_log0 = logpos;
+                    if (logend - logpos < (unsigned)max_d) { cns_bad = true; max_d = 0; }      // the rows of this block may not fit the unit's share of the log
                 } else {
                 if (qleft < SEG_BLK + 100 || tleft < SEG_BLK + 100) {
                     qblk = min(qleft, (int)(tleft + tleft * 0.2));
@@ -772,12 +773,15 @@ __global__ __launch_bounds__(AL_BLOCK, CNS ? CNS_FWD_WAVES_PER_SIMD : DW2_WAVES_
                     int v1;
                     asm("v_add_u16 %0, 1, %1" : "=v"(v1) : "v"(vl));
                     asm("v_max_i16 %0, %1, %2" : "=v"(x) : "v"(v1), "v"(vr));
-                }
-                if (CNS) {
-                    // the step the reference's traceback will read off V (dw.cpp:176-179: from k + 1 when k == min_k, or k != max_k and
-                    // V[k - 1] < V[k + 1]): with the entries the ring holds at a band's two edges (see above) that is "vl >= vr" everywhere
-                    const unsigned long long fb = BALLOT(vl >= vr) & amask;
-                    if (j == 0) fl0 = fb; else if (j == 1) fl1 = fb;
+                    if (CNS) {
+                        // the step the reference's traceback will read off V (dw.cpp:176-179: from k + 1 when k == min_k, or k != max_k and
+                        // V[k - 1] < V[k + 1]): with the entries the ring holds at a band's two edges (see above) that is "vl >= vr"
+                        // everywhere, i.e. vl + 1 > vr: one 16-bit compare of what is in registers anyway (idle lanes: masked by the reader,
+                        // which knows the row's slots)
+                        unsigned long long fb;
+                        asm("v_cmp_gt_i16_e64 %0, %1, %2" : "=s"(fb) : "v"(v1), "v"(vr));
+                        if (j == 0) fl0 = fb; else if (j == 1) fl1 = fb; else if (j == 2) fl2 = fb;
+                    }
                 }
                 // 0 <= y <= t_len and x <= q_len on every live diagonal (a diagonal at an end stops the block); idle lanes sit
                 // at (q_len, 0), where lim == 0
@@ -840,9 +844,13 @@ __global__ __launch_bounds__(AL_BLOCK, CNS ? CNS_FWD_WAVES_PER_SIMD : DW2_WAVES_
             if constexpr (CNS) {
                 constexpr bool BOTH = decltype(both_tag)::value;
                 if (BOTH || inblock) {
-                    const uint32_t lo = (uint32_t)(fl0 >> (hh << 5)), hi = NJ >= 2 ? (uint32_t)(fl1 >> (hh << 5)) : 0u;
-                    if (NJ > 2 || cut >= 127 || logpos >= logend) cns_bad = true;
-                    else if (sl == 0) ca.rowlog[logpos] = CnsRowRec{lo, hi, (uint32_t)last_ns | ((uint32_t)cut << 8), 0u};
+                    // (a block's rows fit the unit's share: checked when the block is set up.  A record holds a row of up to 96 diagonals —
+                    // three passes: 0.01 % of the rows have a third — and its cut, which is below its width; a wider row cannot be
+                    // recorded: the unit is handed over.)
+                    const uint32_t lo = hh ? (uint32_t)(fl0 >> 32) : (uint32_t)fl0, hi = NJ >= 2 ? (hh ? (uint32_t)(fl1 >> 32) : (uint32_t)fl1) : 0u;
+                    const uint32_t top = NJ >= 3 ? (hh ? (uint32_t)(fl2 >> 32) : (uint32_t)fl2) : 0u;
+                    if (NJ > 3) cns_bad = true;
+                    ca.rowlog[logpos] = CnsRowRec{lo, hi, (uint32_t)last_ns | ((uint32_t)cut << 8), top};
                     logpos += 1;
                 }
             }

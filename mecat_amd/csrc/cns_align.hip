@@ -342,6 +342,9 @@ __global__ __launch_bounds__(256) void cns_caps(const mhip_offset_t* __restrict_
 }
 // caps -> first record of every unit, out[m] = total; one workgroup
 __global__ __launch_bounds__(1024) void cns_scan(const uint32_t* __restrict__ caps, int m, uint32_t* __restrict__ out, unsigned long long* __restrict__ total) {
+    caps += (size_t)blockIdx.x * (size_t)m;            // workgroup b: array b of m counts -> array b of m + 1 positions, total[b]
+    out += (size_t)blockIdx.x * ((size_t)m + 1);
+    total += blockIdx.x;
     __shared__ unsigned long long wsum[16];
     __shared__ unsigned long long carry;
     if (threadIdx.x == 0) carry = 0;
@@ -398,7 +401,7 @@ __global__ __launch_bounds__(CT_BLOCK) void cns_trace(const uint32_t* __restrict
             for (int cd = B.end_d; cd >= 1; --cd) {
                 const int t = (ck - mk) >> 1;
                 if (t < 0 || t >= (int)(R.meta & 0xffu)) atomicExch(err_flag, 3);      // (never: the path stays inside its rows)
-                const uint32_t bit = ((t < 32 ? R.lo >> (t & 31) : R.hi >> ((t - 32) & 31)) & 1u);
+                const uint32_t bit = ((t < 32 ? R.lo : t < 64 ? R.hi : R.top) >> (t & 31)) & 1u;
                 if ((cd >> 5) != wi) { path[wv][wi][lane] = word; word = 0; wi = cd >> 5; }
                 word |= bit << (cd & 31);
                 ck += bit ? -1 : 1;
@@ -422,16 +425,34 @@ __global__ __launch_bounds__(CT_BLOCK) void cns_trace(const uint32_t* __restrict
         }
         uint32_t* uops = ops + (size_t)B.unit * dir_words;
         int x = 0, y = 0, c = 0, n_ins = 0, n_del = 0;
+        // 32 bases of either sequence stay in two registers (bases qb .. qb + 31 of the block, first base in the low bits): a row moves
+        // along by three or four bases, so a window is refilled once in four rows instead of being fetched and turned for every snake step
+        int qb = 0, tb = 0;
+        uint32_t q0 = view_word_le(q, B.qidx), q1 = view_word_le(q, B.qidx + 16), t0 = view_word_le(t, B.tidx), t1 = view_word_le(t, B.tidx + 16);
         auto snake = [&]() {
             const int lim = min(B.seg - x, B.seg - y);
             int run = 0;
             while (run < lim) {
-                const uint32_t dlt = view_word_le(q, B.qidx + x + run) ^ view_word_le(t, B.tidx + y + run);
+                const int xx = x + run, yy = y + run;
+                while (xx >= qb + 16) { qb += 16; q0 = q1; q1 = view_word_le(q, B.qidx + qb + 16); }
+                while (yy >= tb + 16) { tb += 16; t0 = t1; t1 = view_word_le(t, B.tidx + tb + 16); }
+                const uint32_t dlt = __builtin_amdgcn_alignbit(q1, q0, (uint32_t)(xx - qb) << 1) ^ __builtin_amdgcn_alignbit(t1, t0, (uint32_t)(yy - tb) << 1);
                 const int m = min(dlt ? (__builtin_ctz(dlt) >> 1) : 16, lim - run);
                 run += m;
                 if (m < 16) break;
             }
             x += run; y += run; c += run;
+        };
+        // the columns of a word are gathered in a register and written once: with a plain store when the word is this block's alone, with
+        // an atomic OR when it holds the block's first or last kept column (its neighbours in the unit write the rest of it)
+        const int gc_lo = B.col0, gc_hi = B.col0 + B.kept_cols - 1;
+        int cw = gc_lo >> 4;
+        uint32_t wacc = 0;
+        auto flush_word = [&]() {
+            if (wacc) {
+                if (cw == (gc_lo >> 4) || cw == (gc_hi >> 4)) atomicOr(&uops[cw], wacc); else uops[cw] = wacc;
+            }
+            wacc = 0;
         };
         snake();
         for (int d = 1; d <= B.end_d && c < B.kept_cols; ++d) {
@@ -439,10 +460,12 @@ __global__ __launch_bounds__(CT_BLOCK) void cns_trace(const uint32_t* __restrict
             x += (int)bit; y += 1 - (int)bit;
             n_del += (int)bit; n_ins += 1 - (int)bit;
             const int gc = B.col0 + c;
-            atomicOr(&uops[gc >> 4], (bit ? 2u : 1u) << ((gc & 15) << 1));
+            if ((gc >> 4) != cw) { flush_word(); cw = gc >> 4; }
+            wacc |= (bit ? 2u : 1u) << ((gc & 15) << 1);
             c += 1;
             snake();
         }
+        flush_word();
         if (B.kept_cols == (B.end_x + (B.end_x - B.end_k) + B.end_d) / 2 && x != B.end_x) atomicExch(err_flag, 4);      // (a whole block ends in its end cell)
         if (n_ins) atomicAdd(&dres[B.unit].ins, n_ins);
         if (n_del) atomicAdd(&dres[B.unit].del, n_del);
@@ -547,8 +570,7 @@ int mhip_cns_align_candidates_dev(mhip_ctx* c, const mhip_volume* ref, const mhi
             HIPCHK(hipMemsetAsync(d_hand, 0, sizeof(uint32_t), c->stream));
             LAUNCH(c, "cns_caps", cns_caps, (nu + 255) / 256, 256, 0, (const mhip_offset_t*)ref->d_offs, (const mhip_offset_t*)reads->d_offs, jobs, nj,
                    error_rate, d_caps, d_caps + nu);
-            LAUNCH(c, "cns_scan", cns_scan, 1, 1024, 0, (const uint32_t*)d_caps, nu, d_base, d_tot);
-            LAUNCH(c, "cns_scan", cns_scan, 1, 1024, 0, (const uint32_t*)(d_caps + nu), nu, d_bbase, d_tot + 1);
+            LAUNCH(c, "cns_scan", cns_scan, 2, 1024, 0, (const uint32_t*)d_caps, nu, d_base, d_tot);      // (two workgroups: rows, block records)
             unsigned long long tot[2] = {0, 0};
             HIPCHK(hipMemcpyAsync(tot, d_tot, sizeof(tot), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
@@ -572,7 +594,8 @@ int mhip_cns_align_candidates_dev(mhip_ctx* c, const mhip_volume* ref, const mhi
             LAUNCH(c, "cns_trace", cns_trace, c->num_cus * 8, CT_BLOCK, 0, (const uint32_t*)ref->d_pac, (const mhip_offset_t*)ref->d_offs,
                    (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs, jobs, (const CnsBlockRec*)a.blocks, block_cap,
                    (const CnsRowRec*)a.rowlog, a.dres, ops_slice, dir_words, d_err);
-            // (cns_extend reads the number of its units on the device: nothing waits for the host)
+            // the units the forward pass handed over (0.2 %): cns_extend, which reads their number on the device (nothing waits for the host).
+            // (On a second stream beside cns_trace it gained nothing: 118 ms either way on 442 k jobs.)
             HIPCHK(hipMemsetAsync(d_cur, 0, sizeof(unsigned int), c->stream));
             LAUNCH(c, "cns_extend", cns_extend<false>, std::min(max_waves / CN_WAVES, (nu + CN_WAVES - 1) / CN_WAVES), CN_BLOCK, 0, (const uint32_t*)ref->d_pac,
                    (const mhip_offset_t*)ref->d_offs, (const uint32_t*)reads->d_pac, (const mhip_offset_t*)reads->d_offs, (const void*)jobs, nj, error_rate, 0.3,

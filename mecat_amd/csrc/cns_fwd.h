@@ -19,8 +19,8 @@ struct CnsDir {                    // one direction of one candidate
 
 struct CnsRowRec {                 // one d-row of a block
     uint32_t lo, hi;               // bit t: diagonal min_k + 2 t of the row took the step from k - 1 (x = V[k - 1] + 1; dw.cpp:176-179)
-    uint32_t meta;                 // slots of the row | cut of the band update behind it << 8 (min_k of row d + 1 = min_k of row d + 2 cut - 1)
-    uint32_t pad;
+    uint32_t meta;                 // slots of the row (<= 96) | cut of the band update behind it << 8 (min_k of row d + 1 = min_k of row d + 2 cut - 1)
+    uint32_t top;                  // bits 64 .. 95 of the same
 };
 
 struct CnsBlockRec {               // one block that contributes columns (dw_in_one_direction, dw.cpp:319-375)

@@ -159,3 +159,34 @@ def test_cns_argument_checks_and_tiny_reads(hip, ctx):
         _check(hip, r, o, q, t, _orc(a, q, qs, t, ts, 0.15, 1))
     O.orc_cns_free(a)
     vol.free()
+
+
+@pytest.mark.parametrize("error_rate,ont", [(0.15, 0), (0.20, 1)])
+def test_two_kernel_realigner_equals_one_unit_per_wave_kernel_at_scale(hip, ctx, error_rate, ont, monkeypatch):
+    """round 5: the re-aligner's default path (forward rows = dw_extend2 under mecat2cns' block rules, one 16-byte record per row;
+    paths by cns_trace, one lane per block; cns_extend for the units the forward pass hands over) against MECAT_CNS_KERNEL=1 (every unit
+    through cns_extend, which keeps every row and is the kernel rounds 1-4 pinned to the reference): results and every column word of
+    ~100 k candidates of a 30x read set, also with the row log cut into slices of 1 GB."""
+    from mecat_amd import workload as W
+    n = 5000
+    codes, lens = W.synth_reads(n, 9000, 0.15 if not ont else 0.12, n * 9000 // 30, 31 + ont, ont)
+    pac, offs, nb = W.pack_volume(codes, lens)
+    vol = hip.Volume(ctx, pac, offs, nb, 0)
+    idx = hip.Index(ctx, vol)
+    p = hip.default_params(ont)
+    cands, cnt = hip.seed_reads(ctx, idx, vol, vol, 0, n, p)
+    jobs = W.jobs_from_candidates(cands, cnt, 0)
+    assert len(jobs) > 50000
+    cap = 16384
+    monkeypatch.setenv("MECAT_CNS_KERNEL", "1")
+    want_r, want_o = hip.cns_align_candidates(ctx, vol, vol, jobs, error_rate, 500, cap)
+    monkeypatch.delenv("MECAT_CNS_KERNEL")
+    for gb in (None, "1"):
+        if gb:
+            monkeypatch.setenv("MECAT_CNS_LOG_GB", gb)
+        got_r, got_o = hip.cns_align_candidates(ctx, vol, vol, jobs, error_rate, 500, cap)
+        assert int((want_r["ok"] != 0).sum()) > 0.8 * len(jobs)
+        assert np.array_equal(got_r, want_r)
+        assert np.array_equal(got_o, want_o)
+    idx.free()
+    vol.free()

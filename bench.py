@@ -189,8 +189,8 @@ def cns_cpu_baseline(codes, lens, rec, tb, ids, templates=100):
         subprocess.run(["rm", "-rf", d])
 
 
-def cns_cpu_leg(d):
-    """child process of cns_cpu_baseline"""
+def cns_cpu_leg(d, part=0, parts=1):
+    """child process of cns_cpu_baseline (and of bench_config4.cpu_leg: templates part, part + parts, ... of the sample)"""
     A = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_cns_accept.so"))
     A.refa_load_reads.argtypes = [C.c_char_p]
     A.refa_consensus_can.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_long, C.POINTER(C.c_long)]
@@ -204,7 +204,7 @@ def cns_cpu_leg(d):
     meta = np.zeros((128, 4), dtype=np.int32)
     naln = nacc = 0
     t0 = time.time()
-    for t in range(len(ids)):
+    for t in range(part, len(ids), parts):
         b, e = int(tb[t]), int(tb[t + 1])
         cand = np.ascontiguousarray(rec[b:e]).copy()
         used = C.c_long()
@@ -317,6 +317,10 @@ def main():
         os.execv(sys.executable, cmd)
 
     from mecat_amd import workload as W
+    if args.workload == "config4":      # BASELINE configs[3]: mecat2cns' re-alignment + accept stage on config 2's candidates (bench_config4.py)
+        import bench_config4
+        bench_config4.run(args)
+        return
     if args.workload in W.GRIDS:        # multi-volume workloads (config 3, a grid cell of config 5): bench_grid.py, same contract line
         import bench_grid
         bench_grid.run(args)
@@ -805,6 +809,9 @@ def main():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) == 5 and sys.argv[1] == "--cns-cpu-leg":
+        cns_cpu_leg(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]))
+        sys.exit(0)
     if len(sys.argv) == 3 and sys.argv[1] == "--cns-cpu-leg":
         cns_cpu_leg(sys.argv[2])
     else:

@@ -18,6 +18,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <sys/mman.h>
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -136,7 +138,54 @@ void decode_rc(const uint8_t* pac, int64_t off, int size, int from, int n, char*
 
 extern "C" {
 
-void mhip_cns_free(void* p) { free(p); }
+// The strings of a batch are gigabytes (14 GB at config 2) that the host threads touch for the first time while they write them: fresh
+// pages from the kernel at 3.5 GB/s on this host — 4 of a batch's 6 seconds.  So the library keeps ONE released string buffer and
+// hands it out again when the next batch fits it (mecat2cns works through its partitions batch after batch): pages that are mapped
+// already.  mhip_cns_free parks a buffer it knows instead of freeing it; a larger request replaces the parked one.
+namespace {
+std::mutex g_strbuf_mu;
+char* g_strbuf_parked = nullptr;          // released, reusable
+size_t g_strbuf_parked_cap = 0;
+std::map<void*, size_t> g_strbuf_out;     // handed to a caller: address -> capacity
+char* strbuf_get(size_t bytes) {
+    {
+        std::lock_guard<std::mutex> lk(g_strbuf_mu);
+        if (g_strbuf_parked && g_strbuf_parked_cap >= bytes) {
+            char* p = g_strbuf_parked;
+            g_strbuf_out[p] = g_strbuf_parked_cap;
+            g_strbuf_parked = nullptr;
+            g_strbuf_parked_cap = 0;
+            return p;
+        }
+    }
+    void* p = nullptr;
+    const size_t two_mb = (size_t)2 << 20, cap = (bytes + bytes / 16 + two_mb - 1) & ~(two_mb - 1);
+    if (posix_memalign(&p, two_mb, cap) != 0) return nullptr;
+    (void)madvise(p, cap, MADV_HUGEPAGE);
+    std::lock_guard<std::mutex> lk(g_strbuf_mu);
+    g_strbuf_out[p] = cap;
+    return (char*)p;
+}
+}  // namespace
+
+void mhip_cns_free(void* p) {
+    if (!p) return;
+    void* to_free = p;
+    {
+        std::lock_guard<std::mutex> lk(g_strbuf_mu);
+        auto it = g_strbuf_out.find(p);
+        if (it != g_strbuf_out.end()) {
+            const size_t cap = it->second;
+            g_strbuf_out.erase(it);
+            if (cap > g_strbuf_parked_cap) {      // park this one, free what was parked (the smaller of the two)
+                to_free = g_strbuf_parked;
+                g_strbuf_parked = (char*)p;
+                g_strbuf_parked_cap = cap;
+            }
+        }
+    }
+    free(to_free);
+}
 
 int mhip_cns_accept_templates(mhip_ctx* c, const mhip_volume* vol, const uint8_t* host_pac, mhip_ext_candidate* cands, const int64_t* tmpl_begin,
                               int num_templates, int tech, int min_align_size, double min_mapping_ratio, int num_threads,
@@ -301,7 +350,8 @@ int mhip_cns_accept_templates(mhip_ctx* c, const mhip_volume* vol, const uint8_t
         A[a].str_offset = sbytes;
         sbytes += 2 * ((int64_t)A[a].aln_size + 1);
     }
-    char* S = (char*)malloc((size_t)std::max<int64_t>(sbytes, 1));
+    // (gigabytes at config 2: the buffer a caller released before is handed out again when it fits, see strbuf_get)
+    char* S = (size_t)sbytes >= ((size_t)64 << 20) ? strbuf_get((size_t)sbytes) : (char*)malloc((size_t)std::max<int64_t>(sbytes, 1));
     if (!S) { free(A); mhip_set_error("out of memory (%lld bytes of aligned strings)", (long long)sbytes); return -1; }
     parallel_for(num_templates, num_threads, [&](int64_t t) {
         std::vector<char> qbuf, tbuf;

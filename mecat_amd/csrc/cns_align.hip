@@ -477,9 +477,10 @@ __device__ __forceinline__ int cns_op(const uint32_t* __restrict__ w, int c) { r
 // dw's merge + GetAlignment's trimming (dw.cpp:397-480, 495-531).  Merged column c: c < L.cols -> left op L.cols - 1 - c, else
 // right op c - L.cols.  One thread per candidate; the scans stop at the first run of four matches from either end.
 __global__ void cns_stitch(const mhip_aln_job* __restrict__ jobs, const CnsDir* __restrict__ dres, const uint32_t* __restrict__ ops,
-                           int dir_cols_cap, int n, int min_aln, mhip_cns_result* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+                           int dir_cols_cap, int n, int min_aln, mhip_cns_result* __restrict__ out, unsigned long long* __restrict__ counters) {
+    const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i0 < n;          // (lanes behind the last candidate redo it and keep nothing: the reductions below want whole waves)
+    const int i = live ? i0 : n - 1;
     const size_t dir_words = ((size_t)dir_cols_cap + 15) / 16;
     const CnsDir L = dres[2 * i], R = dres[2 * i + 1];
     const uint32_t* lw = ops + (size_t)(2 * i) * dir_words;
@@ -520,7 +521,13 @@ __global__ void cns_stitch(const mhip_aln_job* __restrict__ jobs, const CnsDir* 
         r.soff = r.target_start + trb; r.send = r.target_end - tre;
         r.first_col = first; r.last_col = last;
     }
-    out[i] = r;
+    if (live) out[i] = r;
+    // work counters (mecat_hip.h): aligned query bases and alignments like dw_stitch; slot 34: the algorithmic bytes of the job (SURVEY.md
+    // §8d's extension figure for an aligner that returns its columns): the two spans at 2 bits a base, the columns at 2 bits, the record
+    unsigned long long ab = (ok && live) ? (unsigned long long)(r.query_end - r.query_start) : 0ull, cnt = (ok && live) ? 1ull : 0ull;
+    unsigned long long by = !live ? 0ull : (unsigned long long)((r.query_end - r.query_start) + (r.target_end - r.target_start) + size) / 4ull + sizeof(mhip_cns_result);
+    for (int o = 32; o; o >>= 1) { ab += __shfl_xor(ab, o); cnt += __shfl_xor(cnt, o); by += __shfl_xor(by, o); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&counters[6], ab); atomicAdd(&counters[7], cnt); atomicAdd(&counters[34], by); }
 }
 
 extern "C" {
@@ -611,7 +618,7 @@ int mhip_cns_align_candidates_dev(mhip_ctx* c, const mhip_volume* ref, const mhi
         }
     }
     LAUNCH(c, "cns_stitch", cns_stitch, (n + 255) / 256, 256, 0, (const mhip_aln_job*)d_jobs, (const CnsDir*)d_dres, (const uint32_t*)d_ops,
-           dir_cols_cap, n, min_align_size, (mhip_cns_result*)d_results);
+           dir_cols_cap, n, min_align_size, (mhip_cns_result*)d_results, (unsigned long long*)c->d_counters);
     int err = 0;
     HIPCHK(hipMemcpyAsync(&err, d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));

@@ -76,6 +76,19 @@ $(LIBDIR)/libmecat_hip_dwstats.so: $(HIP_SRCS) $(HIP_HDRS)
 	$(HIPCC) $(HIPFLAGS) -DMECAT_DW_STATS -x hip -c $(CSRC)/align.hip -o build/dwstats/align.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC build/dwstats/align.o $(filter-out build/align.o,$(HIP_OBJS)) -o $@
 
+# development variant with the index build's section clocks compiled in (tools/dev/idx_time.py with MECAT_HIP_LIB set)
+ixstats: $(LIBDIR)/libmecat_hip_ixstats.so
+$(LIBDIR)/libmecat_hip_ixstats.so: $(HIP_SRCS) $(HIP_HDRS)
+	@mkdir -p build/ixstats $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -DMECAT_IX_STATS -x hip -c $(CSRC)/index_part.hip -o build/ixstats/index_part.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC build/ixstats/index_part.o $(filter-out build/index_part.o,$(HIP_OBJS)) -o $@
+
+ixknock: $(LIBDIR)/libmecat_hip_ixknock.so
+$(LIBDIR)/libmecat_hip_ixknock.so: $(HIP_SRCS) $(HIP_HDRS)
+	@mkdir -p build/ixknock $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -DMECAT_IX_KNOCK -x hip -c $(CSRC)/index_part.hip -o build/ixknock/index_part.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC build/ixknock/index_part.o $(filter-out build/index_part.o,$(HIP_OBJS)) -o $@
+
 # development variant with xd_extend_w's section clocks compiled in (tools/dev/xd_breakdown.py)
 xdstats: $(LIBDIR)/libmecat_hip_xdstats.so
 $(LIBDIR)/libmecat_hip_xdstats.so: $(HIP_SRCS) $(HIP_HDRS)

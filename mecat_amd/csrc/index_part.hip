@@ -38,6 +38,21 @@
 
 namespace {
 
+#ifdef MECAT_IX_STATS
+// development build only (make ixstats, tools/dev/idx_time.py): s_memrealtime ticks (100 MHz) per section of the three big kernels, summed
+// over the workgroups by thread 0
+__device__ unsigned long long g_ixstats[32];
+
+#define IXS_T(var) const unsigned long long var = wall_clock64()
+#define IXS_ADD(slot, a, b) do { if (threadIdx.x == 0) atomicAdd(&g_ixstats[slot], (b) - (a)); } while (0)
+#else
+#define IXS_T(var)
+#define IXS_ADD(slot, a, b)
+#endif
+
+#ifdef MECAT_IX_KNOCK
+__device__ int g_ixknock;      // timing experiments (make ixknock, env MECAT_IX_KNOCK): 1 = no copy-out stores, 2 = copy-out to dense addresses (results are wrong)
+#endif
 constexpr int NB1 = 1 << IXP_L1_BITS;        // 512 level-1 bins
 constexpr int NB2 = 1 << IXP_L2_BITS;        // 512 sub-bins per level-1 bin
 constexpr int NID = 1 << IXP_ID_BITS;        // 256 k-mer ids per sub-bin
@@ -112,6 +127,31 @@ __device__ __forceinline__ uint32_t wave_rank(uint32_t* cnt_generic, const uint3
     return r;
 }
 
+// The same with 16-bit counters, two bins per LDS word (a wave adds at most 2^16 - 1 entries to a bin between two resets): half the LDS
+// of the per-wave counter tables of the two scatter kernels, which is what decides how many of their workgroups a CU holds.
+// cnt16 = the wave's table as words; bin b lives in half (b & 1) of word b >> 1.
+template <bool STRICT>
+__device__ __forceinline__ uint32_t wave_rank16(uint32_t* cnt_generic, const uint32_t b) {
+    lds_u32_t* cnt = (lds_u32_t*)cnt_generic;
+    const uint32_t sh = (b & 1u) << 4, one = 1u << sh;
+    if (!STRICT) return (__hip_atomic_fetch_add(cnt + (b >> 1), one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> sh) & 0xffffu;
+    volatile lds_u32_t* vc = cnt;
+    const uint32_t before = (vc[b >> 1] >> sh) & 0xffffu;
+    __hip_atomic_fetch_add(cnt + (b >> 1), one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const uint32_t after = (vc[b >> 1] >> sh) & 0xffffu;
+    uint32_t r = before;
+    unsigned long long todo = __ballot(after - before > 1u);       // lanes that share their bin with another lane of this step
+    const unsigned long long below = (1ull << lane_id()) - 1ull;
+    while (todo) {
+        const int l = __ffsll(todo) - 1;
+        const uint32_t bb = (uint32_t)__builtin_amdgcn_readlane((int)b, l);
+        const unsigned long long m = __ballot(b == bb);
+        if (b == bb) r = before + (uint32_t)__popcll(m & below);
+        todo &= ~m;
+    }
+    return r;
+}
+
 // ---- a range of NPOS volume positions starting at q0 (a multiple of 1024): its packed words in LDS, and the bitmap of the positions
 // that start no k-mer — the last 12 bases of every read and its pad base (lookup_table.cpp:77-90: the rolling word restarts at every
 // read, the first k-mer is emitted at j = 12), i.e. [rend - 12, rend] for every read end `rend` in reach.
@@ -136,9 +176,6 @@ __device__ __forceinline__ void range_prepare(uint32_t* words /*[NPOS / 16 + 2]*
     }
     __syncthreads();
 }
-__device__ __forceinline__ bool starts_kmer(const uint32_t* inval, int i, int64_t q0, int num_bases) {
-    return q0 + i < num_bases && !((inval[i >> 5] >> (i & 31)) & 1u);
-}
 // the 13-mer that starts at local position i (first base in the top bits, as the reference's rolling word holds it)
 __device__ __forceinline__ uint32_t kmer_at(const uint32_t* words, int i) {
     const uint32_t hi = words[i >> 4], lo = words[(i >> 4) + 1];
@@ -149,7 +186,8 @@ __device__ __forceinline__ uint32_t kmer_at(const uint32_t* words, int i) {
 
 // ---- level 1, first walk: occupancy of every (tile, bin)
 __global__ __launch_bounds__(T1_THREADS) void ix_hist1(const uint32_t* __restrict__ pac, const mhip_offset_t* __restrict__ offs, int num_reads,
-                                                       int num_bases, const uint32_t* __restrict__ blk, uint32_t* __restrict__ hist1) {
+                                                       int num_bases, const uint32_t* __restrict__ blk, uint32_t* __restrict__ hist1,
+                                                       uint32_t* __restrict__ nokmer) {
     __shared__ uint32_t words[T1_POS / 16 + 2];
     __shared__ uint32_t inval[T1_POS / 32];
     __shared__ uint32_t h[NB1];
@@ -157,9 +195,19 @@ __global__ __launch_bounds__(T1_THREADS) void ix_hist1(const uint32_t* __restric
     const int64_t q0 = (int64_t)tile * T1_POS;
     h[tid] = 0;
     range_prepare<T1_POS, T1_THREADS>(words, inval, pac, offs, num_reads, num_bases, blk, q0);
+    {   // the tile's 512 words of the volume-wide bitmap "no k-mer starts here" (read ends, and everything behind the last base), which
+        // the second walk reads instead of going through the read table again (a chain of dependent loads per round: half of its time)
+        static_assert(T1_POS / 32 == T1_THREADS, "one bitmap word per thread");
+        const int64_t p0 = q0 + 32 * (int64_t)tid, left = (int64_t)num_bases - p0;      // positions p0 .. p0 + 31 of this word
+        uint32_t m = inval[tid];
+        if (left < 32) m |= left <= 0 ? 0xffffffffu : ~((1u << (int)left) - 1u);
+        inval[tid] = m;
+        nokmer[(size_t)tile * (T1_POS / 32) + tid] = m;
+    }
+    __syncthreads();
     for (int j = 0; j < T1_POS / T1_THREADS; ++j) {
         const int i = j * T1_THREADS + tid;
-        if (starts_kmer(inval, i, q0, num_bases)) atomicAdd(&h[kmer_at(words, i) >> (26 - IXP_L1_BITS)], 1u);
+        if (!((inval[i >> 5] >> (i & 31)) & 1u)) atomicAdd(&h[kmer_at(words, i) >> (26 - IXP_L1_BITS)], 1u);
     }
     __syncthreads();
     hist1[(size_t)tile * NB1 + tid] = h[tid];
@@ -212,14 +260,24 @@ __global__ __launch_bounds__(256) void ix_transpose1(const uint32_t* __restrict_
 }
 
 // ---- level 1, second walk: the entries, every (tile, bin) run at its position, input order kept inside a run
+#ifndef IXP_S1_WAVES
+#define IXP_S1_WAVES 6
+#endif
+#ifndef IXP_S2_WAVES
+#define IXP_S2_WAVES 6
+#endif
 template <bool STRICT>
-__global__ __launch_bounds__(T1_THREADS) void ix_scatter1(const uint32_t* __restrict__ pac, const mhip_offset_t* __restrict__ offs, int num_reads,
-                                                          int num_bases, const uint32_t* __restrict__ blk, const uint32_t* __restrict__ hist1,
+__global__ __launch_bounds__(T1_THREADS, IXP_S1_WAVES) void ix_scatter1(const uint32_t* __restrict__ pac, int num_bases, const uint32_t* __restrict__ nokmer,
+                                                          const uint32_t* __restrict__ hist1,
                                                           const uint32_t* __restrict__ grp, uint32_t* __restrict__ ent1, int bin_lo, int bin_hi,
                                                           uint32_t ent_off) {
-    __shared__ uint32_t words[SUB1 / 16 + 2];
-    __shared__ uint32_t inval[SUB1 / 32];
-    __shared__ uint32_t cntw[T1_THREADS / 64][NB1];      // per-wave counters, then each wave's first stage place of a bin
+#ifndef IXP_S1_TILE_STAGE
+#define IXP_S1_TILE_STAGE 0
+#endif
+    constexpr int SPOS = IXP_S1_TILE_STAGE ? T1_POS : SUB1;      // positions whose packed words and bitmap (ix_hist1 made it) are staged at a time
+    __shared__ uint32_t words[SPOS / 16 + 2];
+    __shared__ uint32_t inval[SPOS / 32];
+    __shared__ __attribute__((aligned(16))) uint16_t cntw[T1_THREADS / 64][NB1];      // per-wave counters (wave_rank16), then each wave's first stage place of a bin
     __shared__ uint32_t gdel[NB1];
     __shared__ uint32_t ltotal;
     __shared__ uint32_t stage[SUB1];
@@ -229,23 +287,35 @@ __global__ __launch_bounds__(T1_THREADS) void ix_scatter1(const uint32_t* __rest
     const int tile = blockIdx.x, tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
     uint32_t gcur = hist1[(size_t)tile * NB1 + tid] + grp[(size_t)(tile / G1) * NB1 + tid] - ent_off;      // thread b: next entry of (tile, bin b)
     for (int ww = 0; ww < NW; ++ww) cntw[ww][tid] = 0;
+    const int64_t wlast = ((int64_t)num_bases + 15) >> 4;       // (the volume carries >= 128 zero bytes behind its last base)
     for (int sub = 0; sub < T1_POS / SUB1; ++sub) {
         const int64_t q0 = (int64_t)tile * T1_POS + (int64_t)sub * SUB1;
         if (q0 >= num_bases) break;
-        range_prepare<SUB1, T1_THREADS>(words, inval, pac, offs, num_reads, num_bases, blk, q0);
+        if (IXP_S1_TILE_STAGE ? sub == 0 : true) {
+            IXS_T(s_a);
+            const int64_t w0 = q0 >> 4;
+            for (int i = tid; i < SPOS / 16 + 1; i += T1_THREADS) words[i] = (w0 + i <= wlast) ? pac_word(pac, w0 + i) : 0u;
+            if (tid < SPOS / 32) inval[tid] = nokmer[(size_t)(q0 >> 5) + tid];
+            __syncthreads();
+            IXS_T(s_b);
+            IXS_ADD(0, s_a, s_b);
+        }
+        IXS_T(s_b);
         uint32_t ent[STEPS], bn[STEPS], rk[STEPS];
 #pragma unroll
         for (int j = 0; j < STEPS; ++j) {
-            const int i = w * (SUB1 / NW) + j * 64 + lane;      // wave w owns a contiguous eighth of the round, lanes = consecutive positions
+            const int il = w * (SUB1 / NW) + j * 64 + lane;      // wave w owns a contiguous eighth of the round, lanes = consecutive positions
+            const int i = IXP_S1_TILE_STAGE ? sub * SUB1 + il : il;      // position inside the staged range
             const uint32_t km = kmer_at(words, i);
             const uint32_t b = km >> (26 - IXP_L1_BITS);
-            const bool ok = starts_kmer(inval, i, q0, num_bases);
-            ent[j] = ((km & ((1u << (26 - IXP_L1_BITS)) - 1u)) << 14) | (uint32_t)(sub * SUB1 + i);
+            const bool ok = !((inval[i >> 5] >> (i & 31)) & 1u);
+            ent[j] = ((km & ((1u << (26 - IXP_L1_BITS)) - 1u)) << 14) | (uint32_t)(sub * SUB1 + il);
             bn[j] = ok ? b : 0xffffu;
             rk[j] = 0;
-            if (ok) rk[j] = wave_rank<STRICT>(cntw[w], b);
+            if (ok) rk[j] = wave_rank16<STRICT>((uint32_t*)cntw[w], b);
         }
         __syncthreads();
+        IXS_T(s_c);
         {   // thread b: the waves' counts of bin b -> each wave's first place of bin b in the stage; where the bin's run goes
             uint32_t c[NW], tot = 0;
 #pragma unroll
@@ -256,9 +326,10 @@ __global__ __launch_bounds__(T1_THREADS) void ix_scatter1(const uint32_t* __rest
             gcur += tot;
             if (tid == 0) ltotal = all;
 #pragma unroll
-            for (int ww = 0; ww < NW; ++ww) { cntw[ww][tid] = run; run += c[ww]; }
+            for (int ww = 0; ww < NW; ++ww) { cntw[ww][tid] = (uint16_t)run; run += c[ww]; }
         }
         __syncthreads();
+        IXS_T(s_d);
 #pragma unroll
         for (int j = 0; j < STEPS; ++j)
             if (bn[j] != 0xffffu) {
@@ -267,13 +338,21 @@ __global__ __launch_bounds__(T1_THREADS) void ix_scatter1(const uint32_t* __rest
                 sbin[at] = (uint16_t)bn[j];
             }
         __syncthreads();
+        IXS_T(s_e);
         const uint32_t total = ltotal;
         for (uint32_t i = tid; i < total; i += T1_THREADS) {
             const uint32_t b = sbin[i];
+#ifdef MECAT_IX_KNOCK
+            if (g_ixknock == 1) { if (stage[i] == 0xfffffff1u) ent1[i] = 1; continue; }
+            if (g_ixknock == 2) { ent1[(size_t)tile * T1_POS + sub * SUB1 + i] = stage[i] + gdel[b]; continue; }
+#endif
             if ((int)b >= bin_lo && (int)b < bin_hi) ent1[(size_t)(uint32_t)(gdel[b] + i)] = stage[i];      // (32-bit wrap-around arithmetic: gdel may be "negative")
         }
         __syncthreads();
+        IXS_T(s_f);
+        IXS_ADD(1, s_b, s_c); IXS_ADD(2, s_c, s_d); IXS_ADD(3, s_d, s_e); IXS_ADD(4, s_e, s_f);
         for (int ww = 0; ww < NW; ++ww) cntw[ww][tid] = 0;
+        __syncthreads();      // (the next round's ranks count from zero)
     }
 }
 
@@ -296,7 +375,18 @@ __global__ __launch_bounds__(T2_THREADS) void ix_hist2(const uint32_t* __restric
     __syncthreads();
     const uint32_t* bt = base1T + (size_t)(bin_lo + b1i) * (ntile + 1);
     const uint32_t e0 = bt[g * G1] - ent_off, e1 = bt[min(ntile, (g + 1) * G1)] - ent_off;
-    for (uint32_t e = e0 + tid; e < e1; e += T2_THREADS) atomicAdd(&h[ent1[e] >> (14 + IXP_ID_BITS)], 1u);
+    // four entries per load: the unit's whole 16-byte words, then the up to three entries either side of them
+    const uint32_t a0 = min(e1, (e0 + 3u) & ~3u), a1 = max(a0, e1 & ~3u);
+    const uint4* e4 = (const uint4*)ent1;
+    for (uint32_t q = (a0 >> 2) + tid; q < (a1 >> 2); q += T2_THREADS) {
+        const uint4 v = e4[q];
+        atomicAdd(&h[v.x >> (14 + IXP_ID_BITS)], 1u);
+        atomicAdd(&h[v.y >> (14 + IXP_ID_BITS)], 1u);
+        atomicAdd(&h[v.z >> (14 + IXP_ID_BITS)], 1u);
+        atomicAdd(&h[v.w >> (14 + IXP_ID_BITS)], 1u);
+    }
+    if (tid < 3u && e0 + tid < a0) atomicAdd(&h[ent1[e0 + tid] >> (14 + IXP_ID_BITS)], 1u);
+    if (tid >= 32u && tid < 35u && a1 + (tid - 32u) < e1) atomicAdd(&h[ent1[a1 + (tid - 32u)] >> (14 + IXP_ID_BITS)], 1u);
     __syncthreads();
     hist2[((size_t)b1i * ngroup + g) * NB2 + tid] = h[tid];
 }
@@ -317,11 +407,11 @@ __global__ __launch_bounds__(NB2) void ix_scan2(uint32_t* __restrict__ hist2, in
     if (b1i == nb - 1 && b2 == NB2 - 1) sub_ent[(size_t)nb * NB2] = binbase[bin_lo + nb] - ent_off;
 }
 template <bool STRICT>
-__global__ __launch_bounds__(T2_THREADS) void ix_scatter2(const uint32_t* __restrict__ ent1, const uint32_t* __restrict__ base1T, int ntile, int ngroup, int nb,
+__global__ __launch_bounds__(T2_THREADS, IXP_S2_WAVES) void ix_scatter2(const uint32_t* __restrict__ ent1, const uint32_t* __restrict__ base1T, int ntile, int ngroup, int nb,
                                                           int bin_lo, uint32_t ent_off, const uint32_t* __restrict__ hist2,
                                                           const uint32_t* __restrict__ sub_ent, uint32_t* __restrict__ pos2, uint8_t* __restrict__ id2) {
     __shared__ uint32_t tstart[G1 + 1];
-    __shared__ uint32_t cntw[T2_THREADS / 64][NB2];
+    __shared__ __attribute__((aligned(16))) uint16_t cntw[T2_THREADS / 64][NB2];      // (wave_rank16)
     __shared__ uint32_t gdel[NB2];
     __shared__ uint32_t spos[T2_ENT];
     __shared__ uint16_t sbin[T2_ENT];
@@ -331,6 +421,7 @@ __global__ __launch_bounds__(T2_THREADS) void ix_scatter2(const uint32_t* __rest
     int b1i, g;
     if (!unit_of_block(blockIdx.x, nb, ngroup, b1i, g)) return;
     const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+    IXS_T(u_0);
     const uint32_t* bt = base1T + (size_t)(bin_lo + b1i) * (ntile + 1);
     const int t0 = g * G1, nt = min(G1, ntile - t0);
     for (int i = tid; i <= nt; i += T2_THREADS) tstart[i] = bt[t0 + i] - ent_off;
@@ -338,10 +429,27 @@ __global__ __launch_bounds__(T2_THREADS) void ix_scatter2(const uint32_t* __rest
     for (int ww = 0; ww < NW; ++ww) cntw[ww][tid] = 0;
     __syncthreads();
     const uint32_t e0 = tstart[0], e1 = tstart[nt];
+    IXS_T(u_1);
+    IXS_ADD(8, u_0, u_1);
+    // the entries of a round are loaded one round ahead: behind the copy-out of the round before, their loads would queue up behind its
+    // scattered stores (ent1 carries 64 entries of slack behind its end; what is loaded past e1 is not used)
+    uint32_t vn[STEPS];
+#pragma unroll
+    for (int j = 0; j < STEPS; ++j) {
+        const uint32_t e = e0 + (uint32_t)(w * (T2_ENT / NW) + j * 64 + lane);
+        vn[j] = e < e1 ? ent1[e] : 0u;
+    }
     for (uint32_t c0 = e0; c0 < e1; c0 += T2_ENT) {
+        IXS_T(u_a);
         const uint32_t cn = min((uint32_t)T2_ENT, e1 - c0);
-        uint32_t pos[STEPS], key[STEPS], rk[STEPS];
+        uint32_t pos[STEPS], key[STEPS], rk[STEPS], vc[STEPS];
         int t = 0;
+#pragma unroll
+        for (int j = 0; j < STEPS; ++j) {
+            vc[j] = vn[j];
+            const uint32_t e = c0 + (uint32_t)T2_ENT + (uint32_t)(w * (T2_ENT / NW) + j * 64 + lane);
+            vn[j] = e < e1 ? ent1[e] : 0u;
+        }
 #pragma unroll
         for (int j = 0; j < STEPS; ++j) {
             const uint32_t li = (uint32_t)(w * (T2_ENT / NW) + j * 64 + lane);      // wave w: a contiguous eighth of the round, lanes = consecutive entries
@@ -350,7 +458,7 @@ __global__ __launch_bounds__(T2_THREADS) void ix_scatter2(const uint32_t* __rest
             rk[j] = 0;
             if (li < cn) {
                 const uint32_t e = c0 + li;
-                const uint32_t v = ent1[e];
+                const uint32_t v = vc[j];
                 // the tile of entry e = the last tile whose run starts at or before e: a binary search for the wave's first step of a
                 // round, a few steps forward from the lane's previous tile afterwards (64 entries further on ~ one tile further on)
                 if (j == 0) {
@@ -366,10 +474,11 @@ __global__ __launch_bounds__(T2_THREADS) void ix_scatter2(const uint32_t* __rest
                 }
                 pos[j] = (uint32_t)(t0 + t) * (uint32_t)T1_POS + (v & 0x3fffu);
                 key[j] = v >> 14;                                       // sub-bin : id
-                rk[j] = wave_rank<STRICT>(cntw[w], v >> (14 + IXP_ID_BITS));
+                rk[j] = wave_rank16<STRICT>((uint32_t*)cntw[w], v >> (14 + IXP_ID_BITS));
             }
         }
         __syncthreads();
+        IXS_T(u_b);
         {
             uint32_t c[NW], tot = 0;
 #pragma unroll
@@ -378,9 +487,10 @@ __global__ __launch_bounds__(T2_THREADS) void ix_scatter2(const uint32_t* __rest
             gdel[tid] = gcur - run;
             gcur += tot;
 #pragma unroll
-            for (int ww = 0; ww < NW; ++ww) { cntw[ww][tid] = run; run += c[ww]; }
+            for (int ww = 0; ww < NW; ++ww) { cntw[ww][tid] = (uint16_t)run; run += c[ww]; }
         }
         __syncthreads();
+        IXS_T(u_c);
 #pragma unroll
         for (int j = 0; j < STEPS; ++j)
             if (key[j] != 0xffffffffu) {
@@ -391,12 +501,20 @@ __global__ __launch_bounds__(T2_THREADS) void ix_scatter2(const uint32_t* __rest
                 sid[at] = (uint8_t)(key[j] & (NID - 1));
             }
         __syncthreads();
+        IXS_T(u_d);
         for (uint32_t i = tid; i < cn; i += T2_THREADS) {
+#ifdef MECAT_IX_KNOCK
+            if (g_ixknock == 1) { if (spos[i] == 0xfffffff1u) pos2[i] = sid[i]; continue; }
+            if (g_ixknock == 2) { pos2[c0 + i] = spos[i] + gdel[sbin[i]]; id2[c0 + i] = sid[i]; continue; }
+            if (g_ixknock == 3) { pos2[(size_t)(uint32_t)(gdel[sbin[i]] + i)] = spos[i] + sid[i]; continue; }
+#endif
             const size_t o = (size_t)(uint32_t)(gdel[sbin[i]] + i);
             pos2[o] = spos[i];
             id2[o] = sid[i];
         }
         __syncthreads();
+        IXS_T(u_e);
+        IXS_ADD(9, u_a, u_b); IXS_ADD(10, u_b, u_c); IXS_ADD(11, u_c, u_d); IXS_ADD(12, u_d, u_e);
         for (int ww = 0; ww < NW; ++ww) cntw[ww][tid] = 0;
         __syncthreads();
     }
@@ -483,6 +601,7 @@ __global__ __launch_bounds__(FILL_THREADS) void ix_fill(const uint32_t* __restri
     __shared__ uint32_t isfirst[FILL_CAP / 32];     // places that start a bucket (for the ascending check of the output sweep)
     __shared__ uint32_t wtot[NW];
     const uint32_t sb = blockIdx.x, tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+    IXS_T(f_0);
     const uint32_t e0 = sub_ent[sb], e1 = sub_ent[sb + 1], n = e1 - e0;
     const uint32_t first = sub_off[sb];
     const size_t id0 = ((size_t)sub0 + sb) * NID;           // first k-mer id of the sub-bin
@@ -496,6 +615,7 @@ __global__ __launch_bounds__(FILL_THREADS) void ix_fill(const uint32_t* __restri
     cc[tid][0] = 0; cc[tid][1] = 0;
     isfirst[tid] = 0;      // FILL_CAP / 32 == FILL_THREADS words
     __syncthreads();
+    IXS_T(f_1);
     const uint8_t* idb = (const uint8_t*)ids;
     auto id_of = [&](uint32_t e) -> uint32_t { return staged ? (uint32_t)idb[e - ew0] : (uint32_t)id2[e]; };
     // each wave owns a contiguous quarter of the entries (whole 64-entry steps)
@@ -503,6 +623,7 @@ __global__ __launch_bounds__(FILL_THREADS) void ix_fill(const uint32_t* __restri
     const uint32_t wb = e0 + w * per, we = min(e1, wb + per);
     for (uint32_t e = wb + lane; e < we; e += 64) atomicAdd(&cntw[w][id_of(e)], 1u);
     __syncthreads();
+    IXS_T(f_2);
     {
         uint32_t c[NW], tot = 0;
 #pragma unroll
@@ -519,6 +640,7 @@ __global__ __launch_bounds__(FILL_THREADS) void ix_fill(const uint32_t* __restri
         if (kept && ex < (uint32_t)FILL_CAP) atomicOr(&isfirst[ex >> 5], 1u << (ex & 31));
     }
     __syncthreads();
+    IXS_T(f_3);
     const uint32_t total = lstart[NID];
     const bool in_lds = total <= FILL_CAP;
     int32_t* gdst = offsets + first;
@@ -548,6 +670,8 @@ __global__ __launch_bounds__(FILL_THREADS) void ix_fill(const uint32_t* __restri
     }
     __threadfence_block();
     __syncthreads();
+    IXS_T(f_4);
+    IXS_ADD(16, f_0, f_1); IXS_ADD(17, f_1, f_2); IXS_ADD(18, f_2, f_3); IXS_ADD(19, f_3, f_4);
     if (total == 0) {
         if (recs) recs[id0 + tid] = make_uint4(first, 0u, 0u, 0u);
         return;
@@ -589,6 +713,8 @@ __global__ __launch_bounds__(FILL_THREADS) void ix_fill(const uint32_t* __restri
         for (uint32_t i = tid; i < total; i += FILL_THREADS) slots[first + i] = (uint16_t)(((uint32_t)gdst[i] / 2000u) & 0x7FFFu);
     }
     if (bad) atomicOr(disorder, 1u);
+    IXS_T(f_5);
+    IXS_ADD(20, f_4, f_5);
 }
 
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -620,8 +746,10 @@ int index_build_partitioned(mhip_ctx* c, const mhip_volume* v, int max_bucket, i
     if (c->scratch("ixp_grp", sizeof(uint32_t) * (size_t)ngroup * NB1, (void**)&d_grp)) return -1;
     if (c->scratch("ixp_binbase", sizeof(uint32_t) * (NB1 + 1), (void**)&d_binbase)) return -1;
     if (c->scratch("ixp_base1T", sizeof(uint32_t) * (size_t)NB1 * ((size_t)ntile + 1), (void**)&d_base1T)) return -1;
+    uint32_t* d_nokmer;      // one bit per volume position: no k-mer starts here (ix_hist1 writes it, ix_scatter1 reads it)
+    if (c->scratch("ixp_nokmer", sizeof(uint32_t) * (size_t)ntile * (T1_POS / 32), (void**)&d_nokmer)) return -1;
     LAUNCH(c, "ix_hist1", ix_hist1, ntile, T1_THREADS, 0, (const uint32_t*)v->d_pac, (const mhip_offset_t*)v->d_offs, v->num_reads, v->num_bases,
-           (const uint32_t*)v->d_blk2read, d_hist1);
+           (const uint32_t*)v->d_blk2read, d_hist1, d_nokmer);
     LAUNCH(c, "ix_scan1a", ix_scan1a, ngroup, NB1, 0, d_hist1, ntile, d_grp);
     LAUNCH(c, "ix_scan1b", ix_scan1b, 1, NB1, 0, d_grp, ngroup, d_binbase);
     HIPCHK(hipMemcpyAsync(out->bin_total.data(), d_binbase, sizeof(uint32_t) * (NB1 + 1), hipMemcpyDeviceToHost, c->stream));
@@ -645,6 +773,9 @@ int index_build_partitioned(mhip_ctx* c, const mhip_volume* v, int max_bucket, i
     if (c->scratch("ixp_part", sizeof(uint32_t) * ((size_t)nblk + 1), (void**)&d_part)) return -1;
     uint32_t* d_flag;
     if (c->scratch("ixp_flag", 64, (void**)&d_flag)) return -1;
+#ifdef MECAT_IX_KNOCK
+    { const int kn = getenv("MECAT_IX_KNOCK") ? atoi(getenv("MECAT_IX_KNOCK")) : 0; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_ixknock), &kn, sizeof(kn))); }
+#endif
     TRACE("scratch");
     LAUNCH(c, "ix_transpose1", ix_transpose1, dim3((unsigned)((ntile + 31) / 32), NB1 / 32), 256, 0, (const uint32_t*)d_hist1, (const uint32_t*)d_grp,
            (const uint32_t*)d_binbase, ntile, d_base1T);
@@ -656,11 +787,9 @@ int index_build_partitioned(mhip_ctx* c, const mhip_volume* v, int max_bucket, i
     for (;;) {
         HIPCHK(hipMemsetAsync(d_flag, 0, 4, c->stream));
         if (strict)
-            LAUNCH(c, "ix_scatter1", ix_scatter1<true>, ntile, T1_THREADS, 0, (const uint32_t*)v->d_pac, (const mhip_offset_t*)v->d_offs, v->num_reads, v->num_bases,
-                   (const uint32_t*)v->d_blk2read, (const uint32_t*)d_hist1, (const uint32_t*)d_grp, d_ent1, bin_lo, bin_hi, ent_off);
+            LAUNCH(c, "ix_scatter1", ix_scatter1<true>, ntile, T1_THREADS, 0, (const uint32_t*)v->d_pac, v->num_bases, (const uint32_t*)d_nokmer, (const uint32_t*)d_hist1, (const uint32_t*)d_grp, d_ent1, bin_lo, bin_hi, ent_off);
         else
-            LAUNCH(c, "ix_scatter1", ix_scatter1<false>, ntile, T1_THREADS, 0, (const uint32_t*)v->d_pac, (const mhip_offset_t*)v->d_offs, v->num_reads, v->num_bases,
-                   (const uint32_t*)v->d_blk2read, (const uint32_t*)d_hist1, (const uint32_t*)d_grp, d_ent1, bin_lo, bin_hi, ent_off);
+            LAUNCH(c, "ix_scatter1", ix_scatter1<false>, ntile, T1_THREADS, 0, (const uint32_t*)v->d_pac, v->num_bases, (const uint32_t*)d_nokmer, (const uint32_t*)d_hist1, (const uint32_t*)d_grp, d_ent1, bin_lo, bin_hi, ent_off);
         TRACE("scatter1");
         LAUNCH(c, "ix_hist2", ix_hist2, ublocks, T2_THREADS, 0, (const uint32_t*)d_ent1, (const uint32_t*)d_base1T, ntile, ngroup, nb, bin_lo, ent_off, d_hist2);
         LAUNCH(c, "ix_scan2", ix_scan2, nb, NB2, 0, d_hist2, ngroup, nb, (const uint32_t*)d_binbase, bin_lo, ent_off, d_sub_ent);
@@ -697,6 +826,17 @@ int index_build_partitioned(mhip_ctx* c, const mhip_volume* v, int max_bucket, i
         HIPCHK(hipMemcpyAsync(&flag, d_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         TRACE("fill");
+#ifdef MECAT_IX_STATS
+        {
+            unsigned long long hs[32];
+            HIPCHK(hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_ixstats), sizeof(hs)));
+            const char* nm[32] = {"s1 prepare", "s1 rank", "s1 scan", "s1 stage", "s1 copy-out", 0, 0, 0, "s2 head", "s2 load+search+rank", "s2 scan", "s2 stage", "s2 copy-out", 0, 0, 0,
+                                  "fill stage ids", "fill count", "fill scan", "fill place", "fill out"};
+            for (int i = 0; i < 32; ++i) if (nm[i]) fprintf(stderr, "[ix stats] %-22s %10.1f ms summed over workgroups\n", nm[i], hs[i] * 1e-5);
+            unsigned long long z[32] = {0};
+            HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_ixstats), z, sizeof(z)));
+        }
+#endif
         if (!flag) break;
         if (strict) { mhip_set_error("index build: a bucket is not in ascending position order (internal error)"); return -1; }
         fprintf(stderr, "[mecat_hip] index build: the LDS did not serve one instruction's lanes in lane order; rebuilding with explicit ranks\n");

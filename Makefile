@@ -83,6 +83,13 @@ $(LIBDIR)/libmecat_hip_ixstats.so: $(HIP_SRCS) $(HIP_HDRS)
 	$(HIPCC) $(HIPFLAGS) -DMECAT_IX_STATS -x hip -c $(CSRC)/index_part.hip -o build/ixstats/index_part.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC build/ixstats/index_part.o $(filter-out build/index_part.o,$(HIP_OBJS)) -o $@
 
+# development variant with section clocks in seed_filter_wide / seed_emit (tools/dev/ont_cell.py with MECAT_HIP_LIB set)
+wfprof: $(LIBDIR)/libmecat_hip_wfprof.so
+$(LIBDIR)/libmecat_hip_wfprof.so: $(HIP_SRCS) $(HIP_HDRS)
+	@mkdir -p build/wfprof $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -DWF_PROF -x hip -c $(CSRC)/seed.hip -o build/wfprof/seed.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC build/wfprof/seed.o $(filter-out build/seed.o,$(HIP_OBJS)) -o $@
+
 ixknock: $(LIBDIR)/libmecat_hip_ixknock.so
 $(LIBDIR)/libmecat_hip_ixknock.so: $(HIP_SRCS) $(HIP_HDRS)
 	@mkdir -p build/ixknock $(LIBDIR)

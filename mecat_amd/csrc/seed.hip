@@ -341,6 +341,15 @@ __global__ __launch_bounds__(SEED_BLOCK) void seed_filter(const mhip_offset_t* _
     if (threadIdx.x == 0) { A.strand_hits[s] = kept; A.filtered[s] = filtered ? 1 : 0; }
 }
 
+#ifdef WF_PROF
+// development build (make wfprof): s_memrealtime ticks per section of seed_filter_wide [0..7] and seed_emit [8..15], summed over strands
+__device__ unsigned long long g_wfprof[16];
+#define WF_MARK(i) do { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&g_wfprof[i], t_ - t_prev); t_prev = t_; } } while (0)
+#define WF_T0 unsigned long long t_prev = wall_clock64(); (void)t_prev
+#else
+#define WF_MARK(i) do { } while (0)
+#define WF_T0
+#endif
 // ------------------------------------------------------------------------------------------------ emit
 // keys of the kept hits in (km, position) order = the order the reference visits them: key = seg:21 | km:16 | off:11.
 // The strand's k-mers are taken 64 at a time (16 lanes per bucket, four buckets per group as in for_each_hit16): count the
@@ -358,12 +367,14 @@ __global__ __launch_bounds__(SEED_BLOCK) void seed_emit(const mhip_offset_t* __r
     const int K = kmers_of(L);
     const uint32_t kb = A.km_base[s];
     if (A.strand_hits[s] == 0) return;
+    WF_T0;
     uint64_t* __restrict__ out = A.keysA + A.hit_base[s];
     const bool flt = A.filtered[s] != 0;
     if (flt) {
         for (int i = threadIdx.x; i < REL_WORDS; i += SEED_BLOCK) rel[i] = A.rel_bits[(size_t)s * REL_WORDS + i];
     }
     __syncthreads();
+    WF_MARK(8);
     const int g = threadIdx.x >> 4;
     const uint32_t sub = threadIdx.x & 15;
     const uint32_t below = (1u << sub) - 1u;
@@ -396,6 +407,7 @@ __global__ __launch_bounds__(SEED_BLOCK) void seed_emit(const mhip_offset_t* __r
             if (sub == 0) ccnt[q * 16 + g] = kept;
         }
         __syncthreads();
+        WF_MARK(9);
         if (threadIdx.x < 64) {
             const uint32_t v = ccnt[threadIdx.x];
             uint32_t incl = v;
@@ -407,6 +419,7 @@ __global__ __launch_bounds__(SEED_BLOCK) void seed_emit(const mhip_offset_t* __r
             if (threadIdx.x == 63) s_tot = incl;
         }
         __syncthreads();
+        WF_MARK(10);
         // write
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -427,6 +440,7 @@ __global__ __launch_bounds__(SEED_BLOCK) void seed_emit(const mhip_offset_t* __r
                 put(valid ? (uint32_t)offsets[bs[q] + r] : 0u, valid);
             }
         }
+        WF_MARK(11);
         run += s_tot;
     }
     // the number of keys written: exact, where seed_filter_wide's strand_hits was the room it asked for (an upper bound)
@@ -983,6 +997,7 @@ __global__ __launch_bounds__(FS_THREADS) void seed_filter_wide(const mhip_offset
                                                                unsigned long long* __restrict__ counters) {
     __shared__ uint32_t cnt[WF_M / 8];           // 128 KB: eight 4-bit counters per word
     __shared__ uint32_t rel[REL_WORDS];
+    __shared__ uint32_t hotb[3][REL_WORDS];      // cells with a hot slot; of those, the ones whose reach needs one more cell on the left / right
     __shared__ uint32_t wtot[FS_WAVES];
     __shared__ uint32_t s_wraps, s_self;
     const int s = blockIdx.x, tid = threadIdx.x;
@@ -995,11 +1010,13 @@ __global__ __launch_bounds__(FS_THREADS) void seed_filter_wide(const mhip_offset
         if (tid == 0) { A.strand_hits[s] = 0; A.filtered[s] = 0; }
         return;
     }
+    WF_T0;
     for (int i = tid; i < WF_M / 8; i += FS_THREADS) cnt[i] = 0;
     rel[tid] = 0;                                 // REL_WORDS == FS_THREADS
     static_assert(REL_WORDS == FS_THREADS, "one bitmap word per thread");
     if (tid == 0) { s_wraps = 0; s_self = 0; }
     __syncthreads();
+    WF_MARK(0);
     const uint32_t reach = (uint32_t)min(sweep_reach(L), WF_M / 2 - 1);
     auto mark = [&](int lo, int hi) {            // slots lo .. hi (unwrapped, hi - lo < WF_M) -> their bitmap bits
         uint32_t cell = (uint32_t)(lo >> WF_CELL) & (FLT_M - 1), left = min((uint32_t)((hi >> WF_CELL) - (lo >> WF_CELL) + 1), (uint32_t)FLT_M);
@@ -1028,29 +1045,74 @@ __global__ __launch_bounds__(FS_THREADS) void seed_filter_wide(const mhip_offset
         }
     });
     __syncthreads();
-    // hot slots: thread t owns slots 256 t .. 256 t + 255 = words 32 t .. 32 t + 31 = bitmap word t
+    WF_MARK(1);
+    // hot slots -> relevance bitmap (one bit per cell of 8 slots = one counter word)
     if (own && tid == 0) mark((int)(own_off / (uint32_t)ZV) - (int)reach, (int)((own_off + (uint32_t)L) / (uint32_t)ZV) + (int)reach);
     {
-        uint32_t wprev = cnt[(32 * tid - 1) & (WF_M / 8 - 1)], w = cnt[32 * tid];
+        // Eight counters at a time: the even and the odd nibbles of a word as the bytes of two registers, the four sums inside the pairs
+        // (n0+n1 ..) and the four across them (n1+n2 .., n7 + the next word's n0) as byte adds, "sum >= gate" as the carry into bit 7 of
+        // every byte (sums are at most 30).  A slot is hot when it is occupied and one of its two pairs reaches the gate.  All hot slots
+        // of a word lie in one bitmap cell c, and with reach = 8 a + b their reaches cover the cells c - a .. c + a, one more on the left
+        // when the lowest hot slot of the word is below b, one more on the right when the highest is at 8 - b or above: three cell
+        // bitmaps (hot, needs-left, needs-right), written as wave ballots (lanes = consecutive words: a thread that walks 32 consecutive
+        // words of its own puts all 64 lanes of every read on one LDS bank), and one dilation pass, thread t = bitmap word t.
+        // (Slot by slot, a branch per nibble and an atomicOr loop per hot slot: 22 of the kernel's 56 us per strand; this: 4.)
+        const uint32_t kb7 = (uint32_t)(128 - min(gate, 31)) * 0x01010101u;
+        const int ra = (int)(reach >> 3), rb = (int)(reach & 7u);
+        const bool by_bitmaps = ra <= 16;            // (longer reaches — reads beyond 250 kb — mark hot word by hot word)
+#pragma unroll 4
         for (int j = 0; j < 32; ++j) {
-            const uint32_t wnext = cnt[(32 * tid + j + 1) & (WF_M / 8 - 1)];
-            if (w) {
-#pragma unroll
-                for (int n = 0; n < 8; ++n) {
-                    const int c = (int)((w >> (4 * n)) & 15u);
-                    const int pv = n ? (int)((w >> (4 * n - 4)) & 15u) : (int)(wprev >> 28);
-                    const int nx = n < 7 ? (int)((w >> (4 * n + 4)) & 15u) : (int)(wnext & 15u);
-                    if (c > 0 && (c + nx >= gate || c + pv >= gate)) {
-                        const int e = (32 * tid + j) * 8 + n;
-                        mark(e - (int)reach, e + (int)reach);
-                    }
+            const uint32_t wi = (uint32_t)(j * FS_THREADS + tid);
+            // (all three reads unconditionally: no branch in front of the arithmetic, the reads of the unrolled steps overlap)
+            const uint32_t w = cnt[wi], wprev = cnt[(wi - 1u) & (WF_M / 8 - 1)], wnext = cnt[(wi + 1u) & (WF_M / 8 - 1)];
+            const uint32_t E = w & 0x0F0F0F0Fu, O = (w >> 4) & 0x0F0F0F0Fu;
+            // bit 7 of every byte: the pair's sum reaches the gate / the counter is not zero
+            const uint32_t H1 = E + O + kb7;                                                              // pairs (0,1) (2,3) (4,5) (6,7)
+            const uint32_t H2 = O + __builtin_amdgcn_alignbit(wnext & 15u, E, 8) + kb7;                   // pairs (1,2) (3,4) (5,6) (7,next)
+            const uint32_t hp = ((wprev >> 28) + (w & 15u)) >= (uint32_t)gate ? 0x80u : 0u;              // pair (previous word's 7, 0)
+            const uint32_t hotE = (E + 0x7F7F7F7Fu) & (H1 | (H2 << 8) | hp) & 0x80808080u;
+            const uint32_t hotO = (O + 0x7F7F7F7Fu) & (H1 | H2) & 0x80808080u;
+            const uint32_t m = (hotE >> 7) | (hotO >> 6);          // bit 8 i + j <-> nibble 2 i + j
+            const unsigned long long bh = __ballot(m != 0);
+            if (by_bitmaps) {
+                unsigned long long bl = 0, br = 0;
+                if (bh) {               // (a wave with a hot word: one step in ten)
+                    const int l = __builtin_ctz(m | 0x80000000u), h = 31 - __builtin_clz(m | 1u);
+                    const int lo = ((l >> 3) << 1) | (l & 1), hi = ((h >> 3) << 1) | (h & 1);
+                    bl = __ballot(m != 0 && lo < rb); br = __ballot(m != 0 && hi + rb >= 8);
                 }
+                if ((tid & 63) == 0) {
+                    const uint32_t bw = wi >> 5;          // the wave's 64 words = two bitmap words
+                    hotb[0][bw] = (uint32_t)bh; hotb[0][bw + 1] = (uint32_t)(bh >> 32);
+                    hotb[1][bw] = (uint32_t)bl; hotb[1][bw + 1] = (uint32_t)(bl >> 32);
+                    hotb[2][bw] = (uint32_t)br; hotb[2][bw + 1] = (uint32_t)(br >> 32);
+                }
+            } else if (m) {
+                const int l = __builtin_ctz(m), h = 31 - __builtin_clz(m);
+                const int e0 = (int)wi * 8;
+                mark(e0 + (((l >> 3) << 1) | (l & 1)) - (int)reach, e0 + (((h >> 3) << 1) | (h & 1)) + (int)reach);
             }
-            wprev = w;
-            w = wnext;
+        }
+        if (by_bitmaps) {
+            __syncthreads();
+            // word t of bitmap B moved d cells up (d < 0: down), circular
+            auto moved = [&](const uint32_t* B, int d) -> uint32_t {
+                if (d >= 0) {
+                    const int q = d >> 5, r = d & 31;
+                    const uint32_t x = B[(tid - q) & (REL_WORDS - 1)];
+                    return r ? (x << r) | (B[(tid - q - 1) & (REL_WORDS - 1)] >> (32 - r)) : x;
+                }
+                const int q = (-d) >> 5, r = (-d) & 31;
+                const uint32_t x = B[(tid + q) & (REL_WORDS - 1)];
+                return r ? (x >> r) | (B[(tid + q + 1) & (REL_WORDS - 1)] << (32 - r)) : x;
+            };
+            uint32_t acc = moved(hotb[2], ra + 1) | moved(hotb[1], -(ra + 1));
+            for (int d = -ra; d <= ra; ++d) acc |= moved(hotb[0], d);
+            if (acc) atomicOr(&rel[tid], acc);          // (the wraps of the walk and the read's own segments are in there already)
         }
     }
     __syncthreads();
+    WF_MARK(2);
     // kept hits = hits of the slots whose bit is set
     uint32_t mine = 0;
     {
@@ -1071,6 +1133,7 @@ __global__ __launch_bounds__(FS_THREADS) void seed_filter_wide(const mhip_offset
         A.filtered[s] = 1;
         atomicAdd(&counters[12], (unsigned long long)room);      // debug slot 12: room asked for by this filter
     }
+    WF_MARK(3);
 }
 
 __global__ __launch_bounds__(FS_THREADS) void seed_strand(const mhip_offset_t* __restrict__ roffs, ReadSel sel, int ib,
@@ -1909,6 +1972,16 @@ static int seed_batch(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref
         int in_b = 0;
         if (Htot > 0) {
             LAUNCH(c, "seed_emit", seed_emit, ns, SEED_BLOCK, 0, (const mhip_offset_t*)reads->d_offs, sel, ib, (const int32_t*)idx->d_offsets, B);
+#ifdef WF_PROF
+            {
+                unsigned long long h[16], z[16] = {0};
+                HIPCHK(hipStreamSynchronize(c->stream));
+                HIPCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wfprof), sizeof(h)));
+                HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_wfprof), z, sizeof(z)));
+                const char* nm[16] = {"wf zero", "wf walk", "wf hot", "wf kept+out", 0, 0, 0, 0, "emit bitmap", "emit load+count", "emit scan", "emit write"};
+                for (int i = 0; i < 16; ++i) if (nm[i]) fprintf(stderr, "[wf prof] %-16s %8.1f us per strand (%d strands)\n", nm[i], (double)h[i] / 100.0 / ns, ns);
+            }
+#endif
             const int npass = (nbits + SORT_MAXBITS - 1) / SORT_MAXBITS;
             const int per = (nbits + npass - 1) / npass;
             int done = 0;

@@ -18,5 +18,7 @@ for it in range(2):
     t0 = time.time()
     M.seed_reads_strided_dev(ctx, idx, vol, vol, 0, 1, n, p, dc.data_ptr(), dn.data_ptr()); ctx.sync()
     print("seed %.1f ms" % ((time.time() - t0) * 1e3), "cands", int(dn.sum()), "hits", ctx.counters()["hits"], "walked", ctx.debug_counter(15), "wide filter kept", ctx.debug_counter(12), "(room)")
+import hashlib
+print("candidates sha256", hashlib.sha256(dc.cpu().numpy().tobytes()).hexdigest()[:16], "counts sha256", hashlib.sha256(dn.cpu().numpy().tobytes()).hexdigest()[:16])
 for k, (c, ms) in sorted(ctx.kernel_stats().items(), key=lambda kv: -kv[1][1]):
     print("  %-16s %3d launches %8.2f ms" % (k, c, ms))

@@ -13,8 +13,12 @@
 // string_check's gap shuffling of the left pair (:199-281), the overlap of the two directions on the seed 13-mer, coordinates, the
 // 450-base test, jscore and the 12-field line (:843-948).  Line order inside the .r files is by read here and by thread timing in the
 // tool: the consumer (mecat2asmpwConvert) reads lines one by one.
-// N in a read: the tool restarts its k-mer there in table and query and aligns it as a character (:445, 486, 316-335); here the N
-// positions travel as a second plane beside the 2-bit volume (mhip_volume_set_nplane).  Any other letter outside A, C, G, T is refused.
+// Letters outside A, C, G, T (N, the other IUPAC codes, anything else a read file holds): the tool restarts its k-mer there in table and
+// query (atcttrans gives every one of them 4, :296-304, 445, 486) and aligns it as the character it is — equal only to itself, and its
+// own complement (:583-590).  Here such a base travels as a symbol (code, plane): a non-zero value 1..3 in a second 2-bit plane beside
+// the volume (mhip_volume_set_nplane) and one of the four codes in the volume itself, twelve symbols in all — N is (0, 3), the others
+// are handed out in order of first appearance (the eleven other IUPAC codes fit; a thirteenth distinct character is refused).
+#include <ctype.h>
 #include <errno.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -45,6 +49,25 @@
 
 static const int SEED = 13;
 
+// symbols of the characters that are not A, C, G, T (see the head of the file): sym = code | plane << 2, plane != 0
+#include <mutex>
+static std::mutex g_sym_mu;
+static int g_sym_of[256];            // 0: none yet
+static char g_sym_chr[16];           // the character of symbol (code | plane << 2)
+static int g_sym_next = 0;
+static int symbol_of(unsigned char ch, const char* path, int read_no) {
+    static const int order[11] = {1 | 3 << 2, 2 | 3 << 2, 3 | 3 << 2, 0 | 1 << 2, 1 | 1 << 2, 2 | 1 << 2, 3 | 1 << 2, 0 | 2 << 2, 1 | 2 << 2, 2 | 2 << 2, 3 | 2 << 2};
+    std::lock_guard<std::mutex> lk(g_sym_mu);
+    if (!g_sym_chr[0 | 3 << 2]) { g_sym_chr[0 | 3 << 2] = 'N'; g_sym_of[(int)'N'] = 0 | 3 << 2; }
+    if (g_sym_of[ch]) return g_sym_of[ch];
+    if (g_sym_next >= 11)
+        DIE("%s: character '%c' in read %d: a thirteenth distinct character besides A, C, G, T (this path carries twelve)", path, ch, read_no);
+    const int sym = order[g_sym_next++];
+    g_sym_of[ch] = sym;
+    g_sym_chr[sym] = (char)ch;
+    return sym;
+}
+
 struct Reads {                       // one fasta block: 2-bit volume (one pad base after every read) + its host copy
     std::vector<uint8_t> pac;
     std::vector<mhip_offset_t> offs;
@@ -59,12 +82,13 @@ struct Reads {                       // one fasta block: 2-bit volume (one pad b
         const int64_t idx = (int64_t)offs[(size_t)r].offset + i;
         return (pac[(size_t)(idx >> 2)] >> ((~idx & 3) << 1)) & 3;
     }
-    bool is_n(int r, int i) const {
-        if (!has_n) return false;
+    int plane(int r, int i) const {
+        if (!has_n) return 0;
         const int64_t idx = (int64_t)offs[(size_t)r].offset + i;
-        return ((npac[(size_t)(idx >> 2)] >> ((~idx & 3) << 1)) & 3) != 0;
+        return (npac[(size_t)(idx >> 2)] >> ((~idx & 3) << 1)) & 3;
     }
-    char chr(int r, int i) const { return is_n(r, i) ? 'N' : "ACGT"[base(r, i)]; }
+    bool is_n(int r, int i) const { return plane(r, i) != 0; }
+    char chr(int r, int i) const { const int k = plane(r, i); return k ? g_sym_chr[base(r, i) | k << 2] : "ACGT"[base(r, i)]; }
 };
 
 // load_read / load_fastq (:388-409, :982-1010): ">header" line, one sequence line; lower case is upper-cased
@@ -121,18 +145,19 @@ static void load_block(const std::string& path, int first_no, Reads* R) {
             int c = code[(unsigned char)p[i]];
             const int64_t idx = at + i;
             if (c < 0) {
-                // N: atcttrans() gives it 4, like every character outside A, C, G, T (:296-304) — but the extension compares characters, so
-                // only N itself is taken (any other letter would have to stay distinct from N: refused)
-                if (p[i] != 'N' && p[i] != 'n')
-                    DIE("%s: base '%c' in read %d: only A, C, G, T and N are supported on this path", path.c_str(), p[i], first_no + (int)R->offs.size());
+                // not A, C, G, T: atcttrans() gives it 4 (:296-304: no k-mer over it); the extension compares it as the character it is,
+                // upper-cased like everything the tool reads (:398, 992: every byte from 'a' up goes through toupper)
+                unsigned char ch = (unsigned char)p[i];
+                if (ch >= 'a') ch = (unsigned char)toupper(ch);
+                const int sym = symbol_of(ch, path.c_str(), first_no + (int)R->offs.size());
                 if (!R->has_n) { R->has_n = true; R->npac.assign(R->pac.size(), 0); R->frag = R->offs; }
-                R->npac[(size_t)(idx >> 2)] |= (uint8_t)(3 << ((~idx & 3) << 1));
+                R->npac[(size_t)(idx >> 2)] |= (uint8_t)((sym >> 2) << ((~idx & 3) << 1));
                 mhip_offset_t fr;
                 fr.offset = (int)(at + fstart);
                 fr.size = (int)(i - fstart);
                 R->frag.push_back(fr);
                 fstart = i + 1;
-                c = 0;
+                c = sym & 3;
             }
             pac[idx >> 2] |= (uint8_t)(c << ((~idx & 3) << 1));
         }
@@ -327,11 +352,13 @@ int main(int argc, char** argv) {
                     auto at2 = [](const uint8_t* pl, int64_t idx) -> int { return (pl[(size_t)(idx >> 2)] >> ((~idx & 3) << 1)) & 3; };
                     auto xchr = [&](int pos) -> char {
                         const int64_t idx = xo + pos;
-                        return xn && at2(xn, idx) ? 'N' : "ACGT"[at2(xp, idx)];
+                        const int k = xn ? at2(xn, idx) : 0;
+                        return k ? g_sym_chr[at2(xp, idx) | k << 2] : "ACGT"[at2(xp, idx)];
                     };
                     auto ychr = [&](int pos) -> char {
                         const int64_t idx = yo + (jb.chain ? read_len - 1 - pos : pos);
-                        if (yn && at2(yn, idx)) return 'N';
+                        const int k = yn ? at2(yn, idx) : 0;
+                        if (k) return g_sym_chr[at2(yp, idx) | k << 2];
                         return jb.chain ? "TGCA"[at2(yp, idx)] : "ACGT"[at2(yp, idx)];
                     };
                     auto build = [&](int d, std::string& s1, std::string& s2) {

@@ -154,6 +154,8 @@ __global__ __launch_bounds__(CN_BLOCK, 6) void cns_extend(const uint32_t* __rest
                     const uint32_t a = (in && qnpac) ? view_word(qn, extend1 + (w - 1) * 16) : 0u;
                     const uint32_t b = (in && rnpac) ? view_word(tn, extend2 + (w - 1) * 16) : 0u;
                     Qn[w] = a; Tn[w] = b;
+                    if (q.comp) S.Qp[w] = unflip_symbols(S.Qp[w], a);
+                    if (t.comp) S.Tp[w] = unflip_symbols(S.Tp[w], b);
                     has_n |= (a | b) != 0u;      // (a lane may stage more than one word when the staging size grows)
                 }
             }

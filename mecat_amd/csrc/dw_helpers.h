@@ -88,9 +88,9 @@ __device__ __forceinline__ int match16(const uint32_t* Q, int x, const uint32_t*
     return (int)(lead >> 1);
 }
 
-// match16 for sequences with bases outside A, C, G, T: Qn / Tn hold 3 at such a base (whose code in Q / T is 0) and 0 elsewhere, in the
-// layout of Q / T.  Such a base equals only another such base: the difference word is forced to "differs" where exactly one side has
-// one and to "equal" where both have.
+// match16 for sequences with bases outside A, C, G, T: such a base is a symbol (code in Q / T, a non-zero value in the plane Qn / Tn of
+// the same layout; the planes are 0 at A, C, G, T) and equals only the same symbol.  Staged strand views hold the stored code at such a
+// base (see unflip_symbols), so "equal" is "code and plane equal".
 __device__ __forceinline__ int match16n(const uint32_t* Q, const uint32_t* Qn, int x, const uint32_t* T, const uint32_t* Tn, int y) {
     const int wq = (x + 15) >> 4, wt = (y + 15) >> 4;
     uint32_t sq, st;
@@ -98,10 +98,18 @@ __device__ __forceinline__ int match16n(const uint32_t* Q, const uint32_t* Qn, i
     asm("v_mul_i32_i24 %0, -2, %1" : "=v"(st) : "v"(y));
     const uint32_t dh = __builtin_amdgcn_alignbit(Q[wq], Q[wq + 1], sq) ^ __builtin_amdgcn_alignbit(T[wt], T[wt + 1], st);
     const uint32_t nq = __builtin_amdgcn_alignbit(Qn[wq], Qn[wq + 1], sq), nt = __builtin_amdgcn_alignbit(Tn[wt], Tn[wt + 1], st);
-    const uint32_t d = (dh | nq | nt) & ~(nq & nt);
+    const uint32_t d = dh | (nq ^ nt);
     uint32_t lead;
     asm("v_ffbh_u32 %0, %1" : "=v"(lead) : "v"(d));
     return (int)(lead >> 1);
+}
+
+// A complemented strand view (SeqView::comp) also complements the codes of the bases that are not A, C, G, T, which are their own
+// complement (mecat2asmpw.c:583-590): flip them back — word = 16 codes of the view, plane = the same 16 bases of the plane.
+__device__ __forceinline__ uint32_t unflip_symbols(uint32_t word, uint32_t plane) {
+    uint32_t m = (plane | (plane >> 1)) & 0x55555555u;
+    m |= m << 1;
+    return word ^ m;
 }
 
 // little-endian staged blocks (view_word_le; no pad word: base i lives in word i >> 4)

@@ -1034,6 +1034,12 @@ __global__ __launch_bounds__(FS_THREADS) void seed_filter_wide(const mhip_offset
     const bool own = same_volume && !(s & 1);
     const uint32_t own_off = (uint32_t)roffs[rid].offset;
     fs_walk<FS_LPB2, FS_NP2, FS_Q2, FS_D2, false>(A.km_bstart + kb, A.km_cnt + kb, offsets, K, [&](int km, uint32_t pos) {
+#if defined(WF_KNOCK) && WF_KNOCK == 1
+        if (pos == 0xfffffff1u) atomicAdd(&s_self, 1u);      // timing experiment: the gather alone (results are wrong)
+        return;
+#elif defined(WF_KNOCK) && WF_KNOCK == 2
+        { const uint32_t e_ = (pos / (uint32_t)ZV) & (WF_M - 1); atomicAdd(&cnt[e_ >> 3], 1u << ((e_ & 7u) * 4u)); return; }      // no return value, no wrap test
+#endif
         if (own && pos == own_off + (uint32_t)km * BC) { atomicAdd(&s_self, 1u); return; }
         const uint32_t e = (pos / (uint32_t)ZV) & (WF_M - 1);
         const uint32_t old = atomicAdd(&cnt[e >> 3], 1u << ((e & 7u) * 4u));

@@ -214,10 +214,13 @@ def cns_templates(ec, num_reads, min_cov=4, min_size=5000):
     return np.ascontiguousarray(rec[sel]), tb, ids
 
 
-def asm_blocks_layout(d, nreads, L, genome, nblocks, seed, err=0.02, n_every=0):
+def asm_blocks_layout(d, nreads, L, genome, nblocks, seed, err=0.02, n_every=0, iupac=False):
     """corrected reads (2 % error) laid out as canu hands them to mecat2asmpw / mecat2trimpw (Overlapmecat2asmpw.pm:483-503): <d>/ovlprep
     with one "-allreads -allbases -b <first> -e <last>" line per block and <d>/%06d.fasta, reads numbered from 1.
     n_every > 0: every n_every-th read carries Ns (one, three, a run of five, or one at either end and one inside).
+    iupac: in every read the base behind each occurrence of four fixed 7-mers becomes an IUPAC code (R, Y, K, lower-case m): reads that
+    overlap on the same strand carry the same letter at the same place (a letter equals itself), reads of the other strand and reads with
+    an error there do not (a letter differs from A, C, G, T); every seventh read also gets one of the other seven codes at a random place.
     -> (blocks [(first, last)], total bases)"""
     codes, lens = synth_reads(nreads, L, err, genome, seed, 0)
     starts = np.concatenate([[0], np.cumsum(lens.astype(np.int64))])
@@ -244,6 +247,15 @@ def asm_blocks_layout(d, nreads, L, genome, nblocks, seed, err=0.02, n_every=0):
                         text[pos[0]: pos[0] + 5] = ord("N")
                     else:
                         text[0] = ord("N"); text[-1] = ord("N"); text[pos[1]] = ord("N")
+                if iupac and len(text) > 100:
+                    raw = text.tobytes()
+                    for pat, ch in ((b"ACGTACG", b"R"), (b"TTGACCA", b"Y"), (b"GGATCCA", b"K"), (b"CATGCAT", b"m")):
+                        at = raw.find(pat)
+                        while at >= 0 and at + 7 < len(text):
+                            text[at + 7] = ch[0]
+                            at = raw.find(pat, at + 1)
+                    if rid % 7 == 0:
+                        text[rng.integers(20, len(text) - 20)] = b"SWBDHVn"[(rid // 7) % 7]
                 f.write(b">%d\n" % rid + text.tobytes() + b"\n")
     return blocks, int(lens.sum())
 

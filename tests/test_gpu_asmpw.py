@@ -218,6 +218,34 @@ def test_reads_with_n_equal_the_reference_run_on_this_machine(tmp_path, tool, st
     assert plain != want
 
 
+@pytest.mark.parametrize("tool,start", [("mecat2asmpw", 1), ("mecat2trimpw", 2)])
+def test_reads_with_iupac_codes_equal_the_reference_run_on_this_machine(tmp_path, tool, start):
+    """Every character outside A, C, G, T — not only N: atcttrans gives them all 4 (mecat2asmpw.c:296-304: no k-mer over one), the
+    extension compares them as the characters they are (a letter equals itself and nothing else), the mapped strand keeps them
+    (:583-590), lower case is upper-cased (:398, 992).  2 000 corrected reads in two blocks with R / Y / K / m behind fixed 7-mers of
+    every read (so overlapping reads of one strand agree on them) and S, W, B, D, H, V, n sprinkled in; the UNMODIFIED tool and the
+    drop-in side by side on this machine: sorted outputs equal line by line, and different from the run on the plain reads."""
+    from mecat_amd import workload as W
+    ref = os.path.join(H.ROOT, "oracle", "_ref", tool)
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref/%s is not built (make -C oracle ref, in the container)" % tool)
+    d = str(tmp_path / "iupac")
+    os.makedirs(d)
+    W.asm_blocks_layout(d, 2000, 8000, 500_000, 2, 79, iupac=True)
+    letters = set(open(os.path.join(d, "000001.fasta"), "rb").read()) - set(b">0123456789\nACGT")
+    assert len(letters) >= 8, letters
+    want, _, _ = W.asm_tool_run(ref, d, 16, start, 2)
+    got, _, _ = W.asm_tool_run(os.path.join(H.ROOT, "mecat_amd", "bin", tool), d, 16, start, 2)
+    assert len(want) > 10000
+    bad = [(a, b) for a, b in zip(got, want) if a != b]
+    assert len(got) == len(want) and not bad, (len(got), len(want), bad[:3])
+    d0 = str(tmp_path / "plain")
+    os.makedirs(d0)
+    W.asm_blocks_layout(d0, 2000, 8000, 500_000, 2, 79)
+    plain, _, _ = W.asm_tool_run(ref, d0, 16, start, 2)
+    assert plain != want
+
+
 @pytest.mark.parametrize("tool,start", [("mecat2asmpw50", 1), ("mecat2asmpw50", 2), ("mecat2trimpw50", 1), ("mecat2trimpw50", 2)])
 def test_50_candidate_variants_equal_the_reference_output(tmp_path, tool, start):
     """the `*50` names (MAXC 50, mecat2asmpw50.c:23) on a set dense enough that the top-MAXC cut decides which candidates survive (the

@@ -114,6 +114,13 @@ int  mhip_ctx_counters(mhip_ctx* ctx, int64_t out[8]);
 /* volume: host arrays exactly as load_volume() leaves them (pac = (num_bases+3)/4 bytes) */
 int  mhip_volume_upload(mhip_ctx* ctx, const uint8_t* pac, const mhip_offset_t* offs, int num_reads, int num_bases,
                         int start_read_id, mhip_volume** out);
+/* the same volume made on the device from the residue LETTERS (replaces the packing step of split_raw_dataset,
+   common/split_database.cpp:221-266 + PackedDB::set_char, packed_db.h:98-107, unmasked OR of the 4-bit IUPAC value included).
+   text = the input file's bytes (host), seq_start[r] = index of read r's first residue, line_width[r] = residues per line of read r (0: one
+   line; otherwise every line but the last holds exactly that many and ends in one byte), offs = the volume layout (offset, size; one pad
+   base behind every read).  pac_out, when not NULL, receives the (num_bases + 3) / 4 packed bytes (what dump_volume writes). */
+int  mhip_volume_pack(mhip_ctx* ctx, const uint8_t* text, int64_t text_bytes, const int64_t* seq_start, const int32_t* line_width,
+                      const mhip_offset_t* offs, int num_reads, int num_bases, int start_read_id, mhip_volume** out, uint8_t* pac_out);
 void mhip_volume_free(mhip_volume* v);
 int  mhip_volume_num_reads(const mhip_volume* v);
 int  mhip_volume_num_bases(const mhip_volume* v);

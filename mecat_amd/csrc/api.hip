@@ -219,7 +219,7 @@ int mhip_volume_upload(mhip_ctx* c, const uint8_t* pac, const mhip_offset_t* off
         return -1;
     }
     HIPCHK(hipMemsetAsync(v->d_pac, 0, v->pac_bytes, c->stream));
-    if (nb) HIPCHK(hipMemcpyAsync(v->d_pac, pac, nb, hipMemcpyHostToDevice, c->stream));
+    if (nb && pac) HIPCHK(hipMemcpyAsync(v->d_pac, pac, nb, hipMemcpyHostToDevice, c->stream));      // (pac == NULL: mhip_volume_pack fills it)
     v->h_offs.assign(offs, offs + num_reads);
     if (num_reads) HIPCHK(hipMemcpyAsync(v->d_offs, offs, sizeof(mhip_offset_t) * (size_t)num_reads, hipMemcpyHostToDevice, c->stream));
     // position -> read without a binary search over the offsets (get_read_id_from_offset_list, common/split_database.cpp:15-35,

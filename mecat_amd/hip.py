@@ -77,6 +77,7 @@ def lib():
     L.mhip_ctx_counters.argtypes = [vp, C.POINTER(i64)]
     L.mhip_debug_counter.argtypes = [vp, i32, C.POINTER(i64)]
     L.mhip_volume_upload.argtypes = [vp, vp, vp, i32, i32, i32, C.POINTER(vp)]
+    L.mhip_volume_pack.argtypes = [vp, vp, i64, vp, vp, vp, i32, i32, i32, C.POINTER(vp), vp]
     L.mhip_volume_free.argtypes = [vp]
     L.mhip_volume_set_nplane.argtypes = [vp, vp, vp]
     L.mhip_volume_num_reads.argtypes = [vp]
@@ -211,6 +212,24 @@ class Volume:
         self.start_read_id = start_read_id
         _chk(lib().mhip_volume_upload(ctx.h, pac.ctypes.data, offs.ctypes.data, len(offs), num_bases, start_read_id,
                                       C.byref(self.h)))
+
+    @classmethod
+    def from_letters(cls, ctx, text, seq_start, line_width, offs, num_bases, start_read_id=0):
+        """mhip_volume_pack: the volume packed on the device from the file's bytes -> (Volume, packed bytes uint8[(num_bases+3)//4])"""
+        text = np.ascontiguousarray(np.frombuffer(text, dtype=np.uint8))
+        seq_start = np.ascontiguousarray(seq_start, dtype=np.int64)
+        line_width = np.ascontiguousarray(line_width, dtype=np.int32)
+        offs = np.ascontiguousarray(offs, dtype=np.int32).reshape(-1, 2)
+        pac = np.zeros(((num_bases + 3) // 4,), dtype=np.uint8)
+        self = cls.__new__(cls)
+        self.h = C.c_void_p()
+        self.offs = offs
+        self.num_reads = len(offs)
+        self.num_bases = int(num_bases)
+        self.start_read_id = start_read_id
+        _chk(lib().mhip_volume_pack(ctx.h, text.ctypes.data, len(text), seq_start.ctypes.data, line_width.ctypes.data, offs.ctypes.data, len(offs),
+                                    num_bases, start_read_id, C.byref(self.h), pac.ctypes.data))
+        return self, pac
 
     @classmethod
     def from_file(cls, ctx, path):

@@ -791,6 +791,10 @@ int main(int argc, char* argv[]) {
         if (world > 1) unlink(marker.c_str());
         for (int r = 0; world > 1 && r < world; ++r) unlink(partition_meta_name(opt.output, r).c_str());      // (no rank has started its partition streams yet)
         volume_set_async_dump(world == 1);       // other ranks read the volume files as soon as the run marker exists
+        volume_set_device_packer([&]() -> mhip_ctx* {      // (only used under MECAT_HIP_SPLIT=gpu)
+            if (gpu_setup.joinable()) gpu_setup.join();      // (the set-up thread still uses the context after it has published it)
+            return ctx_state.load() == 1 ? ctx : NULL;
+        });
         num_vols = split_raw_dataset(opt.reads, opt.wrk_dir, opt.num_threads);
         for (int i = 0; i < num_vols; ++i)
             if (access(results_name(opt.wrk_dir, i, false).c_str(), F_OK) != 0) todo.push_back(i);
@@ -838,7 +842,7 @@ int main(int argc, char* argv[]) {
         TraceTimer tt("wait for ctx_create");
         // only the context is needed from here on; a reservation still in flight is waited for inside the library
         while (ctx_state.load() == 0) usleep(500);
-        if (ctx_state.load() < 0) { gpu_setup.join(); DIE("cannot use the GPU: %s", ctx_error.c_str()); }
+        if (ctx_state.load() < 0) { if (gpu_setup.joinable()) gpu_setup.join(); DIE("cannot use the GPU: %s", ctx_error.c_str()); }
     }
     mhip_comm* comm = NULL;
     if (cells) {
@@ -914,7 +918,7 @@ int main(int argc, char* argv[]) {
         MCHK(mhip_comm_barrier(comm));
         mhip_comm_destroy(comm);
     }
-    gpu_setup.join();
+    if (gpu_setup.joinable()) gpu_setup.join();
     {
         TraceTimer tt("ctx_destroy");
         mhip_ctx_destroy(ctx);

@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <atomic>
 #include <fcntl.h>
+#include <functional>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -193,7 +194,11 @@ void run_threads(int nt, F f) {
     for (auto& x : th) x.join();
 }
 
-struct PlainRec { size_t data; int len; };
+struct PlainRec { size_t data; int len; int lw; };      // lw: residues per line (0: one line; -1: lines of different lengths)
+
+// MECAT_HIP_SPLIT=gpu: the packing step on the device (mhip_volume_pack) instead of on the host threads; the hook hands out the context
+// (the driver creates it on a second thread while the input is scanned)
+std::function<mhip_ctx*()> g_device_ctx;
 
 // MECAT_TRACE: seconds per stage of the threaded split on stderr
 struct SplitClock {
@@ -239,7 +244,8 @@ bool split_plain_fasta(const char* reads, const char* wrk_dir, long max_volume_b
             p = hend < size ? hend + 1 : size;
             PlainRec r;
             r.data = p;
-            long len = 0;
+            r.lw = 0;
+            long len = 0, prev_line = -1;
             while (p < size) {                       // data lines up to the next line starting with '>'
                 const unsigned char c0 = (unsigned char)txt[p];
                 if (c0 == '>') break;
@@ -250,9 +256,16 @@ bool split_plain_fasta(const char* reads, const char* wrk_dir, long max_volume_b
                     if (kEnc.t[(unsigned char)txt[q]] >= 16) { plain = 0; return; }     // blanks, digits, ';', '\r', bad residues
                     ++q;
                 }
+                // line widths (for the device packer): every line but the last as long as the first
+                if (prev_line >= 0) {
+                    if (r.lw == 0) r.lw = (int)std::min<long>(prev_line, 0x7fffffffL);
+                    else if (r.lw > 0 && prev_line != r.lw) r.lw = -1;
+                }
+                prev_line = (long)(q - p);
                 len += (long)(q - p);
                 p = q < size ? q + 1 : size;
             }
+            if (r.lw > 0 && prev_line > r.lw) r.lw = -1;      // (the last line may be shorter, not longer)
             if (len == 0 || len > 0x7fffffffL) { plain = 0; return; }
             r.len = (int)len;
             out.push_back(r);
@@ -307,7 +320,34 @@ bool split_plain_fasta(const char* reads, const char* wrk_dir, long max_volume_b
             rcut[(size_t)t] = (size_t)(std::lower_bound(at.begin() + (long)vo.first, at.begin() + (long)(vo.first + vo.count), want) -
                                        (at.begin() + (long)vo.first));
         }
-        run_threads(nt, [&](int t) {
+        bool on_device = false;
+        if (g_device_ctx && getenv("MECAT_HIP_SPLIT") && !strcmp(getenv("MECAT_HIP_SPLIT"), "gpu")) {
+            // the packing step on the device: the file's bytes go over as they are, the packed bytes come back for the volume file
+            bool regular = true;
+            for (size_t i = 0; i < vo.count && regular; ++i) regular = all[vo.first + i].lw >= 0;
+            mhip_ctx* dc = regular ? g_device_ctx() : NULL;
+            if (dc) {
+                const size_t t0 = all[vo.first].data;
+                const PlainRec& lastr = all[vo.first + vo.count - 1];
+                const size_t t1 = std::min(size, lastr.data + (size_t)lastr.len + (lastr.lw > 0 ? (size_t)(lastr.len - 1) / (size_t)lastr.lw : 0));
+                std::vector<int64_t> sstart(vo.count);
+                std::vector<int32_t> lws(vo.count);
+                for (size_t i = 0; i < vo.count; ++i) {
+                    const PlainRec& r = all[vo.first + i];
+                    v.offs[i].offset = (int)at[vo.first + i];
+                    v.offs[i].size = r.len;
+                    sstart[i] = (int64_t)(r.data - t0);
+                    lws[i] = r.lw;
+                }
+                mhip_volume* dv = NULL;
+                if (mhip_volume_pack(dc, (const uint8_t*)txt + t0, (int64_t)(t1 - t0), sstart.data(), lws.data(), v.offs.data(), v.num_reads, v.num_bases,
+                                     v.start_read_id, &dv, v.pac.data()) != 0)
+                    DIE("mhip_volume_pack failed: %s", mhip_last_error());
+                mhip_volume_free(dv);
+                on_device = true;
+            }
+        }
+        if (!on_device) run_threads(nt, [&](int t) {
             uint8_t* pac = v.pac.data();
             for (size_t i = rcut[(size_t)t]; i < rcut[(size_t)t + 1]; ++i) {
                 const PlainRec& r = all[vo.first + i];
@@ -337,7 +377,7 @@ bool split_plain_fasta(const char* reads, const char* wrk_dir, long max_volume_b
                 put();
             }
         });
-        clk.mark("pack");
+        clk.mark(on_device ? "pack (device)" : "pack");
         const std::string name = volume_file_name(wrk_dir, (int)k);
         fprintf(idx_file, "%s\n", name.c_str());
         if (k + 1 == vols.size()) {
@@ -460,6 +500,8 @@ int split_raw_dataset(const char* reads, const char* wrk_dir, int num_threads) {
     fprintf(stderr, "[%s] takes %.2f secs.\n", __func__, t1.tv_sec - t0.tv_sec + 1e-6 * (t1.tv_usec - t0.tv_usec));
     return vol;
 }
+
+void volume_set_device_packer(std::function<mhip_ctx*()> get_ctx) { g_device_ctx = std::move(get_ctx); }
 
 void volume_set_async_dump(bool on) {
     static bool registered = false;

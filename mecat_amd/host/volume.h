@@ -5,6 +5,7 @@
 
 #include <stdint.h>
 
+#include <functional>
 #include <string>
 #include <memory>
 #include <utility>
@@ -49,6 +50,9 @@ std::vector<std::string> load_volume_names(const std::string& idx_file);   // sp
 // One-process runs: the file of the volume that stays in memory is written, and the input unmapped, on a second thread while the
 // caller goes on; volume_wait_pending() returns when that is done (called before a volume file is read back, before the volume's
 // memory is released and at exit).  Multi-process runs keep the write synchronous: other ranks read the file.
+// MECAT_HIP_SPLIT=gpu: plain FASTA whose records have lines of one width is packed on the device (mhip_volume_pack)
+// with the context the hook returns (NULL: on the host after all).  The volume files are the same bytes either way.
+void volume_set_device_packer(std::function<mhip_ctx*()> get_ctx);
 void volume_set_async_dump(bool on);
 void volume_wait_pending();
 // Unmapping a multi-GB input holds the process's mmap lock for tens of milliseconds, which every hipMalloc needs: the mapping of an

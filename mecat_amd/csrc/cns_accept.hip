@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "common.h"
+#include "aln_strings.h"
 
 namespace {
 
@@ -354,7 +355,7 @@ int mhip_cns_accept_templates(mhip_ctx* c, const mhip_volume* vol, const uint8_t
     char* S = (size_t)sbytes >= ((size_t)64 << 20) ? strbuf_get((size_t)sbytes) : (char*)malloc((size_t)std::max<int64_t>(sbytes, 1));
     if (!S) { free(A); mhip_set_error("out of memory (%lld bytes of aligned strings)", (long long)sbytes); return -1; }
     parallel_for(num_templates, num_threads, [&](int64_t t) {
-        std::vector<char> qbuf, tbuf;
+        std::vector<char> qbuf, tbuf, qtmp, ttmp;
         for (int64_t a = afirst[(size_t)t]; a < afirst[(size_t)t + 1]; ++a) {
             const int64_t ji = sel[(size_t)a];
             const mhip_cns_result& r = res[(size_t)ji];
@@ -372,27 +373,22 @@ int mhip_cns_accept_templates(mhip_ctx* c, const mhip_volume* vol, const uint8_t
             const mhip_offset_t qo = vol->h_offs[(size_t)jb.qid_local], so = vol->h_offs[(size_t)jb.sid_local];
             // the bases the columns cover, as characters: query (in the mapped strand's orientation) from the untrimmed start point,
             // template likewise — the column loop below then only picks from them
-            const int ncols = r.left_cols + r.right_cols;
             const int nq = r.query_end - r.query_start, nt = r.target_end - r.target_start;
-            qbuf.resize((size_t)nq + 8);
-            tbuf.resize((size_t)nt + 8);
-            if (jb.chain) decode_rc(host_pac, qo.offset, qo.size, r.query_start, nq, qbuf.data());
-            else decode_fwd(host_pac, qo.offset, r.query_start, nq, qbuf.data());
-            decode_fwd(host_pac, so.offset, r.target_start, nt, tbuf.data());
-            // merged column m: reverse(left) then right; columns [first_col, last_col) are kept (GetAlignment's trimming)
-            int qi = 0, ti = 0;
-            auto put = [&](int m, int op) {
-                const int hq = op != 1, ht = op != 2;
-                if (m >= r.first_col && m < r.last_col) {
-                    qa[m - r.first_col] = hq ? qbuf[(size_t)qi] : '-';
-                    sa[m - r.first_col] = ht ? tbuf[(size_t)ti] : '-';
-                }
-                qi += hq;
-                ti += ht;
-            };
-            for (int m = 0; m < r.left_cols; ++m) { const int k = r.left_cols - 1 - m; put(m, (int)((left[k >> 4] >> ((k & 15) << 1)) & 3u)); }
-            for (int k = 0; k < r.right_cols; ++k) put(r.left_cols + k, (int)((right[k >> 4] >> ((k & 15) << 1)) & 3u));
-            (void)ncols;
+            qbuf.resize((size_t)nq + 24);             // (8 bytes in front of the bases and 8 + the decoders' overrun behind them: aln_strings.h)
+            tbuf.resize((size_t)nt + 24);
+            if (jb.chain) decode_rc(host_pac, qo.offset, qo.size, r.query_start, nq, qbuf.data() + 8);
+            else decode_fwd(host_pac, qo.offset, r.query_start, nq, qbuf.data() + 8);
+            decode_fwd(host_pac, so.offset, r.target_start, nt, tbuf.data() + 8);
+            // merged columns: reverse(left) then right, four at a time (aln_strings.h); columns [first_col, last_col) are kept (GetAlignment's
+            // trimming)
+            {
+                const int ncols = r.left_cols + r.right_cols;
+                qtmp.resize((size_t)ncols + 16);
+                ttmp.resize((size_t)ncols + 16);
+                alnstr::build(left, r.left_cols, right, r.right_cols, qbuf.data() + 8, tbuf.data() + 8, qtmp.data() + 8, ttmp.data() + 8);
+                memcpy(qa, qtmp.data() + 8 + r.first_col, (size_t)o.aln_size);
+                memcpy(sa, ttmp.data() + 8 + r.first_col, (size_t)o.aln_size);
+            }
             qa[o.aln_size] = 0;
             sa[o.aln_size] = 0;
             push_gaps(qa, sa, o.aln_size);

@@ -796,7 +796,7 @@ def main():
             except Exception as e:  # the GPU number must survive a CPU-leg problem
                 line["cpu_baseline"] = {"value": None, "unit": "candidates/s", "cores": os.cpu_count(), "kind": "reference",
                                         "sample": "failed: %r" % (e,)}
-        print(json.dumps(line), flush=True)
+        print(json.dumps(W.annotate_cpu_baseline(line)), flush=True)
     if not released:
         vol.free()
     if comm is not None:

@@ -153,4 +153,4 @@ def run(args):
                 line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
         except Exception as e:      # noqa: BLE001
             line["cpu_baseline"] = {"error": repr(e)[:300]}
-    print(json.dumps(line))
+    print(json.dumps(W.annotate_cpu_baseline(line)))

@@ -478,7 +478,7 @@ def run(args):
                         "source": "tests/golden/big.json"}
             except Exception as e:  # noqa: BLE001
                 line["cpu_baseline"] = {"value": None, "unit": "candidates/s", "cores": os.cpu_count(), "kind": "reference", "sample": "failed: %r" % (e,)}
-        print(json.dumps(line), flush=True)
+        print(json.dumps(W.annotate_cpu_baseline(line)), flush=True)
     released = rank == 0 and world == 1
     if not released:
         for v in vols:

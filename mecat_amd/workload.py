@@ -276,3 +276,31 @@ def asm_tool_run(exe, d, threads, start, nblocks, env=None, timeout=1800):
         os.unlink(p)
     lines.sort()
     return lines, secs, r.stderr
+
+
+def cpu_quota_cores():
+    """CPU time this process tree may use, in cores: the cgroup's quota (cpu.max of cgroup v2, cfs_quota_us / cfs_period_us of v1) — a
+    container can show every hardware thread of the host (os.cpu_count()) and still be held to a fraction of them.  None without a quota."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else round(int(q) / int(per), 2)
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else round(q / per, 2)
+    except Exception:
+        return None
+
+
+def annotate_cpu_baseline(line):
+    """the bench line's cpu_baseline gets the cgroup CPU quota next to the thread count (`cores` = threads started)"""
+    cb = line.get("cpu_baseline")
+    if isinstance(cb, dict):
+        cb["cpu_quota_cores"] = cpu_quota_cores()
+        cb["host_cpus"] = os.cpu_count()
+        fs = cb.get("full_size_same_host")
+        if isinstance(fs, dict):
+            fs["cpu_quota_cores"] = cb["cpu_quota_cores"]
+    return line

@@ -355,6 +355,9 @@ __device__ unsigned long long g_wfprof[16];
 // The strand's k-mers are taken 64 at a time (16 lanes per bucket, four buckets per group as in for_each_hit16): count the
 // kept hits per bucket, scan the 64 counts, write.  The first 32 entries of a bucket stay in registers between the two
 // steps; longer buckets are read again (from cache).
+#ifndef EMIT_NP
+#define EMIT_NP 4                     // 16-entry pieces of a bucket loaded together (the rest, if any, one by one)
+#endif
 __global__ __launch_bounds__(SEED_BLOCK) void seed_emit(const mhip_offset_t* __restrict__ roffs, ReadSel sel, int ib,
                                                         const int32_t* __restrict__ offsets, SeedArrays A) {
     __shared__ uint32_t rel[REL_WORDS];
@@ -379,8 +382,12 @@ __global__ __launch_bounds__(SEED_BLOCK) void seed_emit(const mhip_offset_t* __r
     const uint32_t sub = threadIdx.x & 15;
     const uint32_t below = (1u << sub) - 1u;
     uint32_t run = 0;
+    // EMIT_NP pieces of 16 entries of every bucket are requested together, before any is used: a piece that is loaded when the one in
+    // front of it has been consumed costs the group a memory latency of its own, and at nanopore volume sizes (32 entries per bucket on
+    // average, many at the cap of 128) those serial loads — in a wave, whenever one of its four groups has a long bucket — were the
+    // kernel's time.  The verdict of the count pass on each entry of those pieces stays in a register for the write pass.
     for (int c0 = 0; c0 < K; c0 += 64) {
-        uint32_t bs[4], cn[4], p0[4], p1[4];
+        uint32_t bs[4], cn[4], pc[4][EMIT_NP];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int km = c0 + q * 16 + g;
@@ -388,17 +395,22 @@ __global__ __launch_bounds__(SEED_BLOCK) void seed_emit(const mhip_offset_t* __r
             cn[q] = km < K ? A.km_cnt[kb + km] : 0u;
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            p0[q] = sub < cn[q] ? (uint32_t)offsets[bs[q] + sub] : 0u;
-            p1[q] = sub + 16u < cn[q] ? (uint32_t)offsets[bs[q] + 16 + sub] : 0u;
-        }
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int p = 0; p < EMIT_NP; ++p) pc[q][p] = sub + 16u * p < cn[q] ? (uint32_t)offsets[bs[q] + 16 * p + sub] : 0u;
         // count
+        uint32_t keep = 0;          // bit EMIT_NP q + p: this lane's entry of piece p of bucket q is kept
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             uint32_t kept = 0;
-            if (cn[q] > 0) kept += __popc(group_bits(__ballot(sub < cn[q] && (!flt || rel_test(rel, p0[q] / ZV, A.rel_mask, A.rel_shift)))));
-            if (cn[q] > 16) kept += __popc(group_bits(__ballot(sub + 16u < cn[q] && (!flt || rel_test(rel, p1[q] / ZV, A.rel_mask, A.rel_shift)))));
-            for (uint32_t r0 = 32; r0 < cn[q]; r0 += 16) {
+#pragma unroll
+            for (int p = 0; p < EMIT_NP; ++p)
+                if (16u * p < cn[q]) {
+                    const bool k1 = sub + 16u * p < cn[q] && (!flt || rel_test(rel, pc[q][p] / ZV, A.rel_mask, A.rel_shift));
+                    kept += __popc(group_bits(__ballot(k1)));
+                    keep |= k1 ? 1u << (EMIT_NP * q + p) : 0u;
+                }
+            for (uint32_t r0 = 16 * EMIT_NP; r0 < cn[q]; r0 += 16) {
                 const uint32_t r = r0 + sub;
                 const bool valid = r < cn[q];
                 const uint32_t pos = valid ? (uint32_t)offsets[bs[q] + r] : 0u;
@@ -425,19 +437,20 @@ __global__ __launch_bounds__(SEED_BLOCK) void seed_emit(const mhip_offset_t* __r
         for (int q = 0; q < 4; ++q) {
             const int km = c0 + q * 16 + g;
             uint32_t at = run + coff[q * 16 + g];
-            auto put = [&](uint32_t pos, bool valid) {
+            auto put = [&](uint32_t pos, bool k1) {
                 const uint32_t seg = pos / ZV, so = pos - seg * ZV;
-                const bool k1 = valid && (!flt || rel_test(rel, seg, A.rel_mask, A.rel_shift));
                 const uint32_t bits = group_bits(__ballot(k1));
                 if (k1) out[at + __popc(bits & below)] = ((uint64_t)seg << KEY_SEG_SHIFT) | ((uint64_t)km << KEY_OFF_BITS) | so;
                 at += __popc(bits);
             };
-            if (cn[q] > 0) put(p0[q], sub < cn[q]);
-            if (cn[q] > 16) put(p1[q], sub + 16u < cn[q]);
-            for (uint32_t r0 = 32; r0 < cn[q]; r0 += 16) {
+#pragma unroll
+            for (int p = 0; p < EMIT_NP; ++p)
+                if (16u * p < cn[q]) put(pc[q][p], (keep >> (EMIT_NP * q + p)) & 1u);
+            for (uint32_t r0 = 16 * EMIT_NP; r0 < cn[q]; r0 += 16) {
                 const uint32_t r = r0 + sub;
                 const bool valid = r < cn[q];
-                put(valid ? (uint32_t)offsets[bs[q] + r] : 0u, valid);
+                const uint32_t pos = valid ? (uint32_t)offsets[bs[q] + r] : 0u;
+                put(pos, valid && (!flt || rel_test(rel, pos / ZV, A.rel_mask, A.rel_shift)));
             }
         }
         WF_MARK(11);
@@ -926,12 +939,25 @@ __device__ __forceinline__ void fs_walk(const uint32_t* __restrict__ kbs, const 
                     const bool v = sub + (uint32_t)(p * LPB) < cc[q];
                     if (__any(v)) f(km, cd[q][p], v);
                 }
-                for (uint32_t r = (uint32_t)(NP * LPB) + sub; __any(r < cc[q]); r += LPB) f(km, r < cc[q] ? (uint32_t)arr[cb[q] + r] : 0u, r < cc[q]);
+                // (what the pipeline did not cover, four pieces per round trip: one by one each piece is a memory latency for the whole wave)
+                for (uint32_t r = (uint32_t)(NP * LPB) + sub; __any(r < cc[q]); r += 4 * LPB) {
+                    uint32_t tv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) tv[u] = r + (uint32_t)(u * LPB) < cc[q] ? (uint32_t)arr[cb[q] + r + (uint32_t)(u * LPB)] : 0u;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const bool v = r + (uint32_t)(u * LPB) < cc[q]; if (__any(v)) f(km, tv[u], v); }
+                }
             } else {
 #pragma unroll
                 for (int p = 0; p < NP; ++p)
                     if (sub + (uint32_t)(p * LPB) < cc[q]) f(km, cd[q][p]);
-                for (uint32_t r = (uint32_t)(NP * LPB) + sub; r < cc[q]; r += LPB) f(km, (uint32_t)arr[cb[q] + r]);
+                for (uint32_t r = (uint32_t)(NP * LPB) + sub; r < cc[q]; r += 4 * LPB) {      // (four pieces per round trip, see above)
+                    uint32_t tv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) tv[u] = r + (uint32_t)(u * LPB) < cc[q] ? (uint32_t)arr[cb[q] + r + (uint32_t)(u * LPB)] : 0u;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) if (r + (uint32_t)(u * LPB) < cc[q]) f(km, tv[u]);
+                }
             }
         }
     }

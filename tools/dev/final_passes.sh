@@ -20,8 +20,13 @@ for f in kernel_stats.csv hbm_counters.md hbm_traffic.json instruction_mix.md in
 (timeout 900 python bench.py > $F/config2.json 2> $F/config2.err)
 (timeout 600 python bench.py --workload config3 --steps 2 --warmup 1 > $F/config3.json 2> $F/config3.err)
 (timeout 600 python bench.py --workload config5_cell --steps 2 --warmup 1 > $F/config5_cell.json 2> $F/config5_cell.err)
+(timeout 900 python bench.py --workload config4 > $F/config4.json 2> $F/config4.err)
 if [ -n "$WITH_CONFIG5" ]; then (timeout 2200 python bench.py --workload config5 --steps 1 --warmup 0 > $F/config5.json 2> $F/config5.err); fi
 wc -c $F/*.json
+if [ -n "$WITH_SWEEPS" ]; then      # the randomised parity sweeps against the oracle (profiles/rNN_parity_sweeps.md quotes their last lines)
+  (SEED=4501 N=60 timeout 1500 python tools/dev/parity_sweep.py > gpurun_out/sweep_candidates_$TAG.log 2>&1; tail -2 gpurun_out/sweep_candidates_$TAG.log)
+  (SEED=4503 N=160 JOBS=4000 timeout 1500 python tools/dev/align_sweep.py > gpurun_out/sweep_extensions_$TAG.log 2>&1; tail -2 gpurun_out/sweep_extensions_$TAG.log)
+fi
 timeout 1800 python -m pytest ${TESTS:-tests} -q -m gpu -x > gpurun_out/gputest_$TAG.log 2>&1; echo "pytest rc=$?"
 grep -E "passed|failed|error" gpurun_out/gputest_$TAG.log | tail -3
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1

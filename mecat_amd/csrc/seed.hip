@@ -1014,6 +1014,13 @@ __device__ __forceinline__ uint32_t fs_cnt(const uint32_t* cnt32, uint32_t e) { 
 // the carry ran into) marks the slot relevant on the spot and counts the wrap.  Counters next to a wrapped one are too high by the
 // carry: the bitmap only grows, and the number of kept hits becomes an upper bound (sum over the relevant slots + 16 per wrap) — the
 // room of the strand in the key arrays; seed_emit writes the exact number when it has placed the keys.
+#ifndef WF_LPB
+// the walk of seed_filter_wide: lanes per bucket, pieces loaded ahead, buckets per group and stage, stages in flight (see FS_LPB1)
+#define WF_LPB 8
+#define WF_NP 4
+#define WF_Q 2
+#define WF_D 2
+#endif
 #define WF_BITS 18
 #define WF_M (1 << WF_BITS)
 #define WF_CELL 3                    // log2 slots per relevance bit
@@ -1059,7 +1066,7 @@ __global__ __launch_bounds__(FS_THREADS) void seed_filter_wide(const mhip_offset
     // counted apart, and the read's own segments are relevant whatever the counters say.
     const bool own = same_volume && !(s & 1);
     const uint32_t own_off = (uint32_t)roffs[rid].offset;
-    fs_walk<FS_LPB2, FS_NP2, FS_Q2, FS_D2, false>(A.km_bstart + kb, A.km_cnt + kb, offsets, K, [&](int km, uint32_t pos) {
+    fs_walk<WF_LPB, WF_NP, WF_Q, WF_D, false>(A.km_bstart + kb, A.km_cnt + kb, offsets, K, [&](int km, uint32_t pos) {
 #if defined(WF_KNOCK) && WF_KNOCK == 1
         if (pos == 0xfffffff1u) atomicAdd(&s_self, 1u);      // timing experiment: the gather alone (results are wrong)
         return;

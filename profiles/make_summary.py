@@ -33,6 +33,16 @@ row("config2 (default; BASELINE configs[1])", R + "_bench_config2.json", c2)
 row("config3 (configs[2]: 3 volumes, 6 cells)", R + "_bench_config3.json", c3)
 row("config5_cell (cell (0,1) of configs[4], `-x 1`)", R + "_config5_cell_bench.json", cc)
 row("config5 (configs[4] whole: 19 volumes, 190 cells, `-x 1`)", R + "_bench_config5.json", c5)
+c4name = os.path.join(HERE, R + "_bench_config4.json")
+if os.path.exists(c4name):
+    c4 = load(R + "_bench_config4.json")
+    out.append("")
+    out.append("Config 4 (`--workload config4`, BASELINE configs[3] up to the consensus table; `%s_bench_config4.json`): %d templates (%.2f Gbase), %d re-alignments, "
+               "%d accepted, %.2f s per pass = %.3g template bases/s, %.0f templates/s; re-alignment kernels %.0f ms of it (`cns_forward` %.0f, `cns_trace` %.0f, "
+               "`cns_extend` %.0f); the unmodified `consensus_one_read_can_pacbio` on the same host (%d processes, CPU quota %s cores): %.3g template bases/s." % (
+                   R, c4["config"]["templates"], c4["config"]["template_bases"] / 1e9, c4["alignments_per_step"], c4["accepted_per_step"], c4["ms_per_step"] / 1e3,
+                   c4["value"], c4["templates_per_s"], c4["gpu_kernel_ms_per_step"], c4["kernel_ms_per_step"].get("cns_forward", 0), c4["kernel_ms_per_step"].get("cns_trace", 0),
+                   c4["kernel_ms_per_step"].get("cns_extend", 0), c4["cpu_baseline"]["cores"], c4["cpu_baseline"].get("cpu_quota_cores"), c4["cpu_baseline"]["value"]))
 out.append("")
 if c5["roofline"].get("kernel_source_digest") != cc["roofline"].get("kernel_source_digest"):
     out.append("(The whole-config-5 line takes six minutes and was taken one commit before the others: the sources differ in the record-pool size of "
@@ -55,14 +65,17 @@ out.append("Extras of the config-2 line: `xdrop_extend` %.0f k alignments/s, `cn
 r2, rc = c2["roofline"], cc["roofline"]
 out.append("Roofline blocks.  Config 2 — dominant kernel `%s`: %.1f GB/s of algorithmic bytes = %.4f of the HBM peak, measured HBM traffic %.2f GB per launch "
            "against %.2f GB algorithmic, VALU issue %.2f of the data-sheet ceiling of the kernel's instruction mix.  Config-5 cell — `%s`: %.4f of the HBM peak, "
-           "measured traffic %.0f GB per launch (the script bytes of every DP cell, written once and read back by the traceback: `%s_xd_breakdown.md`), %.3g DP cells/s; "
+           "measured traffic %.0f GB per launch (the script cells of every DP cell, written once and read back by the traceback: DESIGN.md §3.4), %.3g DP cells/s; "
            "phases index / seed / extend at %.3f / %.3f / %.5f of the HBM peak.\n" % (
                r2["kernel"], r2["achieved"], r2["frac"], (r2["traffic"] or 0) / 1e9, r2["algorithmic_bytes_per_launch"] / 1e9, r2.get("valu_issue", {}).get("frac", float("nan")),
-               rc["kernel"], rc["frac"], (rc["traffic"] or 0) / 1e9, R, rc["xdrop"]["dp_cells_per_s"],
+               rc["kernel"], rc["frac"], (rc["traffic"] or 0) / 1e9, rc["xdrop"]["dp_cells_per_s"],
                rc["phases"]["index"]["frac"], rc["phases"]["seed"]["frac"], rc["phases"]["align"]["frac"]))
 out.append("rocprofv3 summaries: `%s_kernel_stats.csv`, `%s_hbm_counters.md`, `%s_instruction_mix.md` (config 2); `%s_config5_cell_*` (the nanopore chain: "
            "`seed_filter_wide`, `seed_emit`, `seed_sort_pass`, `seed_build`, `xd_extend_w`); `%s_cns_kernels.md`, `%s_asm_kernels.md` (`cns_extend`, `asm_seed`, "
-           "`asm_extend`); `%s_xd_breakdown.md` (what bounds the X-drop kernel and what the rebuild changed)." % ((R,) * 7))
+           "`asm_extend`)." % ((R,) * 6)
+           + ("  `%s_xd_breakdown.md`: what bounds the X-drop kernel and what the rebuild changed." % R if os.path.exists(os.path.join(HERE, R + "_xd_breakdown.md")) else "")
+           + ("  `%s_dw_attempt.md`: the round's bounded attempt on `dw_extend2`." % R if os.path.exists(os.path.join(HERE, R + "_dw_attempt.md")) else "")
+           + ("  `%s_parity_sweeps.md`: the randomised sweeps against the oracle." % R if os.path.exists(os.path.join(HERE, R + "_parity_sweeps.md")) else ""))
 with open(os.path.join(HERE, R + "_summary.md"), "w") as f:
     f.write("\n".join(out) + "\n")
 print("\n".join(out))

@@ -4,8 +4,11 @@ torch.zeros(1, device="cuda")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import mecat_amd.hip as M
 from mecat_amd import workload as W
-n = 100000
-codes, lens = W.synth_reads(n, 15000, 0.15, int(5e7), 2, 0)
+n = int(os.environ.get("N", "100000"))
+if os.environ.get("ONT"):      # a nanopore-mode volume at the size limit (config 5: 107 k reads x 20 kb = 2.14 Gbases)
+    codes, lens = W.synth_reads(n, 20000, 0.12, int(1.3e9), 5, 1)
+else:
+    codes, lens = W.synth_reads(n, 15000, 0.15, int(5e7), 2, 0)
 pac, offs, nb = W.pack_volume(codes, lens)
 ctx = M.Context(0); vol = M.Volume(ctx, pac, offs, nb, 0)
 for it in range(2):

@@ -587,12 +587,17 @@ __global__ __launch_bounds__(SC_THREADS) void ix_scan_apply(const uint32_t* __re
 // the ids are staged in LDS by one sweep of independent word loads, the counting pass and the placing pass read them from there, and
 // the placing pass loads its positions eight steps ahead.
 constexpr int FILL_IDS = 12288;              // entries of a sub-bin whose ids fit the LDS stage (larger sub-bins re-read them from global memory)
+#ifndef IXP_FILL_T
+#define IXP_FILL_T 512
+#endif
+constexpr int FILL_T = IXP_FILL_T;          // threads of ix_fill (>= the 256 ids of a sub-bin)
+static_assert(FILL_T >= NID && FILL_T % 64 == 0, "a thread per k-mer id");
 template <bool STRICT>
-__global__ __launch_bounds__(FILL_THREADS) void ix_fill(const uint32_t* __restrict__ pos2, const uint8_t* __restrict__ id2, const uint32_t* __restrict__ sub_ent,
+__global__ __launch_bounds__(FILL_T) void ix_fill(const uint32_t* __restrict__ pos2, const uint8_t* __restrict__ id2, const uint32_t* __restrict__ sub_ent,
                                                         const uint32_t* __restrict__ sub_off, uint32_t max_bucket, uint32_t sub0, uint32_t* __restrict__ starts,
                                                         int32_t* __restrict__ offsets, uint16_t* __restrict__ slots, uint4* __restrict__ recs, int cut_step,
                                                         uint32_t* __restrict__ disorder) {
-    constexpr int NW = FILL_THREADS / 64;
+    constexpr int NW = FILL_T / 64;
     __shared__ uint32_t cntw[NW][NID];       // per-wave counts of an id, then the wave's next place in the id's bucket
     __shared__ uint32_t lstart[NID + 1];
     __shared__ int32_t buf[FILL_CAP];
@@ -609,11 +614,14 @@ __global__ __launch_bounds__(FILL_THREADS) void ix_fill(const uint32_t* __restri
     const bool staged = (e1 - ew0) <= (uint32_t)FILL_IDS;
     if (staged) {
         const uint32_t* id4 = (const uint32_t*)id2;
-        for (uint32_t wi = tid; wi < ((e1 - ew0 + 3) >> 2); wi += FILL_THREADS) ids[wi] = id4[(ew0 >> 2) + wi];
+        for (uint32_t wi = tid; wi < ((e1 - ew0 + 3) >> 2); wi += FILL_T) ids[wi] = id4[(ew0 >> 2) + wi];
     }
-    for (int ww = 0; ww < NW; ++ww) cntw[ww][tid] = 0;
-    cc[tid][0] = 0; cc[tid][1] = 0;
-    isfirst[tid] = 0;      // FILL_CAP / 32 == FILL_THREADS words
+    // (thread t < NID is also "the thread of k-mer id t" in the per-id steps below; with more threads than ids the others only walk entries)
+    if (tid < (uint32_t)NID) {
+        for (int ww = 0; ww < NW; ++ww) cntw[ww][tid] = 0;
+        cc[tid][0] = 0; cc[tid][1] = 0;
+    }
+    for (uint32_t i = tid; i < (uint32_t)(FILL_CAP / 32); i += FILL_T) isfirst[i] = 0;
     __syncthreads();
     IXS_T(f_1);
     const uint8_t* idb = (const uint8_t*)ids;
@@ -625,19 +633,22 @@ __global__ __launch_bounds__(FILL_THREADS) void ix_fill(const uint32_t* __restri
     __syncthreads();
     IXS_T(f_2);
     {
+        const bool isid = tid < (uint32_t)NID;
         uint32_t c[NW], tot = 0;
 #pragma unroll
-        for (int ww = 0; ww < NW; ++ww) { c[ww] = cntw[ww][tid]; tot += c[ww]; }
+        for (int ww = 0; ww < NW; ++ww) { c[ww] = isid ? cntw[ww][tid] : 0u; tot += c[ww]; }
         const uint32_t kept = tot > max_bucket ? 0u : tot;
         uint32_t all;
-        const uint32_t ex = block_excl_scan<FILL_THREADS>(kept, wtot, &all);
-        lstart[tid] = ex;
-        if (tid == NID - 1) lstart[NID] = all;
-        uint32_t run = ex;
+        const uint32_t ex = block_excl_scan<FILL_T>(kept, wtot, &all);
+        if (isid) {
+            lstart[tid] = ex;
+            if (tid == NID - 1) lstart[NID] = all;
+            uint32_t run = ex;
 #pragma unroll
-        for (int ww = 0; ww < NW; ++ww) { cntw[ww][tid] = run; run += c[ww]; }      // (a dropped id's counters are never touched again)
-        starts[id0 + tid] = first + ex;
-        if (kept && ex < (uint32_t)FILL_CAP) atomicOr(&isfirst[ex >> 5], 1u << (ex & 31));
+            for (int ww = 0; ww < NW; ++ww) { cntw[ww][tid] = run; run += c[ww]; }      // (a dropped id's counters are never touched again)
+            starts[id0 + tid] = first + ex;
+            if (kept && ex < (uint32_t)FILL_CAP) atomicOr(&isfirst[ex >> 5], 1u << (ex & 31));
+        }
     }
     __syncthreads();
     IXS_T(f_3);
@@ -673,10 +684,10 @@ __global__ __launch_bounds__(FILL_THREADS) void ix_fill(const uint32_t* __restri
     IXS_T(f_4);
     IXS_ADD(16, f_0, f_1); IXS_ADD(17, f_1, f_2); IXS_ADD(18, f_2, f_3); IXS_ADD(19, f_3, f_4);
     if (total == 0) {
-        if (recs) recs[id0 + tid] = make_uint4(first, 0u, 0u, 0u);
+        if (recs && tid < (uint32_t)NID) recs[id0 + tid] = make_uint4(first, 0u, 0u, 0u);
         return;
     }
-    if (recs) {
+    if (recs && tid < (uint32_t)NID) {
         // the bucket record of this thread's k-mer id (index.hip: idx_cut_records): occurrences below each of the seven position cuts =
         // running sums of the per-cut counters the placing pass made
         const uint32_t b0 = lstart[tid], b1 = lstart[tid + 1];
@@ -699,7 +710,7 @@ __global__ __launch_bounds__(FILL_THREADS) void ix_fill(const uint32_t* __restri
     // a bucket must hold a larger position than the place before it
     bool bad = false;
     if (in_lds) {
-        for (uint32_t i = tid; i < total; i += FILL_THREADS) {
+        for (uint32_t i = tid; i < total; i += FILL_T) {
             const int32_t pos = buf[i];
             const bool starts_bucket = (isfirst[i >> 5] >> (i & 31)) & 1u;
             bad |= !starts_bucket && pos <= buf[i ? i - 1 : 0];
@@ -708,9 +719,9 @@ __global__ __launch_bounds__(FILL_THREADS) void ix_fill(const uint32_t* __restri
         }
     } else {
         // (more kept positions than the LDS buffer holds: they were placed in global memory; checked bucket by bucket)
-        const uint32_t b0 = lstart[tid], b1 = lstart[tid + 1];
+        const uint32_t b0 = tid < (uint32_t)NID ? lstart[tid] : 0u, b1 = tid < (uint32_t)NID ? lstart[tid + 1] : 0u;
         for (uint32_t i = b0 + 1; i < b1; ++i) bad |= gdst[i] <= gdst[i - 1];
-        for (uint32_t i = tid; i < total; i += FILL_THREADS) slots[first + i] = (uint16_t)(((uint32_t)gdst[i] / 2000u) & 0x7FFFu);
+        for (uint32_t i = tid; i < total; i += FILL_T) slots[first + i] = (uint16_t)(((uint32_t)gdst[i] / 2000u) & 0x7FFFu);
     }
     if (bad) atomicOr(disorder, 1u);
     IXS_T(f_5);
@@ -816,10 +827,10 @@ int index_build_partitioned(mhip_ctx* c, const mhip_volume* v, int max_bucket, i
             HIPCHK(hipMemcpyAsync(out->d_starts + ((size_t)nb << (26 - IXP_L1_BITS)), d_sub_off + nsub, sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
         }
         if (strict)
-            LAUNCH(c, "ix_fill", ix_fill<true>, nsub, FILL_THREADS, 0, (const uint32_t*)d_pos2, (const uint8_t*)d_id2, (const uint32_t*)d_sub_ent,
+            LAUNCH(c, "ix_fill", ix_fill<true>, nsub, FILL_T, 0, (const uint32_t*)d_pos2, (const uint8_t*)d_id2, (const uint32_t*)d_sub_ent,
                    (const uint32_t*)d_sub_off, (uint32_t)max_bucket, 0u, out->d_starts, out->d_offsets, out->d_slots, out->d_recs, cut_step, d_flag);
         else
-            LAUNCH(c, "ix_fill", ix_fill<false>, nsub, FILL_THREADS, 0, (const uint32_t*)d_pos2, (const uint8_t*)d_id2, (const uint32_t*)d_sub_ent,
+            LAUNCH(c, "ix_fill", ix_fill<false>, nsub, FILL_T, 0, (const uint32_t*)d_pos2, (const uint8_t*)d_id2, (const uint32_t*)d_sub_ent,
                    (const uint32_t*)d_sub_off, (uint32_t)max_bucket, 0u, out->d_starts, out->d_offsets, out->d_slots, out->d_recs, cut_step, d_flag);
         uint32_t flag = 0;
         HIPCHK(hipGetLastError());

@@ -63,6 +63,14 @@ int mhip_volume_pack(mhip_ctx* c, const uint8_t* text, int64_t text_bytes, const
                      int num_reads, int num_bases, int start_read_id, mhip_volume** out, uint8_t* pac_out) {
     *out = nullptr;
     if (num_reads < 0 || num_bases < 0 || text_bytes < 0) { mhip_set_error("bad volume sizes"); return -1; }
+    {   // the layout has to tile the volume: read r + 1 starts behind read r's pad base, the last pad base ends the volume
+        int64_t at = 0;
+        for (int r = 0; r < num_reads; ++r) {
+            if (offs[r].offset != at) { mhip_set_error("read %d of the layout starts at %d, not at %lld", r, offs[r].offset, (long long)at); return -1; }
+            at += (int64_t)offs[r].size + 1;
+        }
+        if (at != num_bases) { mhip_set_error("the layout holds %lld bases, the volume %d", (long long)at, num_bases); return -1; }
+    }
     for (int r = 0; r < num_reads; ++r) {
         const int64_t lines = line_width[r] > 0 ? ((int64_t)offs[r].size - 1) / line_width[r] : 0;
         if (offs[r].size <= 0 || seq_start[r] < 0 || seq_start[r] + offs[r].size + lines > text_bytes || line_width[r] < 0) {

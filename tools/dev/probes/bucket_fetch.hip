@@ -11,7 +11,7 @@ template <> struct V<4> { typedef uint4 t; };
 __device__ inline uint32_t fold(uint32_t v) { return v; }
 __device__ inline uint32_t fold(uint2 v) { return v.x + v.y; }
 __device__ inline uint32_t fold(uint4 v) { return v.x + v.y + v.z + v.w; }
-template <int LANES, int VEC, int PIECES, int INFL>
+template <int LANES, int VEC, int PIECES, int INFL, int ALIGN_WORDS = 1>
 __global__ __launch_bounds__(256) void fetch(const uint32_t* __restrict__ a, uint64_t nwords, int iters, uint32_t* __restrict__ out) {
     const uint32_t grp = (blockIdx.x * 256u + threadIdx.x) / LANES, sub = threadIdx.x % LANES;
     uint64_t st = 0x9E3779B97F4A7C15ull * (grp + 1u);
@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void fetch(const uint32_t* __restrict__ a, uin
 #pragma unroll
         for (int q = 0; q < INFL; ++q) {
             st = st * 6364136223846793005ull + 1442695040888963407ull;
-            const uint64_t base = (uint64_t)(((st >> 24) * (unsigned __int128)span) >> 40);
+            const uint64_t base = (uint64_t)(((st >> 24) * (unsigned __int128)span) >> 40) & ~(uint64_t)(ALIGN_WORDS - 1);      // (ALIGN_WORDS = 8: buckets that start on 32-byte boundaries)
 #pragma unroll
             for (int p = 0; p < PIECES; ++p) {
                 const uint32_t* src = a + base + (uint64_t)(p * LANES + sub) * VEC;
@@ -38,17 +38,17 @@ __global__ __launch_bounds__(256) void fetch(const uint32_t* __restrict__ a, uin
     }
     if (acc == 0x12345678u) out[0] = acc;
 }
-template <int LANES, int VEC, int PIECES, int INFL>
+template <int LANES, int VEC, int PIECES, int INFL, int ALIGN_WORDS = 1>
 static void run(const uint32_t* d, uint64_t nwords, int cus, int wps, int iters, uint32_t* d_out) {
     const int blocks = cus * wps * 8;
     hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
-    fetch<LANES, VEC, PIECES, INFL><<<blocks, 256>>>(d, nwords, 2, d_out);
+    fetch<LANES, VEC, PIECES, INFL, ALIGN_WORDS><<<blocks, 256>>>(d, nwords, 2, d_out);
     CHK(hipEventRecord(e0));
-    fetch<LANES, VEC, PIECES, INFL><<<blocks, 256>>>(d, nwords, iters, d_out);
+    fetch<LANES, VEC, PIECES, INFL, ALIGN_WORDS><<<blocks, 256>>>(d, nwords, iters, d_out);
     CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
     float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
     const double buckets = (double)blocks * (256.0 / LANES) * iters * INFL;
-    printf("bytes %4d  lanes %2d x %2d B x %d pieces, %d in flight, %d waves/SIMD: %7.2f G buckets/s  %6.0f GB/s\n", LANES * VEC * 4 * PIECES, LANES, VEC * 4, PIECES, INFL, wps,
+    printf("align %2d B  bytes %4d  lanes %2d x %2d B x %d pieces, %d in flight, %d waves/SIMD: %7.2f G buckets/s  %6.0f GB/s\n", ALIGN_WORDS * 4, LANES * VEC * 4 * PIECES, LANES, VEC * 4, PIECES, INFL, wps,
            buckets / (ms * 1e-3) * 1e-9, buckets / (ms * 1e-3) * 1e-9 * LANES * VEC * 4 * PIECES);
 }
 int main(int argc, char** argv) {
@@ -77,6 +77,13 @@ int main(int argc, char** argv) {
         run<8, 1, 1, 4>(d, nwords, cus, wps, iters, d_out);
         run<2, 4, 1, 4>(d, nwords, cus, wps, iters, d_out);
         run<16, 4, 1, 2>(d, nwords, cus, wps, iters, d_out);
+        // the same bytes from 32- and 64-byte aligned starts
+        run<8, 1, 1, 4, 8>(d, nwords, cus, wps, iters, d_out);
+        run<16, 1, 1, 2, 8>(d, nwords, cus, wps, iters, d_out);
+        run<16, 1, 1, 2, 16>(d, nwords, cus, wps, iters, d_out);
+        run<16, 1, 2, 2, 8>(d, nwords, cus, wps, iters, d_out);
+        run<16, 1, 2, 2, 16>(d, nwords, cus, wps, iters, d_out);
+        run<16, 1, 2, 2, 32>(d, nwords, cus, wps, iters, d_out);
     }
     return 0;
 }

@@ -102,3 +102,32 @@ def test_driver_with_the_device_packer_writes_the_same_volume_files(tmp_path):
         outs[mode] = ([hashlib.sha256(open(os.path.join(w, x), "rb").read()).hexdigest() for x in vols], sorted(open(out).read().splitlines()))
     assert len(outs["host"][0]) >= 2
     assert outs["host"] == outs["gpu"]
+
+
+def test_driver_keeps_the_host_packer_for_records_with_ragged_lines(tmp_path):
+    """a record whose lines differ in length (other than a shorter last one) is outside what mhip_volume_pack takes: under
+    MECAT_HIP_SPLIT=gpu the splitter packs such a volume on the host threads, same files"""
+    codes, lens = H.synth_reads(60, 2500, 0.15, 60000, 13, 0)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    starts = np.concatenate([[0], np.cumsum(lens.astype(np.int64))])
+    fa = str(tmp_path / "ragged.fa")
+    with open(fa, "wb") as f:
+        for r in range(len(lens)):
+            raw = lut[codes[starts[r]:starts[r + 1]]].tobytes()
+            cuts = [0, 70, 130, 200] if r == 7 else list(range(0, len(raw), 60))      # read 7: lines of 70, 60, 70 ... bases
+            if r == 7:
+                cuts += list(range(270, len(raw), 70))
+            cuts.append(len(raw))
+            f.write(b">%d\n" % r + b"\n".join(raw[a:b] for a, b in zip(cuts, cuts[1:]) if b > a) + b"\n")
+    outs = {}
+    for mode in ("host", "gpu"):
+        w = str(tmp_path / ("w_" + mode))
+        out = str(tmp_path / (mode + ".can"))
+        env = dict(os.environ, MECAT_TRACE="1")
+        if mode == "gpu":
+            env["MECAT_HIP_SPLIT"] = "gpu"
+        r = subprocess.run([BIN, "-j", "0", "-d", fa, "-o", out, "-w", w, "-t", "4"], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "pack (device)" not in r.stderr
+        outs[mode] = (hashlib.sha256(open(os.path.join(w, "vol0"), "rb").read()).hexdigest(), sorted(open(out).read().splitlines()))
+    assert outs["host"] == outs["gpu"]

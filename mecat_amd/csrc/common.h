@@ -67,6 +67,7 @@ struct mhip_ctx {
     size_t as_clean_nrec = 0;
     int ae_n = 0;                         // jobs and dense words of the last mhip_asm_extend_run (what mhip_asm_extend_fetch copies)
     int64_t ae_total = 0;
+    int ix_s1_ranges = -1;                // index build, ix_scatter1's tile order: -1 not measured yet, 0 tile = block, 1 a contiguous eighth of the tiles per XCD
 
     // returns a device buffer of at least `bytes` (contents undefined)
     int scratch(const char* name, size_t bytes, void** out);

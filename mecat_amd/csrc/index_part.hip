@@ -270,7 +270,7 @@ template <bool STRICT>
 __global__ __launch_bounds__(T1_THREADS, IXP_S1_WAVES) void ix_scatter1(const uint32_t* __restrict__ pac, int num_bases, const uint32_t* __restrict__ nokmer,
                                                           const uint32_t* __restrict__ hist1,
                                                           const uint32_t* __restrict__ grp, uint32_t* __restrict__ ent1, int bin_lo, int bin_hi,
-                                                          uint32_t ent_off) {
+                                                          uint32_t ent_off, int xcd_ranges) {
 #ifndef IXP_S1_TILE_STAGE
 #define IXP_S1_TILE_STAGE 0
 #endif
@@ -284,7 +284,15 @@ __global__ __launch_bounds__(T1_THREADS, IXP_S1_WAVES) void ix_scatter1(const ui
     __shared__ uint16_t sbin[SUB1];
     __shared__ uint32_t wtot[T1_THREADS / 64];
     constexpr int NW = T1_THREADS / 64, STEPS = SUB1 / T1_THREADS;
-    const int tile = blockIdx.x, tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+    // Which block takes which tile.  Blocks go to the XCDs round robin (block x on XCD x mod 8: observed), so "tile = block" spreads
+    // neighbouring tiles — whose runs of a bin are neighbours in memory — over all eight L2s, and every 32-byte run leaves its L2 as
+    // partial sectors of its own.  With xcd_ranges an XCD works through a contiguous eighth of the tiles, the tiles its CUs hold at any
+    // time are neighbours, and their runs meet in the one L2: 6.85 -> 5.26 ms at config 2 on the boxes where "tile = block" takes 6.85
+    // (on others it takes 5.0 - 5.3 as it is; the build times both orders once per context and keeps the faster, see the launch).
+    const int per8 = (int)gridDim.x >> 3;                  // (the grid is a multiple of 8 blocks)
+    const int tile = xcd_ranges ? (int)(blockIdx.x & 7u) * per8 + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if ((int64_t)tile * T1_POS >= num_bases) return;
+    const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
     uint32_t gcur = hist1[(size_t)tile * NB1 + tid] + grp[(size_t)(tile / G1) * NB1 + tid] - ent_off;      // thread b: next entry of (tile, bin b)
     for (int ww = 0; ww < NW; ++ww) cntw[ww][tid] = 0;
     const int64_t wlast = ((int64_t)num_bases + 15) >> 4;       // (the volume carries >= 128 zero bytes behind its last base)
@@ -728,6 +736,7 @@ __global__ __launch_bounds__(FILL_T) void ix_fill(const uint32_t* __restrict__ p
     IXS_ADD(20, f_4, f_5);
 }
 
+#define S1_GRID(n) ((((n) + 7) / 8) * 8)
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 }  // namespace
@@ -797,10 +806,37 @@ int index_build_partitioned(mhip_ctx* c, const mhip_volume* v, int max_bucket, i
     bool strict = getenv("MECAT_IDX_STRICT") && atoi(getenv("MECAT_IDX_STRICT")) != 0;
     for (;;) {
         HIPCHK(hipMemsetAsync(d_flag, 0, 4, c->stream));
-        if (strict)
-            LAUNCH(c, "ix_scatter1", ix_scatter1<true>, ntile, T1_THREADS, 0, (const uint32_t*)v->d_pac, v->num_bases, (const uint32_t*)d_nokmer, (const uint32_t*)d_hist1, (const uint32_t*)d_grp, d_ent1, bin_lo, bin_hi, ent_off);
-        else
-            LAUNCH(c, "ix_scatter1", ix_scatter1<false>, ntile, T1_THREADS, 0, (const uint32_t*)v->d_pac, v->num_bases, (const uint32_t*)d_nokmer, (const uint32_t*)d_hist1, (const uint32_t*)d_grp, d_ent1, bin_lo, bin_hi, ent_off);
+        {
+            // ix_scatter1's tile order (see the kernel): MECAT_IDX_S1_XCD=0 / 1 fixes it; otherwise the first large build of a context runs the
+            // kernel once in each order (same output) and the context keeps the faster one
+            auto launch_s1 = [&](int ranges) {
+                if (strict)
+                    LAUNCH(c, "ix_scatter1", ix_scatter1<true>, S1_GRID(ntile), T1_THREADS, 0, (const uint32_t*)v->d_pac, v->num_bases, (const uint32_t*)d_nokmer,
+                           (const uint32_t*)d_hist1, (const uint32_t*)d_grp, d_ent1, bin_lo, bin_hi, ent_off, ranges);
+                else
+                    LAUNCH(c, "ix_scatter1", ix_scatter1<false>, S1_GRID(ntile), T1_THREADS, 0, (const uint32_t*)v->d_pac, v->num_bases, (const uint32_t*)d_nokmer,
+                           (const uint32_t*)d_hist1, (const uint32_t*)d_grp, d_ent1, bin_lo, bin_hi, ent_off, ranges);
+            };
+            if (const char* e = getenv("MECAT_IDX_S1_XCD")) c->ix_s1_ranges = atoi(e) != 0;
+            if (c->ix_s1_ranges < 0 && ntile >= 8192) {
+                hipEvent_t ev[3];
+                for (auto& x : ev) HIPCHK(hipEventCreate(&x));
+                HIPCHK(hipEventRecord(ev[0], c->stream));
+                launch_s1(0);
+                HIPCHK(hipEventRecord(ev[1], c->stream));
+                launch_s1(1);
+                HIPCHK(hipEventRecord(ev[2], c->stream));
+                HIPCHK(hipEventSynchronize(ev[2]));
+                float ms0 = 0.f, ms1 = 0.f;
+                HIPCHK(hipEventElapsedTime(&ms0, ev[0], ev[1]));
+                HIPCHK(hipEventElapsedTime(&ms1, ev[1], ev[2]));
+                for (auto& x : ev) (void)hipEventDestroy(x);
+                c->ix_s1_ranges = ms1 < ms0 ? 1 : 0;
+                if (trace) fprintf(stderr, "[idx trace] ix_scatter1: tile = block %.2f ms, XCD ranges %.2f ms: keeping %s\n", ms0, ms1, c->ix_s1_ranges ? "the ranges" : "tile = block");
+            } else {
+                launch_s1(c->ix_s1_ranges > 0 ? 1 : 0);
+            }
+        }
         TRACE("scatter1");
         LAUNCH(c, "ix_hist2", ix_hist2, ublocks, T2_THREADS, 0, (const uint32_t*)d_ent1, (const uint32_t*)d_base1T, ntile, ngroup, nb, bin_lo, ent_off, d_hist2);
         LAUNCH(c, "ix_scan2", ix_scan2, nb, NB2, 0, d_hist2, ngroup, nb, (const uint32_t*)d_binbase, bin_lo, ent_off, d_sub_ent);

@@ -347,6 +347,11 @@ int  mhip_cns_accept_templates(mhip_ctx* ctx, const mhip_volume* vol, const uint
                                int num_threads, mhip_cns_accepted** out_accepted, int64_t* out_count, char** out_strings,
                                int64_t* out_strings_bytes, int64_t* out_jobs /* alignments computed, may be NULL */);
 void mhip_cns_free(void* p);
+/* mhip_cns_free does not return a string buffer to the system at once: the library keeps the LARGEST released one (gigabytes — about
+ * 14 GB for a config-2-sized batch) and hands it out again to the next batch that fits, because first-touching fresh pages costs
+ * more than the batch's GPU time.  The parked buffer belongs to the process, not to a context (mhip_ctx_destroy leaves it).  This call
+ * frees it; a process that is done with mecat2cns batches but lives on should call it. */
+void mhip_cns_release_parked(void);
 
 #ifdef __cplusplus
 }

@@ -1049,18 +1049,28 @@ __global__ __launch_bounds__(AL_BLOCK, CNS ? CNS_FWD_WAVES_PER_SIMD : DW2_WAVES_
                 const int kept_q = end_x - qcnt, kept_t = end_y - tcnt, kept_cols = aln_size - acnt;      // (last block: nothing was walked)
                 keep = keep && kept_q != 0;
                 if (keep && Rc + kept_cols > ca.dir_cols_cap) { keep = false; if (sl == 0) atomicExch(ca.err_flag, 1); }
-                if (keep) {
+                if (keep && blkpos >= blkend) {
+                    // the unit's share of block records ((ext >> 8) + 4, cns_caps) is used up — blocks that each advance by fewer than 256
+                    // bases: like the other limits of the record format, the unit goes to cns_extend, which redoes it from its start
+                    // (cns_trace skips the blocks of a handed-over unit)
                     if (sl == 0) {
-                        if (blkpos < blkend) {
+                        ca.hand_units[1u + atomicAdd(ca.hand_units, 1u)] = unit;
+                        CnsDir D = {0, 0, 0, 0, 0, -1};
+                        ca.dres[unit] = D;
+                        nhand += 1;
+                    }
+                } else {
+                    if (keep) {
+                        if (sl == 0) {
                             CnsBlockRec B = {unit, qidx, tidx, qblk, end_d, end_k, end_mk, end_x, Rc, kept_cols, blk_log0, 0};
                             ca.blocks[blkpos] = B;
-                        } else atomicExch(ca.err_flag, 2);
+                        }
+                        blkpos += 1;
+                        Rc += kept_cols; Rq += kept_q; Rt += kept_t;
+                        if (!last_block) { qidx += kept_q; tidx += kept_t; done = false; }
                     }
-                    blkpos += 1;
-                    Rc += kept_cols; Rq += kept_q; Rt += kept_t;
-                    if (!last_block) { qidx += kept_q; tidx += kept_t; done = false; }
+                    if (done && sl == 0) { CnsDir D = {Rc, Rq, Rt, 0, 0, 0}; ca.dres[unit] = D; }
                 }
-                if (done && sl == 0) { CnsDir D = {Rc, Rq, Rt, 0, 0, 0}; ca.dres[unit] = D; }
             }
             if (done) need_unit = true;
             inblock = false;

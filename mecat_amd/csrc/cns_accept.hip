@@ -188,6 +188,18 @@ void mhip_cns_free(void* p) {
     free(to_free);
 }
 
+// gives the parked string buffer (see above) back to the system; buffers still in a caller's hands are not touched
+void mhip_cns_release_parked(void) {
+    void* p;
+    {
+        std::lock_guard<std::mutex> lk(g_strbuf_mu);
+        p = g_strbuf_parked;
+        g_strbuf_parked = nullptr;
+        g_strbuf_parked_cap = 0;
+    }
+    free(p);
+}
+
 int mhip_cns_accept_templates(mhip_ctx* c, const mhip_volume* vol, const uint8_t* host_pac, mhip_ext_candidate* cands, const int64_t* tmpl_begin,
                               int num_templates, int tech, int min_align_size, double min_mapping_ratio, int num_threads,
                               mhip_cns_accepted** out_accepted, int64_t* out_count, char** out_strings, int64_t* out_strings_bytes,

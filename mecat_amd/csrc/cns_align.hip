@@ -327,10 +327,11 @@ __global__ __launch_bounds__(CN_BLOCK, 6) void cns_extend(const uint32_t* __rest
 
 // rows a unit may log: an O(ND) block of size s runs at most max_d = 4 e s rows (dw.cpp:163) and typically (e_q + e_t) s of them; the
 // share is 2.7 e of the unit's reach plus one block that fails at max_d (a unit that outgrows it is handed over to cns_extend).
-// blocks: one per 256 bases of reach + 4 (a block that contributes advances by about its size; fewer records than blocks is an error).
+// blocks: one per 256 bases of reach + 4 (a block that contributes advances by about its size; a unit with more blocks than records is
+// handed over to cns_extend as well).
 __global__ __launch_bounds__(256) void cns_caps(const mhip_offset_t* __restrict__ roffs, const mhip_offset_t* __restrict__ qoffs,
                                                 const mhip_aln_job* __restrict__ jobs, int n, double error_rate, uint32_t* __restrict__ caps,
-                                                uint32_t* __restrict__ bcaps) {
+                                                uint32_t* __restrict__ bcaps, int bshift, uint32_t bextra) {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u < 2 * n) {
         const mhip_aln_job jb = jobs[u >> 1];
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(256) void cns_caps(const mhip_offset_t* __restrict_
         const int qs = right ? qsize - jb.qstart : jb.qstart, ts = right ? tsize - jb.sstart : jb.sstart;
         const int ext = (jb.qstart < 0 || jb.sstart < 0) ? 0 : max(min(qs, ts), 0);
         caps[u] = (uint32_t)(2.7 * error_rate * ext) + (uint32_t)(4.0 * error_rate * (CN_SEG + 100)) + 64u;
-        bcaps[u] = (uint32_t)(ext >> 8) + 4u;
+        bcaps[u] = (uint32_t)(ext >> bshift) + bextra;      // (8, 4 unless the test knob says otherwise)
     }
 }
 // caps -> first record of every unit, out[m] = total; one workgroup
@@ -577,8 +578,12 @@ int mhip_cns_align_candidates_dev(mhip_ctx* c, const mhip_volume* ref, const mhi
             if (c->scratch("cnf_hand", sizeof(uint32_t) * ((size_t)nu + 1), (void**)&d_hand)) return -1;
             HIPCHK(hipMemsetAsync(d_tot, 0, 64, c->stream));
             HIPCHK(hipMemsetAsync(d_hand, 0, sizeof(uint32_t), c->stream));
+            int bshift = 8, bextra = 4;
+            if (const char* e = getenv("MECAT_CNS_BLOCK_SHARE")) {      // test knob "shift,extra": small shares, so that units run out of block records
+                if (sscanf(e, "%d,%d", &bshift, &bextra) != 2 || bshift < 0 || bshift > 30 || bextra < 0) { bshift = 8; bextra = 4; }
+            }
             LAUNCH(c, "cns_caps", cns_caps, (nu + 255) / 256, 256, 0, (const mhip_offset_t*)ref->d_offs, (const mhip_offset_t*)reads->d_offs, jobs, nj,
-                   error_rate, d_caps, d_caps + nu);
+                   error_rate, d_caps, d_caps + nu, bshift, (uint32_t)bextra);
             LAUNCH(c, "cns_scan", cns_scan, 2, 1024, 0, (const uint32_t*)d_caps, nu, d_base, d_tot);      // (two workgroups: rows, block records)
             unsigned long long tot[2] = {0, 0};
             HIPCHK(hipMemcpyAsync(tot, d_tot, sizeof(tot), hipMemcpyDeviceToHost, c->stream));
@@ -626,7 +631,7 @@ int mhip_cns_align_candidates_dev(mhip_ctx* c, const mhip_volume* ref, const mhi
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipGetLastError());
     if (err == 1) { mhip_set_error("mecat2cns aligner: a direction needed more than dir_cols_cap = %d columns", dir_cols_cap); return -1; }
-    if (err) { mhip_set_error("mecat2cns aligner: internal error %d (2: more blocks than records; 3: a path left its rows; 4: a path missed its end)", err); return -1; }
+    if (err) { mhip_set_error("mecat2cns aligner: internal error %d (3: a path left its rows; 4: a path missed its end)", err); return -1; }
     return 0;
 }
 

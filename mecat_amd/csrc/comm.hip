@@ -848,6 +848,10 @@ int mhip_index_build_auto(mhip_comm* cm, const mhip_volume* v, mhip_index** out,
     if (cm->index_choice < 0) {
         double t[2] = {0.0, 0.0};
         mhip_index* keep[2] = {nullptr, nullptr};
+        struct KeepGuard {      // an error return frees what was built so far
+            mhip_index** k; bool armed = true;
+            ~KeepGuard() { if (armed) for (int i = 0; i < 2; ++i) if (k[i]) { mhip_index_free(k[i]); k[i] = nullptr; } }
+        } keep_guard{keep};
         for (int pass = 0; pass < 2; ++pass)
             for (int how = 0; how < 2; ++how) {
                 if (keep[how]) { mhip_index_free(keep[how]); keep[how] = nullptr; }
@@ -873,6 +877,7 @@ int mhip_index_build_auto(mhip_comm* cm, const mhip_volume* v, mhip_index** out,
         if (getenv("MECAT_TRACE") && cm->rank == 0)
             fprintf(stderr, "[mecat_hip] index build over %d ranks: every rank for itself %.1f ms, key-range shards + all-gather %.1f ms -> %s\n", P,
                     cm->index_ms[0], cm->index_ms[1], cm->index_choice ? "sharded" : "replicated");
+        keep_guard.armed = false;
         mhip_index_free(keep[1 - cm->index_choice]);
         *out = keep[cm->index_choice];
     } else {

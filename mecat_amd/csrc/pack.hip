@@ -11,7 +11,21 @@
 
 namespace {
 
-__constant__ uint8_t c_enc[256];      // the letter table (fasta reader / PackedDB: "-ACMGRSVTWYHKDBN" -> 15, 0, 1, 6, 2, 4, 9, 13, 3, 8, 5, 12, 7, 11, 10, 14; others 0)
+// built at compile time and loaded with the code object on every device (no per-process "uploaded" flag: a context on a second GPU of
+// the same process gets the same table)
+struct EncTable {
+    uint8_t t[256];
+    constexpr EncTable() : t() {
+        const char letters[] = "-acmgrsvtwyhkdbn";
+        const uint8_t vals[] = {15, 0, 1, 6, 2, 4, 9, 13, 3, 8, 5, 12, 7, 11, 10, 14};
+        for (int i = 0; i < 16; ++i) {
+            t[(unsigned char)letters[i]] = vals[i];
+            t[(unsigned char)(letters[i] >= 'a' ? letters[i] - 32 : letters[i])] = vals[i];
+        }
+    }
+};
+__constant__ EncTable c_enc_tab = EncTable();
+#define c_enc c_enc_tab.t      // the letter table (fasta reader / PackedDB: "-ACMGRSVTWYHKDBN" -> 15, 0, 1, 6, 2, 4, 9, 13, 3, 8, 5, 12, 7, 11, 10, 14; others 0)
 
 __global__ __launch_bounds__(256) void pack_letters(const uint8_t* __restrict__ text, const int64_t* __restrict__ seq_start, const int32_t* __restrict__ line_width,
                                                     const mhip_offset_t* __restrict__ offs, int num_reads, int num_bases, uint32_t* __restrict__ pac) {
@@ -78,16 +92,7 @@ int mhip_volume_pack(mhip_ctx* c, const uint8_t* text, int64_t text_bytes, const
             return -1;
         }
     }
-    static bool table_ready = false;
     HIPCHK(hipSetDevice(c->device));
-    if (!table_ready) {
-        uint8_t t[256] = {0};
-        const char* letters = "-acmgrsvtwyhkdbn";
-        const uint8_t vals[] = {15, 0, 1, 6, 2, 4, 9, 13, 3, 8, 5, 12, 7, 11, 10, 14};
-        for (int i = 0; letters[i]; ++i) { t[(unsigned char)letters[i]] = vals[i]; t[(unsigned char)(letters[i] >= 'a' ? letters[i] - 32 : letters[i])] = vals[i]; }
-        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_enc), t, sizeof(t)));
-        table_ready = true;
-    }
     mhip_volume* v = nullptr;
     if (mhip_volume_upload(c, nullptr, offs, num_reads, num_bases, start_read_id, &v)) return -1;      // buffers, read table, lookup table; pac zeroed
     struct Guard { mhip_volume*& v; ~Guard() { if (v) mhip_volume_free(v); } } guard{v};

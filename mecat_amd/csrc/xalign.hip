@@ -399,7 +399,8 @@ __device__ void xdrop_block_w(XwLds<HFN>& S, const XView& q, int qidx, int M, co
 // group of eight rows: group g of a wave's scratch = 64 dwords, lane l's dword = the cells rs[a] + l of rows 8 g .. 8 g + 7 — one
 // coalesced 256-byte store per eight rows instead of a 64-byte store per row.  Cells 64.. of the rows that have them (one row in ten)
 // go the same way into a second array of groups behind the first; a bit per group says whether it was written.
-#define XR_GROUPS ((X_MAXN + 2 + 7) / 8)                     // groups of eight rows
+#define XR_GROUPS ((X_MAXN + 2 + 7) / 8 + 2)                 // groups of eight rows; two spare groups, because the traceback's first window
+                                                             // loads groups (wlo >> 3) + 2 and + 3 with wlo up to (X_MAXN & ~15) - 16
 #define XR_STATE_BYTES ((size_t)XR_GROUPS * 256 * 2)        // first chunks, second chunks
 #define XN_GA 2
 #define XN_GB 3
@@ -410,7 +411,7 @@ struct XrLds {
     uint8_t Tb[X_MAXN + 72 + 64];        // Tb[b] = target base b - 1 (idle and tail lanes read up to 128 cells behind the window)
     uint16_t rs[X_MAXN + 4];             // first column of every row's script cells
     uint32_t win[2][4][64];              // traceback window: [chunk][group & 3][lane], 32 rows
-    uint32_t two[4];                     // groups that wrote a second chunk
+    uint32_t two[(XR_GROUPS + 31) / 32 + 1];   // groups that wrote a second chunk (one spare word: issue_groups reads words (g0 >> 5) and + 1)
 };
 
 __device__ void xdrop_block_ring(XrLds& S, const XView& q, int qidx, int M, const XView& t, int tidx, int N, uint8_t* __restrict__ st, XBlockOut& o) {
@@ -437,7 +438,8 @@ __device__ void xdrop_block_ring(XrLds& S, const XView& q, int qidx, int M, cons
     uint32_t* __restrict__ st32 = (uint32_t*)st;                    // first chunks: group g at dwords 64 g ..
     uint32_t* __restrict__ st32b = st32 + (size_t)XR_GROUPS * 64;   // second chunks
     if (lane <= n_init) S.HF[lane] = make_int2(-lane, -lane - 1);
-    if (lane < 4) S.two[lane] = 0;
+    static_assert((((X_MAXN & ~15) - 16) >> 3) + 3 < XR_GROUPS, "the traceback's first window stays inside the wave's group arrays");
+    if (lane < (int)(sizeof(S.two) / sizeof(S.two[0]))) S.two[lane] = 0;
     if (lane == 0) S.rs[0] = 0;
     // row 0 (xdrop_gapalign.cpp:45-57): cells 1 .. n_init are GAP_IN_A
     uint32_t acc = (lane >= 1 && lane <= n_init) ? (uint32_t)XN_GA : 0u, acc2 = 0u;

@@ -745,10 +745,12 @@ int main(int argc, char* argv[]) {
         // at once; older — either the attempt before (and the peer of this one has not started yet: it will remove it), or this attempt
         // with the peer started, and dead, more than a launcher's skew before this rank (that peer also removed its heartbeat,
         // so nothing else would ever notice).  The two are told apart by waiting: an older marker that is still there `grace` seconds
-        // after this rank started (MECAT_HIP_PEER_GRACE_S, default 15) is believed.  The 60 s silence rule applies to a peer only once a
+        // after this rank started (MECAT_HIP_PEER_GRACE_S, default 120: the time after which a peer without a heartbeat counts as "not
+        // running" anyway, so a peer that is merely late — slow launcher, GPU lease wait, ranks started by hand — is not declared dead any
+        // earlier on account of a stale marker) is believed.  The 60 s silence rule applies to a peer only once a
         // heartbeat of THIS attempt has been seen from it.
         const double t_mine = t_start - 1.0;                     // st_mtime has one-second granularity on some file systems
-        const double grace = env_int("MECAT_HIP_PEER_GRACE_S", NULL, 15);
+        const double grace = env_int("MECAT_HIP_PEER_GRACE_S", NULL, 120);
         beat = std::thread([&beat_stop, alive, peer_failed, peer_alive, watch, rank, t_mine, grace]() {
             std::vector<char> seen(peer_alive.size(), 0);
             auto mtime_of = [](const struct stat& sb) { return (double)sb.st_mtim.tv_sec + 1e-9 * (double)sb.st_mtim.tv_nsec; };
@@ -940,7 +942,7 @@ int main(int argc, char* argv[]) {
             struct stat sb;
             // (by now every rank that started in this attempt has removed the failure marker of an earlier one: a marker that is there is
             // this attempt's, or that of a rank that never started — dead either way; same rule as the watchdog's)
-            if (stat(rf.failed(owner).c_str(), &sb) == 0 && ((double)sb.st_mtime >= t_start - 1.0 || now_s() - t_start > env_int("MECAT_HIP_PEER_GRACE_S", NULL, 15)))
+            if (stat(rf.failed(owner).c_str(), &sb) == 0 && ((double)sb.st_mtime >= t_start - 1.0 || now_s() - t_start > env_int("MECAT_HIP_PEER_GRACE_S", NULL, 120)))
                 DIE("rank %d failed before it finished volume %d", owner, i);
             const double now = now_s();
             if (stat(rf.alive(owner).c_str(), &sb) == 0) {
@@ -976,7 +978,8 @@ int main(int argc, char* argv[]) {
             for (int r = 1; r < world; ++r)
                 while (access(partition_meta_name(opt.output, r).c_str(), F_OK) != 0) {
                     struct stat sb;
-                    if (stat(rf.failed(r).c_str(), &sb) == 0) DIE("rank %d failed before it finished its partition streams", r);
+                    if (stat(rf.failed(r).c_str(), &sb) == 0 && ((double)sb.st_mtime >= t_start - 1.0 || now_s() - t_start > env_int("MECAT_HIP_PEER_GRACE_S", NULL, 120)))
+                        DIE("rank %d failed before it finished its partition streams", r);
                     if (now_s() - w0 > merge_wait) DIE("gave up waiting for the partition streams of rank %d after %.0f s", r, merge_wait);
                     usleep(20 * 1000);
                 }

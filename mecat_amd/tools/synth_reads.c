@@ -44,6 +44,61 @@ void synth_genome(uint8_t* g, int64_t G, uint64_t seed) {
     }
 }
 
+/*
+ * Repeat structure laid over a genome from synth_genome (seeds recorded by the caller: everything derives from `seed`):
+ *   nfam interspersed families   one element of 300 .. 5 000 bases each, 2 .. max_copies copies pasted at uniform positions, every copy
+ *                                with its own divergence of 0 .. 5 % (substitutions and single-base indels) and on either strand —
+ *                                rRNA operons / IS elements / transposons: identical k-mers from many loci, which is what fills
+ *                                k-mer buckets up to and beyond the index's cap of 128, fires the 41st-seed replacement rule on hits
+ *                                that are not self hits and produces tied scores in the top-MAXC list
+ *   nsat microsatellites         a motif of 1 .. 6 bases (1 = a homopolymer run) repeated over 40 .. 600 bases
+ * stats[0] = bases covered by family copies, stats[1] = bases covered by microsatellites, stats[2] = copies pasted.
+ */
+void synth_genome_repeats(uint8_t* g, int64_t G, uint64_t seed, int nfam, int max_copies, int nsat, int64_t* stats) {
+    rng_t r; rng_seed(&r, splitmix64(seed) ^ 0x5245504541545321ull);
+    int64_t fam_bases = 0, sat_bases = 0, copies_total = 0;
+    uint8_t* el = (uint8_t*)malloc(5000);
+    uint8_t* cp = (uint8_t*)malloc(5600);
+    for (int f = 0; f < nfam && el && cp; ++f) {
+        int len = 300 + (int)(rng_unit(&r) * 4701.0);
+        if (len > G / 4) len = (int)(G / 4);
+        if (len < 20) break;
+        for (int i = 0; i < len; ++i) el[i] = (uint8_t)(rng_next(&r) >> 62);
+        int copies = 2 + (int)(rng_unit(&r) * (double)(max_copies > 2 ? max_copies - 1 : 1));
+        for (int c = 0; c < copies; ++c) {
+            const double div = rng_unit(&r) * 0.05;
+            const int rev = (int)(rng_next(&r) >> 63);
+            int n = 0;
+            for (int i = 0; i < len && n < 5590; ++i) {
+                uint8_t b = rev ? (uint8_t)(3 - el[len - 1 - i]) : el[i];
+                const double u = rng_unit(&r);
+                if (u < div * 0.6) cp[n++] = (uint8_t)(rng_next(&r) >> 62);            /* substitution (may redraw the same base) */
+                else if (u < div * 0.8) { /* deletion */ }
+                else if (u < div) { cp[n++] = b; cp[n++] = (uint8_t)(rng_next(&r) >> 62); } /* insertion */
+                else cp[n++] = b;
+            }
+            if (n > G) n = (int)G;
+            int64_t at = (int64_t)(rng_unit(&r) * (double)(G - n + 1));
+            if (at > G - n) at = G - n;
+            memcpy(g + at, cp, (size_t)n);
+            fam_bases += n; ++copies_total;
+        }
+    }
+    for (int s = 0; s < nsat; ++s) {
+        const int m = 1 + (int)(rng_unit(&r) * 6.0);
+        uint8_t motif[8];
+        for (int i = 0; i < m; ++i) motif[i] = (uint8_t)(rng_next(&r) >> 62);
+        int64_t len = 40 + (int64_t)(rng_unit(&r) * 561.0);
+        if (len > G) len = G;
+        int64_t at = (int64_t)(rng_unit(&r) * (double)(G - len + 1));
+        if (at > G - len) at = G - len;
+        for (int64_t i = 0; i < len; ++i) g[at + i] = motif[i % m];
+        sat_bases += len;
+    }
+    free(el); free(cp);
+    if (stats) { stats[0] = fam_bases; stats[1] = sat_bases; stats[2] = copies_total; }
+}
+
 /* one read -> codes 0..3 in out (capacity cap); returns length */
 int synth_one_read(const uint8_t* g, int64_t G, int64_t idx, int L, double pdel, double psub, double pins,
                    uint64_t seed, uint8_t* out, int cap) {
@@ -183,7 +238,7 @@ int synth_write_fasta(const char* path, const uint8_t* bases, const int32_t* len
    set (config 5) needs a few GB of memory, not the whole read set.  Output is byte-identical to synth_reads + synth_write_fasta. */
 int main(int argc, char** argv) {
     if (argc < 7) {
-        fprintf(stderr, "usage: %s out.fa nreads L err genome_len seed [ont=0]\n", argv[0]);
+        fprintf(stderr, "usage: %s out.fa nreads L err genome_len seed [ont=0 [nfam max_copies nsat]]\n", argv[0]);
         return 1;
     }
     const char* out = argv[1];
@@ -194,6 +249,11 @@ int main(int argc, char** argv) {
     uint8_t* g = (uint8_t*)malloc((size_t)G);
     if (!g) { fprintf(stderr, "out of memory (genome)\n"); return 2; }
     synth_genome(g, G, seed);
+    if (argc > 10) {       /* repeat-structured genome */
+        int64_t st[3];
+        synth_genome_repeats(g, G, seed, atoi(argv[8]), atoi(argv[9]), atoi(argv[10]), st);
+        fprintf(stderr, "synth_reads: repeats: %lld bases in %lld family copies, %lld bases of microsatellites\n", (long long)st[0], (long long)st[2], (long long)st[1]);
+    }
     const int cap = (int)(L * 1.25) + 64;
     const int64_t B = 65536;
     uint8_t* bases = (uint8_t*)malloc((size_t)(B * cap));

@@ -255,6 +255,16 @@ int orc_extract_kmers(const char* s, int ssize, int* kmer_ids)
     return num_kmers;
 }
 
+/* sweep statistics (tools/dev/parity_sweep.py; not part of the restated algorithm): how often the 41st-seed rule ran, how often on
+   a hit outside the query read's own copy in the ref volume ([self_lo, self_hi), set by orc_seed_read), and its three outcomes
+   [0] calls  [1] calls on non-self hits  [2] tail replaced (all 41 agree)  [3] one entry dropped  [4] new seed ignored
+   [5] non-self calls that dropped an entry.  Plain globals: the sweeps call the oracle from one thread. */
+static int64_t g_stat[8];
+static int64_t g_self_lo = -1, g_self_hi = -1;
+static int g_stat_nonself = 0;
+void orc_stats_reset(void) { memset(g_stat, 0, sizeof(g_stat)); }
+void orc_stats_get(int64_t* out) { memcpy(out, g_stat, sizeof(g_stat)); }
+
 /* pw_impl.cpp:121-159.  FP: int/(int*float) is an f32 divide; "- 1.0" and the compare are f64. */
 void orc_insert_loc(orc_back_list* spr, int loc, int seedn, float len, double cutoff)
 {
@@ -278,16 +288,19 @@ void orc_insert_loc(orc_back_list* spr, int loc, int seedn, float len, double cu
             }
     for (i = 0; i < ORC_SI; i++)
         if (minval > list_score[i]) { minval = list_score[i]; mini = i; }
+    g_stat[0]++; g_stat[1] += g_stat_nonself;
     if (minval == ORC_SM) {
         spr->loczhi[ORC_SM - 1] = (int16_t)loc;
         spr->seedno[ORC_SM - 1] = (int16_t)seedn;
+        g_stat[2]++;
     } else if (minval < ORC_SM && mini < ORC_SM) {
         for (i = mini; i < ORC_SM; i++) {
             spr->loczhi[i] = (int16_t)list_loc[i + 1];
             spr->seedno[i] = (int16_t)list_seed[i + 1];
         }
         spr->score--;
-    }
+        g_stat[3]++; g_stat[5] += g_stat_nonself;
+    } else g_stat[4]++;
 }
 
 /* pw_impl.cpp:161-239.  FP: everything before the compare is f32 ("- 1" converts the int). */
@@ -361,7 +374,10 @@ int orc_seeding(const char* read, int read_size, const orc_index* ridx, orc_seed
             if (spr->score == 0 || spr->seednum < km + 1) {
                 int loc = ++spr->score;
                 if (loc <= ORC_SM) { spr->loczhi[loc - 1] = (int16_t)seg_off; spr->seedno[loc - 1] = (int16_t)(km + 1); }
-                else orc_insert_loc(spr, seg_off, km + 1, ORC_BC, 0.25 /* ddfs_cutoff: 0.25 for both techs, pw_impl.cpp:21-23 */);
+                else {
+                    g_stat_nonself = !(seed_arr[sid] >= g_self_lo && seed_arr[sid] < g_self_hi);      /* statistics only */
+                    orc_insert_loc(spr, seg_off, km + 1, ORC_BC, 0.25 /* ddfs_cutoff: 0.25 for both techs, pw_impl.cpp:21-23 */);
+                }
                 int s_k;
                 if (seg_id > 0) s_k = spr->score + (spr - 1)->score;
                 else s_k = spr->score;
@@ -541,6 +557,11 @@ int orc_seed_read(const orc_volume* ref, const orc_volume* reads, const orc_inde
     orc_extract_one_seq(reads, rid, read1);
     orc_reverse_complement(read2, read1, rsize);
     int n = 0;
+    {   /* statistics only: where the query read's own copy lies in the ref volume, if it is there */
+        int lr = rid + reads->start_read_id - ref->start_read_id;
+        g_self_lo = g_self_hi = -1;
+        if (lr >= 0 && lr < ref->num_reads) { g_self_lo = ref->offs[lr].offset; g_self_hi = g_self_lo + ref->offs[lr].size; }
+    }
     for (int s = 0; s < 2; ++s) {
         const char* read = s ? read2 : read1;
         char chain = chain_as_char ? (s ? 'R' : 'F') : (char)(s ? 1 : 0);

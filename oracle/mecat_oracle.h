@@ -112,6 +112,10 @@ void orc_insert_loc(orc_back_list* spr, int loc, int seedn, float len, double cu
 int orc_find_location(int* t_loc, int* t_seedn, int* t_score, int* loc, int k, int* rep_loc,
                       float len, int read_len1, double cutoff);                          /* pw_impl.cpp:161-239 */
 int orc_seeding(const char* read, int read_size, const orc_index* ridx, orc_seeding_bk* bk); /* pw_impl.cpp:241-286 */
+/* sweep statistics of the 41st-seed rule (see mecat_oracle.c) */
+void orc_stats_reset(void);
+void orc_stats_get(int64_t* out8);
+
 int orc_get_candidates(const orc_volume* ref, orc_seeding_bk* bk, int num_segs, int read_id, int read_size,
                        char chain, orc_candidate* cands, int candidatenum, const orc_params* p); /* :288-465 */
 /* both strands of one read (loop body of candidate_detect, pw_impl.cpp:742-765); chain stored as 0/1 (FWD/REV) when

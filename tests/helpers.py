@@ -49,6 +49,28 @@ def synth_reads(nreads, L, err, genome, seed, ont=0):
     return bases[:tot].copy(), lens
 
 
+def synth_reads_rep(nreads, L, err, genome, seed, ont=0, nfam=6, max_copies=40, nsat=20):
+    """reads of a REPEAT-STRUCTURED genome (synth_genome_repeats in mecat_amd/tools/synth_reads.c: interspersed families of 300 - 5 000
+    base elements at 0 - 5 % divergence on either strand, microsatellites and homopolymer runs), everything derived from `seed`
+    -> (codes uint8[total], lens int32[nreads], stats dict)"""
+    lib = synth_lib()
+    vp = C.c_void_p
+    lib.synth_genome.argtypes = [vp, C.c_int64, C.c_uint64]
+    lib.synth_genome_repeats.argtypes = [vp, C.c_int64, C.c_uint64, C.c_int, C.c_int, C.c_int, vp]
+    lib.synth_reads_range.restype = C.c_int64
+    lib.synth_reads_range.argtypes = [vp, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_double, C.c_int, C.c_uint64, vp, C.c_int64, vp]
+    g = np.empty(genome, dtype=np.uint8)
+    lib.synth_genome(g.ctypes.data, genome, seed)
+    st = np.zeros(3, dtype=np.int64)
+    lib.synth_genome_repeats(g.ctypes.data, genome, seed, nfam, max_copies, nsat, st.ctypes.data)
+    cap = nreads * (int(L * 1.25) + 64)
+    bases = np.empty(cap, dtype=np.uint8)
+    lens = np.empty(nreads, dtype=np.int32)
+    tot = lib.synth_reads_range(g.ctypes.data, genome, 0, nreads, L, err, ont, seed, bases.ctypes.data, cap, lens.ctypes.data)
+    assert tot >= 0, tot
+    return bases[:tot].copy(), lens, dict(family_bases=int(st[0]), satellite_bases=int(st[1]), copies=int(st[2]))
+
+
 def write_fasta(path, codes, lens):
     assert synth_lib().synth_write_fasta(path.encode(), codes.ctypes.data, lens.ctypes.data, len(lens)) == 0
 
@@ -353,3 +375,48 @@ def dense_reads(n=1400, L=10000, flank=6250, seed=77, err=0.135):
         prev = r
     lens = np.array([len(r) for r in reads], dtype=np.int32)
     return np.concatenate(reads).astype(np.uint8), lens
+
+
+# ----------------------------------------------------------------------------- repeat-structured sets
+# name -> (nreads, L, err, genome, seed, ont, nfam, max_copies, nsat); both techs, buckets pushed to and beyond the cap of 128
+REP_SETS = {
+    "rep_pb": (700, 5000, 0.08, 250000, 601, 0, 10, 80, 25),
+    "rep_ont": (500, 6000, 0.08, 200000, 602, 1, 4, 90, 30),
+}
+# the CLI pin: config-1 size (1 000 reads x 10 kb @ 15 %), repeat-rich
+REP_CLI = (1000, 10000, 0.15, 500000, 603, 0, 8, 120, 40)
+
+
+def rep_set(name):
+    n, L, err, G, seed, ont, nfam, mc, nsat = REP_CLI if name == "rep_cli" else REP_SETS[name]
+    codes, lens, st = synth_reads_rep(n, L, err, G, seed, ont, nfam, mc, nsat)
+    return codes, lens, ont, st
+
+
+def orc_stats_reset():
+    orc().orc_stats_reset()
+
+
+def orc_stats():
+    """statistics of the oracle's 41st-seed rule since the last reset (test infrastructure, see oracle/mecat_oracle.c)"""
+    a = np.zeros(8, dtype=np.int64)
+    orc().orc_stats_get.argtypes = [C.c_void_p]
+    orc().orc_stats_get(a.ctypes.data)
+    return dict(insert_loc=int(a[0]), non_self=int(a[1]), tail_replaced=int(a[2]), dropped=int(a[3]), ignored=int(a[4]), non_self_dropped=int(a[5]))
+
+
+def bucket_stats(codes, lens, cap=128):
+    """k-mer bucket sizes of a read set, from the reads themselves (numpy): buckets at the cap, buckets dropped beyond it"""
+    starts = np.concatenate([[0], np.cumsum(lens.astype(np.int64))])
+    c = codes.astype(np.int64)
+    n = len(c)
+    if n < 13:
+        return dict(at_cap=0, dropped=0, largest=0)
+    k = np.zeros(n - 12, dtype=np.int64)
+    for j in range(13):
+        k = (k << 2) | c[j: n - 12 + j]
+    ok = np.ones(n - 12, dtype=bool)
+    for s in starts[1:-1]:
+        ok[max(0, s - 12): s] = False      # k-mers that would span two reads
+    u, cnt = np.unique(k[ok], return_counts=True)
+    return dict(at_cap=int((cnt == cap).sum()), near_cap=int(((cnt >= cap - 28) & (cnt <= cap)).sum()), dropped=int((cnt > cap).sum()), largest=int(cnt.max()))

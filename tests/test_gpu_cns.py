@@ -188,5 +188,13 @@ def test_two_kernel_realigner_equals_one_unit_per_wave_kernel_at_scale(hip, ctx,
         assert int((want_r["ok"] != 0).sum()) > 0.8 * len(jobs)
         assert np.array_equal(got_r, want_r)
         assert np.array_equal(got_o, want_o)
+    # units that run out of block records (a share of reach / 4096 + 2 instead of reach / 256 + 4) go to cns_extend like the units that
+    # outgrow their share of the row log: same results (this used to fail the whole batch with "internal error 2")
+    monkeypatch.delenv("MECAT_CNS_LOG_GB")
+    monkeypatch.setenv("MECAT_CNS_BLOCK_SHARE", "12,2")
+    got_r, got_o = hip.cns_align_candidates(ctx, vol, vol, jobs[:20000], error_rate, 500, cap)
+    assert np.array_equal(got_r, want_r[:20000])
+    assert np.array_equal(got_o, want_o[:20000])
+    monkeypatch.delenv("MECAT_CNS_BLOCK_SHARE")
     idx.free()
     vol.free()

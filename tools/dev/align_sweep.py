@@ -25,7 +25,10 @@ for it in range(int(os.environ.get("N", "20"))):
     cov = float(rng.choice([4, 10, 25]))
     genome = max(20000, int(nreads * L / cov))
     seed = int(rng.integers(1, 1 << 30))
-    codes, lens = H.synth_reads(nreads, L, err, genome, seed, ont)
+    if int(os.environ.get("REP", "0")):      # repeat-structured genome: low-complexity and multi-copy sequence under the aligners
+        codes, lens, _st = H.synth_reads_rep(nreads, L, err, genome, seed, ont, int(rng.integers(2, 9)), int(rng.choice([8, 30, 100])), int(rng.integers(0, 40)))
+    else:
+        codes, lens = H.synth_reads(nreads, L, err, genome, seed, ont)
     t0 = time.time()
     ov = H.orc_pack(codes, lens)
     offs, pac = H.vol_arrays(ov)

@@ -8,6 +8,8 @@ import helpers as H
 import mecat_amd.hip as M
 
 rng = np.random.default_rng(int(os.environ.get("SEED", "2024")))
+REP = int(os.environ.get("REP", "0"))
+tot_stats = dict(at_cap=0, dropped=0, insert_loc=0, non_self=0, non_self_dropped=0)
 ctx = M.Context(0)
 bad_total = 0
 for it in range(int(os.environ.get("N", "14"))):
@@ -19,7 +21,13 @@ for it in range(int(os.environ.get("N", "14"))):
     genome = max(20000, int(nreads * L / cov))
     seed = int(rng.integers(1, 1 << 30))
     maxc = int(rng.choice([100, 100, 10, 3]))
-    codes, lens = H.synth_reads(nreads, L, err, genome, seed, ont)
+    rep = ""
+    if REP:      # repeat-structured genome (synth_genome_repeats): families at 0 - 5 % divergence, microsatellites, homopolymer runs
+        nfam, mc, nsat = int(rng.integers(2, 9)), int(rng.choice([8, 30, 100])), int(rng.integers(0, 40))
+        codes, lens, st = H.synth_reads_rep(nreads, L, err, genome, seed, ont, nfam, mc, nsat)
+        rep = " rep(fam %d copies<=%d sat %d: %d copies)" % (nfam, mc, nsat, st["copies"])
+    else:
+        codes, lens = H.synth_reads(nreads, L, err, genome, seed, ont)
     if it % 3 == 0:        # ragged: cut some reads short (down to below k)
         starts = np.concatenate([[0], np.cumsum(lens.astype(np.int64))])
         parts, nl = [], []
@@ -37,12 +45,17 @@ for it in range(int(os.environ.get("N", "14"))):
     ctx.reset_stats()
     got, cnt = M.seed_reads(ctx, gi, gv, gv, 0, len(lens), p)
     took, left = ctx.debug_counter(13), ctx.debug_counter(14)
+    H.orc_stats_reset()
     want = H.orc_seed_all(ov, ov, oidx, H.orc_params(tech=ont, maxc=maxc))
+    os_, bs_ = H.orc_stats(), H.bucket_stats(codes, lens)
+    for k in tot_stats:
+        tot_stats[k] += os_.get(k, 0) + bs_.get(k, 0)
     # (reads of 4 .. 12 bases: one k-mer running past the read in the reference — undefined there, no k-mers here — are left out)
     bad = [r for r, w in enumerate(want) if not (4 <= lens[r] < 13) and not (cnt[r] == len(w) and all(np.array_equal(got[r][: cnt[r]][f], w[f]) for f in H.CAND_DTYPE.names))]
     bad_total += len(bad)
-    print("set %2d: ont %d reads %4d L %5d err %.2f cov %4.0f maxc %3d ragged %d: %6d candidates, strands fused %d chain %d, differing reads %d  (%.1f s)"
-          % (it, ont, len(lens), L, err, cov, maxc, it % 3 == 0, int(cnt.sum()), took, left, len(bad), time.time() - t0), flush=True)
+    print("set %2d: ont %d reads %4d L %5d err %.2f cov %4.0f maxc %3d ragged %d: %6d candidates, strands fused %d chain %d, differing reads %d  (%.1f s)%s  buckets at cap %d dropped %d, 41st-seed rule %d (non-self %d, dropped one %d)"
+          % (it, ont, len(lens), L, err, cov, maxc, it % 3 == 0, int(cnt.sum()), took, left, len(bad), time.time() - t0, rep, bs_["at_cap"], bs_["dropped"], os_["insert_loc"], os_["non_self"], os_["non_self_dropped"]), flush=True)
     gi.free(); gv.free()
+print("TOTAL buckets at the cap of 128: %(at_cap)d, dropped beyond it: %(dropped)d; 41st-seed rule ran %(insert_loc)d times, %(non_self)d on non-self hits (%(non_self_dropped)d of those dropped an entry)" % tot_stats)
 print("TOTAL differing reads:", bad_total)
 sys.exit(1 if bad_total else 0)

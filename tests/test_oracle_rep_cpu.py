@@ -79,7 +79,7 @@ def test_candidates_identical_on_repeats(rep, maxc):
 def _run_ref(rep, args, name):
     out = os.path.join(rep["dir"], name)
     wrk = os.path.join(rep["dir"], "w_" + name)
-    subprocess.run([H.ref_bin(), "-d", rep["fa"], "-o", out, "-w", wrk, "-t", "4"] + args, check=True,
+    subprocess.run([H.ref_bin(), "-d", rep["fa"], "-o", out, "-w", wrk, "-t", "16"] + args, check=True,
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return sorted(open(out).read().splitlines())
 

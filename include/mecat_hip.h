@@ -324,7 +324,8 @@ int mhip_cns_align_candidates_dev(mhip_ctx* ctx, const mhip_volume* ref, const m
  * consensus_one_read_can_pacbio / _nanopore (mecat2cns/mecat_correction.cpp:388-450, 452-515) for a batch of template reads.
  * cands: ExtensionCandidate records (common/alignment.h:8-19, the 13 ints of a .can line as mecat2cns normalises them: sdir == 0,
  * sid = the template), grouped by template: template t owns cands[tmpl_begin[t] .. tmpl_begin[t + 1]); they are sorted IN PLACE by
- * (score desc, qid, qext) as the reference does.  All reads live in `vol` (host_pac = the packed bytes given to mhip_volume_upload).
+ * (score desc, qid, qext) as the reference does.  All reads live in `vol` (host_pac, the packed bytes given to mhip_volume_upload, is no
+ * longer read and may be NULL: since round 6 the aligned strings are built on the device and copied into the result buffer).
  * tech 0: error rate 0.15, at most 60 accepted; tech 1: 0.20 / 100.  min_mapping_ratio is the option value (0.9 / 0.4), the
  * function subtracts the reference's 0.02.  Output (malloc'ed, release with mhip_cns_free): one record per accepted alignment
  * in the order the reference would add them, template by template, and the gap-normalised aligned strings
@@ -347,6 +348,9 @@ int  mhip_cns_accept_templates(mhip_ctx* ctx, const mhip_volume* vol, const uint
                                int num_threads, mhip_cns_accepted** out_accepted, int64_t* out_count, char** out_strings,
                                int64_t* out_strings_bytes, int64_t* out_jobs /* alignments computed, may be NULL */);
 void mhip_cns_free(void* p);
+/* test hook: normalize_gaps' gap pushing (reads_correction_aux.cpp:36-67) by the device kernel of the accept stage, in place, on n_pairs
+ * pairs of NUL-terminated host strings: pair p = buf + off[p] (len[p] characters + NUL) and its partner right behind it */
+int  mhip_debug_push_gaps(mhip_ctx* ctx, char* buf, int64_t bytes, const int64_t* off, const int32_t* len, int n_pairs);
 /* mhip_cns_free does not return a string buffer to the system at once: the library keeps the LARGEST released one (gigabytes — about
  * 14 GB for a config-2-sized batch) and hands it out again to the next batch that fits, because first-touching fresh pages costs
  * more than the batch's GPU time.  The parked buffer belongs to the process, not to a context (mhip_ctx_destroy leaves it).  This call

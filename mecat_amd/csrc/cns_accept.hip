@@ -11,9 +11,9 @@
 //         check_cov_stats: the aligned template range must have >= 200 positions below coverage 20, then ++coverage   :372-386
 //         normalize_gaps(qaln, saln, push = true) -> meap_add_one_aln, add_aln    reads_correction_aux.cpp:3-81
 // — and every alignment depends on nothing but the two reads, so the <= 200 candidates of every template of the batch are
-// re-aligned speculatively in ONE device launch (mhip_cns_align_candidates_dev), the sequential accept decisions are replayed
-// over the results on host threads, only the 2-bit column strings of the ACCEPTED alignments are gathered on the device and
-// brought back, and the gap-normalised strings are rebuilt from them and the host copy of the reads.
+// re-aligned speculatively on the device (mhip_cns_align_candidates_dev, a slice of the batch's templates per launch), the sequential
+// accept decisions are replayed over the results on host threads, and the gap-normalised strings of the ACCEPTED alignments are
+// built on the device as well (cns_strings.hip) and copied into the result buffer while the next slice re-aligns.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -27,8 +27,10 @@
 #include <thread>
 #include <vector>
 
+#include <functional>
+
 #include "common.h"
-#include "aln_strings.h"
+#include "cns_strings.h"
 
 namespace {
 
@@ -57,90 +59,12 @@ void parallel_for(int64_t n, int nthreads, F f) {
     for (auto& x : th) x.join();
 }
 
-inline int host_base(const uint8_t* pac, int64_t idx) { return (pac[idx >> 2] >> ((~idx & 3) << 1)) & 3; }      // packed_db.h:103-107
-
-// normalize_gaps (reads_correction_aux.cpp:3-81), push = true; q / t are NUL-terminated work buffers of equal length n
-void push_gaps(char* q, char* t, int64_t n) {
-    for (int64_t i = 0; i + 1 < n; ++i) {
-        if (t[i] == '-') {
-            int64_t j = i;
-            for (;;) {
-                const char c = t[++j];
-                if (c != '-' || j > n - 1) {
-                    if (c == q[i]) { t[i] = c; t[j] = '-'; }
-                    break;
-                }
-            }
-        }
-        if (q[i] == '-') {
-            int64_t j = i;
-            for (;;) {
-                const char c = q[++j];
-                if (c != '-' || j > n - 1) {
-                    if (c == t[i]) { q[i] = c; q[j] = '-'; }
-                    break;
-                }
-            }
-        }
-    }
-}
-
-// the 2-bit columns of the accepted jobs -> one dense buffer: one wave per accepted alignment, its left words then its right words at
-// woff[i] (a direction fills a fraction of its worst-case stride: 119 MB instead of 424 MB cross the PCIe link at config 2's 28 000 accepted)
-__global__ __launch_bounds__(256) void cns_gather_ops(const uint32_t* __restrict__ ops, const int32_t* __restrict__ sel, const int32_t* __restrict__ lw,
-                                                      const int32_t* __restrict__ rw, const unsigned long long* __restrict__ woff, int nsel, int row_words,
-                                                      uint32_t* __restrict__ out) {
-    const int lane = (int)threadIdx.x & 63;
-    for (size_t i = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < (size_t)nsel; i += (size_t)gridDim.x * 4) {
-        const uint32_t* src = ops + (size_t)sel[i] * row_words;
-        uint32_t* dst = out + woff[i];
-        const int nl = lw[i], nr = rw[i];
-        for (int j = lane; j < nl; j += 64) dst[j] = src[j];
-        for (int j = lane; j < nr; j += 64) dst[nl + j] = src[row_words / 2 + j];
-    }
-}
-
-// four bases of a packed byte as characters (first base in the high bits: packed_db.h:103-107), forward and reverse-complemented
-struct BaseLut {
-    uint32_t fwd[256], rc[256];
-    BaseLut() {
-        for (int b = 0; b < 256; ++b) {
-            char f[4], r[4];
-            for (int k = 0; k < 4; ++k) {
-                const int c = (b >> ((3 - k) << 1)) & 3;
-                f[k] = "ACGT"[c];
-                r[3 - k] = "ACGT"[3 - c];
-            }
-            memcpy(&fwd[b], f, 4);
-            memcpy(&rc[b], r, 4);
-        }
-    }
-};
-const BaseLut g_lut;
-
-// bases [from, from + n) of the read at `off` as characters (n + up to 7 bytes of dst are written)
-void decode_fwd(const uint8_t* pac, int64_t off, int from, int n, char* dst) {
-    int64_t idx = off + from;
-    int k = 0;
-    for (; k < n && (idx & 3); ++k, ++idx) dst[k] = "ACGT"[host_base(pac, idx)];
-    for (; k < n; k += 4, idx += 4) memcpy(dst + k, &g_lut.fwd[pac[idx >> 2]], 4);
-}
-// the same range of the read's reverse complement: position i of the strand is the complement of base size - 1 - i
-void decode_rc(const uint8_t* pac, int64_t off, int size, int from, int n, char* dst) {
-    // strand positions from .. from + n - 1  <->  read positions size - 1 - from  down to  size - from - n
-    int64_t idx = off + size - 1 - from;                 // read index of the first character, walking down
-    int k = 0;
-    for (; k < n && ((idx & 3) != 3); ++k, --idx) dst[k] = "ACGT"[3 - host_base(pac, idx)];
-    for (; k + 4 <= n; k += 4, idx -= 4) memcpy(dst + k, &g_lut.rc[pac[idx >> 2]], 4);
-    for (; k < n; ++k, --idx) dst[k] = "ACGT"[3 - host_base(pac, idx)];
-}
-
 }  // namespace
 
 extern "C" {
 
-// The strings of a batch are gigabytes (14 GB at config 2) that the host threads touch for the first time while they write them: fresh
-// pages from the kernel at 3.5 GB/s on this host — 4 of a batch's 6 seconds.  So the library keeps ONE released string buffer and
+// The strings of a batch are gigabytes (24 GB at config 2), and pages that are touched for the first time cost more than the copy that
+// fills them.  So the library keeps ONE released string buffer and
 // hands it out again when the next batch fits it (mecat2cns works through its partitions batch after batch): pages that are mapped
 // already.  mhip_cns_free parks a buffer it knows instead of freeing it; a larger request replaces the parked one.
 namespace {
@@ -148,7 +72,15 @@ std::mutex g_strbuf_mu;
 char* g_strbuf_parked = nullptr;          // released, reusable
 size_t g_strbuf_parked_cap = 0;
 std::map<void*, size_t> g_strbuf_out;     // handed to a caller: address -> capacity
-char* strbuf_get(size_t bytes) {
+std::set<void*> g_strbuf_reg;             // page-locked (hipHostRegister): the copy engine fills them without a staging copy, asynchronously
+void strbuf_free(void* p) {               // (g_strbuf_mu held or not: only the set is shared)
+    if (!p) return;
+    bool reg;
+    { std::lock_guard<std::mutex> lk(g_strbuf_mu); reg = g_strbuf_reg.erase(p) != 0; }
+    if (reg) (void)hipHostUnregister(p);
+    free(p);
+}
+char* strbuf_get(size_t bytes, int num_threads) {
     {
         std::lock_guard<std::mutex> lk(g_strbuf_mu);
         if (g_strbuf_parked && g_strbuf_parked_cap >= bytes) {
@@ -163,8 +95,14 @@ char* strbuf_get(size_t bytes) {
     const size_t two_mb = (size_t)2 << 20, cap = (bytes + bytes / 16 + two_mb - 1) & ~(two_mb - 1);
     if (posix_memalign(&p, two_mb, cap) != 0) return nullptr;
     (void)madvise(p, cap, MADV_HUGEPAGE);
+    // first touch on the host threads (huge pages: 8 GB in 30 ms on 32 threads), then page-locked — 70 ms for 8 GB of touched pages, against
+    // 0.4 s untouched and 1.9 s for a hipHostMalloc of the size (tools/dev/probes/pin_probe.hip)
+    parallel_for((int64_t)(cap / two_mb), num_threads, [&](int64_t pg) { ((volatile char*)p)[(size_t)pg * two_mb] = 0; });
+    const bool reg = hipHostRegister(p, cap, hipHostRegisterDefault) == hipSuccess;
+    if (!reg) (void)hipGetLastError();      // stays pageable: the copies still work, through the runtime's staging
     std::lock_guard<std::mutex> lk(g_strbuf_mu);
     g_strbuf_out[p] = cap;
+    if (reg) g_strbuf_reg.insert(p);
     return (char*)p;
 }
 }  // namespace
@@ -185,7 +123,7 @@ void mhip_cns_free(void* p) {
             }
         }
     }
-    free(to_free);
+    strbuf_free(to_free);      // (a plain malloc'ed buffer — the accepted records, small string buffers — is just freed)
 }
 
 // gives the parked string buffer (see above) back to the system; buffers still in a caller's hands are not touched
@@ -197,10 +135,10 @@ void mhip_cns_release_parked(void) {
         g_strbuf_parked = nullptr;
         g_strbuf_parked_cap = 0;
     }
-    free(p);
+    strbuf_free(p);
 }
 
-int mhip_cns_accept_templates(mhip_ctx* c, const mhip_volume* vol, const uint8_t* host_pac, mhip_ext_candidate* cands, const int64_t* tmpl_begin,
+int mhip_cns_accept_templates(mhip_ctx* c, const mhip_volume* vol, const uint8_t* /*host_pac: not read any more (the strings are built on the device)*/, mhip_ext_candidate* cands, const int64_t* tmpl_begin,
                               int num_templates, int tech, int min_align_size, double min_mapping_ratio, int num_threads,
                               mhip_cns_accepted** out_accepted, int64_t* out_count, char** out_strings, int64_t* out_strings_bytes,
                               int64_t* out_jobs) {
@@ -253,7 +191,6 @@ int mhip_cns_accept_templates(mhip_ctx* c, const mhip_volume* vol, const uint8_t
     if (nj == 0) return 0;
     if (nj > 0x7fffffffLL) { mhip_set_error("cns accept: too many jobs in one batch"); return -1; }
     std::vector<mhip_aln_job> jobs((size_t)nj);
-    int max_len = 16;
     parallel_for(num_templates, num_threads, [&](int64_t t) {
         for (int64_t k = 0; k < jfirst[(size_t)t + 1] - jfirst[(size_t)t]; ++k) {
             const mhip_ext_candidate& ec = cands[tmpl_begin[t] + k];
@@ -266,150 +203,229 @@ int mhip_cns_accept_templates(mhip_ctx* c, const mhip_volume* vol, const uint8_t
             jobs[(size_t)(jfirst[(size_t)t] + k)] = j;
         }
     });
+    int max_len = 16;
     for (int64_t i = 0; i < nj; ++i)
         max_len = std::max(max_len, std::max(vol->h_offs[(size_t)jobs[(size_t)i].qid_local].size, vol->h_offs[(size_t)jobs[(size_t)i].sid_local].size));
     // columns of one direction <= bases of both reads on that side; 16-column words
     const int cap = (int)(((int64_t)max_len * 2 + 64 + 15) / 16 * 16);
     const int row_words = 2 * (cap / 16);
 
-    lap(1);
-    // 3. one speculative device launch
-    mhip_aln_job* d_jobs;
-    mhip_cns_result* d_res;
-    uint32_t* d_ops;
-    if (c->scratch("ca_jobs", sizeof(mhip_aln_job) * (size_t)nj, (void**)&d_jobs)) return -1;
-    if (c->scratch("ca_res", sizeof(mhip_cns_result) * (size_t)nj, (void**)&d_res)) return -1;
-    if (c->scratch("ca_ops", sizeof(uint32_t) * (size_t)row_words * (size_t)nj, (void**)&d_ops)) return -1;
-    HIPCHK(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(mhip_aln_job) * (size_t)nj, hipMemcpyHostToDevice, c->stream));
-    if (mhip_cns_align_candidates_dev(c, vol, vol, d_jobs, (int)nj, error_rate, min_align_size, cap, d_res, d_ops)) return -1;
-    std::vector<mhip_cns_result> res((size_t)nj);
-    HIPCHK(hipMemcpyAsync(res.data(), d_res, sizeof(mhip_cns_result) * (size_t)nj, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-
-    lap(2);
-    // 4. the sequential accept decisions, per template
-    std::vector<std::vector<int32_t>> acc((size_t)num_templates);      // accepted job indices, in acceptance order
-    parallel_for(num_templates, num_threads, [&](int64_t t) {
-        const int64_t b = tmpl_begin[t], n = tmpl_begin[t + 1] - b;
-        if (n == 0) return;
-        const int ssize = vol->h_offs[(size_t)(cands[b].sid - start_id)].size;      // (== every candidate's ssize: checked above)
-        std::vector<uint8_t> cov((size_t)std::max(ssize, 1), 0);
-        std::set<int> used;
-        int num_added = 0, num_ext = 0;
-        for (int64_t i = 0; i < n && num_added < max_added && num_ext < max_ext; ++i) {
-            ++num_ext;
-            const mhip_ext_candidate& ec = cands[b + i];
-            if (used.find(ec.qid) != used.end()) continue;
-            const int64_t ji = jfirst[(size_t)t] + i;          // i < max_ext here: the job exists
-            const mhip_cns_result& r = res[(size_t)ji];
-            if (!r.ok) continue;
-            const int oq = r.qend - r.qoff, qqs = (int)(ec.qsize * ratio), os = r.send - r.soff, qss = (int)(ec.ssize * ratio);      // :191-200
-            if (!(oq >= qqs || os >= qss)) continue;
-            int full = 0;                                        // check_cov_stats, :372-386
-            for (int p = r.soff; p < r.send; ++p) full += cov[(size_t)p] >= 20;
-            if (!(r.send - r.soff >= full + 200)) continue;
-            for (int p = r.soff; p < r.send; ++p) ++cov[(size_t)p];
-            ++num_added;
-            used.insert(ec.qid);
-            acc[(size_t)t].push_back((int32_t)ji);
-        }
-    });
-    std::vector<int64_t> afirst((size_t)num_templates + 1, 0);
-    for (int t = 0; t < num_templates; ++t) afirst[(size_t)t + 1] = afirst[(size_t)t] + (int64_t)acc[(size_t)t].size();
-    const int64_t na = afirst[(size_t)num_templates];
-    if (na == 0) return 0;
-
-    lap(3);
-    // 5. the accepted alignments' columns, packed: left words then right words of every accepted alignment
-    std::vector<int32_t> sel((size_t)na), lw((size_t)na), rw((size_t)na);
-    std::vector<unsigned long long> woff((size_t)na + 1);
-    for (int t = 0; t < num_templates; ++t) std::copy(acc[(size_t)t].begin(), acc[(size_t)t].end(), sel.begin() + afirst[(size_t)t]);
-    woff[0] = 0;
-    for (int64_t a = 0; a < na; ++a) {
-        const mhip_cns_result& r = res[(size_t)sel[(size_t)a]];
-        lw[(size_t)a] = (r.left_cols + 15) >> 4;
-        rw[(size_t)a] = (r.right_cols + 15) >> 4;
-        woff[(size_t)a + 1] = woff[(size_t)a] + (unsigned long long)(lw[(size_t)a] + rw[(size_t)a]);
+    // 3. The batch goes through the device in SLICES of whole templates (at most MECAT_CNS_SLICE_JOBS jobs, default 1.2 M: four slices
+    // at config 2) with two sets of buffers in turn:
+    //     slice k + 1 is re-aligned on the GPU      while   a host thread replays the accept decisions of slice k
+    //     the strings of slice k are built on the GPU behind it, and cross the PCIe link on a second stream while slice k + 2 re-aligns
+    // The host side is the replay only; the string buffer is filled by the copy engine.
+    int64_t slice_jobs = 1200000;
+    if (const char* e = getenv("MECAT_CNS_SLICE_JOBS")) slice_jobs = std::max<int64_t>(1, atoll(e));
+    std::vector<int> sl_t;                                    // first template of every slice, and one behind the last
+    for (int t = 0; t < num_templates;) {
+        sl_t.push_back(t);
+        int u = t + 1;
+        while (u < num_templates && jfirst[(size_t)u + 1] - jfirst[(size_t)t] <= slice_jobs) ++u;
+        t = u;
     }
-    const size_t dense_words = (size_t)woff[(size_t)na];
-    int32_t *d_sel, *d_lw, *d_rw;
-    unsigned long long* d_woff;
-    uint32_t* d_pack;
-    if (c->scratch("ca_sel", sizeof(int32_t) * (size_t)na, (void**)&d_sel)) return -1;
-    if (c->scratch("ca_lw", sizeof(int32_t) * (size_t)na, (void**)&d_lw)) return -1;
-    if (c->scratch("ca_rw", sizeof(int32_t) * (size_t)na, (void**)&d_rw)) return -1;
-    if (c->scratch("ca_woff", sizeof(unsigned long long) * ((size_t)na + 1), (void**)&d_woff)) return -1;
-    if (c->scratch("ca_pack", sizeof(uint32_t) * std::max<size_t>(dense_words, 1), (void**)&d_pack)) return -1;
-    HIPCHK(hipMemcpyAsync(d_sel, sel.data(), sizeof(int32_t) * (size_t)na, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(d_lw, lw.data(), sizeof(int32_t) * (size_t)na, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(d_rw, rw.data(), sizeof(int32_t) * (size_t)na, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(d_woff, woff.data(), sizeof(unsigned long long) * ((size_t)na + 1), hipMemcpyHostToDevice, c->stream));
-    LAUNCH(c, "cns_gather_ops", cns_gather_ops, (unsigned)std::min<size_t>(((size_t)na + 3) / 4, (size_t)c->num_cus * 32), 256, 0, (const uint32_t*)d_ops,
-           (const int32_t*)d_sel, (const int32_t*)d_lw, (const int32_t*)d_rw, (const unsigned long long*)d_woff, (int)na, row_words, d_pack);
-    uint32_t* ops = nullptr;                                   // page-locked: the copy is one DMA
-    HIPCHK(hipHostMalloc((void**)&ops, sizeof(uint32_t) * std::max<size_t>(dense_words, 1), hipHostMallocDefault));
-    struct HostFree { uint32_t* p; ~HostFree() { (void)hipHostFree(p); } } ops_guard{ops};
-    HIPCHK(hipMemcpyAsync(ops, d_pack, sizeof(uint32_t) * dense_words, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    sl_t.push_back(num_templates);
+    const int nslices = (int)sl_t.size() - 1;
+    int64_t max_slice = 0;
+    for (int k = 0; k < nslices; ++k) max_slice = std::max(max_slice, jfirst[(size_t)sl_t[(size_t)k + 1]] - jfirst[(size_t)sl_t[(size_t)k]]);
 
-    lap(4);
-    // 6. strings: m5qaln / m5saln from the columns and the reads, then normalize_gaps(push = true)
+    mhip_aln_job* d_jobs;
+    if (c->scratch("ca_jobs", sizeof(mhip_aln_job) * (size_t)nj, (void**)&d_jobs)) return -1;
+    HIPCHK(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(mhip_aln_job) * (size_t)nj, hipMemcpyHostToDevice, c->stream));
+    mhip_cns_result* d_res[2] = {nullptr, nullptr};
+    uint32_t* d_ops[2] = {nullptr, nullptr};
+    for (int b = 0; b < std::min(2, nslices); ++b) {
+        if (c->scratch(b ? "ca_res1" : "ca_res", sizeof(mhip_cns_result) * (size_t)max_slice, (void**)&d_res[b])) return -1;
+        if (c->scratch(b ? "ca_ops1" : "ca_ops", sizeof(uint32_t) * (size_t)row_words * (size_t)max_slice, (void**)&d_ops[b])) return -1;
+    }
+    std::vector<mhip_cns_result> res((size_t)nj);           // every slice's results land in their place
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_built[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
+    struct Cleanup {
+        hipStream_t& s; hipEvent_t* a; hipEvent_t* b;
+        ~Cleanup() {
+            if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+            for (int i = 0; i < 2; ++i) { if (a[i]) (void)hipEventDestroy(a[i]); if (b[i]) (void)hipEventDestroy(b[i]); }
+        }
+    } cleanup{copy_stream, ev_built, ev_copied};
+    HIPCHK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+    for (int b = 0; b < 2; ++b) {
+        HIPCHK(hipEventCreateWithFlags(&ev_built[b], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ev_copied[b], hipEventDisableTiming));
+    }
+
+    // the result buffer: sized after the first slice's replay from its bytes per template (+ 15 %); a later slice that does not fit
+    // gets a larger one, the strings copied so far moved over (MECAT_CNS_STR_ESTIMATE=<percent> scales the estimate: test knob)
+    char* S = nullptr;
+    size_t S_cap = 0, S_used = 0;
+    bool S_big = false;
+    auto s_release = [&]() {
+        if (S && copy_stream) (void)hipStreamSynchronize(copy_stream);      // no copy may still be writing into it
+        if (S) { if (S_big) mhip_cns_free(S); else free(S); }
+        S = nullptr; S_cap = 0;
+    };
+    struct SGuard { std::function<void()> f; bool armed = true; ~SGuard() { if (armed) f(); } } s_guard{s_release};
+    auto s_reserve = [&](size_t want) -> int {
+        if (want <= S_cap) return 0;
+        if (hipStreamSynchronize(copy_stream) != hipSuccess) { mhip_set_error("cns accept: copy stream failed"); return -1; }      // the copies into the old buffer have landed
+        const bool big = want >= ((size_t)64 << 20);
+        char* nS = big ? strbuf_get(want, num_threads) : (char*)malloc(std::max<size_t>(want, 1));
+        if (!nS) { mhip_set_error("out of memory (%lld bytes of aligned strings)", (long long)want); return -1; }
+        if (S_used) {
+            const size_t piece = (size_t)64 << 20;
+            parallel_for((int64_t)((S_used + piece - 1) / piece), num_threads, [&](int64_t pc) {
+                const size_t o = (size_t)pc * piece;
+                memcpy(nS + o, S + o, std::min(piece, S_used - o));
+            });
+        }
+        s_release();
+        S = nS; S_cap = want; S_big = big;
+        return 0;
+    };
+    double est_scale = 1.15;
+    if (const char* e = getenv("MECAT_CNS_STR_ESTIMATE")) est_scale = std::max(0.01, atof(e) / 100.0);
+
+    struct Slice {
+        int t0 = 0, t1 = 0;
+        int64_t j0 = 0, nj = 0;
+        std::vector<std::vector<int32_t>> acc;      // per template: accepted job indices (batch-wide), in acceptance order
+        std::vector<int64_t> afirst;               // per template: first accepted record of the slice
+        std::vector<CnsStrItem> items;
+        size_t sbytes = 0;
+    };
+    std::vector<mhip_cns_accepted> Avec;
+    lap(1);
+
+    auto align_slice = [&](Slice& sl, int b) -> int {
+        if (mhip_cns_align_candidates_dev(c, vol, vol, d_jobs + sl.j0, (int)sl.nj, error_rate, min_align_size, cap, d_res[b], d_ops[b])) return -1;
+        HIPCHK(hipMemcpyAsync(res.data() + sl.j0, d_res[b], sizeof(mhip_cns_result) * (size_t)sl.nj, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        return 0;
+    };
+    // the sequential accept decisions, per template (host threads)
+    auto replay_slice = [&](Slice& sl) {
+        const int nt = sl.t1 - sl.t0;
+        sl.acc.assign((size_t)nt, std::vector<int32_t>());
+        parallel_for(nt, num_threads, [&](int64_t tl) {
+            const int64_t t = sl.t0 + tl;
+            const int64_t b = tmpl_begin[t], n = tmpl_begin[t + 1] - b;
+            if (n == 0) return;
+            const int ssize = vol->h_offs[(size_t)(cands[b].sid - start_id)].size;      // (== every candidate's ssize: checked above)
+            std::vector<uint8_t> cov((size_t)std::max(ssize, 1), 0);
+            std::set<int> used;
+            int num_added = 0, num_ext = 0;
+            for (int64_t i = 0; i < n && num_added < max_added && num_ext < max_ext; ++i) {
+                ++num_ext;
+                const mhip_ext_candidate& ec = cands[b + i];
+                if (used.find(ec.qid) != used.end()) continue;
+                const int64_t ji = jfirst[(size_t)t] + i;          // i < max_ext here: the job exists
+                const mhip_cns_result& r = res[(size_t)ji];
+                if (!r.ok) continue;
+                const int oq = r.qend - r.qoff, qqs = (int)(ec.qsize * ratio), os = r.send - r.soff, qss = (int)(ec.ssize * ratio);      // :191-200
+                if (!(oq >= qqs || os >= qss)) continue;
+                int full = 0;                                        // check_cov_stats, :372-386
+                for (int p = r.soff; p < r.send; ++p) full += cov[(size_t)p] >= 20;
+                if (!(r.send - r.soff >= full + 200)) continue;
+                for (int p = r.soff; p < r.send; ++p) ++cov[(size_t)p];
+                ++num_added;
+                used.insert(ec.qid);
+                sl.acc[(size_t)tl].push_back((int32_t)ji);
+            }
+        });
+        sl.afirst.assign((size_t)nt + 1, 0);
+        for (int tl = 0; tl < nt; ++tl) sl.afirst[(size_t)tl + 1] = sl.afirst[(size_t)tl] + (int64_t)sl.acc[(size_t)tl].size();
+        const int64_t na = sl.afirst[(size_t)nt];
+        sl.items.resize((size_t)na);
+        size_t off = 0;
+        for (int tl = 0; tl < nt; ++tl)
+            for (size_t k = 0; k < sl.acc[(size_t)tl].size(); ++k) {
+                const int64_t ji = sl.acc[(size_t)tl][k];
+                const mhip_cns_result& r = res[(size_t)ji];
+                CnsStrItem& it = sl.items[(size_t)(sl.afirst[(size_t)tl] + (int64_t)k)];
+                it.job = (int32_t)(ji - sl.j0);
+                it.aln_size = r.last_col - r.first_col;          // O(ND) columns are matches or indels: normalising adds no columns
+                it.off = (unsigned long long)off;
+                off += 2 * ((size_t)it.aln_size + 1);
+            }
+        sl.sbytes = off;
+    };
+    // strings of an (aligned, replayed) slice: built on the device behind whatever the stream holds, copied on the second stream
+    auto strings_slice = [&](Slice& sl, int b, int k) -> int {
+        const int64_t na = (int64_t)sl.items.size();
+        if (na == 0) return 0;
+        size_t want = S_used + sl.sbytes;
+        if (want > S_cap && k + 1 < nslices)
+            want = std::max(want, (size_t)((double)want / (double)sl.t1 * (double)num_templates * est_scale) + ((size_t)1 << 20));
+        if (s_reserve(want)) return -1;
+        // the accepted records (what the caller gets beside the strings)
+        const size_t a0 = Avec.size();
+        Avec.resize(a0 + (size_t)na);
+        parallel_for(sl.t1 - sl.t0, num_threads, [&](int64_t tl) {
+            const int64_t t = sl.t0 + tl;
+            for (size_t kk = 0; kk < sl.acc[(size_t)tl].size(); ++kk) {
+                const int64_t ji = sl.acc[(size_t)tl][kk];
+                const mhip_cns_result& r = res[(size_t)ji];
+                const CnsStrItem& it = sl.items[(size_t)(sl.afirst[(size_t)tl] + (int64_t)kk)];
+                const mhip_ext_candidate& ec = cands[tmpl_begin[t] + (ji - jfirst[(size_t)t])];
+                mhip_cns_accepted& o = Avec[a0 + (size_t)(sl.afirst[(size_t)tl] + (int64_t)kk)];
+                o.template_index = (int32_t)t;
+                o.cand_index = tmpl_begin[t] + (ji - jfirst[(size_t)t]);
+                o.qid = ec.qid; o.sid = ec.sid;
+                o.qoff = r.qoff; o.qend = r.qend; o.soff = r.soff; o.send = r.send;
+                o.aln_size = it.aln_size;
+                o.str_offset = (int64_t)(S_used + it.off);
+            }
+        });
+        if (k >= 2) HIPCHK(hipEventSynchronize(ev_copied[b]));      // the copy out of this set's string buffer two slices ago (the buffer may move)
+        char* d_str;
+        CnsStrItem* d_items;
+        if (c->scratch(b ? "ca_str1" : "ca_str", sl.sbytes + 128, (void**)&d_str)) return -1;
+        if (c->scratch(b ? "ca_items1" : "ca_items", sizeof(CnsStrItem) * (size_t)na, (void**)&d_items)) return -1;
+        HIPCHK(hipMemcpyAsync(d_items, sl.items.data(), sizeof(CnsStrItem) * (size_t)na, hipMemcpyHostToDevice, c->stream));
+        if (cns_strings_launch(c, vol, d_jobs + sl.j0, d_res[b], d_ops[b], row_words, d_items, (int)na, d_str)) return -1;
+        HIPCHK(hipEventRecord(ev_built[b], c->stream));
+        HIPCHK(hipStreamWaitEvent(copy_stream, ev_built[b], 0));
+        HIPCHK(hipMemcpyAsync(S + S_used, d_str, sl.sbytes, hipMemcpyDeviceToHost, copy_stream));
+        HIPCHK(hipEventRecord(ev_copied[b], copy_stream));
+        S_used += sl.sbytes;
+        return 0;
+    };
+
+    std::vector<Slice> slices((size_t)nslices);
+    for (int k = 0; k < nslices; ++k) {
+        Slice& sl = slices[(size_t)k];
+        sl.t0 = sl_t[(size_t)k]; sl.t1 = sl_t[(size_t)k + 1];
+        sl.j0 = jfirst[(size_t)sl.t0]; sl.nj = jfirst[(size_t)sl.t1] - sl.j0;
+    }
+    if (slices[0].nj > 0 && align_slice(slices[0], 0)) return -1;
+    lap(2);
+    for (int k = 0; k < nslices; ++k) {
+        Slice& sl = slices[(size_t)k];
+        std::thread rp([&]() { replay_slice(sl); });
+        struct Join { std::thread& t; ~Join() { if (t.joinable()) t.join(); } } join{rp};
+        int rc = 0;
+        if (k + 1 < nslices && slices[(size_t)k + 1].nj > 0) rc = align_slice(slices[(size_t)k + 1], (k + 1) & 1);
+        lap(2);
+        rp.join();
+        lap(3);
+        if (rc) return -1;
+        if (strings_slice(sl, k & 1, k)) return -1;
+        sl.acc.clear(); sl.acc.shrink_to_fit(); sl.items.clear(); sl.items.shrink_to_fit();
+        lap(4);
+    }
+    HIPCHK(hipStreamSynchronize(copy_stream));
+    const int64_t na = (int64_t)Avec.size();
+    if (na == 0) return 0;
     mhip_cns_accepted* A = (mhip_cns_accepted*)malloc(sizeof(mhip_cns_accepted) * (size_t)na);
     if (!A) { mhip_set_error("out of memory"); return -1; }
-    int64_t sbytes = 0;
-    for (int64_t a = 0; a < na; ++a) {
-        const mhip_cns_result& r = res[(size_t)sel[(size_t)a]];
-        A[a].aln_size = r.last_col - r.first_col;          // O(ND) columns are matches or indels: normalising adds no columns
-        A[a].str_offset = sbytes;
-        sbytes += 2 * ((int64_t)A[a].aln_size + 1);
-    }
-    // (gigabytes at config 2: the buffer a caller released before is handed out again when it fits, see strbuf_get)
-    char* S = (size_t)sbytes >= ((size_t)64 << 20) ? strbuf_get((size_t)sbytes) : (char*)malloc((size_t)std::max<int64_t>(sbytes, 1));
-    if (!S) { free(A); mhip_set_error("out of memory (%lld bytes of aligned strings)", (long long)sbytes); return -1; }
-    parallel_for(num_templates, num_threads, [&](int64_t t) {
-        std::vector<char> qbuf, tbuf, qtmp, ttmp;
-        for (int64_t a = afirst[(size_t)t]; a < afirst[(size_t)t + 1]; ++a) {
-            const int64_t ji = sel[(size_t)a];
-            const mhip_cns_result& r = res[(size_t)ji];
-            const mhip_aln_job& jb = jobs[(size_t)ji];
-            const mhip_ext_candidate& ec = cands[tmpl_begin[t] + (ji - jfirst[(size_t)t])];
-            mhip_cns_accepted& o = A[a];
-            o.template_index = (int32_t)t;
-            o.cand_index = tmpl_begin[t] + (ji - jfirst[(size_t)t]);
-            o.qid = ec.qid; o.sid = ec.sid;
-            o.qoff = r.qoff; o.qend = r.qend; o.soff = r.soff; o.send = r.send;
-            char* qa = S + o.str_offset;
-            char* sa = qa + o.aln_size + 1;
-            const uint32_t* left = ops + woff[(size_t)a];
-            const uint32_t* right = left + lw[(size_t)a];
-            const mhip_offset_t qo = vol->h_offs[(size_t)jb.qid_local], so = vol->h_offs[(size_t)jb.sid_local];
-            // the bases the columns cover, as characters: query (in the mapped strand's orientation) from the untrimmed start point,
-            // template likewise — the column loop below then only picks from them
-            const int nq = r.query_end - r.query_start, nt = r.target_end - r.target_start;
-            qbuf.resize((size_t)nq + 24);             // (8 bytes in front of the bases and 8 + the decoders' overrun behind them: aln_strings.h)
-            tbuf.resize((size_t)nt + 24);
-            if (jb.chain) decode_rc(host_pac, qo.offset, qo.size, r.query_start, nq, qbuf.data() + 8);
-            else decode_fwd(host_pac, qo.offset, r.query_start, nq, qbuf.data() + 8);
-            decode_fwd(host_pac, so.offset, r.target_start, nt, tbuf.data() + 8);
-            // merged columns: reverse(left) then right, four at a time (aln_strings.h); columns [first_col, last_col) are kept (GetAlignment's
-            // trimming)
-            {
-                const int ncols = r.left_cols + r.right_cols;
-                qtmp.resize((size_t)ncols + 16);
-                ttmp.resize((size_t)ncols + 16);
-                alnstr::build(left, r.left_cols, right, r.right_cols, qbuf.data() + 8, tbuf.data() + 8, qtmp.data() + 8, ttmp.data() + 8);
-                memcpy(qa, qtmp.data() + 8 + r.first_col, (size_t)o.aln_size);
-                memcpy(sa, ttmp.data() + 8 + r.first_col, (size_t)o.aln_size);
-            }
-            qa[o.aln_size] = 0;
-            sa[o.aln_size] = 0;
-            push_gaps(qa, sa, o.aln_size);
-        }
-    });
+    memcpy(A, Avec.data(), sizeof(mhip_cns_accepted) * (size_t)na);
+    const int64_t sbytes = (int64_t)S_used;
+    s_guard.armed = false;
     lap(5);
     if (times)
-        fprintf(stderr, "[cns_accept] %d templates, %lld jobs, %lld accepted: sort + checks %.3f s, jobs %.3f, re-alignment on the device %.3f, accept replay %.3f, "
-                        "columns gathered + copied %.3f, strings %.3f\n", num_templates, (long long)nj, (long long)na, tk[0], tk[1], tk[2], tk[3], tk[4], tk[5]);
+        fprintf(stderr, "[cns_accept] %d templates, %lld jobs in %d slices, %lld accepted, %.2f GB of strings: sort + checks %.3f s, jobs %.3f, re-alignment on the "
+                        "device %.3f, accept replay beyond it %.3f, strings launched %.3f, last copies %.3f\n", num_templates, (long long)nj, nslices, (long long)na,
+                (double)sbytes / 1e9, tk[0], tk[1], tk[2], tk[3], tk[4], tk[5]);
     *out_accepted = A;
     *out_count = na;
     *out_strings = S;

@@ -66,4 +66,15 @@ int refa_consensus_can(int tech, int* cands, int n, int read_id, int min_align_s
     return k;
 }
 
+// the reference's normalize_gaps(.., push = true) on one pair of strings (reads_correction_aux.cpp:3-81): pins the device kernel that
+// pushes the gaps of the accepted alignments (cns_strings.hip) on adversarial gap patterns.  Returns the normalised length.
+int refa_normalize_gaps(const char* q, const char* t, int n, char* qout, char* tout, int cap) {
+    std::string qn, tn;
+    normalize_gaps(q, t, n, qn, tn, true);
+    if ((int)qn.size() + 1 > cap) return -1;
+    memcpy(qout, qn.c_str(), qn.size() + 1);
+    memcpy(tout, tn.c_str(), tn.size() + 1);
+    return (int)qn.size();
+}
+
 }  // extern "C"

@@ -780,7 +780,11 @@ __global__ __launch_bounds__(AL_BLOCK, CNS ? CNS_FWD_WAVES_PER_SIMD : DW2_WAVES_
                         // which knows the row's slots)
                         unsigned long long fb;
                         asm("v_cmp_gt_i16_e64 %0, %1, %2" : "=s"(fb) : "v"(v1), "v"(vr));
-                        if (j == 0) fl0 = fb; else if (j == 1) fl1 = fb; else if (j == 2) fl2 = fb;
+                        // (selects of values, not `if (j == 0) fl0 = fb; else ...`: the compiler sinks the three stores of that form into ONE store
+                        // through a selected address, which pins fl0 .. fl2 — and with them every read in log_row — to scratch memory)
+                        fl0 = j == 0 ? fb : fl0;
+                        fl1 = j == 1 ? fb : fl1;
+                        fl2 = j == 2 ? fb : fl2;
                     }
                 }
                 // 0 <= y <= t_len and x <= q_len on every live diagonal (a diagonal at an end stops the block); idle lanes sit

@@ -397,21 +397,41 @@ __global__ __launch_bounds__(CT_BLOCK) void cns_trace(const uint32_t* __restrict
             continue;
         }
         // ---- backwards: the steps
+        // The records of rows end_d .. 1 are read in aligned groups of four (64 bytes, four 16-byte loads of one line): a lane that fetched
+        // one record per step pulled the same line in from memory up to four times (the lanes of a wave walk 64 different blocks; r05:
+        // 62.9 GB fetched for 19 GB of records).  Row d's first diagonal follows from row d + 1's by row d's own cut, so a record is all
+        // a step needs.
         {
             int ck = B.end_k, mk = B.end_mk, wi = B.end_d >> 5;
             uint32_t word = 0;
-            CnsRowRec R = rowlog[B.log0 + (unsigned)B.end_d];
-            for (int cd = B.end_d; cd >= 1; --cd) {
-                const int t = (ck - mk) >> 1;
-                if (t < 0 || t >= (int)(R.meta & 0xffu)) atomicExch(err_flag, 3);      // (never: the path stays inside its rows)
-                const uint32_t bit = ((t < 32 ? R.lo : t < 64 ? R.hi : R.top) >> (t & 31)) & 1u;
-                if ((cd >> 5) != wi) { path[wv][wi][lane] = word; word = 0; wi = cd >> 5; }
-                word |= bit << (cd & 31);
-                ck += bit ? -1 : 1;
-                R = rowlog[B.log0 + (unsigned)(cd - 1)];
-                mk = mk - 2 * (int)((R.meta >> 8) & 0x7fu) + 1;
+            bool bad = false;
+            unsigned int rec = B.log0 + (unsigned)B.end_d;                 // record of the row in hand
+            const unsigned int rec_last = B.log0 + 1u;                     // record of row 1
+            const uint4* log4 = (const uint4*)rowlog;
+            while (rec >= rec_last && B.end_d >= 1) {
+                const unsigned int g = rec & ~3u;
+                uint4 R4[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) R4[k] = log4[g + (unsigned)k];      // (records in front of the block or behind its end row: loaded, not used)
+#pragma unroll
+                for (int k = 3; k >= 0; --k) {
+                    const unsigned int r = g + (unsigned)k;
+                    if (r > rec || r < rec_last) continue;
+                    const uint4 R = R4[k];                                   // {lo, hi, meta, top}
+                    const int cd = (int)(r - B.log0);
+                    if (cd != B.end_d) mk = mk - 2 * (int)((R.z >> 8) & 0x7fu) + 1;
+                    const int t = (ck - mk) >> 1;
+                    bad |= t < 0 || t >= (int)(R.z & 0xffu);                 // (never: the path stays inside its rows)
+                    const uint32_t bit = ((t < 32 ? R.x : t < 64 ? R.y : R.w) >> (t & 31)) & 1u;
+                    if ((cd >> 5) != wi) { path[wv][wi][lane] = word; word = 0; wi = cd >> 5; }
+                    word |= bit << (cd & 31);
+                    ck += bit ? -1 : 1;
+                }
+                if (g <= rec_last) break;
+                rec = g - 1u;
             }
             path[wv][wi][lane] = word;
+            if (bad) atomicExch(err_flag, 3);
         }
         // ---- forwards: the columns
         const mhip_aln_job jb = jobs[B.unit >> 1];
@@ -596,7 +616,7 @@ int mhip_cns_align_candidates_dev(mhip_ctx* c, const mhip_volume* ref, const mhi
             if (tot[1] >= (1ull << 32)) { mhip_set_error("mecat2cns aligner: too many block records for %d jobs", nj); return -1; }
             const unsigned int block_cap = (unsigned int)tot[1];
             a.blockbase = d_bbase;
-            if (c->scratch("cnf_rowlog", sizeof(CnsRowRec) * (size_t)std::max<unsigned long long>(tot[0], 1), (void**)&a.rowlog)) return -1;
+            if (c->scratch("cnf_rowlog", sizeof(CnsRowRec) * ((size_t)tot[0] + 8), (void**)&a.rowlog)) return -1;      // (+ 8: cns_trace reads whole groups of four records)
             if (c->scratch("cnf_blocks", sizeof(CnsBlockRec) * (size_t)std::max(block_cap, 1u), (void**)&a.blocks)) return -1;
             HIPCHK(hipMemsetAsync(a.blocks, 0xff, sizeof(CnsBlockRec) * (size_t)block_cap, c->stream));
             a.hand_units = d_hand;

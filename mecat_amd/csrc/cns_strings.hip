@@ -15,7 +15,8 @@
 //                       gap to a later column j, which a later iteration reads), so it is replayed as written, in place, column by column.
 //                       Each lane keeps the 32-byte block of either string that holds column i in LDS (68 bytes per lane: the lanes of a
 //                       wave hit 64 different banks); look-aheads and swaps that leave the block go to memory directly — a lane's own
-//                       stores are visible to its later loads — and a block is written back only when it was changed.
+//                       stores are visible to its later loads — and a block is written back only when it was changed.  A 32-bit mask of the block's
+//                       gap bytes lets a lane step from gap to gap instead of from column to column.
 //
 // O(ND) columns are matches or indels, so normalize_gaps' first loop (mismatch -> two indel columns) changes nothing: aln_size is the
 // number of kept columns (as on the host before).
@@ -151,13 +152,22 @@ struct Win {
     char* g;                // the string
     int n;                  // its length (the NUL at g[n] is never written)
     uintptr_t blk;          // address >> 5 of the block in the window
+    uint32_t gaps;          // bit b: byte b of the block is '-'
     bool dirty;
 };
+// bit k of the result: byte k of w is '-' (exact zero-byte test on w ^ "----", then the four flag bits gathered by one multiply)
+__device__ __forceinline__ uint32_t gap_nibble(uint32_t w) {
+    const uint32_t x = w ^ 0x2D2D2D2Du;
+    const uint32_t z = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);      // 0x80 in every byte that was '-'
+    return (((z >> 7) * 0x00204081u) >> 21) & 0xFu;
+}
 __device__ __forceinline__ void win_load(Win& w, uintptr_t blk) {
     const uint4* p = (const uint4*)(blk << 5);
     const uint4 a = p[0], b = p[1];
     uint32_t* d = (uint32_t*)w.lds;
     d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+    w.gaps = gap_nibble(a.x) | (gap_nibble(a.y) << 4) | (gap_nibble(a.z) << 8) | (gap_nibble(a.w) << 12) | (gap_nibble(b.x) << 16) | (gap_nibble(b.y) << 20) |
+             (gap_nibble(b.z) << 24) | (gap_nibble(b.w) << 28);
     w.blk = blk;
     w.dirty = false;
 }
@@ -181,8 +191,12 @@ __device__ __forceinline__ char win_get(const Win& w, int i) {
 }
 __device__ __forceinline__ void win_set(Win& w, int i, char v) {
     const uintptr_t a = (uintptr_t)(w.g + i);
-    if ((a >> 5) == w.blk) { w.lds[a & 31u] = (uint8_t)v; w.dirty = true; }
-    else *(volatile char*)a = v;
+    if ((a >> 5) == w.blk) {
+        w.lds[a & 31u] = (uint8_t)v;
+        const uint32_t bit = 1u << (a & 31u);
+        w.gaps = v == '-' ? (w.gaps | bit) : (w.gaps & ~bit);
+        w.dirty = true;
+    } else *(volatile char*)a = v;
 }
 
 __global__ __launch_bounds__(64 * PG_WAVES) void cns_push_gaps(const CnsStrItem* __restrict__ items, int n_items, char* __restrict__ out) {
@@ -193,7 +207,7 @@ __global__ __launch_bounds__(64 * PG_WAVES) void cns_push_gaps(const CnsStrItem*
     Win Q, T;
     Q.lds = &lds[wv][lane * PG_STRIDE];
     T.lds = Q.lds + 32;
-    Q.g = T.g = out; Q.n = T.n = 0; Q.blk = T.blk = 0; Q.dirty = T.dirty = false;
+    Q.g = T.g = out; Q.n = T.n = 0; Q.blk = T.blk = 0; Q.gaps = T.gaps = 0; Q.dirty = T.dirty = false;
     if (a < (size_t)n_items) {
         const CnsStrItem it = items[a];
         n = it.aln_size;
@@ -201,24 +215,31 @@ __global__ __launch_bounds__(64 * PG_WAVES) void cns_push_gaps(const CnsStrItem*
         Q.n = T.n = n;
     }
     if (n >= 2) { win_load(Q, (uintptr_t)Q.g >> 5); win_load(T, (uintptr_t)T.g >> 5); }
-    for (int i = 0; i + 1 < n; ++i) {
-        const uintptr_t qb = (uintptr_t)(Q.g + i) >> 5, tb = (uintptr_t)(T.g + i) >> 5;
-        if (qb != Q.blk) { win_flush(Q); win_load(Q, qb); }
-        if (tb != T.blk) { win_flush(T); win_load(T, tb); }
+    for (int i = 0; i + 1 < n;) {
+        const uintptr_t qa = (uintptr_t)(Q.g + i), ta = (uintptr_t)(T.g + i);
+        if ((qa >> 5) != Q.blk) { win_flush(Q); win_load(Q, qa >> 5); }
+        if ((ta >> 5) != T.blk) { win_flush(T); win_load(T, ta >> 5); }
+        // columns without a gap in either string do nothing: skip to the next gap the two blocks show (or to the end of a block)
+        const int pq = (int)(qa & 31u), pt = (int)(ta & 31u);
+        const uint32_t gaps = (Q.gaps >> pq) | (T.gaps >> pt);
+        const int room = min(min(32 - pq, 32 - pt), n - 1 - i);
+        const int run = min(gaps ? __builtin_ctz(gaps) : 32, room);
+        if (run > 0) { i += run; continue; }
         // push target gaps (reads_correction_aux.cpp:41-52)
-        if ((char)T.lds[(uintptr_t)(T.g + i) & 31u] == '-') {
+        if ((char)T.lds[pt] == '-') {
             int j = i;
             char c;
             do { c = win_get(T, ++j); } while (c == '-');          // (ends at the NUL behind the string at the latest: j <= n)
-            if (c == (char)Q.lds[(uintptr_t)(Q.g + i) & 31u]) { win_set(T, i, c); win_set(T, j, '-'); }
+            if (c == (char)Q.lds[pq]) { win_set(T, i, c); win_set(T, j, '-'); }
         }
         // push query gaps (:54-65)
-        if ((char)Q.lds[(uintptr_t)(Q.g + i) & 31u] == '-') {
+        if ((char)Q.lds[pq] == '-') {
             int j = i;
             char c;
             do { c = win_get(Q, ++j); } while (c == '-');
-            if (c == (char)T.lds[(uintptr_t)(T.g + i) & 31u]) { win_set(Q, i, c); win_set(Q, j, '-'); }
+            if (c == (char)T.lds[pt]) { win_set(Q, i, c); win_set(Q, j, '-'); }
         }
+        ++i;
     }
     win_flush(Q);
     win_flush(T);

@@ -292,6 +292,82 @@ def issue_ceilings():
         return {"error": repr(e)[:200]}
 
 
+def simulate_ranks(args, M, W, ctx, vol, params, n, ont, one_step, stream, d_counts):
+    """no multi-GPU node has been available to any round, so the scaling estimate is turned into a measurement as far as
+    one GPU allows.  For P in --simulate-ranks and every rank r < P: a communicator WITHOUT transport (mhip_comm_init_solo) makes the library's
+    own sharded calls — mhip_index_build_sharded, mhip_seed_reads_sharded, mhip_align_sharded, the calls bench.py --gpus P and the driver
+    make — do exactly rank r's share on the device: its key range of the index, its chunks of 500 reads, the pack / scatter kernels of the
+    exchanges.  Reported: per-rank wall ms per phase (second of two runs), max / mean imbalance, the bytes every rank would put on the links,
+    and the compute-only bound  T(1 GPU) / max over ranks  for both ways of building the index.  What is NOT in it: link time and the
+    RCCL calls themselves."""
+    import torch
+    CH = M.SHARD_CHUNK
+
+    def wall(f):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = f()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3, r
+
+    one_step()
+    base = np.mean([one_step()["ms"] for _ in range(3)], axis=0)
+    ncand = int(d_counts.sum().item())
+    idx_full = M.Index(ctx, vol)
+    out = {"what": "every rank's share of the sharded calls, alone on one MI355X, no transport (mhip_comm_init_solo)", "workload": args.workload,
+           "one_gpu_phase_ms": {"index": float(base[0]), "seed": float(base[1]), "align": float(base[2])}, "one_gpu_step_ms": float(base.sum()),
+           "candidates": ncand, "P": {}}
+    for P in [int(x) for x in args.simulate_ranks.split(",") if x]:
+        ranks = []
+        for r in range(P):
+            cm = M.Comm(ctx, P, r, solo=True)
+            ms_i = ms_s = ms_a = 0.0
+            b_i = b_s = b_a = 0
+            kst = {}
+            for rep in range(3):      # (the fastest of three: the first run of a rank also sizes its scratch buffers)
+                if rep == 2 and r == 0:
+                    ctx.set_profiling(True)
+                    ctx.reset_stats()
+                s0 = cm.bytes_sent()
+                t_i, ix = wall(lambda: cm.index_build_sharded(vol))
+                ix.free()
+                s1 = cm.bytes_sent()
+                t_s, _ = wall(lambda: cm.seed_reads_sharded(idx_full, vol, vol, 0, n, params, chunk=CH, cell_shift=0, host=False))
+                s2 = cm.bytes_sent()
+                t_a, _ = wall(lambda: cm.align_sharded(vol, vol, params.min_align_size, tech=ont, host=False)) if not args.no_align else (0.0, None)
+                s3 = cm.bytes_sent()
+                ms_i, ms_s, ms_a = (t_i, t_s, t_a) if rep == 0 else (min(ms_i, t_i), min(ms_s, t_s), min(ms_a, t_a))
+                if rep == 2 and r == 0:
+                    kst = {k: round(v[1], 3) for k, v in sorted(ctx.kernel_stats().items(), key=lambda kv: -kv[1][1]) if v[1] >= 0.05}
+                    ctx.set_profiling(False)
+                b_i, b_s, b_a = (s1 - s0) // max(1, P - 1), (s2 - s1) // max(1, P - 1), (s3 - s2) // max(1, P - 1)
+            ranks.append({"rank": r, "reads": M.lib().mhip_shard_local_count(0, n, CH, 0, r, P), "candidates": cm.local_jobs(),
+                          "index_slice_ms": ms_i, "seed_ms": ms_s, "align_ms": ms_a, **({"kernel_ms_of_one_pass": kst} if kst else {}),
+                          "bytes_to_each_peer": {"index_slice": int(b_i), "candidates": int(b_s), "results": int(b_a)}})
+            cm.close()
+        seed = np.array([x["seed_ms"] for x in ranks]); aln = np.array([x["align_ms"] for x in ranks]); isl = np.array([x["index_slice_ms"] for x in ranks])
+        tot_rep = float(base[0]) + seed + aln
+        tot_shd = isl + seed + aln
+        recv = {k: int(sum(x["bytes_to_each_peer"][k] for x in ranks)) for k in ("index_slice", "candidates", "results")}
+        out["P"][str(P)] = {
+            "ranks": ranks,
+            "sum_of_rank_candidates": int(sum(x["candidates"] for x in ranks)),
+            "imbalance_max_over_mean": {"seed": float(seed.max() / seed.mean()), "align": float(aln.max() / aln.mean()) if aln.mean() > 0 else None,
+                                        "index_slice": float(isl.max() / isl.mean())},
+            "slowest_rank_ms": {"index_rebuilt_on_every_rank": float(tot_rep.max()), "index_in_key_range_shards": float(tot_shd.max())},
+            "compute_only_speedup_bound": {"index_rebuilt_on_every_rank": float(base.sum() / tot_rep.max()), "index_in_key_range_shards": float(base.sum() / tot_shd.max())},
+            "bytes_received_per_rank_about": {k: int(v * (P - 1) / P) for k, v in recv.items()},
+            "link_time_at_153_GBps_per_link_ms": {k: float(v / P / 153e9 * 1e3) for k, v in recv.items()},
+            "note": "bytes_received_per_rank_about = what the P - 1 peers send to one rank; link_time: each peer's share over its own xGMI link (7 links x "
+                    "153 GB/s, MI355X_MICROARCH.md), links in parallel — arithmetic, not measured",
+        }
+        log("[simulate] P=%d: slowest rank %.1f ms (index rebuilt) / %.1f ms (index sharded), 1 GPU %.1f ms -> compute-only bound %.2fx / %.2fx; imbalance seed %.3f align %.3f"
+            % (P, tot_rep.max(), tot_shd.max(), base.sum(), base.sum() / tot_rep.max(), base.sum() / tot_shd.max(), seed.max() / seed.mean(),
+               (aln.max() / aln.mean()) if aln.mean() > 0 else 0.0))
+    idx_full.free()
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -304,6 +380,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed cns_realign / xdrop_extend measurements")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end CLI leg (FASTA -> .can / .m4 wall clock)")
     ap.add_argument("--stats", default="", help="write per-kernel stats JSON here (rank 0)")
+    ap.add_argument("--simulate-ranks", default="", help="e.g. 2,4,8: on ONE GPU, run every rank's share of the sharded calls alone (no transport) and report "
+                                                         "per-rank times, imbalance, link bytes and the compute-only speed-up bound (prints its own JSON line)")
     args = ap.parse_args()
 
     # `python bench.py --gpus N` without a launcher around it (no WORLD_SIZE in the environment): start N ranks of this script, one per
@@ -441,6 +519,14 @@ def main():
         out["host_ms"] = [(h1 - h0) * 1e3, (time.perf_counter() - h1) * 1e3]
         return out
 
+    if args.simulate_ranks:
+        if world != 1:
+            raise SystemExit("--simulate-ranks runs on one GPU (it plays the ranks one after the other)")
+        simulate_ranks(args, M, W, ctx, vol, params, n, ont, one_step, stream, d_counts)
+        vol.free()
+        ctx.close()
+        return
+
     ctx.set_profiling(True)         # on during warm-up too, so the event pool exists before the timed region
     for _ in range(args.warmup):
         one_step()
@@ -496,7 +582,8 @@ def main():
         exch["records_per_step"] = ncand
         exch["index_build"] = index_how          # how the cell's table is built, and the two measured times the choice rests on
         # every rank's own phase times (HIP events on its stream, mean over the timed steps) and wall time: where a short curve fell short
-        mine = {"rank": rank, "phase_ms": [float(x) for x in np.mean([o["ms"] for o in outs], axis=0)],
+        mine = {"rank": rank, "local_candidates": comm.local_jobs(), "bytes_sent_total": comm.bytes_sent(),
+                "phase_ms": [float(x) for x in np.mean([o["ms"] for o in outs], axis=0)],
                 "host_ms_per_step": float(np.mean([sum(o["host_ms"]) for o in outs]))}
         allr = [None] * world
         dist.all_gather_object(allr, mine)
@@ -648,20 +735,22 @@ def main():
                 h_cands = d_cands.cpu().numpy().view(M.CAND_DTYPE).reshape(n, maxc)
                 ec = W.ext_candidates_from_table(h_cands, h_cnt, lens)
                 rec, tb, ids = W.cns_templates(ec, n)
-                T = min(len(ids), 4000)
+                T = min(len(ids), 10000)
                 rec_orig = np.ascontiguousarray(rec[: tb[T]]).copy()      # (the call sorts its records in place; the reference leg below wants them as loaded)
                 rec_s = rec_orig.copy()
-                pac_h, _, _ = W.pack_volume(W.synth_reads(n, L, err, G, seed, ont)[0], lens)
                 c0 = time.perf_counter()
-                acc, strs, nja = M.cns_accept_templates(ctx, vol, pac_h, rec_s, tb[: T + 1], ont, 2000 if not ont else 500, 0.9 if not ont else 0.4,
+                acc, strs, nja = M.cns_accept_templates(ctx, vol, None, rec_s, tb[: T + 1], ont, 2000 if not ont else 500, 0.9 if not ont else 0.4,
                                                         threads=min(64, os.cpu_count() or 1))
                 dtc = time.perf_counter() - c0
                 tbases = int(lens[ids[:T]].astype(np.int64).sum())
-                line["cns_accept"] = {"templates": T, "alignments": int(nja), "accepted": int(len(acc)), "seconds": dtc,
+                line["cns_accept"] = {"workload": "BASELINE config 4 (mecat2cns' per-template stage on config 2's candidates), first %d templates; the whole-config "
+                                                  "line is `bench.py --workload config4`" % T,
+                                      "templates": T, "alignments": int(nja), "accepted": int(len(acc)), "seconds": dtc,
                                       "templates_per_s": T / dtc, "alignments_per_s": nja / dtc, "template_gbase_per_s": tbases / 1e9 / dtc,
                                       "aligned_string_bytes": len(strs),
                                       "note": "BASELINE config 4 up to the consensus table: sort + <= 200 re-alignments per template on the GPU + accept replay + "
-                                              "normalised strings on %d host threads; the consensus table / POA after it stay with mecat2cns" % min(64, os.cpu_count() or 1)}
+                                              "normalised strings built on the GPU, accept decisions replayed on %d host threads; the consensus table / POA after it "
+                                              "stay with mecat2cns" % min(64, os.cpu_count() or 1)}
                 # parity: the first templates against what the UNMODIFIED consensus_one_read_can_pacbio accepted on the same records
                 # (tests/golden/cns_config2.npz, written by tests/golden/make_golden_cns_config2.py in the build container)
                 try:
@@ -683,7 +772,7 @@ def main():
                 except Exception as e:      # noqa: BLE001
                     line["cns_accept"]["parity_vs_reference"] = {"error": repr(e)[:200]}
                 keep["cns"] = (rec_orig, tb.copy(), ids.copy())
-                del h_cands, ec, rec, rec_s, acc, strs, pac_h
+                del h_cands, ec, rec, rec_s, acc, strs
             except Exception as e:      # noqa: BLE001
                 log("[bench] cns_accept skipped: %r" % (e,))
         # not part of the metric either: the X-drop aligner (nanopore mode) on the first 100 000 candidates
@@ -730,6 +819,28 @@ def main():
                 line["e2e"] = e2e_cli(args.workload, codes, lens, min(32, os.cpu_count() or 1))
             except Exception as e:  # noqa: BLE001
                 line["e2e"] = {"error": repr(e)[:300]}
+        # not part of the metric: one grid cell of BASELINE config 5 (volumes 0 and 1 of the 2 M-read ONT-style set, -x 1: wide seeding filter +
+        # the X-drop aligner) as its own bench line, compacted — candidates/s, X-drop alignments/s, phase times and the cell's `.can` hash
+        # against the unmodified reference's (tests/golden/big.json); the full line is `bench.py --workload config5_cell`
+        if world == 1 and not args.no_extras and not args.no_align and args.workload == "config2":
+            try:
+                time.sleep(3.0)
+                c0 = time.time()
+                p5 = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "config5_cell", "--steps", "2", "--warmup", "1", "--no-cpu"],
+                                    stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+                l5 = [ln for ln in p5.stdout.splitlines() if ln.startswith("{")]
+                if p5.returncode != 0 or not l5:
+                    line["config5_cell"] = {"error": p5.stderr[-300:]}
+                else:
+                    d5 = json.loads(l5[-1])
+                    xk = {k: v for k, v in d5.get("kernel_ms_per_step", {}).items() if k.startswith(("xd_", "seed_filter_wide", "seed_emit"))}
+                    line["config5_cell"] = {"workload": d5["config"]["workload"], "value": d5["value"], "unit": d5["unit"], "ms_per_step": d5["ms_per_step"],
+                                            "phase_ms": d5["phase_ms"], "candidates": d5["candidates"], "xdrop_alignments_per_s": d5["candidates"] / (d5["phase_ms"]["align"] / 1e3),
+                                            "overlaps_ok": d5["overlaps_ok"], "aligned_gbase_per_s": d5["aligned_gbase_per_s"], "kernel_ms_per_step": xk,
+                                            "parity_vs_reference": d5.get("parity_vs_reference"), "roofline": {k: d5["roofline"].get(k) for k in ("kernel", "achieved", "frac", "traffic")},
+                                            "wall_s_incl_generating_two_volumes": time.time() - c0}
+            except Exception as e:  # noqa: BLE001
+                line["config5_cell"] = {"error": repr(e)[:300]}
         # not part of the metric: mecat2canu's overlapper for corrected reads as the drop-in tool, end to end through its
         # own command line on 20 000 synthetic corrected reads (161 Mbases, 2 blocks as canu lays them out); the unmodified tool on the same
         # files, same machine, belongs to the CPU leg below

@@ -239,7 +239,7 @@ def run(args):
             e0 = torch.cuda.Event(enable_timing=True); e0.record(stream)
             idx = comm.index_build_auto(vols[i])[0] if comm is not None else M.Index(ctx, vols[i])
             e1 = torch.cuda.Event(enable_timing=True); e1.record(stream)
-            evs.append(("index", e0, e1))
+            evs.append(("index", e0, e1, i, i))
             keep["num_kmers"][i] = idx.num_kmers
             for (ci, j) in cells:
                 if ci != i:
@@ -263,8 +263,8 @@ def run(args):
                     else:
                         _, njobs = comm.align_sharded(vols[i], vols[j], params.min_align_size, tech=ont, host=False)
                 c = torch.cuda.Event(enable_timing=True); c.record(stream)
-                evs.append(("seed", a, b))
-                evs.append(("align", b, c))
+                evs.append(("seed", a, b, i, j))
+                evs.append(("align", b, c, i, j))
                 if collect and comm is None:
                     stream.synchronize()
                     h_cnt = d_counts[:nj_reads].cpu().numpy()
@@ -286,8 +286,12 @@ def run(args):
                     keep["cell"]["%d,%d" % (i, j)] = cell
             stream.synchronize()
             idx.free()
-        for k, a, b in evs:
-            ms[k] += a.elapsed_time(b)
+        per_row = {}
+        for k, a, b, ri, _cj in evs:
+            t = a.elapsed_time(b)
+            ms[k] += t
+            per_row[ri] = per_row.get(ri, 0.0) + t
+        keep["row_ms"] = per_row          # the last step's time per grid row (index build + every cell of the row)
         return ms
 
     ctx.set_profiling(True)
@@ -436,6 +440,22 @@ def run(args):
         }
         if exch:
             line["exchange"] = exch
+        # rows mode as a measurement: with at least as many grid rows as ranks the driver deals whole rows out
+        # (mhip_shard_deal_rows; nothing is exchanged), so P ranks take max-over-ranks of the summed row times — computed here from the times
+        # this one GPU just measured for every row (index build + its cells; the untimed collecting pass, which also copies the tables out)
+        if world == 1 and keep.get("row_ms") and len(keep["row_ms"]) >= 2:
+            rm = keep["row_ms"]
+            allrows = sorted(rm)
+            tot = float(sum(rm.values()))
+            sim = {"row_ms": {str(i): rm[i] for i in allrows}, "P": {}}
+            for P in (2, 4, 8):
+                if P > len(allrows):
+                    continue
+                own, _h = M.deal_rows(len(hv), np.array(allrows, dtype=np.int32), P)
+                per = [float(sum(rm[i] for i in allrows if own[i] == r)) for r in range(P)]
+                sim["P"][str(P)] = {"rank_ms": per, "rows_of_rank": [[int(i) for i in allrows if own[i] == r] for r in range(P)],
+                                    "imbalance_max_over_mean": max(per) / (sum(per) / P), "compute_only_speedup_bound": tot / max(per)}
+            line["simulated_rows_mode"] = sim
         # reference pins of the cells (tests/golden/big.json: line counts and sorted-output hashes of the unmodified mecat2pw -j 0)
         if keep["cell"]:
             line["cells"] = keep["cell"]

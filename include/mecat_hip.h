@@ -203,7 +203,14 @@ void mhip_comm_destroy(mhip_comm* comm);
 /* transport: 0 = RCCL, 1 = host files (test hook); rccl_ranks = ncclCommCount of the communicator (0 with host files).  With the
  * context profiling (mhip_ctx_set_profiling) every exchange is timed on the stream under the kernel-stat names "xg_exchange"
  * (candidate / result all-gathers) and "xg_exchange_index" (mhip_index_build_sharded). */
-int  mhip_comm_info(const mhip_comm* comm, int* transport, int* rccl_ranks);
+int  mhip_comm_info(const mhip_comm* comm, int* transport, int* rccl_ranks);      /* transport 0 RCCL, 1 host files, 2 none (solo) */
+/* BENCH HOOK (bench.py --simulate-ranks): rank `rank` of `nranks` with no transport.  The sharded calls below then do exactly this rank's
+ * share of the work on the device — its key range of mhip_index_build_sharded, its chunks in mhip_seed_reads_sharded / mhip_align_sharded,
+ * the pack and scatter kernels of the exchanges — and its peers' contributions read as zero counts: what one rank of P computes, timed
+ * alone.  mhip_comm_bytes_sent = the bytes this rank's contributions put on the links (its bytes x (P - 1) peers), in any transport. */
+int  mhip_comm_init_solo(mhip_ctx* ctx, int nranks, int rank, mhip_comm** out);
+int64_t mhip_comm_bytes_sent(const mhip_comm* comm);
+int64_t mhip_comm_local_jobs(const mhip_comm* comm);         /* candidates of this rank's own reads in the last mhip_seed_reads_sharded slab */
 int  mhip_comm_rank(const mhip_comm* comm);
 int  mhip_comm_nranks(const mhip_comm* comm);
 int  mhip_comm_barrier(mhip_comm* comm);

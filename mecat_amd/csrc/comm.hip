@@ -105,6 +105,10 @@ struct mhip_comm {
     ncclComm_t nc = nullptr;
     // host-file transport (test hook)
     bool hostfile = false;
+    // no transport at all (bench hook, mhip_comm_init_solo): this rank does its own share of every sharded call, its peers' contributions read
+    // as zero bytes / zero counts — what one rank of P computes, alone on the device (bench.py --simulate-ranks)
+    bool solo = false;
+    int64_t bytes_sent = 0;                 // what this rank's contributions amount to on the links: its bytes to each of the P - 1 peers
     std::string dir, run_id;
     unsigned long seq = 0;
     // state of the last mhip_seed_reads_sharded call (consumed by mhip_align_sharded)
@@ -243,6 +247,12 @@ int allgatherv(mhip_comm* cm, const void* d_send, void* d_recv, const std::vecto
     if (P == 1) return 0;
     for (int r = 0; r < P; ++r)
         if (r != me) cm->bytes_received += (int64_t)bytes[r];
+    cm->bytes_sent += (int64_t)bytes[me] * (int64_t)(P - 1);
+    if (cm->solo) {      // the peers' slots read as zeros (their sizes are whatever this rank believes them to be: zero counts -> zero bytes)
+        for (int r = 0; r < P; ++r)
+            if (r != me && bytes[r]) HIPCHK(hipMemsetAsync((char*)d_recv + displ[r], 0, bytes[r], c->stream));
+        return 0;
+    }
     LaunchTimer xt(c, cm->xlabel);
     if (!cm->hostfile) {
         RcclApi* R = rccl();
@@ -405,6 +415,25 @@ int mhip_comm_init_hostfile(mhip_ctx* ctx, int nranks, int rank, const char* dir
     return 0;
 }
 
+// bench hook (bench.py --simulate-ranks): rank `rank` of `nranks` with NO transport — every sharded call does this rank's share of the
+// work (its key range of the index, its chunks of the reads, the pack / scatter kernels of the exchanges) and moves nothing
+int mhip_comm_init_solo(mhip_ctx* ctx, int nranks, int rank, mhip_comm** out) {
+    *out = nullptr;
+    if (nranks < 1 || rank < 0 || rank >= nranks) { mhip_set_error("bad solo communicator arguments"); return -1; }
+    mhip_comm* cm = new mhip_comm();
+    cm->ctx = ctx;
+    cm->nranks = nranks;
+    cm->rank = rank;
+    cm->solo = true;
+    void* d_status;
+    if (ctx->scratch("xg_status", sizeof(int32_t) * (size_t)(nranks + 1), &d_status)) { delete cm; return -1; }
+    *out = cm;
+    return 0;
+}
+int64_t mhip_comm_bytes_sent(const mhip_comm* cm) { return cm->bytes_sent; }
+// candidates (= extension jobs) of this rank's own reads in the slab of the last mhip_seed_reads_sharded call
+int64_t mhip_comm_local_jobs(const mhip_comm* cm) { return cm->totals.empty() ? 0 : cm->totals[(size_t)cm->rank]; }
+
 void mhip_comm_destroy(mhip_comm* cm) {
     if (!cm) return;
     if (cm->nc) {
@@ -449,10 +478,10 @@ int mhip_comm_selftest(mhip_ctx* c) {
 // what the communicator really is: transport 0 = RCCL, 1 = host files (test hook); rccl_ranks = ncclCommCount of the RCCL
 // communicator (0 with the host-file transport) — a bench line that claims N GPUs shows that RCCL saw N ranks
 int mhip_comm_info(const mhip_comm* cm, int* transport, int* rccl_ranks) {
-    if (transport) *transport = cm->hostfile ? 1 : 0;
+    if (transport) *transport = cm->solo ? 2 : (cm->hostfile ? 1 : 0);
     if (rccl_ranks) {
         *rccl_ranks = 0;
-        if (!cm->hostfile && cm->nc) {
+        if (!cm->hostfile && !cm->solo && cm->nc) {
             RcclApi* R = rccl();
             if (!R) return -1;
             int n = 0;

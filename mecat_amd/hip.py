@@ -381,10 +381,11 @@ def cns_accept_templates(ctx, vol, host_pac, cands, tmpl_begin, tech, min_align_
     place.  -> (accepted [k] ACCEPTED_DTYPE, strings as a uint8 array over the library's buffer, number of alignments computed)"""
     cands = np.ascontiguousarray(cands)
     tb = np.ascontiguousarray(tmpl_begin, dtype=np.int64)
-    pac = np.ascontiguousarray(host_pac, dtype=np.uint8)
+    # (host_pac is no longer read by the library: the strings are built on the device; kept in the signature)
+    pac = np.ascontiguousarray(host_pac, dtype=np.uint8) if host_pac is not None else None
     acc, st = C.c_void_p(), C.c_void_p()
     na, sb, nj = C.c_int64(), C.c_int64(), C.c_int64()
-    _chk(lib().mhip_cns_accept_templates(ctx.h, vol.h, pac.ctypes.data, cands.ctypes.data, tb.ctypes.data, len(tb) - 1, tech, min_align_size,
+    _chk(lib().mhip_cns_accept_templates(ctx.h, vol.h, pac.ctypes.data if pac is not None else None, cands.ctypes.data, tb.ctypes.data, len(tb) - 1, tech, min_align_size,
                                          float(min_mapping_ratio), threads, C.byref(acc), C.byref(na), C.byref(st), C.byref(sb), C.byref(nj)))
     a = np.ctypeslib.as_array(C.cast(acc, C.POINTER(C.c_uint8)), shape=(na.value * 48,)).view(ACCEPTED_DTYPE).copy() if na.value else np.zeros(0, ACCEPTED_DTYPE)
     lib().mhip_cns_free(acc)
@@ -412,10 +413,13 @@ def comm_unique_id():
 class Comm:
     """mhip_comm: RCCL communicator over one context per rank (hostfile_dir: the test-hook transport)"""
 
-    def __init__(self, ctx, nranks, rank, unique_id=None, hostfile_dir=None, run_id="0"):
+    def __init__(self, ctx, nranks, rank, unique_id=None, hostfile_dir=None, run_id="0", solo=False):
         self.h = C.c_void_p()
         self.ctx, self.nranks, self.rank = ctx, nranks, rank
-        if hostfile_dir is not None:
+        if solo:        # bench hook: this rank's share of every sharded call, no transport (mecat_hip.h: mhip_comm_init_solo)
+            lib().mhip_comm_init_solo.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+            _chk(lib().mhip_comm_init_solo(ctx.h, nranks, rank, C.byref(self.h)))
+        elif hostfile_dir is not None:
             _chk(lib().mhip_comm_init_hostfile(ctx.h, nranks, rank, hostfile_dir.encode(), run_id.encode(), C.byref(self.h)))
         else:
             buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id if unique_id is not None else bytes(COMM_ID_BYTES))
@@ -434,6 +438,16 @@ class Comm:
         t, n = C.c_int(), C.c_int()
         _chk(lib().mhip_comm_info(self.h, C.byref(t), C.byref(n)))
         return t.value, n.value
+
+    def bytes_sent(self):
+        lib().mhip_comm_bytes_sent.restype = C.c_int64
+        lib().mhip_comm_bytes_sent.argtypes = [C.c_void_p]
+        return int(lib().mhip_comm_bytes_sent(self.h))
+
+    def local_jobs(self):
+        lib().mhip_comm_local_jobs.restype = C.c_int64
+        lib().mhip_comm_local_jobs.argtypes = [C.c_void_p]
+        return int(lib().mhip_comm_local_jobs(self.h))
 
     def bytes_received(self):
         return int(lib().mhip_comm_bytes_received(self.h))

@@ -35,6 +35,15 @@ def test_bench_line_one_rank_and_two_ranks_agree():
     # the line says what the communicator was and what the exchanges cost (the first run on a node must show rccl / N ranks here)
     x = b["exchange"]
     assert x["transport"].startswith("host files") and x["rccl_ranks"] == 0 and x["ms"] > 0 and x["calls_per_step"] >= 2
+    # --simulate-ranks 2 (every rank's share alone on the GPU, no transport: the scaling bound of profiles/r06_simulated_scaling.json) hands
+    # each simulated rank the reads and finds the candidates the real 2-rank run's ranks had
+    r3 = subprocess.run([sys.executable, bench, "--gpus", "1", "--simulate-ranks", "2"] + FLAGS, capture_output=True, text=True, timeout=600)
+    assert r3.returncode == 0, r3.stderr[-2000:]
+    s = _line(r3.stdout)["P"]["2"]
+    assert s["sum_of_rank_candidates"] == a["candidates"]
+    assert [k["candidates"] for k in s["ranks"]] == [k["local_candidates"] for k in sorted(x["per_rank"], key=lambda k: k["rank"])]
+    assert all(k["seed_ms"] > 0 and k["align_ms"] > 0 and k["index_slice_ms"] > 0 for k in s["ranks"])
+    assert 0.2 < s["compute_only_speedup_bound"]["index_rebuilt_on_every_rank"] <= 2.05      # (config 1 is a few milliseconds of work: launch overheads)
 
 
 @pytest.mark.parametrize("wl,tech", [("grid_tiny", 0), ("grid_tiny_ont", 1)])

@@ -291,8 +291,75 @@ def run(args):
             t = a.elapsed_time(b)
             ms[k] += t
             per_row[ri] = per_row.get(ri, 0.0) + t
-        keep["row_ms"] = per_row          # the last step's time per grid row (index build + every cell of the row)
+        if not collect:
+            keep["row_ms"] = per_row      # the last timed step's time per grid row (index build + every cell of the row)
         return ms
+
+    if getattr(args, "simulate_ranks", ""):
+        # cells mode as a measurement (bench.py's simulate_ranks for one cell, here over the grid): every rank's share
+        # of every cell — its key range of the row's index, its chunks of the query volume — alone on this GPU, no transport
+        if world != 1:
+            raise SystemExit("--simulate-ranks runs on one GPU")
+
+        def wall(f):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r = f()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) * 1e3, r
+
+        one_step()
+        base = one_step()
+        out = {"what": "every rank's share of the sharded calls of every cell, alone on one MI355X, no transport (mhip_comm_init_solo)", "workload": args.workload,
+               "one_gpu_phase_ms": base, "one_gpu_step_ms": float(sum(base.values())), "P": {}}
+        for P in [int(x) for x in args.simulate_ranks.split(",") if x]:
+            ranks = []
+            for r in range(P):
+                cm = M.Comm(ctx, P, r, solo=True)
+                best = None
+                for rep in range(2):
+                    t = {"index_slice_ms": 0.0, "index_rebuilt_ms": 0.0, "seed_ms": 0.0, "align_ms": 0.0}
+                    cand = 0
+                    s0 = cm.bytes_sent()
+                    for i in rows:
+                        ms, ix = wall(lambda: cm.index_build_sharded(vols[i]))
+                        t["index_slice_ms"] += ms
+                        ix.free()
+                        ms, idx = wall(lambda: M.Index(ctx, vols[i]))
+                        t["index_rebuilt_ms"] += ms
+                        for (ci, j) in cells:
+                            if ci != i:
+                                continue
+                            nq = len(hv[j]["lens"])
+                            ms, _ = wall(lambda: cm.seed_reads_sharded(idx, vols[i], vols[j], 0, nq, params, chunk=CH, cell_shift=j, host=False))
+                            t["seed_ms"] += ms
+                            cand += cm.local_jobs()
+                            if not args.no_align:
+                                ms, _ = wall(lambda: cm.align_sharded(vols[i], vols[j], params.min_align_size, tech=ont, host=False))
+                                t["align_ms"] += ms
+                        idx.free()
+                    t["bytes_to_each_peer"] = (cm.bytes_sent() - s0) // max(1, P - 1)
+                    t["candidates"] = cand
+                    if best is None or t["seed_ms"] + t["align_ms"] < best["seed_ms"] + best["align_ms"]:
+                        best = t
+                best["rank"] = r
+                ranks.append(best)
+                cm.close()
+            rep_t = np.array([x["index_rebuilt_ms"] + x["seed_ms"] + x["align_ms"] for x in ranks])
+            shd_t = np.array([x["index_slice_ms"] + x["seed_ms"] + x["align_ms"] for x in ranks])
+            one = float(sum(base.values()))
+            out["P"][str(P)] = {"ranks": ranks, "sum_of_rank_candidates": int(sum(x["candidates"] for x in ranks)),
+                                "imbalance_max_over_mean": {"seed": float(max(x["seed_ms"] for x in ranks) / np.mean([x["seed_ms"] for x in ranks])),
+                                                            "align": float(max(x["align_ms"] for x in ranks) / max(1e-9, np.mean([x["align_ms"] for x in ranks])))},
+                                "slowest_rank_ms": {"index_rebuilt_on_every_rank": float(rep_t.max()), "index_in_key_range_shards": float(shd_t.max())},
+                                "compute_only_speedup_bound": {"index_rebuilt_on_every_rank": one / float(rep_t.max()), "index_in_key_range_shards": one / float(shd_t.max())}}
+            log("[simulate] %s cells mode P=%d: slowest rank %.1f / %.1f ms (index rebuilt / sharded), 1 GPU %.1f ms -> bound %.2fx / %.2fx"
+                % (args.workload, P, rep_t.max(), shd_t.max(), one, one / rep_t.max(), one / shd_t.max()))
+        print(json.dumps(out), flush=True)
+        for v in vols:
+            v.free()
+        ctx.close()
+        return
 
     ctx.set_profiling(True)
     for _ in range(args.warmup):

@@ -81,6 +81,10 @@ int  mhip_device_count(void);
  * Additive (the reference has no counterpart: its buffers never leave the host). */
 int  mhip_host_alloc(size_t bytes, void** out);
 void mhip_host_free(void* p);
+/* page-lock / release a caller-owned host buffer around the calls that copy from or into it (0 = locked; a failure leaves it pageable,
+ * which only costs copy speed) */
+int  mhip_host_register(void* p, size_t bytes);
+void mhip_host_unregister(void* p);
 
 /* `stream` may be NULL (the context creates its own) or a hipStream_t the caller owns (e.g. torch's current stream). */
 int  mhip_ctx_create(int device, void* stream, mhip_ctx** out);

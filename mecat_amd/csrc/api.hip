@@ -92,6 +92,17 @@ void mhip_host_free(void* p) {
     if (p) (void)hipHostFree(p);
 }
 
+// page-locks a caller's buffer for the copies of the calls in between (a 400 MB volume out of pageable memory goes up at a tenth of the
+// link's rate); pages that are touched already (huge pages best) are locked in milliseconds.  Returns 0 when the buffer is locked.
+int mhip_host_register(void* p, size_t bytes) {
+    if (!p || !bytes) return -1;
+    if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return 0;
+}
+void mhip_host_unregister(void* p) {
+    if (p && hipHostUnregister(p) != hipSuccess) (void)hipGetLastError();
+}
+
 int mhip_ctx_reserve_index(mhip_ctx* c, int64_t bases) {
     if (bases <= 0) return 0;
     // ix_ent1 (every k-mer start of the volume) and ix_ent2 (the ping buffer of one group of coarse bins: a quarter of the

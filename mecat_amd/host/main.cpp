@@ -17,6 +17,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <sys/time.h>
 #include <errno.h>
@@ -127,16 +128,29 @@ static inline char* put_int(char* p, int v) {
 // growable array in page-locked host memory (contents are not preserved across a grow: every user refills it)
 template <typename T>
 struct PinnedBuf {
+    // buffers that cross the PCIe link: 2 MB-aligned huge pages, touched here and then page-locked (mhip_host_register) — 100 MB in a few
+    // milliseconds, where a hipHostMalloc of the size takes 25 - 60 ms (tools/dev/probes/pin_probe.hip)
     T* p = nullptr;
     size_t cap = 0, n = 0;
-    ~PinnedBuf() { mhip_host_free(p); }
+    bool locked = false;
+    void release() {
+        if (!p) return;
+        if (locked) mhip_host_unregister(p);
+        free(p);
+        p = nullptr;
+        locked = false;
+    }
+    ~PinnedBuf() { release(); }
     void resize(size_t want) {
         if (want > cap) {
-            mhip_host_free(p);
-            p = nullptr;
+            release();
             cap = want + want / 8 + 1024;
+            const size_t huge = (size_t)2 << 20, bytes = (cap * sizeof(T) + huge - 1) & ~(huge - 1);
             void* q = nullptr;
-            MCHK(mhip_host_alloc(cap * sizeof(T), &q));
+            if (posix_memalign(&q, huge, bytes) != 0) DIE("out of memory (%zu bytes of transfer buffer)", bytes);
+            (void)madvise(q, bytes, MADV_HUGEPAGE);
+            for (size_t o = 0; o < bytes; o += huge) ((volatile char*)q)[o] = 0;
+            locked = mhip_host_register(q, bytes) == 0;      // (not locked: the copies still work, slower)
             p = (T*)q;
         }
         n = want;
@@ -177,6 +191,19 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
     int slab = slab_env ? std::max(1, atoi(slab_env)) : (opt.tech == TECH_NANOPORE && opt.task == TASK_ALN ? 60000 : 20000);
     if (comm) slab = std::max(shard_chunk, slab - slab % shard_chunk);      // slabs start on chunk boundaries
     const bool writes = out != NULL;
+    // One process, PacBio gates: slabs of SHRINKING size — 70 % of the reads that are left, down to 2 000.  Formatting a slab takes a third
+    // of the time its extension takes, so slab s is always written out before slab s + 1 comes off the GPU and only the LAST slab's
+    // formatting is exposed at the end of the volume: the smaller it is the better, while every slab costs a fixed few milliseconds on
+    // the device (the second extension launch for the handed-over units, the tails of the launches, the copies): 70 000 / 21 000 /
+    // 6 300 / 2 700 reads at config 2 instead of five slabs of 20 000.  MECAT_HIP_SLAB keeps a fixed size.
+    const bool shrinking = !slab_env && !comm && !(opt.tech == TECH_NANOPORE && opt.task == TASK_ALN);
+    auto slab_len = [&](int rb, int end) {
+        const int left = end - rb;
+        if (!shrinking) return std::min(slab, left);
+        int s2 = std::max(2000, (int)(0.7 * left));
+        if (left - s2 < 2000) s2 = left;
+        return std::min(s2, left);
+    };
 
     struct SlabBuf {
         PinnedBuf<mhip_candidate> cands;      // buffers that cross the PCIe link: page-locked
@@ -192,7 +219,7 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
     std::thread prealloc;
     if (writes)
         prealloc = std::thread([&]() {
-            const size_t rows = (size_t)std::min(slab, std::max(ref.num_reads, 1));
+            const size_t rows = (size_t)std::max(1, slab_len(0, std::max(ref.num_reads, 1)));      // (other query volumes of the row are no larger; buffers grow when one is)
             for (SlabBuf& B : slabs) {
                 B.cands.resize(comm ? rows * (size_t)P.maxc : rows * 32);       // packed lists in a one-process run (grown when a slab holds more)
                 B.counts.resize(rows);
@@ -200,7 +227,14 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
             }
         });
     mhip_volume* dref = NULL;
-    { TraceTimer tt("volume_upload"); MCHK(mhip_volume_upload(ctx, ref.pac.data(), ref.offs.data(), ref.num_reads, ref.num_bases, ref.start_read_id, &dref)); }
+    {
+        TraceTimer tt("volume_upload");
+        // (the packed bytes sit in huge pages the packer threads have touched: locking them takes a few milliseconds and the copy then runs
+        // at the link's rate instead of through the runtime's staging buffers)
+        const bool locked = !ref.pac.empty() && mhip_host_register(ref.pac.data(), ref.pac.size()) == 0;
+        MCHK(mhip_volume_upload(ctx, ref.pac.data(), ref.offs.data(), ref.num_reads, ref.num_bases, ref.start_read_id, &dref));
+        if (locked) mhip_host_unregister(ref.pac.data());
+    }
     mhip_index* idx = NULL;
     {
         ScopedTimer t("create_ref_index");
@@ -227,7 +261,9 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
         if (vid != svid) {
             load_volume(vn[vid], &rd_store);
             rd = &rd_store;
+            const bool locked = !rd_store.pac.empty() && mhip_host_register(rd_store.pac.data(), rd_store.pac.size()) == 0;
             MCHK(mhip_volume_upload(ctx, rd->pac.data(), rd->offs.data(), rd->num_reads, rd->num_bases, rd->start_read_id, &dreads));
+            if (locked) mhip_host_unregister(rd_store.pac.data());
         }
         // candidate_detect aborts on a read of MAX_SEQ_SIZE bases or more (pw_impl.cpp:743-746); pairwise_mapping would
         // overrun its MAX_SEQ_SIZE buffers there.  Same limit, same message, for both tasks.
@@ -410,7 +446,7 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
             size_t budget = std::min<size_t>(free_b / 4, (size_t)32 << 30);
             if (const char* e = getenv("MECAT_HIP_CELL_MB")) budget = (size_t)std::max(1L, atol(e)) << 20;
             const size_t per_read = sizeof(mhip_candidate) * (size_t)P.maxc + sizeof(int32_t);
-            const size_t fit = std::max<size_t>(1, budget / per_read / (size_t)slab) * (size_t)slab;
+            const size_t fit = shrinking ? std::max<size_t>(2000, budget / per_read) : std::max<size_t>(1, budget / per_read / (size_t)slab) * (size_t)slab;
             super_reads = (int)std::min<size_t>((size_t)std::max(rd->num_reads, 1), fit);
         }
         auto seed_super = [&](int first) {
@@ -423,8 +459,11 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
             MCHK(mhip_ctx_sync(ctx));
         };
         int sno = 0;
-        for (int rb = 0; rb < rd->num_reads; rb += slab, ++sno) {
-            const int re = std::min(rd->num_reads, rb + slab), nr = re - rb;
+        for (int rb = 0, step = 0; rb < rd->num_reads; rb += step, ++sno) {
+            // (a slab never straddles two super-slabs of the resident table: it ends where the super-slab that holds its first read ends)
+            const int super_end = comm ? rd->num_reads : std::min(rd->num_reads, (rb / super_reads + 1) * super_reads);
+            step = slab_len(rb, super_end);
+            const int re = rb + step, nr = re - rb;
             {
                 std::unique_lock<std::mutex> lk(pm);                  // the buffers of slab sno - 2 must have been written out
                 pcv.wait(lk, [&]() { return consumed >= sno - 1; });
@@ -991,5 +1030,8 @@ int main(int argc, char* argv[]) {
         else partition_m4_text(opt.output, part_ratio, part_batch, part_min, opt.num_threads);
     }
     if (getenv("MECAT_TRACE")) fprintf(stderr, "[trace] main returns at    %.3f s\n", now_s() - t_start);
-    return 0;
+    // Everything this run owes the caller is on disk and closed.  What a plain `return` would still do — the HIP runtime's own teardown
+    // (code objects, queues, its threads) and the destructors of this file's statics — takes 40 - 80 ms and produces nothing: leave at once.
+    fflush(NULL);
+    _exit(0);
 }

@@ -503,6 +503,20 @@ int split_raw_dataset(const char* reads, const char* wrk_dir, int num_threads) {
 
 void volume_set_device_packer(std::function<mhip_ctx*()> get_ctx) { g_device_ctx = std::move(get_ctx); }
 
+void* volume_big_alloc(size_t bytes) {
+    const size_t huge = (size_t)2 << 20;
+    void* p = NULL;
+    if (bytes >= 8 * huge) {
+        if (posix_memalign(&p, huge, (bytes + huge - 1) & ~(huge - 1)) != 0) throw std::bad_alloc();
+        (void)madvise(p, (bytes + huge - 1) & ~(huge - 1), MADV_HUGEPAGE);
+        return p;
+    }
+    p = malloc(std::max<size_t>(bytes, 1));
+    if (!p) throw std::bad_alloc();
+    return p;
+}
+void volume_big_free(void* p, size_t) { free(p); }
+
 void volume_set_async_dump(bool on) {
     static bool registered = false;
     g_async_dump = on;

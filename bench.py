@@ -379,6 +379,8 @@ def main():
     ap.add_argument("--no-align", action="store_true", help="-j 0 only (index + candidates)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed cns_realign / xdrop_extend measurements")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end CLI leg (FASTA -> .can / .m4 wall clock)")
+    ap.add_argument("--e2e", action="store_true", help="multi-volume workloads (config3, config5): ONLY the end-to-end leg — the drop-in binary on the workload's FASTA, "
+                                                      "-j 0 and -j 1 -g 1, wall clock with the stages traced (prints its own JSON line)")
     ap.add_argument("--stats", default="", help="write per-kernel stats JSON here (rank 0)")
     ap.add_argument("--simulate-ranks", default="", help="e.g. 2,4,8: on ONE GPU, run every rank's share of the sharded calls alone (no transport) and report "
                                                          "per-rank times, imbalance, link bytes and the compute-only speed-up bound (prints its own JSON line)")

@@ -169,6 +169,68 @@ static void run_threads(int nt, F f) {
     for (auto& x : th) x.join();
 }
 
+// Query volumes stay RESIDENT across the grid: row i visits volumes i .. V - 1, row i + 1 visits i + 1 .. V - 1 again, and loading a 535 MB
+// volume file, page-locking it, uploading it and freeing it again cost ~0.09 s per cell — 16 of the 43 s of config 5's `-j 0` run (190
+// cells).  A volume is uploaded once per process and kept (device: the packed bytes and read table; host: the read table the formatter
+// needs) while the resident volumes stay inside a budget of a quarter of the device memory (MECAT_HIP_VOLCACHE_MB overrides; 0 turns
+// the cache off); volumes beyond the budget are loaded per cell as before.
+struct ResidentVolume {
+    HostVolume hv;               // pac released once the bytes are on the device (and the volume file, if still being written, is done)
+    mhip_volume* dv = NULL;
+    size_t bytes = 0;
+};
+static std::vector<ResidentVolume*> g_resident;
+static size_t g_resident_bytes = 0;
+static void resident_clear() {
+    for (ResidentVolume* r : g_resident)
+        if (r) { if (r->dv) mhip_volume_free(r->dv); delete r; }
+    g_resident.clear();
+    g_resident_bytes = 0;
+}
+// volume `vid`, on the device: from the cache, or loaded + uploaded now (and kept when it fits the budget: *cached says so; a volume that
+// is not kept is the caller's to free, host part in *own_host, device part in the return value)
+static mhip_volume* resident_get(mhip_ctx* ctx, const std::vector<std::string>& vn, int vid, const HostVolume** hv_out, HostVolume* own_host, bool* cached) {
+    if (g_resident.size() < vn.size()) g_resident.resize(vn.size(), NULL);
+    if (g_resident[(size_t)vid]) { *hv_out = &g_resident[(size_t)vid]->hv; *cached = true; return g_resident[(size_t)vid]->dv; }
+    size_t budget;
+    if (const char* e = getenv("MECAT_HIP_VOLCACHE_MB")) budget = (size_t)std::max(0L, atol(e)) << 20;
+    else {
+        size_t free_b = 0, total_b = 0;
+        MCHK(mhip_ctx_mem_info(ctx, &free_b, &total_b));
+        budget = total_b / 4;
+    }
+    HostVolume tmp;
+    { TraceTimer tt("load_volume"); load_volume(vn[(size_t)vid], &tmp); }
+    mhip_volume* dv = NULL;
+    {
+        TraceTimer tt("volume_upload");
+        // (the packed bytes sit in huge pages the packer / reader has touched: locking them takes a few milliseconds and the copy then runs
+        // at the link's rate instead of through the runtime's staging buffers)
+        const bool locked = !tmp.pac.empty() && mhip_host_register(tmp.pac.data(), tmp.pac.size()) == 0;
+        MCHK(mhip_volume_upload(ctx, tmp.pac.data(), tmp.offs.data(), tmp.num_reads, tmp.num_bases, tmp.start_read_id, &dv));
+        if (locked) mhip_host_unregister(tmp.pac.data());
+    }
+    const size_t bytes = tmp.pac.size() + sizeof(mhip_offset_t) * tmp.offs.size();
+    if (g_resident_bytes + bytes <= budget) {
+        ResidentVolume* r = new ResidentVolume();
+        r->hv = std::move(tmp);
+        // the bytes live on the device now — unless the file of the volume that stayed in memory is still being written from these very
+        // bytes (one-volume runs: nothing waits for that write; the host copy then goes with the cache)
+        if (!volume_dump_in_flight()) { std::vector<uint8_t, NoInitAlloc<uint8_t>> none; r->hv.pac.swap(none); }
+        r->dv = dv;
+        r->bytes = bytes;
+        g_resident[(size_t)vid] = r;
+        g_resident_bytes += bytes;
+        *hv_out = &r->hv;
+        *cached = true;
+        return dv;
+    }
+    *own_host = std::move(tmp);
+    *hv_out = own_host;
+    *cached = false;
+    return dv;
+}
+
 // comm == NULL: this process computes the whole grid row.  Otherwise every rank of the communicator runs this function for the
 // same row: the reads of a slab are dealt out in chunks (chunk c of query volume j -> rank (c + j) mod P), each rank seeds and
 // extends its own, the lists are all-gathered (mhip_seed_reads_sharded / mhip_align_sharded), and every rank formats and writes the
@@ -181,8 +243,11 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
     P.min_align_size = opt.min_align_size;
     P.min_kmer_match = opt.min_kmer_match;
 
-    HostVolume ref;
-    { TraceTimer tt("load_volume"); load_volume(vn[svid], &ref); }
+    HostVolume ref_own;
+    const HostVolume* refp = NULL;
+    bool ref_cached = false;
+    mhip_volume* dref = resident_get(ctx, vn, svid, &refp, &ref_own, &ref_cached);
+    const HostVolume& ref = *refp;
 
     const char* slab_env = getenv("MECAT_HIP_SLAB");
     // 20 000 reads per slab; nanopore extension: 60 000 — an X-drop call ends with the tail of its longest units (the waves pull units,
@@ -226,15 +291,6 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
                 if (opt.task != TASK_SEED) B.res.resize(rows * 32);       // (grown when a slab holds more candidates)
             }
         });
-    mhip_volume* dref = NULL;
-    {
-        TraceTimer tt("volume_upload");
-        // (the packed bytes sit in huge pages the packer threads have touched: locking them takes a few milliseconds and the copy then runs
-        // at the link's rate instead of through the runtime's staging buffers)
-        const bool locked = !ref.pac.empty() && mhip_host_register(ref.pac.data(), ref.pac.size()) == 0;
-        MCHK(mhip_volume_upload(ctx, ref.pac.data(), ref.offs.data(), ref.num_reads, ref.num_bases, ref.start_read_id, &dref));
-        if (locked) mhip_host_unregister(ref.pac.data());
-    }
     mhip_index* idx = NULL;
     {
         ScopedTimer t("create_ref_index");
@@ -258,13 +314,8 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
         HostVolume rd_store;
         const HostVolume* rd = &ref;
         mhip_volume* dreads = dref;
-        if (vid != svid) {
-            load_volume(vn[vid], &rd_store);
-            rd = &rd_store;
-            const bool locked = !rd_store.pac.empty() && mhip_host_register(rd_store.pac.data(), rd_store.pac.size()) == 0;
-            MCHK(mhip_volume_upload(ctx, rd->pac.data(), rd->offs.data(), rd->num_reads, rd->num_bases, rd->start_read_id, &dreads));
-            if (locked) mhip_host_unregister(rd_store.pac.data());
-        }
+        bool rd_cached = true;
+        if (vid != svid) dreads = resident_get(ctx, vn, vid, &rd, &rd_store, &rd_cached);
         // candidate_detect aborts on a read of MAX_SEQ_SIZE bases or more (pw_impl.cpp:743-746); pairwise_mapping would
         // overrun its MAX_SEQ_SIZE buffers there.  Same limit, same message, for both tasks.
         for (int r = 0; r < rd->num_reads; ++r)
@@ -585,10 +636,10 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
         if (getenv("MECAT_TRACE"))
             fprintf(stderr, "[trace] volume %d stages: seed %.3f s, jobs %.3f s, extend %.3f s, format %.3f s, write + copies %.3f s, page-locked buffers %.3f s\n",
                     vid, st[0], st[1], st[2], st[3], st[4], st[5]);
-        if (dreads != dref) mhip_volume_free(dreads);
+        if (dreads != dref && !rd_cached) mhip_volume_free(dreads);
     }
     mhip_index_free(idx);
-    mhip_volume_free(dref);
+    if (!ref_cached) mhip_volume_free(dref);
     volume_wait_pending();       // the volume's file is written from `ref`'s buffers
 }
 
@@ -962,6 +1013,7 @@ int main(int argc, char* argv[]) {
     if (gpu_setup.joinable()) gpu_setup.join();
     {
         TraceTimer tt("ctx_destroy");
+        resident_clear();
         mhip_ctx_destroy(ctx);
     }
     if (getenv("MECAT_TRACE")) fprintf(stderr, "[trace] main up to here     %.3f s\n", now_s() - t_start);
@@ -971,7 +1023,7 @@ int main(int argc, char* argv[]) {
     }
 
     // merge_results, pw.cpp:34-46 (rank 0; in rows mode it waits for the rows of the other ranks, but not for a dead one)
-    TraceTimer tt_merge("merge_results");
+    TraceTimer* tt_merge = new TraceTimer("merge_results");
     const double merge_wait = env_int("MECAT_HIP_WAIT_S", NULL, 6 * 3600);
     for (int i = 0; i < num_vols; ++i) {
         const std::string fin = results_name(opt.wrk_dir, i, false);
@@ -1006,6 +1058,7 @@ int main(int argc, char* argv[]) {
         const std::string cmd = std::string("cat ") + fin + (i == 0 ? " >" : " >> ") + opt.output;
         if (system(cmd.c_str()) != 0) DIE("'%s' failed", cmd.c_str());
     }
+    delete tt_merge;
     if (pw) {
         TraceTimer tt("partition_files");
         pw->finish();

@@ -61,6 +61,7 @@ std::vector<std::string> load_volume_names(const std::string& idx_file);   // sp
 void volume_set_device_packer(std::function<mhip_ctx*()> get_ctx);
 void volume_set_async_dump(bool on);
 void volume_wait_pending();
+bool volume_dump_in_flight();      // the second thread may still be writing a volume file out of the kept volume's buffers
 // Unmapping a multi-GB input holds the process's mmap lock for tens of milliseconds, which every hipMalloc needs: the mapping of an
 // asynchronous split is let go (on its own thread) only when the caller says the device allocations are made.  Without the call it
 // goes with the process.

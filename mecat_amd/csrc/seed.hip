@@ -1175,19 +1175,10 @@ __global__ __launch_bounds__(FS_THREADS) void seed_filter_wide(const mhip_offset
     WF_MARK(3);
 }
 
-// WIDE = true (round 5): the same pipeline behind seed_filter_wide, for the low gates of nanopore mode.  That filter has walked the
-// strand's buckets once and left its relevance bitmap (2^18 slots, one bit per 8) and an upper bound of the kept hits (`wide_hits`, the room
-// it asked for); here the bitmap replaces the pipeline's own relevance step — walk 1 counts, per slot of the 2^15-slot table, only the hits
-// the bitmap keeps (from offsets[]: the slot array's 15 bits cannot be tested against 18-bit cells), every counted slot is an occupied
-// relevant slot, walk 2 keeps a hit by the same bitmap test — and everything from the region starts on is the pipeline as it is.  The
-// kept set is exactly seed_emit's, so the tables are the chain's (tests: both paths, same candidates).  A strand this kernel finishes
-// clears its room in the chain's arrays (`wide_hits[s] = 0`): seed_emit / seed_sort_pass / seed_build skip it.
-template <bool WIDE>
 __global__ __launch_bounds__(FS_THREADS) void seed_strand(const mhip_offset_t* __restrict__ roffs, ReadSel sel, int ib,
                                                           const uint16_t* __restrict__ slots, const int32_t* __restrict__ offsets, SeedArrays A,
                                                           int gate, int hi_bits, int min_kmer_match, double cutoff, unsigned long long cap,
-                                                          FusedCtl* __restrict__ ctl, unsigned long long* __restrict__ counters, RefReads R,
-                                                          const uint32_t* __restrict__ wide_rel, uint32_t* __restrict__ wide_hits, const int32_t* __restrict__ wide_filtered) {
+                                                          FusedCtl* __restrict__ ctl, unsigned long long* __restrict__ counters, RefReads R) {
     __shared__ FsLds L;
     const int s = blockIdx.x;
     const int tid = threadIdx.x, lane = lane_id(), wv = threadIdx.x >> 6;
@@ -1202,30 +1193,19 @@ __global__ __launch_bounds__(FS_THREADS) void seed_strand(const mhip_offset_t* _
         if (tid == 0) { A.fused[s] = 0; atomicAdd(&ctl->n_fallback, 1u); atomicAdd(&counters[14], 1ull); }      // debug slot 14: strands left to the kernel chain
     };
     if (Hall == 0) {
-        if (tid == 0) { A.fused[s] = 1; A.strand_hits[s] = 0; A.hit_base[s] = 0; A.nseg[s] = 0; A.nrec[s] = 0; A.ngated[s] = 0; if (WIDE) wide_hits[s] = 0; }
+        if (tid == 0) { A.fused[s] = 1; A.strand_hits[s] = 0; A.hit_base[s] = 0; A.nseg[s] = 0; A.nrec[s] = 0; A.ngated[s] = 0; }
         return;
     }
-    if (WIDE) {
-        // only kept hits are counted: the filter's upper bound of them has to fit (the 16-bit counters and the arrays of FS_CAP entries)
-        if (!wide_filtered[s] || wide_hits[s] > (uint32_t)FS_CAP || K > 32767) { fail(); return; }
-    } else {
-        if (Hall >= 65536u || K > 32767) { fail(); return; }        // a 16-bit counter could wrap; km has 15 bits in the payload
-    }
+    if (Hall >= 65536u || K > 32767) { fail(); return; }        // a 16-bit counter could wrap; km has 15 bits in the payload
 
     unsigned long long t_prev = wall_clock64(); (void)t_prev;
     // ---- walk 1: hits per table slot
     for (int i = tid; i < FLT_M / 2; i += FS_THREADS) L.x.cnt32[i] = 0;
-    for (int i = tid; i < REL_WORDS; i += FS_THREADS) L.rel[i] = WIDE ? wide_rel[(size_t)s * REL_WORDS + i] : 0u;
+    for (int i = tid; i < REL_WORDS; i += FS_THREADS) L.rel[i] = 0u;
     if (tid < 8) L.misc[tid] = 0;
     __syncthreads();
     FS_MARK(0);
-    if (WIDE)
-        fs_walk<FS_LPB2, FS_NP2, FS_Q2, FS_D2, false>(kbs, kcn, offsets, K, [&](int, uint32_t pos) {
-            const uint32_t seg = pos / (uint32_t)ZV;
-            if (rel_test(L.rel, seg, WF_M - 1, WF_CELL)) { const uint32_t e = seg & (FLT_M - 1); atomicAdd(&L.x.cnt32[e >> 1], 1u << ((e & 1u) * 16u)); }
-        });
-    else
-        fs_walk<FS_LPB1, FS_NP1, FS_Q1, FS_D1, false>(kbs, kcn, slots, K, [&](int, uint32_t e) { atomicAdd(&L.x.cnt32[e >> 1], 1u << ((e & 1u) * 16u)); });
+    fs_walk<FS_LPB1, FS_NP1, FS_Q1, FS_D1, false>(kbs, kcn, slots, K, [&](int, uint32_t e) { atomicAdd(&L.x.cnt32[e >> 1], 1u << ((e & 1u) * 16u)); });
     __syncthreads();
     FS_MARK(1);
 
@@ -1240,7 +1220,7 @@ __global__ __launch_bounds__(FS_THREADS) void seed_strand(const mhip_offset_t* _
         cw[0] = L.x.cnt32[(16 * tid - 1) & (FLT_M / 2 - 1)];
         cw[17] = L.x.cnt32[(16 * tid + 16) & (FLT_M / 2 - 1)];
         uint32_t hot = 0;
-        if (!WIDE) {
+        {
 #pragma unroll
         for (int j = 1; j <= 16; ++j) {
             const int lo = (int)(cw[j] & 0xFFFFu), hi = (int)(cw[j] >> 16), pl = (int)(cw[j - 1] >> 16), nx = (int)(cw[j + 1] & 0xFFFFu);
@@ -1267,7 +1247,7 @@ __global__ __launch_bounds__(FS_THREADS) void seed_strand(const mhip_offset_t* _
     // ---- occupied relevant slots, region starts
     uint32_t kept;
     {
-        const uint32_t r = WIDE ? 0xFFFFFFFFu : L.rel[tid];      // (WIDE: only kept hits were counted)
+        const uint32_t r = L.rel[tid];
         uint32_t occ = 0, mine = 0;
         bool toolong = false;
 #pragma unroll
@@ -1297,7 +1277,7 @@ __global__ __launch_bounds__(FS_THREADS) void seed_strand(const mhip_offset_t* _
         if (L.misc[3]) { fail(); return; }
     }
     if (kept == 0) {
-        if (tid == 0) { A.fused[s] = 1; A.strand_hits[s] = 0; A.hit_base[s] = 0; A.nseg[s] = 0; A.nrec[s] = 0; A.ngated[s] = 0; if (WIDE) wide_hits[s] = 0; }
+        if (tid == 0) { A.fused[s] = 1; A.strand_hits[s] = 0; A.hit_base[s] = 0; A.nseg[s] = 0; A.nrec[s] = 0; A.ngated[s] = 0; }
         return;
     }
     // room in the shared output arrays
@@ -1332,8 +1312,7 @@ __global__ __launch_bounds__(FS_THREADS) void seed_strand(const mhip_offset_t* _
             const uint32_t seg = pos / (uint32_t)ZV;
             const uint32_t e = seg & (FLT_M - 1);
             const uint32_t oc = valid ? L.occ[e >> 5] : 0u;
-            // (WIDE: a slot of the 2^15-slot table is shared by segments the filter keeps and segments it does not)
-            const bool keep = WIDE ? valid && rel_test(L.rel, seg, WF_M - 1, WF_CELL) : (bool)((oc >> (e & 31u)) & 1u);
+            const bool keep = (bool)((oc >> (e & 31u)) & 1u);
             const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
             if (m) {
                 if (keep) {
@@ -1555,7 +1534,6 @@ __global__ __launch_bounds__(FS_THREADS) void seed_strand(const mhip_offset_t* _
         atomicAdd(&counters[13], 1ull);                   // debug slot 13: strands that went through this kernel with hits
         A.fused[s] = 1;
         A.strand_hits[s] = kept;
-        if (WIDE) wide_hits[s] = 0;
         A.hit_base[s] = hb;
         A.nseg[s] = nseg;
         A.nrec[s] = nrec;
@@ -1913,7 +1891,6 @@ static int bits_for(uint32_t maxv) {
 
 static bool filter_enabled(const mhip_params* P);
 static bool fused_enabled(const mhip_params* P);
-static bool fused_wide_enabled(const mhip_params* P);
 static bool wide_filter_enabled(const mhip_params* P);
 static bool predrop_enabled();
 static bool cuts_enabled(const mhip_params* P);
@@ -1956,8 +1933,10 @@ static int seed_batch(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref
     SeedArrays F = A;
     SeedArrays B = A;
     unsigned int nfallback = (unsigned int)ns;
-    // wide = false: PacBio gates, the kernel does its own relevance filter; wide = true: behind seed_filter_wide (B holds its bitmaps and rooms)
-    auto run_strand_pipeline = [&](const bool wide) -> int {
+    // (PacBio gates only.  A form of this kernel behind seed_filter_wide, for the low gates of nanopore mode, was built in round 5 and measured
+    // slower than the chain it replaced — 59.4 ms against seed_emit 26.6 + seed_sort_pass 13.7 + seed_build 8.6 = 48.9 ms on 100 000 ONT-style
+    // reads of 20 kb, its second bucket walk costing more than the two sort passes and the build it saved — and was removed in round 6.)
+    auto run_strand_pipeline = [&]() -> int {
         // room: the relevance filter keeps about one bucket hit in nine; a strand that finds the arrays full takes the kernel chain
         const double hits_per_lookup = (double)idx->num_kmers / (double)NKMER + 2.0;
         size_t capF = (size_t)((double)sumK * hits_per_lookup / 5.0) + (size_t)ns * 256 + 64;
@@ -1977,14 +1956,9 @@ static int seed_batch(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref
         if (c->scratch("sf_segscore", sizeof(int32_t) * capF, (void**)&F.seg_score)) return -1;
         if (c->scratch("sf_gated", sizeof(uint32_t) * capF, (void**)&F.gated)) return -1;
         HIPCHK(hipMemsetAsync(d_ctl, 0, sizeof(FusedCtl), c->stream));
-        if (wide)
-            LAUNCH(c, "seed_strand_wide", seed_strand<true>, ns, FS_THREADS, 0, (const mhip_offset_t*)reads->d_offs, sel, ib, (const uint16_t*)idx->d_slots,
-                   (const int32_t*)idx->d_offsets, F, gate, std::max(0, nbits - FLT_BITS), (int)P->min_kmer_match, P->ddfs_cutoff,
-                   (unsigned long long)capF, d_ctl, (unsigned long long*)c->d_counters, RR, (const uint32_t*)B.rel_bits, B.strand_hits, (const int32_t*)B.filtered);
-        else
-            LAUNCH(c, "seed_strand", seed_strand<false>, ns, FS_THREADS, 0, (const mhip_offset_t*)reads->d_offs, sel, ib, (const uint16_t*)idx->d_slots,
-                   (const int32_t*)idx->d_offsets, F, gate, std::max(0, nbits - FLT_BITS), (int)P->min_kmer_match, P->ddfs_cutoff,
-                   (unsigned long long)capF, d_ctl, (unsigned long long*)c->d_counters, RR, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const int32_t*)nullptr);
+        LAUNCH(c, "seed_strand", seed_strand, ns, FS_THREADS, 0, (const mhip_offset_t*)reads->d_offs, sel, ib, (const uint16_t*)idx->d_slots,
+               (const int32_t*)idx->d_offsets, F, gate, std::max(0, nbits - FLT_BITS), (int)P->min_kmer_match, P->ddfs_cutoff,
+               (unsigned long long)capF, d_ctl, (unsigned long long*)c->d_counters, RR);
         FusedCtl ctl;
         HIPCHK(hipMemcpyAsync(&ctl, d_ctl, sizeof(ctl), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));   // also orders the kmb host buffer
@@ -2003,11 +1977,9 @@ static int seed_batch(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref
         }
         return 0;
     };
-    if (fused_enabled(P) && run_strand_pipeline(false)) return -1;
-    const bool strand_behind_wide = fused_wide_enabled(P);
+    if (fused_enabled(P) && run_strand_pipeline()) return -1;
 
-    // ---- the kernel chain for every other strand (with the low gates of nanopore mode its filter comes first, and the strand pipeline takes
-    // the strands whose kept hits fit it)
+    // ---- the kernel chain for every other strand (with the low gates of nanopore mode its own filter comes first)
     if (nfallback > 0) {
         if (c->scratch("sd_hits", sizeof(uint32_t) * (size_t)ns, (void**)&B.strand_hits)) return -1;
         if (c->scratch("sd_filtered", sizeof(int32_t) * (size_t)ns, (void**)&B.filtered)) return -1;
@@ -2021,7 +1993,6 @@ static int seed_batch(mhip_ctx* c, const mhip_index* idx, const mhip_volume* ref
             B.rel_shift = WF_CELL;
             LAUNCH(c, "seed_filter_wide", seed_filter_wide, ns, FS_THREADS, 0, (const mhip_offset_t*)reads->d_offs, sel, ib,
                    (const int32_t*)idx->d_offsets, B, gate, ref == reads ? 1 : 0, (unsigned long long*)c->d_counters);
-            if (strand_behind_wide && run_strand_pipeline(true)) return -1;
         } else {
             B.rel_mask = FLT_M - 1;
             B.rel_shift = 0;
@@ -2100,15 +2071,6 @@ static bool wide_filter_enabled(const mhip_params* P) {
     const char* fe = getenv("MECAT_SEED_FILTER");      // the same knob: 0 disables every relevance filter
     const int gate = 2 * P->min_kmer_match;
     return gate >= 4 && gate < 6 && !(fe && atoi(fe) == 0);
-}
-
-static bool fused_wide_enabled(const mhip_params* P) {
-    // Off unless asked for (MECAT_SEED_FUSED_WIDE=1).  Measured in round 5 on 100 000 ONT-style reads of 20 kb against the table of another
-    // 100 000 (8 batches): seed_strand<true> 59.4 ms against seed_emit 26.6 + seed_sort_pass 13.7 + seed_build 8.6 = 48.9 ms for the chain it
-    // replaces (diagonal cell: 50.5 against 40.0) — its second bucket walk, the one that counts the kept hits per slot, costs more than the
-    // two sort passes and the build it saves.  Same candidates either way (tests/test_gpu_parity.py).
-    const char* fe = getenv("MECAT_SEED_FUSED_WIDE");
-    return wide_filter_enabled(P) && fe && atoi(fe) != 0;
 }
 
 static bool fused_enabled(const mhip_params* P) {

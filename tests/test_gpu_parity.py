@@ -180,34 +180,6 @@ def test_strand_pipeline_equals_kernel_chain(hip, ctx):
         assert np.array_equal(got[r][: cnt[r]], got2[r][: cnt[r]]), r
 
 
-def test_strand_pipeline_behind_the_wide_filter_equals_kernel_chain(hip, ctx):
-    """nanopore gates: seed_strand<WIDE> (MECAT_SEED_FUSED_WIDE=1 — the strand pipeline fed by seed_filter_wide's bitmap: counts only the
-    kept hits, no relevance step of its own) and the default seed_emit / seed_sort_pass / seed_build chain give the same lists (which
-    test_candidates_* compare with the oracle's); the strands whose kept hits fit the pipeline take it, the others fall back to the chain inside the same call"""
-    d = dataset("tiny_ont", hip, ctx)
-    p = hip.default_params(1)
-    ctx.reset_stats()
-    got, cnt = _gpu_cands(hip, ctx, d, p)
-    assert ctx.debug_counter(13) == 0                # the chain is the default
-    os.environ["MECAT_SEED_FUSED_WIDE"] = "1"
-    try:
-        ctx.reset_stats()
-        got2, cnt2 = _gpu_cands(hip, ctx, d, p)
-        took, left = ctx.debug_counter(13), ctx.debug_counter(14)
-        assert took > 0 and took + left <= 2 * len(cnt), (took, left, len(cnt))
-        os.environ["MECAT_SEED_FUSED_ROOM"] = "3000"      # and with room for a few strands only: the rest takes the chain
-        ctx.reset_stats()
-        got3, cnt3 = _gpu_cands(hip, ctx, d, p)
-        assert ctx.debug_counter(14) > 0
-    finally:
-        del os.environ["MECAT_SEED_FUSED_WIDE"]
-        os.environ.pop("MECAT_SEED_FUSED_ROOM", None)
-    assert np.array_equal(cnt, cnt2) and np.array_equal(cnt, cnt3)
-    for r in range(len(cnt)):
-        assert np.array_equal(got[r][: cnt[r]], got2[r][: cnt[r]]), r
-        assert np.array_equal(got[r][: cnt[r]], got3[r][: cnt[r]]), r
-
-
 @pytest.mark.parametrize("name", ["tiny", "tiny_ont", "config1"])
 def test_early_drop_of_higher_id_subjects_changes_nothing(name, hip, ctx):
     """gated segments whose possible subject reads all have a higher id than the query are not listed for get_candidates (it

@@ -146,6 +146,27 @@ def run(args):
                              "rows: the HBM fraction is small by construction (SURVEY.md §8d), its row log (16 bytes per d-row) and the traffic "
                              "counters are in profiles/"},
     }
+    # HBM bytes of the dominant kernel: PMC counters cannot be read from inside the run; they are quoted from the committed rocprofv3 passes of
+    # this command (tools/dev/profile_next_rows.sh -> profiles/<round>_config4_hbm_traffic.json) while profiles/<round>_pmc_source.json names
+    # the kernel sources that are compiled now (same rule as bench.py's config-2 line)
+    try:
+        import re
+        import bench as B0
+        prof = os.path.join(ROOT, "profiles")
+        sfile = sorted(f for f in os.listdir(prof) if re.match(r"r\d+_pmc_source\.json$", f))[-1]
+        tag = sfile[: -len("_pmc_source.json")]
+        digest = B0.src_digest()
+        line["roofline"]["kernel_source_digest"] = digest
+        if json.load(open(os.path.join(prof, sfile))).get("kernel_source_digest") == digest:
+            t = json.load(open(os.path.join(prof, tag + "_config4_hbm_traffic.json"))).get("dw_extend2<true>" if dname == "cns_forward" else dname)
+            if t:
+                line["roofline"]["traffic"] = t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]
+                line["roofline"]["traffic_source"] = ("profiles/%s_config4_hbm_traffic.json: per launch of a 23 700-template run of this command (launches there are slices of "
+                                                      "the same size class); same kernel sources" % tag)
+        else:
+            line["roofline"]["traffic_note"] = "committed PMC passes (profiles/%s) describe other kernel sources: not quoted" % sfile
+    except Exception as e:      # noqa: BLE001
+        line["roofline"]["traffic_note"] = "no committed PMC pass: %r" % (e,)
     if not args.no_cpu:
         try:
             line["cpu_baseline"] = cpu_leg(codes, lens, rec, tb, ids, os.cpu_count() or 1)

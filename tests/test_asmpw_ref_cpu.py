@@ -2,7 +2,7 @@
 *.S2.sorted files hold what the UNMODIFIED tools (oracle/_ref/mecat2asmpw, mecat2trimpw: gcc on the reference's single C files)
 print for a seeded set of corrected reads laid out as canu lays out its overlap blocks.  Where the reference binaries exist
 (the build container) this test re-runs them and checks the committed goldens; everywhere it checks the fixtures' integrity.
-The restatement and the kernels for this path are not written yet (DESIGN.md §6 lists the deltas to mecat2pw)."""
+(The restatement of the candidate stage is oracle/asmpw_oracle.c, the device path mecat_amd/csrc/asm_seed.hip: tests/test_gpu_asmpw.py.)"""
 import hashlib
 import json
 import os

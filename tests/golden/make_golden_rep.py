@@ -37,6 +37,11 @@ for name, (n, L, err, G, seed, ont, nfam, mc, nsat) in sorted(sets.items()):
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         lines = sorted(open(o).read().splitlines())
         e[task] = {"args": a, "lines": len(lines), "sorted_sha256": H.sha256_lines(lines)}
+        if name == "rep_ont" and task == "m4_g1":
+            # the reference needs 95 s for this run (one chunk of 500 reads = one thread): the CPU test compares the oracle with these lines — the
+            # first 40 query reads' (column 2) — instead of starting the binary again
+            with open(os.path.join(H.GOLDEN, "rep_ont.m4_g1.q40.sorted"), "w") as f:
+                f.write("".join(ln + "\n" for ln in lines if int(ln.split()[1]) < 40))
     print(name, json.dumps(e), flush=True)
     out[name] = e
 json.dump(out, open(os.path.join(H.GOLDEN, "rep.json"), "w"), indent=1)

@@ -38,8 +38,8 @@ if os.path.exists(c4name):
     c4 = load(R + "_bench_config4.json")
     out.append("")
     out.append("Config 4 (`--workload config4`, BASELINE configs[3] up to the consensus table; `%s_bench_config4.json`): %d templates (%.2f Gbase), %d re-alignments, "
-               "%d accepted, %.2f s per pass = %.3g template bases/s, %.0f templates/s; re-alignment kernels %.0f ms of it (`cns_forward` %.0f, `cns_trace` %.0f, "
-               "`cns_extend` %.0f); the unmodified `consensus_one_read_can_pacbio` on the same host (%d processes, CPU quota %s cores): %.3g template bases/s." % (
+               "%d accepted, %.2f s per pass = %.3g template bases/s, %.0f templates/s; device kernels %.0f ms of it (`cns_forward` %.0f, `cns_trace` %.0f, "
+               "`cns_extend` %.0f; `cns_push_gaps` + `cns_strings_build` " + "%.0f" % (c4["kernel_ms_per_step"].get("cns_push_gaps", 0) + c4["kernel_ms_per_step"].get("cns_strings_build", 0)) + "); the unmodified `consensus_one_read_can_pacbio` on the same host (%d processes, CPU quota %s cores): %.3g template bases/s." % (
                    R, c4["config"]["templates"], c4["config"]["template_bases"] / 1e9, c4["alignments_per_step"], c4["accepted_per_step"], c4["ms_per_step"] / 1e3,
                    c4["value"], c4["templates_per_s"], c4["gpu_kernel_ms_per_step"], c4["kernel_ms_per_step"].get("cns_forward", 0), c4["kernel_ms_per_step"].get("cns_trace", 0),
                    c4["kernel_ms_per_step"].get("cns_extend", 0), c4["cpu_baseline"]["cores"], c4["cpu_baseline"].get("cpu_quota_cores"), c4["cpu_baseline"]["value"]))
@@ -76,6 +76,47 @@ out.append("rocprofv3 summaries: `%s_kernel_stats.csv`, `%s_hbm_counters.md`, `%
            + ("  `%s_xd_breakdown.md`: what bounds the X-drop kernel and what the rebuild changed." % R if os.path.exists(os.path.join(HERE, R + "_xd_breakdown.md")) else "")
            + ("  `%s_dw_attempt.md`: the round's bounded attempt on `dw_extend2`." % R if os.path.exists(os.path.join(HERE, R + "_dw_attempt.md")) else "")
            + ("  `%s_parity_sweeps.md`: the randomised sweeps against the oracle." % R if os.path.exists(os.path.join(HERE, R + "_parity_sweeps.md")) else ""))
+# round 6 additions: the end-to-end legs of the multi-volume configs and the simulated multi-GPU shares, when their files exist
+def maybe(name):
+    try:
+        return load(name)
+    except (OSError, ValueError, IndexError):
+        return None
+e3, e5 = maybe(R + "_e2e_config3.json"), maybe(R + "_e2e_config5.json")
+if e3 or e5:
+    out.append("")
+    out.append("End to end through the drop-in binary (`bench.py --workload … --e2e`; FASTA in /dev/shm, stages from the driver's own timers):\n")
+    out.append("| workload | task | wall s | lines | hot path s (index + seed + extend) | split s | largest stage outside the hot path |")
+    out.append("|---|---|---|---|---|---|---|")
+    for nm, e in (("config3", e3), ("config5", e5)):
+        if not e:
+            continue
+        for key, task in (("j0", "-j 0"), ("j1", "-j 1 -g 1")):
+            r = e["e2e"].get(key)
+            if r and "wall_s" in r:
+                big = list(r["largest_stage_outside_the_hot_path"].items())[0]
+                out.append("| %s | `%s` | %.1f | %d | %.1f | %.2f | %s %.2f s |" % (nm, task, r["wall_s"], r["lines"], r["hot_path_s"], r["stages_s"]["split_raw_dataset"], big[0], big[1]))
+sim = maybe(R + "_simulated_scaling.json")
+if sim:
+    out.append("")
+    out.append("Simulated multi-GPU shares (`bench.py --simulate-ranks`: every rank's share of the library's sharded calls alone on one GPU, no transport; "
+               "`%s_simulated_scaling.json`): compute-only bound T(1) / slowest rank, index rebuilt on every rank / built in key-range shards:\n" % R)
+    out.append("| workload | P | slowest rank ms (rebuilt / sharded) | bound (rebuilt / sharded) | imbalance max/mean (seed, align) |")
+    out.append("|---|---|---|---|---|")
+    for wl, d in sim.items():
+        if not isinstance(d, dict) or "P" not in d:
+            continue
+        for P, v in d["P"].items():
+            if "slowest_rank_ms" not in v:
+                continue
+            sr, cb, im = v["slowest_rank_ms"], v["compute_only_speedup_bound"], v["imbalance_max_over_mean"]
+            out.append("| %s | %s | %.1f / %.1f of %.1f | %.2f / %.2f | %.3f, %.3f |" % (wl, P, sr["index_rebuilt_on_every_rank"], sr["index_in_key_range_shards"], d["one_gpu_step_ms"],
+                       cb["index_rebuilt_on_every_rank"], cb["index_in_key_range_shards"], im["seed"], im["align"] or 0))
+    rm = c5.get("simulated_rows_mode")
+    if rm:
+        out.append("")
+        out.append("Config 5 in rows mode, from the row times of the whole-config run above (`mhip_shard_deal_rows`, nothing moves): " + "; ".join(
+            "P = %s: bound %.2f x (imbalance %.3f)" % (P, v["compute_only_speedup_bound"], v["imbalance_max_over_mean"]) for P, v in rm["P"].items()) + ".")
 with open(os.path.join(HERE, R + "_summary.md"), "w") as f:
     f.write("\n".join(out) + "\n")
 print("\n".join(out))

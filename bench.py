@@ -829,7 +829,7 @@ def main():
                 time.sleep(3.0)
                 c0 = time.time()
                 p5 = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "config5_cell", "--steps", "2", "--warmup", "1", "--no-cpu"],
-                                    stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+                                    stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=dict(os.environ, MECAT_BENCH_PARITY="1"))
                 l5 = [ln for ln in p5.stdout.splitlines() if ln.startswith("{")]
                 if p5.returncode != 0 or not l5:
                     line["config5_cell"] = {"error": p5.stderr[-300:]}

@@ -39,10 +39,10 @@ if os.path.exists(c4name):
     out.append("")
     out.append("Config 4 (`--workload config4`, BASELINE configs[3] up to the consensus table; `%s_bench_config4.json`): %d templates (%.2f Gbase), %d re-alignments, "
                "%d accepted, %.2f s per pass = %.3g template bases/s, %.0f templates/s; device kernels %.0f ms of it (`cns_forward` %.0f, `cns_trace` %.0f, "
-               "`cns_extend` %.0f; `cns_push_gaps` + `cns_strings_build` " + "%.0f" % (c4["kernel_ms_per_step"].get("cns_push_gaps", 0) + c4["kernel_ms_per_step"].get("cns_strings_build", 0)) + "); the unmodified `consensus_one_read_can_pacbio` on the same host (%d processes, CPU quota %s cores): %.3g template bases/s." % (
+               "`cns_extend` %.0f; strings: `cns_push_gaps` + `cns_strings_build` %.0f); the unmodified `consensus_one_read_can_pacbio` on the same host (%d processes, CPU quota %s cores): %.3g template bases/s." % (
                    R, c4["config"]["templates"], c4["config"]["template_bases"] / 1e9, c4["alignments_per_step"], c4["accepted_per_step"], c4["ms_per_step"] / 1e3,
                    c4["value"], c4["templates_per_s"], c4["gpu_kernel_ms_per_step"], c4["kernel_ms_per_step"].get("cns_forward", 0), c4["kernel_ms_per_step"].get("cns_trace", 0),
-                   c4["kernel_ms_per_step"].get("cns_extend", 0), c4["cpu_baseline"]["cores"], c4["cpu_baseline"].get("cpu_quota_cores"), c4["cpu_baseline"]["value"]))
+                   c4["kernel_ms_per_step"].get("cns_extend", 0), c4["kernel_ms_per_step"].get("cns_push_gaps", 0) + c4["kernel_ms_per_step"].get("cns_strings_build", 0), c4["cpu_baseline"]["cores"], c4["cpu_baseline"].get("cpu_quota_cores"), c4["cpu_baseline"]["value"]))
 out.append("")
 if c5["roofline"].get("kernel_source_digest") != cc["roofline"].get("kernel_source_digest"):
     out.append("(The whole-config-5 line takes six minutes and was taken one commit before the others: the sources differ in the record-pool size of "
@@ -81,7 +81,10 @@ def maybe(name):
     try:
         return load(name)
     except (OSError, ValueError, IndexError):
-        return None
+        try:
+            return json.load(open(os.path.join(HERE, name)))
+        except (OSError, ValueError):
+            return None
 e3, e5 = maybe(R + "_e2e_config3.json"), maybe(R + "_e2e_config5.json")
 if e3 or e5:
     out.append("")

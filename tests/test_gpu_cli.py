@@ -105,6 +105,22 @@ def test_cli_multi_volume_grid(tmp_path):
     assert len(got) > 300
     for i in range(3):
         assert os.path.exists(os.path.join(str(wrk), "r_%d" % i))
+    # the driver keeps query volumes resident across the grid rows (round 6); with the cache off (every cell loads, uploads and frees its
+    # query volume, as the reference does) and with room for one volume only the lines are the same, for both tasks
+    for task in ("0", "1"):
+        outs = []
+        for cache in (None, "0", "1"):
+            o = str(tmp_path / ("c%s_%s" % (cache, task)))
+            e = dict(env)
+            if cache is not None:
+                e["MECAT_HIP_VOLCACHE_MB"] = cache
+            r = subprocess.run([BIN, "-j", task, "-g", "1", "-d", fa, "-o", o, "-w", str(tmp_path / ("wc%s_%s" % (cache, task))), "-t", "4"], capture_output=True,
+                               text=True, env=e)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs.append(sorted(open(o).read().splitlines()))
+        assert outs[0] == outs[1] == outs[2] and len(outs[0]) > 300
+        if task == "0":
+            assert outs[0] == got
 
 
 @pytest.mark.parametrize("task", ["0", "1"])

@@ -277,6 +277,8 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
         PinnedBuf<mhip_aln_result> res;
         std::vector<size_t> jfirst;       // first entry of read r's list in res[] (and in cands[] when packed)
         int rb = 0, nr = 0;
+        const HostVolume* rd = NULL;      // the query volume the slab belongs to, and its number (the writer thread works across cells)
+        int vid = 0;
         bool packed = false;              // cands[] holds only the occupied entries, read-major (one process); else [nr][maxc]
     };
     SlabBuf slabs[2];                         // slab s is written out while slab s + 1 is on the GPU
@@ -306,25 +308,10 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
 
     if (prealloc.joinable()) prealloc.join();
 
-    for (int vid = svid; vid < (int)vn.size(); ++vid) {
-        char info[64];
-        snprintf(info, sizeof(info), "process volume %d", vid);
-        ScopedTimer t(info);
-        fprintf(stderr, "[%s, %u] processing %s\n\n", __func__, __LINE__, vn[vid].c_str());
-        HostVolume rd_store;
-        const HostVolume* rd = &ref;
-        mhip_volume* dreads = dref;
-        bool rd_cached = true;
-        if (vid != svid) dreads = resident_get(ctx, vn, vid, &rd, &rd_store, &rd_cached);
-        // candidate_detect aborts on a read of MAX_SEQ_SIZE bases or more (pw_impl.cpp:743-746); pairwise_mapping would
-        // overrun its MAX_SEQ_SIZE buffers there.  Same limit, same message, for both tasks.
-        for (int r = 0; r < rd->num_reads; ++r)
-            if (rd->offs[(size_t)r].size >= MHIP_MAX_SEQ_SIZE) {
-                printf("rsize = %d\t%d\n", rd->offs[(size_t)r].size, MHIP_MAX_SEQ_SIZE);
-                fflush(stdout);
-                abort();
-            }
-        double st[6] = {0, 0, 0, 0, 0, 0};      // MECAT_TRACE: seconds in seeding, job assembly, extension, formatting, writing, page-locked buffers
+        // One writer for the whole grid row: the text of cell n's last slabs is assembled while cell n + 1 is being seeded (a slab carries the
+        // query volume it belongs to) — at `-j 0` a cell is one seeding call and then nothing but copies and formatting, which used to run with
+        // the GPU idle: 3 of the 29 s of config 5's 190 cells.
+        double st[6] = {0, 0, 0, 0, 0, 0}, st_shown[6] = {0, 0, 0, 0, 0, 0};      // MECAT_TRACE: seconds in seeding, job assembly, extension, formatting, writing, page-locked buffers
         struct StageClock {
             double* acc; double t0;
             static double now() { struct timeval t; gettimeofday(&t, NULL); return t.tv_sec + 1e-6 * t.tv_usec; }
@@ -345,7 +332,7 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
             // of r_<i>; rank 0 strings the parts together (main).  The line order of r_<i> is then "by rank" instead of "by read": the
             // multiset of lines is the contract, the reference's own order depends on its thread timing.
             const int c_rank = comm ? mhip_comm_rank(comm) : 0, c_world = comm ? mhip_comm_nranks(comm) : 1;
-            auto mine = [&](int r) { return c_world == 1 || ((rb + r) / shard_chunk + vid) % c_world == c_rank; };
+            auto mine = [&](int r) { return c_world == 1 || ((rb + r) / shard_chunk + B.vid) % c_world == c_rank; };
             std::vector<std::string> text((size_t)nt);
             auto range_of = [&](int t, int* lo, int* hi) { *lo = (int)((long long)nr * t / nt); *hi = (int)((long long)nr * (t + 1) / nt); };
             if (opt.task == TASK_SEED) {
@@ -359,7 +346,7 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
                     char line[160];
                     for (int r = lo; r < hi; ++r) {
                         if (!mine(r)) continue;
-                        const int qsize = rd->offs[(size_t)(rb + r)].size, qid = rb + r + rd->start_read_id;
+                        const int qsize = B.rd->offs[(size_t)(rb + r)].size, qid = rb + r + B.rd->start_read_id;
                         const size_t c0 = B.packed ? jfirst[(size_t)r] : (size_t)r * P.maxc;
                         for (int k = 0; k < counts[(size_t)r]; ++k) {
                             const mhip_candidate& c = cands[c0 + k];
@@ -394,7 +381,7 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
                 char line[320];
                 for (int r = lo; r < hi; ++r) {
                     if (!mine(r)) continue;
-                    const int qsize = rd->offs[(size_t)(rb + r)].size, qid = rb + r + rd->start_read_id;
+                    const int qsize = B.rd->offs[(size_t)(rb + r)].size, qid = rb + r + B.rd->start_read_id;
                     size_t ji = jfirst[(size_t)r];
                     const size_t c0 = B.packed ? jfirst[(size_t)r] : (size_t)r * P.maxc;
                     m4v.clear();
@@ -482,6 +469,25 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
                 pcv.notify_all();
             }
         });
+    int sno = 0;      // slabs of the row so far (the two slab buffers alternate across cells as well)
+    for (int vid = svid; vid < (int)vn.size(); ++vid) {
+        char info[64];
+        snprintf(info, sizeof(info), "process volume %d", vid);
+        ScopedTimer t(info);
+        fprintf(stderr, "[%s, %u] processing %s\n\n", __func__, __LINE__, vn[vid].c_str());
+        HostVolume rd_store;
+        const HostVolume* rd = &ref;
+        mhip_volume* dreads = dref;
+        bool rd_cached = true;
+        if (vid != svid) dreads = resident_get(ctx, vn, vid, &rd, &rd_store, &rd_cached);
+        // candidate_detect aborts on a read of MAX_SEQ_SIZE bases or more (pw_impl.cpp:743-746); pairwise_mapping would
+        // overrun its MAX_SEQ_SIZE buffers there.  Same limit, same message, for both tasks.
+        for (int r = 0; r < rd->num_reads; ++r)
+            if (rd->offs[(size_t)r].size >= MHIP_MAX_SEQ_SIZE) {
+                printf("rsize = %d\t%d\n", rd->offs[(size_t)r].size, MHIP_MAX_SEQ_SIZE);
+                fflush(stdout);
+                abort();
+            }
         // One process: the candidate lists of the whole cell are made in one go and stay in HBM; a slab is then job assembly and
         // extension on the device plus the copies the text needs (a seeding call per slab cost 5 x 17 ms instead of 59 at config 2,
         // and the host-side job assembly kept the GPU waiting).  With a communicator the sharded calls below do all of this.
@@ -509,7 +515,7 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
             MCHK(mhip_seed_reads_dev(ctx, idx, dref, dreads, first, first + cell_reads, &P, d_cell_cands, d_cell_counts));
             MCHK(mhip_ctx_sync(ctx));
         };
-        int sno = 0;
+        bool first_of_cell = true;
         for (int rb = 0, step = 0; rb < rd->num_reads; rb += step, ++sno) {
             // (a slab never straddles two super-slabs of the resident table: it ends where the super-slab that holds its first read ends)
             const int super_end = comm ? rd->num_reads : std::min(rd->num_reads, (rb / super_reads + 1) * super_reads);
@@ -527,7 +533,10 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
             B.rb = rb;
             B.nr = nr;
             B.packed = !comm;
-            if (!comm && (sno == 0 || rb >= cell_first + cell_reads)) seed_super(rb);      // (slabs never straddle super-slabs)
+            B.rd = rd;
+            B.vid = vid;
+            if (!comm && (first_of_cell || rb >= cell_first + cell_reads)) seed_super(rb);      // (slabs never straddle super-slabs)
+            first_of_cell = false;
             const int cb = rb - cell_first;                                                // the slab inside the resident table
             if (writes) {
                 StageClock sc(&st[5]);
@@ -627,17 +636,26 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
             }
             pcv.notify_all();
         }
-        {
-            std::lock_guard<std::mutex> lk(pm);
-            closing = true;
+        if (!rd_cached) {      // this cell's query volume goes away with the cell: its slabs have to be written out first
+            std::unique_lock<std::mutex> lk(pm);
+            pcv.wait(lk, [&]() { return consumed >= produced; });
         }
-        pcv.notify_all();
-        writer.join();
-        if (getenv("MECAT_TRACE"))
+        if (getenv("MECAT_TRACE")) {      // (what the clocks gathered since the last line; formatting of this cell's tail shows up in the next line)
             fprintf(stderr, "[trace] volume %d stages: seed %.3f s, jobs %.3f s, extend %.3f s, format %.3f s, write + copies %.3f s, page-locked buffers %.3f s\n",
-                    vid, st[0], st[1], st[2], st[3], st[4], st[5]);
+                    vid, st[0] - st_shown[0], st[1] - st_shown[1], st[2] - st_shown[2], st[3] - st_shown[3], st[4] - st_shown[4], st[5] - st_shown[5]);
+            for (int k = 0; k < 6; ++k) st_shown[k] = st[k];
+        }
         if (dreads != dref && !rd_cached) mhip_volume_free(dreads);
     }
+    {
+        std::lock_guard<std::mutex> lk(pm);
+        closing = true;
+    }
+    pcv.notify_all();
+    writer.join();
+    if (getenv("MECAT_TRACE") && (st[3] - st_shown[3] > 0.0005 || st[4] - st_shown[4] > 0.0005))
+        fprintf(stderr, "[trace] volume -1 stages: seed %.3f s, jobs %.3f s, extend %.3f s, format %.3f s, write + copies %.3f s, page-locked buffers %.3f s\n",
+                st[0] - st_shown[0], st[1] - st_shown[1], st[2] - st_shown[2], st[3] - st_shown[3], st[4] - st_shown[4], st[5] - st_shown[5]);
     mhip_index_free(idx);
     if (!ref_cached) mhip_volume_free(dref);
     volume_wait_pending();       // the volume's file is written from `ref`'s buffers

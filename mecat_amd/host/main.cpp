@@ -311,7 +311,7 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
         // One writer for the whole grid row: the text of cell n's last slabs is assembled while cell n + 1 is being seeded (a slab carries the
         // query volume it belongs to) — at `-j 0` a cell is one seeding call and then nothing but copies and formatting, which used to run with
         // the GPU idle: 3 of the 29 s of config 5's 190 cells.
-        double st[6] = {0, 0, 0, 0, 0, 0}, st_shown[6] = {0, 0, 0, 0, 0, 0};      // MECAT_TRACE: seconds in seeding, job assembly, extension, formatting, writing, page-locked buffers
+        double st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_shown[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // MECAT_TRACE (… [6] waits for a slab buffer, [7] device memory query): seconds in seeding, job assembly, extension, formatting, writing, page-locked buffers
         struct StageClock {
             double* acc; double t0;
             static double now() { struct timeval t; gettimeofday(&t, NULL); return t.tv_sec + 1e-6 * t.tv_usec; }
@@ -499,7 +499,7 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
         int cell_first = 0, cell_reads = 0, super_reads = rd->num_reads;
         if (!comm) {
             size_t free_b = 0, total_b = 0;
-            MCHK(mhip_ctx_mem_info(ctx, &free_b, &total_b));
+            { StageClock sc(&st[7]); MCHK(mhip_ctx_mem_info(ctx, &free_b, &total_b)); }
             size_t budget = std::min<size_t>(free_b / 4, (size_t)32 << 30);
             if (const char* e = getenv("MECAT_HIP_CELL_MB")) budget = (size_t)std::max(1L, atol(e)) << 20;
             const size_t per_read = sizeof(mhip_candidate) * (size_t)P.maxc + sizeof(int32_t);
@@ -522,6 +522,7 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
             step = slab_len(rb, super_end);
             const int re = rb + step, nr = re - rb;
             {
+                StageClock sc(&st[6]);
                 std::unique_lock<std::mutex> lk(pm);                  // the buffers of slab sno - 2 must have been written out
                 pcv.wait(lk, [&]() { return consumed >= sno - 1; });
             }
@@ -641,9 +642,9 @@ static void process_one_volume(const Options& opt, mhip_ctx* ctx, int svid, cons
             pcv.wait(lk, [&]() { return consumed >= produced; });
         }
         if (getenv("MECAT_TRACE")) {      // (what the clocks gathered since the last line; formatting of this cell's tail shows up in the next line)
-            fprintf(stderr, "[trace] volume %d stages: seed %.3f s, jobs %.3f s, extend %.3f s, format %.3f s, write + copies %.3f s, page-locked buffers %.3f s\n",
-                    vid, st[0] - st_shown[0], st[1] - st_shown[1], st[2] - st_shown[2], st[3] - st_shown[3], st[4] - st_shown[4], st[5] - st_shown[5]);
-            for (int k = 0; k < 6; ++k) st_shown[k] = st[k];
+            fprintf(stderr, "[trace] volume %d stages: seed %.3f s, jobs %.3f s, extend %.3f s, format %.3f s, write + copies %.3f s, page-locked buffers %.3f s, slab buffer waits %.3f s, memory query %.3f s\n",
+                    vid, st[0] - st_shown[0], st[1] - st_shown[1], st[2] - st_shown[2], st[3] - st_shown[3], st[4] - st_shown[4], st[5] - st_shown[5], st[6] - st_shown[6], st[7] - st_shown[7]);
+            for (int k = 0; k < 8; ++k) st_shown[k] = st[k];
         }
         if (dreads != dref && !rd_cached) mhip_volume_free(dreads);
     }
